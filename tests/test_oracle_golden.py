@@ -51,9 +51,12 @@ def test_proposals(run):
 
 def test_cascade(run):
     g, res, it, _ = run
+    def canon(cls, reg):   # row order follows proposal order, which may swap exact score ties (see test_proposals)
+        a = np.concatenate([cls, reg], 1)
+        return a[np.lexsort((np.round(a[:, 2], 3), np.round(a[:, 1], 3), np.round(a[:, 0], 3)))]
     for k in range(3):
-        np.testing.assert_allclose(it['stage_cls'][k].numpy(), g[f'cls{k}'], rtol=0, atol=2e-5)
-        np.testing.assert_allclose(it['stage_reg'][k].numpy(), g[f'reg{k}'], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(canon(it['stage_cls'][k].numpy(), it['stage_reg'][k].numpy()),
+                                   canon(g[f'cls{k}'], g[f'reg{k}']), rtol=0, atol=2e-5)
 
 
 def test_detections_and_masks(run):
