@@ -1,0 +1,146 @@
+/* nuhtc_hip.h — C ABI of libnuhtc_hip.so, the MI355X (gfx950) engine for NuHTC's htc_lite_swin
+ * tile-inference path.
+ *
+ * What it replaces in the reference (paths relative to the boyden/NuHTC tree, `mmdet/` =
+ * thirdparty/mmdetection/mmdet/): the reference has no native code of its own; its native seam is
+ * mmcv's pybind extension (`mmcv._ext`: roi_align_forward, nms; call sites
+ * mmdet/models/roi_heads/roi_extractors/base_roi_extractor.py:53-58, mmdet/models/dense_heads/rpn_head.py:232,
+ * nuhtc/models/bbox_head.py:93) plus torch ATen.  This library replaces the whole device side of
+ * `inference_detector(model, imgs)` (mmdet/apis/inference.py:90-153 ->
+ * nuhtc/models/htc_cus.py:110-121 `simple_test`), i.e. everything between "uint8 tiles" and
+ * "(bbox_results, segm_results)", and additionally the per-tile filter + mask-NMS of
+ * tools/infer_wsi.py:510-531,60-84.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative NUHTC_E_* code; nothing throws across the ABI;
+ *     nuhtc_last_error() gives the message of the last failure on that engine (or of a failed create).
+ *   - plain pointers and sizes only.  `dev` pointers are HIP device pointers owned by the caller
+ *     (e.g. torch tensors); `host` pointers are host memory.  The engine owns weights + workspace.
+ *   - all work is enqueued on the `stream` passed in (a hipStream_t cast to void*, NULL = default
+ *     stream); functions that return counts to the host synchronise that stream, others do not.
+ *   - one engine per (device, stream user); an engine is not thread-safe; engines are independent.
+ */
+#ifndef NUHTC_HIP_H
+#define NUHTC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NUHTC_ABI_VERSION 1
+
+enum {
+  NUHTC_OK = 0,
+  NUHTC_E_INVALID = -1,   /* bad argument / unsupported configuration */
+  NUHTC_E_HIP = -2,       /* a HIP runtime call failed */
+  NUHTC_E_STATE = -3,     /* call order violated (e.g. infer before finalize, missing weight) */
+  NUHTC_E_CAPACITY = -4,  /* a per-tile capacity (proposals) overflowed; results would be truncated */
+  NUHTC_E_NOTFOUND = -5   /* unknown weight / buffer name */
+};
+
+/* channel handling of the two reference entry points:
+ *   0: tools/infer.py      (file -> BGR -> to_rgb): tile channels are used as given (RGB vs RGB means)
+ *   1: tools/infer_wsi.py  (RGB ndarray run through the BGR pipeline): channels are reversed first     */
+enum { NUHTC_CH_AS_IS = 0, NUHTC_CH_SWAP = 1 };
+
+typedef struct nuhtc_engine nuhtc_engine;
+
+/* Mirrors the `model` / `test_cfg` / `test_pipeline` keys of
+ * configs/nuhtc/htc_lite_swin_pytorch_fpn_{PanNuke,CoNSeP,...}_seasaw_CAS.py that the path reads. */
+typedef struct nuhtc_config {
+  int32_t abi_version;       /* = NUHTC_ABI_VERSION */
+  int32_t num_classes;       /* 5 (PanNuke) / 4 (CoNSeP) ...                      config:5   */
+  int32_t tile_h, tile_w;    /* input tile size in pixels (256)                              */
+  int32_t max_batch;         /* workspace is sized for this many tiles per nuhtc_infer call  */
+  float   scale_factor;      /* 2.0 : MultiScaleFlipAug(scale_factor) / 80/mag    config:6   */
+  float   mean[3], std[3];   /* img_norm_cfg                                     config:8   */
+  /* test_cfg.rpn                                                                config:256-261 */
+  int32_t rpn_nms_pre;       /* 3000 */
+  int32_t rpn_max_per_img;   /* 1000 */
+  float   rpn_nms_iou;       /* 0.7  */
+  float   rpn_min_bbox_size; /* 10   */
+  /* test_cfg.rcnn                                                               config:262-266 */
+  float   score_thr;         /* 0.35 */
+  float   nms_iou;           /* 0.5  */
+  int32_t max_per_img;       /* 500  */
+  float   mask_thr_binary;   /* 0.5  */
+  /* roi_head                                                                    config:72-160 */
+  float   att_thres;         /* 0.965926 : AttentionRoIExtractor thres */
+  int32_t watershed_proposal;/* 1 : prepend connected-component proposals (htc_roi_head_cus.py:2217-2221) */
+  int32_t max_cc_proposals;  /* capacity for those per tile (the reference has no cap; overflow -> NUHTC_E_CAPACITY) */
+  float   stage_stds[3][4];  /* bbox_coder.target_stds of the 3 cascade stages  config:97,115,133 */
+  /* tools/infer_wsi.py post-processing (args.margin, args.min_area, mask_nms thr)  infer_wsi.py:510-526 */
+  int32_t margin;            /* 2    */
+  int32_t min_area;          /* 10   */
+  float   mask_nms_thr;      /* 0.05 */
+} nuhtc_config;
+
+/* Fills `cfg` with the PanNuke defaults listed above. */
+void nuhtc_default_config(nuhtc_config* cfg);
+
+/* Creates an engine on HIP device `device`.  Replaces `build_detector(cfg.model)` +
+ * `.to(device)` of nuhtc/apis/inference.py:11-57. */
+int nuhtc_create(const nuhtc_config* cfg, int device, nuhtc_engine** out);
+void nuhtc_destroy(nuhtc_engine* e);
+const char* nuhtc_last_error(const nuhtc_engine* e);
+
+/* Uploads one tensor of the mmdet state_dict (SURVEY Appendix B naming, fp32, host memory, C order).
+ * Replaces `load_checkpoint(model, ckpt)` (nuhtc/apis/inference.py:44); unknown names are rejected. */
+int nuhtc_load_weight(nuhtc_engine* e, const char* name, const float* host_data, const int64_t* shape, int ndim);
+
+/* Checks that every tensor of the path was loaded and pre-packs weights (NHWC / k-major layouts,
+ * NormedLinear row normalisation, relative-position bias (nH,49,49), shift masks, window maps). */
+int nuhtc_finalize(nuhtc_engine* e);
+
+/* Per-tile results in device memory, capacity `max_per_img` rows per tile (caller-allocated).
+ * Row r of tile b lives at index b*max_per_img + r.  Rows are in the reference's NMS order
+ * (score descending); `bbox2result` class grouping is done by the host mirror. */
+typedef struct nuhtc_dets {
+  float*    boxes;      /* dev [B*max_per_img*5]  x1,y1,x2,y2,score in original-tile pixels */
+  int32_t*  labels;     /* dev [B*max_per_img] */
+  int32_t*  counts;     /* dev [B]  detections per tile */
+  uint32_t* masks;      /* dev [B*max_per_img * tile_h * (tile_w/32)] bit-packed rows, bit (x&31) of word x>>5; may be NULL */
+  int32_t*  areas;      /* dev [B*max_per_img] mask pixel counts; may be NULL */
+  uint8_t*  keep;       /* dev [B*max_per_img] 1 = survives the infer_wsi.py margin/min_area filter + mask-NMS; may be NULL */
+} nuhtc_dets;
+
+/* The hot path: B tiles (B <= max_batch) of tile_h x tile_w x 3 uint8 HWC in device memory ->
+ * detections.  Replaces `inference_detector(model, [ndarray]*B)` (mmdet/apis/inference.py:90) and,
+ * when out->keep != NULL, tools/infer_wsi.py:510-531.  Enqueues on `stream`; does not synchronise. */
+int nuhtc_infer(nuhtc_engine* e, const uint8_t* tiles_dev, int B, int channel_mode, void* stream, const nuhtc_dets* out);
+
+/* Fixed-load variant for benchmarking with synthetic weights: the proposal stage is
+ * computed but replaced by `rois_dev` (dev [B*n_rois*4] x1,y1,x2,y2 in network pixels), and exactly
+ * `n_dets` highest-scoring (roi,class) pairs per tile are carried into the mask branch. */
+int nuhtc_infer_fixed_load(nuhtc_engine* e, const uint8_t* tiles_dev, int B, int channel_mode, const float* rois_dev,
+                           int n_rois, int n_dets, void* stream, const nuhtc_dets* out);
+
+/* Synchronises `stream` and reports whether the last nuhtc_infer overflowed a capacity
+ * (returns NUHTC_E_CAPACITY) — call before trusting the results. */
+int nuhtc_check(nuhtc_engine* e, void* stream);
+
+/* Parity-test access to intermediate tensors of the last nuhtc_infer call (device pointers into the
+ * engine workspace; valid until the next call).  Names: "img", "c0".."c3", "x0".."x3", "rpn0".."rpn3",
+ * "sem_pred", "sem_feat", "rpn_props", "rpn_counts", "cc_mask", "cc_props", "cc_counts", "rois", "roi_counts",
+ * "cls0".."cls2", "reg0".."reg2", "bbox_feats", "mask_prob", "tokens<stage><block>" ...
+ * shape receives up to 6 dims; *dtype: 0=f32, 1=i32, 2=u8, 3=u32. */
+int nuhtc_get_buffer(nuhtc_engine* e, const char* name, void** dev_ptr, int64_t* shape, int* ndim, int* dtype);
+
+/* Stand-alone ops for kernel-level parity tests (all pointers device memory, fp32). */
+/* C[M,N] = act(A[M,K] * W[N,K]^T + bias[N]);  act: 0 none, 1 relu, 2 gelu(erf).  K%32==0, N%32==0. */
+int nuhtc_op_gemm(nuhtc_engine* e, const float* A, const float* W, const float* bias, float* C, int M, int N, int K,
+                  int act, void* stream);
+/* mmcv RoIAlign(avg, aligned=True) on an NHWC map: feat [N,H,W,C=64], rois [R,5] -> out [R,P,P,C]. */
+int nuhtc_op_roi_align(nuhtc_engine* e, const float* feat_nhwc, int N, int H, int W, const float* rois, int R, int P,
+                       float spatial_scale, int sampling_ratio, float* out, void* stream);
+/* mmcv nms on n boxes (n <= 16384): keep_idx[0..*count) in descending-score order (ties: lower index). */
+int nuhtc_op_nms(nuhtc_engine* e, const float* boxes, const float* scores, int n, float iou_thr, int32_t* keep_idx,
+                 int32_t* count_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NUHTC_HIP_H */

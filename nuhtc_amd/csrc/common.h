@@ -1,0 +1,123 @@
+// Internal definitions shared by the HIP translation units of libnuhtc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/nuhtc_hip.h"
+
+#define WS 7            // Swin window size
+#define WS2 49
+#define HEAD_DIM 32
+#define FPN_C 64
+#define FC_C 256
+
+struct HostTensor {
+  std::vector<float> data;
+  std::vector<int64_t> shape;
+};
+
+struct BufInfo {
+  void* ptr;
+  std::vector<int64_t> shape;
+  int dtype;  // 0 f32, 1 i32, 2 u8, 3 u32
+};
+
+struct EngineError {
+  int code;
+  std::string msg;
+};
+
+#define HIP_CHECK(e, expr)                                                                              \
+  do {                                                                                                  \
+    hipError_t _err = (expr);                                                                           \
+    if (_err != hipSuccess) {                                                                           \
+      (e)->err = std::string(#expr) + " failed: " + hipGetErrorString(_err) + " at " + __FILE__ + ":" + \
+                 std::to_string(__LINE__);                                                              \
+      return NUHTC_E_HIP;                                                                               \
+    }                                                                                                   \
+  } while (0)
+
+#define FAIL(e, code, message) \
+  do {                         \
+    (e)->err = (message);      \
+    return (code);             \
+  } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ----------------------------------------------------------------------------- GEMM (gemm.hip)
+// C[row_map(m), n] = epilogue( sum_k A(m,k) * W[n,k] )      fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32
+enum AMode { A_PLAIN = 0, A_CONV3 = 1 };
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_COS = 3 /* relu(v*ri[m]*rj[n]-tau)+tau */ };
+enum StoreMode { ST_PLAIN = 0, ST_ROWMAP = 1, ST_DECONV2 = 2 };
+
+struct GemmParams {
+  const float* A;
+  const float* W;      // [N][K] row-major
+  const float* bias;   // [N] or null
+  float* C;
+  int M, N, K;
+  int lda, ldc;        // row strides in floats
+  const int* m_dev;    // optional device-side row count (rows >= min(M, *m_dev * m_mul) are skipped)
+  int m_mul;
+  int amode;
+  int cH, cW, cC;      // A_CONV3: NHWC image geometry (rows = b*cH*cW + y*cW + x), K = 9*cC
+  int act;
+  float alpha;         // multiplies the accumulated sum before bias (1.0 default)
+  const float* res;    // optional residual, added after activation: res[rmap(m)*ldr + n]
+  int ldr;
+  const float* up;     // optional FPN top-down term: up[(b, y/2, x/2), n], coarse map is (cH/2... ) see upH/upW
+  int upH, upW;        // geometry of the *fine* map whose rows m index (b, y, x); coarse = ceil(/2)
+  const int* row_map;  // ST_ROWMAP: destination row per m (-1 = skip); also used for `res`
+  int store;
+  const float* cos_ri; // ACT_COS: per-row and per-col reciprocal norms
+  const float* cos_rj;
+  float cos_tau;
+  // batching (blockIdx.z)
+  int batch;
+  long long sA, sW, sC, sRi, sRj;
+};
+int launch_gemm(const GemmParams& p, hipStream_t s);
+
+// ----------------------------------------------------------------------------- Swin kernels (swin.hip)
+int launch_preproc(const uint8_t* tiles, float* img, int B, int th, int tw, int swap, const float* mean_istd, hipStream_t s);
+int launch_patch_embed(const float* img, const float* w, const float* b, const float* g, const float* beta, float* tok,
+                       int B, int Hn, int Wn, hipStream_t s);
+// LayerNorm of `rows` rows of C channels: dst row m reads src row src_map[m] (or m when src_map==null); src_map[m]<0 -> zeros
+int launch_layernorm(const float* x, const int* src_map, const float* g, const float* b, float* y, int rows, int C, hipStream_t s);
+// PatchMerging gather + LN(4C): out[(b,y2,x2), (kh*2+kw)*C + c] (weights pre-permuted to this order)
+int launch_merge_ln(const float* x, const float* g, const float* b, float* y, int B, int H, int W, int C, hipStream_t s);
+// window attention: qkv [nWin*49, 3C] -> out [nWin*49, C]; bias [nH,49,49]; mask [nW,49,49] or null
+int launch_window_attn(const float* qkv, const float* bias, const float* mask, float* out, int nWinTotal, int nWperImg, int C,
+                       int nH, hipStream_t s);
+
+// ----------------------------------------------------------------------------- dense heads (dense.hip)
+int launch_sem_fuse(const float* g0, const float* g1, const float* g2, const float* g3, float* out, int B, int H, int W,
+                    hipStream_t s);
+int launch_conv1x1_n1(const float* x, const float* w, const float* b, float* y, int rows, int C, hipStream_t s);
+int launch_rownorm_inv(const float* x, float* inv, int rows, int C, hipStream_t s);
+int launch_transpose(const float* x, float* y, int batch, int rows, int cols, hipStream_t s);
+
+// ----------------------------------------------------------------------------- proposals (proposals.hip)
+struct RpnLevel { const float* out; int h, w, stride; };   // out: [B, h*w, 16] (3 cls logits + 12 deltas + pad)
+int launch_rpn_topk(const RpnLevel* lv, int B, int nms_pre, float* cand_boxes, float* cand_scores, int* cand_level,
+                    int* cand_count, int cand_cap, int img_h, int img_w, float min_size, unsigned long long* scratch_keys,
+                    hipStream_t s);
+// generic per-image sorted NMS: n_i = counts[b] candidates at b*cap; optional ids -> coordinate offset trick.
+// Writes kept rows (x1,y1,x2,y2,score) + kept source index, at most max_keep per image.
+int launch_batched_nms(const float* boxes, const float* scores, const int* ids, const int* counts, int cap, int B,
+                       float iou_thr, int max_keep, float* out_dets, int* out_src, int* out_counts,
+                       unsigned long long* sort_keys, unsigned long long* mask_words, hipStream_t s);
+size_t nms_mask_words_per_image(int cap);
+int launch_cc_proposals(const float* sem_pred, int B, int h, int w, int img_h, int img_w, int min_area, float* boxes,
+                        int* counts, int cap, unsigned char* mask_a, unsigned char* mask_b, int* labels, int* stats,
+                        int* overflow, hipStream_t s);
+
+// ----------------------------------------------------------------------------- RoI path (roi.hip)
+int launch_roi_align(const float* feat, int N, int H, int W, int C, const float* rois, int R, const int* r_dev, int P,
+                     float scale, int sr, float* out, int accumulate, hipStream_t s);

@@ -1,0 +1,60 @@
+// Engine state of libnuhtc_hip.so (host side).
+#pragma once
+#include "common.h"
+
+struct StageGeom {
+  int H, W, C, nH;     // token grid, channels, heads
+  int Hp, Wp, nW;      // padded grid (multiple of 7) and windows per image
+  int* map[2];         // dev: window-row -> token index (-1 = padding), [max_batch*nW*49], un-shifted / shifted
+  float* mask;         // dev: shift mask [nW][49][49]
+};
+
+struct BlockW {
+  float *n1g, *n1b, *relb, *qkv_w, *qkv_b, *proj_w, *proj_b, *n2g, *n2b, *f1_w, *f1_b, *f2_w, *f2_b;
+};
+
+struct nuhtc_engine {
+  nuhtc_config cfg;
+  int device = 0;
+  std::string err;
+  std::map<std::string, HostTensor> raw;
+  std::map<std::string, BufInfo> bufs;
+  std::vector<void*> allocs;
+  size_t bytes_allocated = 0;
+  bool finalized = false;
+  bool debug_tokens = false;
+  int lastB = 0;
+  int Hn = 0, Wn = 0;
+
+  StageGeom st[4];
+  // backbone weights
+  float *pe_w = nullptr, *pe_b = nullptr, *pe_g = nullptr, *pe_beta = nullptr;
+  std::vector<BlockW> blocks[4];
+  float *on_g[4], *on_b[4], *mg_g[3], *mg_b[3], *mg_w[3];
+  // neck / dense heads
+  float *lat_w[4], *lat_b[4], *fpn_w[4], *fpn_b[4];
+  float *rpn_w, *rpn_b, *rpn_hw, *rpn_hb;
+  float *sem_lw[4], *sem_lb[4], *sem_cw[4], *sem_cb[4], *sem_ew, *sem_eb, *sem_gw, *sem_gb;
+  // roi heads
+  float *fc1_w[3], *fc1_b[3], *fc2_w[3], *fc2_b[3], *head_w[3], *head_b[3];   // head_w: [16][256] rows 0..nc+1 normed cls, then 4 reg
+  float *mk_w[4], *mk_b[4], *mk_up_w, *mk_up_b, *mk_lw, *mk_lb;
+
+  // workspace
+  float *img, *tokA, *tokB, *xw, *qkv, *att, *hid;
+  float *c[4], *lat[4], *x[4], *rpn[4], *semg[4];
+  float *tmpA, *tmpB, *sem_feat, *sem_pred;
+  // proposals / roi path
+  int roi_cap = 0;          // rois per tile: max_cc_proposals + rpn_max_per_img
+  int cand_cap = 0;         // rpn candidates per tile (<= 4 * nms_pre), det candidates per tile
+  int* overflow = nullptr;  // dev int[4]
+  struct RoiWs* rw = nullptr;
+};
+
+int finalize_roi(nuhtc_engine* e);
+int alloc_roi_workspace(nuhtc_engine* e);
+// rois_fixed != null -> fixed-load mode
+int run_roi_path(nuhtc_engine* e, int B, const float* rois_fixed, int n_rois, int n_dets, hipStream_t s, const nuhtc_dets* out);
+int run_backbone(nuhtc_engine* e, int B, hipStream_t s);
+int run_neck_heads(nuhtc_engine* e, int B, hipStream_t s);
+int launch_conv1x1_n1_dev(const float* x, const float* w, const float* b, float* y, int rows_cap, const int* rows_dev, int rows_mul,
+                          int sigmoid, hipStream_t s);

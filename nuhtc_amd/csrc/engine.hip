@@ -1,0 +1,522 @@
+// libnuhtc_hip.so — C ABI (include/nuhtc_hip.h), weight packing, workspace and the launch sequence of the
+// htc_lite_swin tile-inference path (reference call stack: SURVEY §3.3; nuhtc/models/htc_cus.py:110-121,
+// nuhtc/models/htc_roi_head_cus.py:2184-2372).  Host code only enqueues kernels; there is no CPU fallback.
+#include <cmath>
+#include <cstring>
+
+#include "common.h"
+#include "engine.h"
+
+// =============================================================================== small helpers
+static const int DEPTHS[4] = {2, 2, 6, 2};
+static const int NHEADS[4] = {3, 6, 12, 24};
+
+static thread_local std::string g_create_error;
+
+void nuhtc_default_config(nuhtc_config* c) {
+  memset(c, 0, sizeof(*c));
+  c->abi_version = NUHTC_ABI_VERSION;
+  c->num_classes = 5;
+  c->tile_h = c->tile_w = 256;
+  c->max_batch = 16;
+  c->scale_factor = 2.0f;
+  const float mean[3] = {123.675f, 116.28f, 103.53f}, std[3] = {58.395f, 57.12f, 57.375f};
+  for (int i = 0; i < 3; ++i) { c->mean[i] = mean[i]; c->std[i] = std[i]; }
+  c->rpn_nms_pre = 3000; c->rpn_max_per_img = 1000; c->rpn_nms_iou = 0.7f; c->rpn_min_bbox_size = 10.f;
+  c->score_thr = 0.35f; c->nms_iou = 0.5f; c->max_per_img = 500; c->mask_thr_binary = 0.5f;
+  c->att_thres = 0.965926f;
+  c->watershed_proposal = 1;
+  c->max_cc_proposals = 512;
+  const float st[3][4] = {{0.1f, 0.1f, 0.2f, 0.2f}, {0.05f, 0.05f, 0.1f, 0.1f}, {0.033f, 0.033f, 0.067f, 0.067f}};
+  memcpy(c->stage_stds, st, sizeof(st));
+  c->margin = 2; c->min_area = 10; c->mask_nms_thr = 0.05f;
+}
+
+const char* nuhtc_last_error(const nuhtc_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+int nuhtc_create(const nuhtc_config* cfg, int device, nuhtc_engine** out) {
+  if (!cfg || !out) { g_create_error = "null argument"; return NUHTC_E_INVALID; }
+  if (cfg->abi_version != NUHTC_ABI_VERSION) { g_create_error = "abi_version mismatch"; return NUHTC_E_INVALID; }
+  if (cfg->scale_factor != 2.0f) { g_create_error = "only scale_factor == 2.0 is supported (40x slides / PanNuke config)"; return NUHTC_E_INVALID; }
+  if (cfg->tile_h % 16 || cfg->tile_w % 16 || cfg->tile_h <= 0 || cfg->tile_w <= 0) { g_create_error = "tile size must be a positive multiple of 16"; return NUHTC_E_INVALID; }
+  if (cfg->tile_w % 32) { g_create_error = "tile_w must be a multiple of 32 (bit-packed mask rows)"; return NUHTC_E_INVALID; }
+  if (cfg->num_classes < 1 || cfg->num_classes > 16) { g_create_error = "num_classes out of range"; return NUHTC_E_INVALID; }
+  if (cfg->max_batch < 1 || cfg->max_batch > 256) { g_create_error = "max_batch out of range"; return NUHTC_E_INVALID; }
+  if (cfg->rpn_nms_pre < 1 || cfg->rpn_nms_pre > 4096 || cfg->rpn_max_per_img < 1 || cfg->rpn_max_per_img > 4096) { g_create_error = "rpn_nms_pre / rpn_max_per_img out of range (<=4096)"; return NUHTC_E_INVALID; }
+  if (cfg->max_per_img < 1 || cfg->max_per_img > 2048) { g_create_error = "max_per_img out of range"; return NUHTC_E_INVALID; }
+  if (cfg->max_cc_proposals < 0 || cfg->max_cc_proposals > 4096) { g_create_error = "max_cc_proposals out of range"; return NUHTC_E_INVALID; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { g_create_error = "no such HIP device"; return NUHTC_E_HIP; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) { g_create_error = "hipGetDeviceProperties failed"; return NUHTC_E_HIP; }
+  if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) { g_create_error = std::string("this library is built for gfx950 only, device is ") + prop.gcnArchName; return NUHTC_E_INVALID; }
+  nuhtc_engine* e = new nuhtc_engine();
+  e->cfg = *cfg;
+  e->device = device;
+  *out = e;
+  return 0;
+}
+
+void nuhtc_destroy(nuhtc_engine* e) {
+  if (!e) return;
+  hipSetDevice(e->device);
+  for (void* p : e->allocs) hipFree(p);
+  delete e;
+}
+
+int nuhtc_load_weight(nuhtc_engine* e, const char* name, const float* host, const int64_t* shape, int ndim) {
+  if (!e || !name || !host || !shape || ndim < 1 || ndim > 4) return NUHTC_E_INVALID;
+  if (e->finalized) FAIL(e, NUHTC_E_STATE, "load_weight after finalize");
+  HostTensor t;
+  size_t n = 1;
+  for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+  t.data.assign(host, host + n);
+  e->raw[name] = std::move(t);
+  return 0;
+}
+
+// =============================================================================== device allocation
+static int dev_alloc(nuhtc_engine* e, void** p, size_t bytes) {
+  bytes = (bytes + 255) & ~(size_t)255;
+  if (bytes == 0) bytes = 256;
+  HIP_CHECK(e, hipMalloc(p, bytes));
+  e->allocs.push_back(*p);
+  e->bytes_allocated += bytes;
+  return 0;
+}
+
+static int upload(nuhtc_engine* e, float** dst, const std::vector<float>& v) {
+  int rc = dev_alloc(e, (void**)dst, v.size() * sizeof(float));
+  if (rc) return rc;
+  HIP_CHECK(e, hipMemcpy(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+  return 0;
+}
+
+static int upload_i(nuhtc_engine* e, int** dst, const std::vector<int>& v) {
+  int rc = dev_alloc(e, (void**)dst, v.size() * sizeof(int));
+  if (rc) return rc;
+  HIP_CHECK(e, hipMemcpy(*dst, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
+  return 0;
+}
+
+template <typename T>
+static int ws(nuhtc_engine* e, T** p, const char* name, std::vector<int64_t> shape, int dtype) {
+  size_t n = 1;
+  for (auto d : shape) n *= (size_t)d;
+  int rc = dev_alloc(e, (void**)p, n * sizeof(T));
+  if (rc) return rc;
+  if (name) e->bufs[name] = BufInfo{(void*)*p, shape, dtype};
+  return 0;
+}
+
+static const HostTensor* raw(nuhtc_engine* e, const std::string& name, std::initializer_list<int64_t> shape) {
+  auto it = e->raw.find(name);
+  if (it == e->raw.end()) { e->err = "missing weight: " + name; return nullptr; }
+  std::vector<int64_t> s(shape);
+  if (it->second.shape != s) { e->err = "bad shape for weight: " + name; return nullptr; }
+  return &it->second;
+}
+
+#define RAW(var, name, ...)                                 \
+  const HostTensor* var = raw(e, (name), {__VA_ARGS__});    \
+  if (!var) return NUHTC_E_STATE;
+
+// [O][I][3][3] -> [O][(ky*3+kx)*I + i]
+static std::vector<float> pack_conv3(const HostTensor& w, int O, int I) {
+  std::vector<float> p((size_t)O * 9 * I);
+  for (int o = 0; o < O; ++o)
+    for (int i = 0; i < I; ++i)
+      for (int t = 0; t < 9; ++t) p[((size_t)o * 9 + t) * I + i] = w.data[((size_t)o * I + i) * 9 + t];
+  return p;
+}
+
+// =============================================================================== finalize
+static int build_stage_maps(nuhtc_engine* e, int s) {
+  StageGeom& g = e->st[s];
+  const int B = e->cfg.max_batch;
+  // window-row -> token maps (un-shifted and shifted), (mmdet/models/backbones/swin.py:182-226,254-283)
+  for (int sh = 0; sh < 2; ++sh) {
+    std::vector<int> m((size_t)B * g.nW * WS2);
+    for (int b = 0; b < B; ++b)
+      for (int wy = 0; wy < g.Hp / WS; ++wy)
+        for (int wx = 0; wx < g.Wp / WS; ++wx)
+          for (int py = 0; py < WS; ++py)
+            for (int px = 0; px < WS; ++px) {
+              int ys = wy * WS + py, xs = wx * WS + px;                        // coordinates in the rolled frame
+              int y = sh ? (ys + 3) % g.Hp : ys, x = sh ? (xs + 3) % g.Wp : xs;  // roll(-3): rolled[ys] = padded[(ys+3) % Hp]
+              size_t row = ((size_t)b * g.nW + (size_t)wy * (g.Wp / WS) + wx) * WS2 + py * WS + px;
+              m[row] = (y < g.H && x < g.W) ? (b * g.H * g.W + y * g.W + x) : -1;
+            }
+    int rc = upload_i(e, &g.map[sh], m);
+    if (rc) return rc;
+  }
+  // shift mask on the padded grid (swin.py:197-218)
+  std::vector<int> ids((size_t)g.Hp * g.Wp);
+  auto region = [](int v, int n) { return v < n - WS ? 0 : (v < n - 3 ? 1 : 2); };
+  for (int y = 0; y < g.Hp; ++y)
+    for (int x = 0; x < g.Wp; ++x) ids[(size_t)y * g.Wp + x] = region(y, g.Hp) * 3 + region(x, g.Wp);
+  std::vector<float> mask((size_t)g.nW * WS2 * WS2);
+  for (int wy = 0; wy < g.Hp / WS; ++wy)
+    for (int wx = 0; wx < g.Wp / WS; ++wx) {
+      int w = wy * (g.Wp / WS) + wx;
+      for (int p = 0; p < WS2; ++p)
+        for (int q = 0; q < WS2; ++q) {
+          int ip = ids[(size_t)(wy * WS + p / WS) * g.Wp + wx * WS + p % WS];
+          int iq = ids[(size_t)(wy * WS + q / WS) * g.Wp + wx * WS + q % WS];
+          mask[((size_t)w * WS2 + p) * WS2 + q] = ip == iq ? 0.f : -100.f;
+        }
+    }
+  return upload(e, &g.mask, mask);
+}
+
+int nuhtc_finalize(nuhtc_engine* e) {
+  if (!e) return NUHTC_E_INVALID;
+  if (e->finalized) FAIL(e, NUHTC_E_STATE, "finalize called twice");
+  HIP_CHECK(e, hipSetDevice(e->device));
+  const nuhtc_config& c = e->cfg;
+  const int B = c.max_batch;
+  const int Hn = 2 * c.tile_h, Wn = 2 * c.tile_w;
+  e->Hn = Hn; e->Wn = Wn;
+  int rc;
+  // ---- geometry
+  for (int s = 0; s < 4; ++s) {
+    StageGeom& g = e->st[s];
+    g.H = Hn >> (2 + s); g.W = Wn >> (2 + s); g.C = 96 << s; g.nH = NHEADS[s];
+    g.Hp = cdiv(g.H, WS) * WS; g.Wp = cdiv(g.W, WS) * WS;
+    g.nW = (g.Hp / WS) * (g.Wp / WS);
+    if ((rc = build_stage_maps(e, s))) return rc;
+  }
+  // ---- patch embed: [96][3][4][4] -> [48][96], k = (kh*4+kw)*3 + c
+  {
+    RAW(w, "backbone.patch_embed.projection.weight", 96, 3, 4, 4);
+    RAW(b, "backbone.patch_embed.projection.bias", 96);
+    RAW(g, "backbone.patch_embed.norm.weight", 96);
+    RAW(be, "backbone.patch_embed.norm.bias", 96);
+    std::vector<float> p(48 * 96);
+    for (int o = 0; o < 96; ++o)
+      for (int ch = 0; ch < 3; ++ch)
+        for (int kh = 0; kh < 4; ++kh)
+          for (int kw = 0; kw < 4; ++kw) p[((kh * 4 + kw) * 3 + ch) * 96 + o] = w->data[((o * 3 + ch) * 4 + kh) * 4 + kw];
+    if ((rc = upload(e, &e->pe_w, p)) || (rc = upload(e, &e->pe_b, b->data)) || (rc = upload(e, &e->pe_g, g->data)) ||
+        (rc = upload(e, &e->pe_beta, be->data)))
+      return rc;
+  }
+  // ---- Swin blocks
+  std::vector<int> rel(WS2 * WS2);
+  for (int a = 0; a < WS2; ++a)
+    for (int b2 = 0; b2 < WS2; ++b2) rel[a * WS2 + b2] = (a / WS - b2 / WS + WS - 1) * (2 * WS - 1) + (a % WS - b2 % WS + WS - 1);
+  for (int s = 0; s < 4; ++s) {
+    const int C = 96 << s, nH = NHEADS[s];
+    for (int b = 0; b < DEPTHS[s]; ++b) {
+      BlockW bw{};
+      std::string p = "backbone.stages." + std::to_string(s) + ".blocks." + std::to_string(b) + ".";
+      RAW(n1w, p + "norm1.weight", C); RAW(n1b, p + "norm1.bias", C);
+      RAW(tab, p + "attn.w_msa.relative_position_bias_table", 169, nH);
+      RAW(qw, p + "attn.w_msa.qkv.weight", 3 * C, C); RAW(qb, p + "attn.w_msa.qkv.bias", 3 * C);
+      RAW(pw, p + "attn.w_msa.proj.weight", C, C); RAW(pb, p + "attn.w_msa.proj.bias", C);
+      RAW(n2w, p + "norm2.weight", C); RAW(n2b, p + "norm2.bias", C);
+      RAW(f1w, p + "ffn.layers.0.0.weight", 4 * C, C); RAW(f1b, p + "ffn.layers.0.0.bias", 4 * C);
+      RAW(f2w, p + "ffn.layers.1.weight", C, 4 * C); RAW(f2b, p + "ffn.layers.1.bias", C);
+      std::vector<float> rb((size_t)nH * WS2 * WS2);
+      for (int h = 0; h < nH; ++h)
+        for (int i = 0; i < WS2 * WS2; ++i) rb[(size_t)h * WS2 * WS2 + i] = tab->data[(size_t)rel[i] * nH + h];
+      if ((rc = upload(e, &bw.n1g, n1w->data)) || (rc = upload(e, &bw.n1b, n1b->data)) || (rc = upload(e, &bw.relb, rb)) ||
+          (rc = upload(e, &bw.qkv_w, qw->data)) || (rc = upload(e, &bw.qkv_b, qb->data)) || (rc = upload(e, &bw.proj_w, pw->data)) ||
+          (rc = upload(e, &bw.proj_b, pb->data)) || (rc = upload(e, &bw.n2g, n2w->data)) || (rc = upload(e, &bw.n2b, n2b->data)) ||
+          (rc = upload(e, &bw.f1_w, f1w->data)) || (rc = upload(e, &bw.f1_b, f1b->data)) || (rc = upload(e, &bw.f2_w, f2w->data)) ||
+          (rc = upload(e, &bw.f2_b, f2b->data)))
+        return rc;
+      e->blocks[s].push_back(bw);
+    }
+    {
+      std::string p = "backbone.norm" + std::to_string(s) + ".";
+      RAW(w, p + "weight", C); RAW(b, p + "bias", C);
+      if ((rc = upload(e, &e->on_g[s], w->data)) || (rc = upload(e, &e->on_b[s], b->data))) return rc;
+    }
+    if (s < 3) {
+      // PatchMerging: nn.Unfold order k = c*4 + q (q = kh*2+kw)  ->  gather order k' = q*C + c   (transformer.py:363-385)
+      std::string p = "backbone.stages." + std::to_string(s) + ".downsample.";
+      RAW(nw, p + "norm.weight", 4 * C); RAW(nb, p + "norm.bias", 4 * C); RAW(rw, p + "reduction.weight", 2 * C, 4 * C);
+      std::vector<float> g2(4 * C), b2(4 * C), w2((size_t)2 * C * 4 * C);
+      for (int q = 0; q < 4; ++q)
+        for (int ch = 0; ch < C; ++ch) {
+          g2[q * C + ch] = nw->data[ch * 4 + q];
+          b2[q * C + ch] = nb->data[ch * 4 + q];
+          for (int n = 0; n < 2 * C; ++n) w2[(size_t)n * 4 * C + q * C + ch] = rw->data[(size_t)n * 4 * C + ch * 4 + q];
+        }
+      if ((rc = upload(e, &e->mg_g[s], g2)) || (rc = upload(e, &e->mg_b[s], b2)) || (rc = upload(e, &e->mg_w[s], w2))) return rc;
+    }
+  }
+  // ---- FPN
+  for (int i = 0; i < 4; ++i) {
+    const int C = 96 << i;
+    RAW(lw, "neck.lateral_convs." + std::to_string(i) + ".conv.weight", 64, C, 1, 1);
+    RAW(lb, "neck.lateral_convs." + std::to_string(i) + ".conv.bias", 64);
+    RAW(fw, "neck.fpn_convs." + std::to_string(i) + ".conv.weight", 64, 64, 3, 3);
+    RAW(fb, "neck.fpn_convs." + std::to_string(i) + ".conv.bias", 64);
+    if ((rc = upload(e, &e->lat_w[i], lw->data)) || (rc = upload(e, &e->lat_b[i], lb->data)) ||
+        (rc = upload(e, &e->fpn_w[i], pack_conv3(*fw, 64, 64))) || (rc = upload(e, &e->fpn_b[i], fb->data)))
+      return rc;
+  }
+  // ---- RPN: 3x3 conv, then cls(3)+reg(12) fused into one N=32 pointwise layer (cols 0-2 cls, 3-14 reg, rest 0)
+  {
+    RAW(cw, "rpn_head.rpn_conv.weight", 64, 64, 3, 3); RAW(cb, "rpn_head.rpn_conv.bias", 64);
+    RAW(kw, "rpn_head.rpn_cls.weight", 3, 64, 1, 1); RAW(kb, "rpn_head.rpn_cls.bias", 3);
+    RAW(rw, "rpn_head.rpn_reg.weight", 12, 64, 1, 1); RAW(rb, "rpn_head.rpn_reg.bias", 12);
+    std::vector<float> w(32 * 64, 0.f), b(32, 0.f);
+    for (int n = 0; n < 3; ++n) { b[n] = kb->data[n]; for (int k = 0; k < 64; ++k) w[n * 64 + k] = kw->data[n * 64 + k]; }
+    for (int n = 0; n < 12; ++n) { b[3 + n] = rb->data[n]; for (int k = 0; k < 64; ++k) w[(3 + n) * 64 + k] = rw->data[n * 64 + k]; }
+    if ((rc = upload(e, &e->rpn_w, pack_conv3(*cw, 64, 64))) || (rc = upload(e, &e->rpn_b, cb->data)) ||
+        (rc = upload(e, &e->rpn_hw, w)) || (rc = upload(e, &e->rpn_hb, b)))
+      return rc;
+  }
+  // ---- semantic head
+  {
+    const std::string p = "roi_head.semantic_head.";
+    for (int i = 0; i < 4; ++i) {
+      RAW(lw, p + "lateral_convs." + std::to_string(i) + ".conv.weight", 64, 64, 1, 1);
+      RAW(lb, p + "lateral_convs." + std::to_string(i) + ".conv.bias", 64);
+      RAW(cw, p + "convs." + std::to_string(i) + ".conv.weight", 64, 64, 3, 3);
+      RAW(cb, p + "convs." + std::to_string(i) + ".conv.bias", 64);
+      if ((rc = upload(e, &e->sem_lw[i], lw->data)) || (rc = upload(e, &e->sem_lb[i], lb->data)) ||
+          (rc = upload(e, &e->sem_cw[i], pack_conv3(*cw, 64, 64))) || (rc = upload(e, &e->sem_cb[i], cb->data)))
+        return rc;
+    }
+    RAW(ew, p + "conv_embedding.conv.weight", 64, 64, 1, 1); RAW(eb, p + "conv_embedding.conv.bias", 64);
+    RAW(gw, p + "conv_logits.weight", 1, 64, 1, 1); RAW(gb, p + "conv_logits.bias", 1);
+    if ((rc = upload(e, &e->sem_ew, ew->data)) || (rc = upload(e, &e->sem_eb, eb->data)) || (rc = upload(e, &e->sem_gw, gw->data)) ||
+        (rc = upload(e, &e->sem_gb, gb->data)))
+      return rc;
+  }
+  if ((rc = finalize_roi(e))) return rc;
+
+  // ---- workspace (sized for max_batch)
+  const StageGeom& g0 = e->st[0];
+  if ((rc = ws(e, &e->img, "img", {B, Hn, Wn, 3}, 0))) return rc;
+  size_t max_tok = 0, max_win = 0, max_qkv = 0, max_hid = 0;
+  for (int s = 0; s < 4; ++s) {
+    const StageGeom& g = e->st[s];
+    max_tok = std::max(max_tok, (size_t)g.H * g.W * g.C);
+    max_win = std::max(max_win, (size_t)g.nW * WS2 * g.C);
+    max_qkv = std::max(max_qkv, (size_t)g.nW * WS2 * 3 * g.C);
+    max_hid = std::max(max_hid, (size_t)g.H * g.W * 4 * g.C);
+  }
+  if ((rc = ws(e, &e->tokA, "tokens", {B, (int64_t)max_tok}, 0)) || (rc = ws(e, &e->tokB, nullptr, {B, (int64_t)max_tok}, 0)) ||
+      (rc = ws(e, &e->xw, nullptr, {B, (int64_t)max_win}, 0)) || (rc = ws(e, &e->qkv, nullptr, {B, (int64_t)max_qkv}, 0)) ||
+      (rc = ws(e, &e->att, nullptr, {B, (int64_t)max_win}, 0)) || (rc = ws(e, &e->hid, nullptr, {B, (int64_t)std::max(max_hid, max_qkv)}, 0)))
+    return rc;
+  for (int s = 0; s < 4; ++s) {
+    const StageGeom& g = e->st[s];
+    std::string n = std::to_string(s);
+    if ((rc = ws(e, &e->c[s], ("c" + n).c_str(), {B, g.H, g.W, g.C}, 0)) || (rc = ws(e, &e->lat[s], ("lat" + n).c_str(), {B, g.H, g.W, 64}, 0)) ||
+        (rc = ws(e, &e->x[s], ("x" + n).c_str(), {B, g.H, g.W, 64}, 0)) || (rc = ws(e, &e->rpn[s], ("rpn" + n).c_str(), {B, g.H, g.W, 32}, 0)) ||
+        (rc = ws(e, &e->semg[s], nullptr, {B, g.H, g.W, 64}, 0)))
+      return rc;
+  }
+  if ((rc = ws(e, &e->tmpA, nullptr, {B, g0.H, g0.W, 64}, 0)) || (rc = ws(e, &e->tmpB, nullptr, {B, g0.H, g0.W, 64}, 0)) ||
+      (rc = ws(e, &e->sem_feat, "sem_feat", {B, g0.H, g0.W, 64}, 0)) || (rc = ws(e, &e->sem_pred, "sem_pred", {B, g0.H, g0.W}, 0)))
+    return rc;
+  if ((rc = alloc_roi_workspace(e))) return rc;
+  HIP_CHECK(e, hipDeviceSynchronize());
+  e->raw.clear();
+  e->finalized = true;
+  return 0;
+}
+
+// =============================================================================== dense part of the path
+static GemmParams gp(const float* A, const float* W, const float* bias, float* C, int M, int N, int K) {
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.A = A; p.W = W; p.bias = bias; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldc = N; p.alpha = 1.f; p.m_mul = 1;
+  return p;
+}
+
+#define RUN(expr)                                                                          \
+  do {                                                                                     \
+    int _rc = (expr);                                                                      \
+    if (_rc) { e->err = std::string(#expr) + " failed (" + std::to_string(_rc) + ")"; return _rc; } \
+  } while (0)
+
+static int conv3x3(nuhtc_engine* e, const float* in, const float* w, const float* b, float* out, int nimg, int H, int W, int act,
+                   const int* m_dev, int m_mul, hipStream_t s) {
+  GemmParams p = gp(in, w, b, out, nimg * H * W, 64, 576);
+  p.amode = A_CONV3; p.cH = H; p.cW = W; p.cC = 64; p.act = act; p.m_dev = m_dev; p.m_mul = m_mul;
+  return launch_gemm(p, s);
+}
+
+int run_backbone(nuhtc_engine* e, int B, hipStream_t s) {
+  const int Hn = e->Hn, Wn = e->Wn;
+  RUN(launch_patch_embed(e->img, e->pe_w, e->pe_b, e->pe_g, e->pe_beta, e->tokA, B, Hn, Wn, s));
+  float* x = e->tokA;
+  float* xalt = e->tokB;
+  for (int st = 0; st < 4; ++st) {
+    const StageGeom& g = e->st[st];
+    const int T = B * g.H * g.W, Mw = B * g.nW * WS2, C = g.C;
+    for (size_t b = 0; b < e->blocks[st].size(); ++b) {
+      const BlockW& w = e->blocks[st][b];
+      const int sh = (int)(b & 1);
+      // x += proj(attn(LN1(x)))      (mmdet swin.py:356-363)
+      RUN(launch_layernorm(x, g.map[sh], w.n1g, w.n1b, e->xw, Mw, C, s));
+      RUN(launch_gemm(gp(e->xw, w.qkv_w, w.qkv_b, e->qkv, Mw, 3 * C, C), s));
+      RUN(launch_window_attn(e->qkv, w.relb, sh ? g.mask : nullptr, e->att, B * g.nW, g.nW, C, g.nH, s));
+      {
+        GemmParams p = gp(e->att, w.proj_w, w.proj_b, x, Mw, C, C);
+        p.store = ST_ROWMAP; p.row_map = g.map[sh]; p.res = x; p.ldr = C;
+        RUN(launch_gemm(p, s));
+      }
+      // x += W2·gelu(W1·LN2(x))      (swin.py:365-367, mmcv FFN)
+      RUN(launch_layernorm(x, nullptr, w.n2g, w.n2b, e->xw, T, C, s));
+      {
+        GemmParams p = gp(e->xw, w.f1_w, w.f1_b, e->hid, T, 4 * C, C);
+        p.act = ACT_GELU;
+        RUN(launch_gemm(p, s));
+      }
+      {
+        GemmParams p = gp(e->hid, w.f2_w, w.f2_b, x, T, C, 4 * C);
+        p.res = x; p.ldr = C;
+        RUN(launch_gemm(p, s));
+      }
+      if (e->debug_tokens) {
+        auto it = e->bufs.find("tok_s" + std::to_string(st) + "b" + std::to_string(b));
+        if (it != e->bufs.end()) hipMemcpyAsync(it->second.ptr, x, (size_t)T * C * sizeof(float), hipMemcpyDeviceToDevice, s);
+      }
+    }
+    RUN(launch_layernorm(x, nullptr, e->on_g[st], e->on_b[st], e->c[st], T, C, s));   // swin.py:756-762 (tokens == NHWC)
+    if (st < 3) {
+      RUN(launch_merge_ln(x, e->mg_g[st], e->mg_b[st], e->xw, B, g.H, g.W, C, s));
+      RUN(launch_gemm(gp(e->xw, e->mg_w[st], nullptr, xalt, T / 4, 2 * C, 4 * C), s));
+      std::swap(x, xalt);
+    }
+  }
+  return 0;
+}
+
+int run_neck_heads(nuhtc_engine* e, int B, hipStream_t s) {
+  // FPN (mmdet/models/necks/fpn.py:152-179): laterals coarse->fine with the nearest-upsampled coarser lateral added in the epilogue
+  for (int i = 3; i >= 0; --i) {
+    const StageGeom& g = e->st[i];
+    GemmParams p = gp(e->c[i], e->lat_w[i], e->lat_b[i], e->lat[i], B * g.H * g.W, 64, g.C);
+    if (i < 3) { p.up = e->lat[i + 1]; p.upH = g.H; p.upW = g.W; }
+    RUN(launch_gemm(p, s));
+  }
+  for (int i = 0; i < 4; ++i) {
+    const StageGeom& g = e->st[i];
+    RUN(conv3x3(e, e->lat[i], e->fpn_w[i], e->fpn_b[i], e->x[i], B, g.H, g.W, ACT_NONE, nullptr, 1, s));
+  }
+  // RPN head (mmdet/models/dense_heads/rpn_head.py:62-68)
+  for (int i = 0; i < 4; ++i) {
+    const StageGeom& g = e->st[i];
+    RUN(conv3x3(e, e->x[i], e->rpn_w, e->rpn_b, e->tmpA, B, g.H, g.W, ACT_RELU, nullptr, 1, s));
+    RUN(launch_gemm(gp(e->tmpA, e->rpn_hw, e->rpn_hb, e->rpn[i], B * g.H * g.W, 32, 64), s));
+  }
+  // FusedSemanticHead (fused_semantic_head.py:97-111)
+  for (int i = 0; i < 4; ++i) {
+    const StageGeom& g = e->st[i];
+    RUN(launch_gemm(gp(e->x[i], e->sem_lw[i], e->sem_lb[i], e->semg[i], B * g.H * g.W, 64, 64), s));
+  }
+  const StageGeom& g0 = e->st[0];
+  RUN(launch_sem_fuse(e->semg[0], e->semg[1], e->semg[2], e->semg[3], e->tmpA, B, g0.H, g0.W, s));
+  float* a = e->tmpA;
+  float* b = e->tmpB;
+  for (int j = 0; j < 4; ++j) {
+    RUN(conv3x3(e, a, e->sem_cw[j], e->sem_cb[j], b, B, g0.H, g0.W, ACT_RELU, nullptr, 1, s));
+    std::swap(a, b);
+  }
+  RUN(launch_conv1x1_n1(a, e->sem_gw, e->sem_gb, e->sem_pred, B * g0.H * g0.W, 64, s));
+  {
+    GemmParams p = gp(a, e->sem_ew, e->sem_eb, e->sem_feat, B * g0.H * g0.W, 64, 64);
+    p.act = ACT_RELU;
+    RUN(launch_gemm(p, s));
+  }
+  return 0;
+}
+
+// =============================================================================== public entry points
+static int check_infer_args(nuhtc_engine* e, const uint8_t* tiles, int B) {
+  if (!e) return NUHTC_E_INVALID;
+  if (!e->finalized) FAIL(e, NUHTC_E_STATE, "nuhtc_infer before nuhtc_finalize");
+  if (!tiles || B < 1 || B > e->cfg.max_batch) FAIL(e, NUHTC_E_INVALID, "bad tiles pointer or batch size (1..max_batch)");
+  return 0;
+}
+
+int nuhtc_infer(nuhtc_engine* e, const uint8_t* tiles, int B, int channel_mode, void* stream, const nuhtc_dets* out) {
+  int rc = check_infer_args(e, tiles, B);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  HIP_CHECK(e, hipSetDevice(e->device));
+  e->lastB = B;
+  float mi[6];
+  for (int i = 0; i < 3; ++i) { mi[i] = e->cfg.mean[i]; mi[3 + i] = (float)(1.0 / (double)e->cfg.std[i]); }
+  RUN(launch_preproc(tiles, e->img, B, e->cfg.tile_h, e->cfg.tile_w, channel_mode == NUHTC_CH_SWAP, mi, s));
+  RUN(run_backbone(e, B, s));
+  RUN(run_neck_heads(e, B, s));
+  RUN(run_roi_path(e, B, nullptr, 0, 0, s, out));
+  return 0;
+}
+
+int nuhtc_infer_fixed_load(nuhtc_engine* e, const uint8_t* tiles, int B, int channel_mode, const float* rois, int n_rois, int n_dets,
+                           void* stream, const nuhtc_dets* out) {
+  int rc = check_infer_args(e, tiles, B);
+  if (rc) return rc;
+  if (!rois || n_rois < 1 || n_rois > e->roi_cap || n_dets < 1 || n_dets > e->cfg.max_per_img) FAIL(e, NUHTC_E_INVALID, "bad fixed-load arguments");
+  hipStream_t s = (hipStream_t)stream;
+  HIP_CHECK(e, hipSetDevice(e->device));
+  e->lastB = B;
+  float mi[6];
+  for (int i = 0; i < 3; ++i) { mi[i] = e->cfg.mean[i]; mi[3 + i] = (float)(1.0 / (double)e->cfg.std[i]); }
+  RUN(launch_preproc(tiles, e->img, B, e->cfg.tile_h, e->cfg.tile_w, channel_mode == NUHTC_CH_SWAP, mi, s));
+  RUN(run_backbone(e, B, s));
+  RUN(run_neck_heads(e, B, s));
+  RUN(run_roi_path(e, B, rois, n_rois, n_dets, s, out));
+  return 0;
+}
+
+int nuhtc_check(nuhtc_engine* e, void* stream) {
+  if (!e) return NUHTC_E_INVALID;
+  HIP_CHECK(e, hipSetDevice(e->device));
+  HIP_CHECK(e, hipStreamSynchronize((hipStream_t)stream));
+  if (e->overflow) {
+    int h[4] = {0, 0, 0, 0};
+    HIP_CHECK(e, hipMemcpy(h, e->overflow, sizeof(h), hipMemcpyDeviceToHost));
+    if (h[0]) FAIL(e, NUHTC_E_CAPACITY, "connected-component proposals exceeded max_cc_proposals on at least one tile");
+  }
+  return 0;
+}
+
+int nuhtc_get_buffer(nuhtc_engine* e, const char* name, void** ptr, int64_t* shape, int* ndim, int* dtype) {
+  if (!e || !name || !ptr) return NUHTC_E_INVALID;
+  if (strcmp(name, "__enable_token_dump") == 0) {
+    // allocate per-block token snapshots (parity tests only)
+    if (!e->debug_tokens) {
+      for (int s = 0; s < 4; ++s)
+        for (int b = 0; b < DEPTHS[s]; ++b) {
+          float* p;
+          const StageGeom& g = e->st[s];
+          int rc = ws(e, &p, ("tok_s" + std::to_string(s) + "b" + std::to_string(b)).c_str(), {e->cfg.max_batch, g.H * g.W, g.C}, 0);
+          if (rc) return rc;
+        }
+      e->debug_tokens = true;
+    }
+    *ptr = nullptr;
+    if (ndim) *ndim = 0;
+    return 0;
+  }
+  auto it = e->bufs.find(name);
+  if (it == e->bufs.end()) FAIL(e, NUHTC_E_NOTFOUND, std::string("unknown buffer: ") + name);
+  *ptr = it->second.ptr;
+  if (ndim) *ndim = (int)it->second.shape.size();
+  if (shape)
+    for (size_t i = 0; i < it->second.shape.size() && i < 6; ++i) shape[i] = it->second.shape[i];
+  if (dtype) *dtype = it->second.dtype;
+  return 0;
+}
+
+int nuhtc_op_gemm(nuhtc_engine* e, const float* A, const float* W, const float* bias, float* C, int M, int N, int K, int act, void* stream) {
+  if (!e || !A || !W || !C) return NUHTC_E_INVALID;
+  HIP_CHECK(e, hipSetDevice(e->device));
+  GemmParams p = gp(A, W, bias, C, M, N, K);
+  p.act = act;
+  int rc = launch_gemm(p, (hipStream_t)stream);
+  if (rc) FAIL(e, rc, "gemm launch failed (K%32, N%32 required)");
+  return 0;
+}

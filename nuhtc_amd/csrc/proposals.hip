@@ -1,0 +1,560 @@
+// Proposal generation on the device (gfx950, wave64).  Compiled with -ffp-contract=off: box arithmetic follows the
+// reference's separate float32 mul/add steps so that threshold decisions match the CPU path.
+//   rpn_level_kernel : sigmoid, per-level top-k by (score desc, index asc) via radix select + LDS bitonic sort,
+//                      anchor generation, delta2bbox, clamp, min-size filter
+//                      (mmdet/models/dense_heads/rpn_head.py:150-229, core/anchor/anchor_generator.py:151-281,
+//                       core/bbox/coder/delta_xywh_bbox_coder.py:230-260)
+//   nms_*            : mmcv batched_nms / nms (rpn_head.py:232, nuhtc/models/bbox_head.py:93): per-id coordinate
+//                      offset in f32, stable sort by score, 64x64 bit-mask IoU matrix, chunked greedy reduce
+//   cc_*             : "watershed" proposals (nuhtc/models/htc_roi_head_cus.py:283-342) = upsample x4 + 5x5
+//                      Gaussian + >0 + open(5x5,2) + hole fill + 4-connected components in raster order + boxes
+//                      (the watershed call is an identity on these inputs)
+#include "common.h"
+#include "proposals.h"
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ unsigned f2key(float f) { return __float_as_uint(f); }   // scores are >= 0: uint order == float order
+
+// in-LDS bitonic sort of n (power of two) u64 keys, ascending, by the whole block
+__device__ void bitonic_sort_lds(u64* keys, int n) {
+  for (int k = 2; k <= n; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < (n >> 1); t += blockDim.x) {
+        int lo = ((t / j) * (j << 1)) + (t % j);   // t -> pair (lo, lo+j)
+        int hi = lo + j;
+        bool asc = ((lo & k) == 0);
+        u64 a = keys[lo], b = keys[hi];
+        if ((a > b) == asc) { keys[lo] = b; keys[hi] = a; }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__device__ __forceinline__ int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+// block-wide exclusive scan of one int per thread (blockDim.x == 1024), returns exclusive prefix, *total gets the sum
+__device__ int block_exscan_1024(int v, int* lds16, int* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+  if (lane == 63) lds16[wave] = incl;
+  __syncthreads();
+  if (wave == 0) {
+    int w = lane < 16 ? lds16[lane] : 0;
+    int wi = w;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { int t = __shfl_up(wi, o); if (lane >= o) wi += t; }
+    if (lane < 16) lds16[lane] = wi - w;
+    if (lane == 15) lds16[16] = wi;
+  }
+  __syncthreads();
+  int res = lds16[wave] + incl - v;
+  *total = lds16[16];
+  __syncthreads();
+  return res;
+}
+
+// ------------------------------------------------------------------------------------------- RPN per-level selection
+__global__ __launch_bounds__(1024) void rpn_level_kernel(RpnLevels lv, RpnSelParams p) {
+  __shared__ u64 keys[4096];
+  __shared__ int hist[256];
+  __shared__ int sc16[17];
+  __shared__ unsigned s_prefix;
+  __shared__ int s_need, s_cnt;
+  const int b = blockIdx.x, L = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int h = lv.h[L], w = lv.w[L], stride = lv.stride[L];
+  const int n = h * w * 3;
+  const float* out = lv.out[L] + (long long)b * h * w * 32;
+  const int k = p.nms_pre;
+  auto score_of = [&](int idx) -> float {
+    int pix = idx / 3, a = idx - pix * 3;
+    float x = out[(long long)pix * 32 + a];
+    return 1.0f / (1.0f + expf(-x));
+  };
+  int nsel;
+  if (n > k) {
+    // radix select: find key T of rank k (descending) over 32-bit score keys
+    unsigned prefix = 0, maskbits = 0;
+    int need = k;   // still to take from the candidates matching `prefix` under `maskbits`
+    for (int pass = 0; pass < 4; ++pass) {
+      const int shift = 24 - 8 * pass;
+      for (int i = tid; i < 256; i += 1024) hist[i] = 0;
+      __syncthreads();
+      for (int idx = tid; idx < n; idx += 1024) {
+        unsigned key = f2key(score_of(idx));
+        if ((key & maskbits) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int acc = 0, bin = 255;
+        for (; bin >= 0; --bin) {
+          if (acc + hist[bin] >= need) break;
+          acc += hist[bin];
+        }
+        if (bin < 0) bin = 0;
+        s_prefix = prefix | ((unsigned)bin << shift);
+        s_need = need - acc;
+      }
+      __syncthreads();
+      prefix = s_prefix;
+      need = s_need;
+      maskbits |= 0xFFu << shift;
+      __syncthreads();
+    }
+    const unsigned T = prefix;   // keys > T are all taken; `need` of the keys == T, lowest index first
+    if (tid == 0) s_cnt = 0;
+    for (int i = tid; i < 4096; i += 1024) keys[i] = ~0ull;
+    __syncthreads();
+    int eq_before = 0;
+    for (int base = 0; base < n; base += 1024) {
+      int idx = base + tid;
+      unsigned key = idx < n ? f2key(score_of(idx)) : 0u;
+      int is_eq = (idx < n && key == T) ? 1 : 0;
+      int tot;
+      int rank = block_exscan_1024(is_eq, sc16, &tot) + eq_before;
+      bool take = idx < n && (key > T || (is_eq && rank < need));
+      if (take) {
+        int pos = atomicAdd(&s_cnt, 1);
+        keys[pos] = ((u64)(~key) << 32) | (unsigned)idx;
+      }
+      eq_before += tot;
+    }
+    __syncthreads();
+    nsel = s_cnt;   // == k
+    bitonic_sort_lds(keys, 4096);
+  } else {
+    // n <= nms_pre: the reference does not sort (rpn_head.py:167) -> index order
+    for (int i = tid; i < 4096; i += 1024) keys[i] = i < n ? (((u64)(~f2key(score_of(i)))) << 32 | (unsigned)i) : ~0ull;
+    __syncthreads();
+    nsel = n;
+  }
+  // decode + min-size filter, ordered compaction into the level's slot
+  const float ratios[3] = {0.5f, 1.0f, 2.0f};
+  float* cb = p.cand_boxes + ((long long)(b * 4 + L) * p.slot) * 4;
+  float* cs = p.cand_scores + (long long)(b * 4 + L) * p.slot;
+  int written = 0;
+  for (int base = 0; base < nsel; base += 1024) {
+    int pos = base + tid;
+    bool valid = false;
+    float x1 = 0, y1 = 0, x2 = 0, y2 = 0, score = 0;
+    if (pos < nsel) {
+      u64 key = keys[pos];
+      int idx = (int)(key & 0xFFFFFFFFu);
+      score = __uint_as_float(~(unsigned)(key >> 32));
+      int pix = idx / 3, a = idx - pix * 3;
+      int py = pix / w, px = pix - py * w;
+      // AnchorGenerator: scales [4], ratios (.5,1,2), centre offset 0 (anchor_generator.py:151-194)
+      float hr = sqrtf(ratios[a]);
+      float wr = 1.0f / hr;
+      float wsz = (float)stride * wr * 4.0f, hsz = (float)stride * hr * 4.0f;
+      float sx = (float)px * (float)stride, sy = (float)py * (float)stride;
+      float ax1 = -0.5f * wsz + sx, ay1 = -0.5f * hsz + sy, ax2 = 0.5f * wsz + sx, ay2 = 0.5f * hsz + sy;
+      const float* d = out + (long long)pix * 32 + 3 + 4 * a;
+      float dx = d[0], dy = d[1], dw = d[2], dh = d[3];
+      const float MR = 4.135166556742356f;   // |log(16/1000)|
+      dw = fminf(fmaxf(dw, -MR), MR);
+      dh = fminf(fmaxf(dh, -MR), MR);
+      float pxc = (ax1 + ax2) * 0.5f, pyc = (ay1 + ay2) * 0.5f;
+      float pw = ax2 - ax1, ph = ay2 - ay1;
+      float gx = pxc + pw * dx, gy = pyc + ph * dy;
+      float gw = pw * expf(dw), gh = ph * expf(dh);
+      x1 = gx - gw * 0.5f; y1 = gy - gh * 0.5f; x2 = gx + gw * 0.5f; y2 = gy + gh * 0.5f;
+      x1 = fminf(fmaxf(x1, 0.f), (float)p.img_w); x2 = fminf(fmaxf(x2, 0.f), (float)p.img_w);
+      y1 = fminf(fmaxf(y1, 0.f), (float)p.img_h); y2 = fminf(fmaxf(y2, 0.f), (float)p.img_h);
+      valid = (x2 - x1 > p.min_size) && (y2 - y1 > p.min_size);
+    }
+    int tot;
+    int off = block_exscan_1024(valid ? 1 : 0, sc16, &tot) + written;
+    if (valid) {
+      cb[off * 4 + 0] = x1; cb[off * 4 + 1] = y1; cb[off * 4 + 2] = x2; cb[off * 4 + 3] = y2;
+      cs[off] = score;
+    }
+    written += tot;
+  }
+  if (tid == 0) p.cand_count[b * 4 + L] = written;
+}
+
+int launch_rpn_select(const RpnLevels& lv, const RpnSelParams& p, int B, hipStream_t s) {
+  if (p.nms_pre > 4096 || p.slot < p.nms_pre) return NUHTC_E_INVALID;
+  hipLaunchKernelGGL(rpn_level_kernel, dim3(B, 4), dim3(1024), 0, s, lv, p);
+  return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
+}
+
+// ------------------------------------------------------------------------------------------- NMS
+// Gather the per-group slots of image b into one ordered candidate list (group-major), apply the batched_nms
+// coordinate offset (id * (max_coord + 1), float32) and sort by (score desc, position asc).
+__global__ __launch_bounds__(1024) void nms_prepare_kernel(NmsParams p) {
+  extern __shared__ u64 keys[];      // npad_max entries
+  __shared__ float red[16];
+  __shared__ float s_max;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  // group offsets
+  int goff[NMS_MAX_GROUPS + 1];
+  goff[0] = 0;
+  for (int g = 0; g < p.n_groups; ++g) goff[g + 1] = goff[g] + p.group_count[b * p.n_groups + g];
+  const int n = goff[p.n_groups];
+  const int npad = next_pow2(n < 2 ? 2 : n);
+  // max coordinate over all candidate boxes (boxes.max() of mmcv batched_nms)
+  float mx = -3.0e38f;
+  for (int i = tid; i < n; i += 1024) {
+    int g = 0;
+    while (i >= goff[g + 1]) ++g;
+    const float* bx = p.boxes + ((long long)(b * p.n_groups + g) * p.slot + (i - goff[g])) * 4;
+    mx = fmaxf(mx, fmaxf(fmaxf(bx[0], bx[1]), fmaxf(bx[2], bx[3])));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  if (tid == 0) { float m = red[0]; for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]); s_max = m; }
+  __syncthreads();
+  const float maxp1 = s_max + 1.0f;
+  for (int i = tid; i < npad; i += 1024) {
+    u64 key = ~0ull;
+    if (i < n) {
+      int g = 0;
+      while (i >= goff[g + 1]) ++g;
+      float sc = p.scores[(long long)(b * p.n_groups + g) * p.slot + (i - goff[g])];
+      key = ((u64)(~f2key(sc)) << 32) | (unsigned)i;
+    }
+    keys[i] = key;
+  }
+  __syncthreads();
+  bitonic_sort_lds(keys, npad);
+  for (int r = tid; r < n; r += 1024) {
+    int i = (int)(keys[r] & 0xFFFFFFFFu);
+    int g = 0;
+    while (i >= goff[g + 1]) ++g;
+    long long src = (long long)(b * p.n_groups + g) * p.slot + (i - goff[g]);
+    const float* bx = p.boxes + src * 4;
+    int id = p.ids ? p.ids[src] : g;
+    float off = (float)id * maxp1;
+    float* sb = p.sorted_boxes + ((long long)b * p.cap + r) * 4;
+    sb[0] = bx[0] + off; sb[1] = bx[1] + off; sb[2] = bx[2] + off; sb[3] = bx[3] + off;
+    p.sorted_src[(long long)b * p.cap + r] = (int)src;
+  }
+  if (tid == 0) p.n_total[b] = n;
+}
+
+// mmcv nms_cuda: thread t of block (cb, rb) compares row rb*64+t with the 64 boxes of column block cb
+__global__ __launch_bounds__(64) void nms_mask_kernel(NmsParams p) {
+  const int b = blockIdx.z, rb = blockIdx.y, cb = blockIdx.x;
+  const int n = p.n_total[b];
+  if (cb < rb || rb * 64 >= n || cb * 64 >= n) return;
+  __shared__ float4 cbx[64];
+  const float4* sb = reinterpret_cast<const float4*>(p.sorted_boxes) + (long long)b * p.cap;
+  const int t = threadIdx.x;
+  const int ncol = min(n - cb * 64, 64);
+  if (t < ncol) cbx[t] = sb[cb * 64 + t];
+  __syncthreads();
+  const int row = rb * 64 + t;
+  if (row >= n) return;
+  const float4 a = sb[row];
+  const float sa = (a.z - a.x) * (a.w - a.y);
+  u64 bits = 0;
+  const int start = (rb == cb) ? t + 1 : 0;
+  for (int j = start; j < ncol; ++j) {
+    const float4 c = cbx[j];
+    float left = fmaxf(a.x, c.x), right = fminf(a.z, c.z);
+    float top = fmaxf(a.y, c.y), bottom = fminf(a.w, c.w);
+    float wdt = fmaxf(right - left, 0.f), hgt = fmaxf(bottom - top, 0.f);
+    float inter = wdt * hgt;
+    float sb2 = (c.z - c.x) * (c.w - c.y);
+    float ovr = inter / (sa + sb2 - inter);
+    if (ovr > p.iou_thr) bits |= 1ull << j;
+  }
+  p.mask[((long long)b * p.cap + row) * (p.cap / 64) + cb] = bits;
+}
+
+// greedy reduce, 64 sorted rows at a time; stops after max_keep kept rows
+__global__ __launch_bounds__(256) void nms_reduce_kernel(NmsParams p) {
+  __shared__ u64 removed[NMS_MAX_CAP / 64];
+  __shared__ u64 s_keepbits;
+  __shared__ int s_kept;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int n = p.n_total[b];
+  const int nw = p.cap / 64;
+  const int nchunks = (n + 63) / 64;
+  for (int i = tid; i < nw; i += 256) removed[i] = 0;
+  if (tid == 0) s_kept = 0;
+  __syncthreads();
+  const u64* mask = p.mask + (long long)b * p.cap * nw;
+  for (int c = 0; c < nchunks; ++c) {
+    const int kept_before = s_kept;
+    if (kept_before >= p.max_keep) break;
+    if (tid < 64) {
+      const int row = c * 64 + lane;
+      u64 d = row < n ? mask[(long long)row * nw + c] : 0ull;   // upper-triangular diagonal word
+      u64 cur = removed[c];
+      u64 keep = 0;
+      int room = p.max_keep - kept_before;
+      const int rows_here = min(64, n - c * 64);
+      for (int i = 0; i < rows_here; ++i) {
+        u64 di = __shfl(d, i);
+        if (!((cur >> i) & 1ull) && room > 0) { keep |= 1ull << i; cur |= di; --room; }
+      }
+      if (lane == 0) s_keepbits = keep;
+      // emit kept rows in order
+      if ((keep >> lane) & 1ull) {
+        int k = kept_before + __popcll(keep & ((1ull << lane) - 1ull));
+        int src = p.sorted_src[(long long)b * p.cap + row];
+        const float* bx = p.boxes + (long long)src * 4;
+        float* o = p.out_dets + ((long long)b * p.max_keep + k) * 5;
+        o[0] = bx[0]; o[1] = bx[1]; o[2] = bx[2]; o[3] = bx[3]; o[4] = p.scores[src];
+        p.out_src[(long long)b * p.max_keep + k] = src;
+      }
+      if (lane == 0) s_kept = kept_before + __popcll(keep);
+    }
+    __syncthreads();
+    const u64 keep = s_keepbits;
+    if (keep) {
+      for (int wv = c + 1 + tid; wv < nw; wv += 256) {
+        u64 acc = 0;
+        u64 kb = keep;
+        while (kb) {
+          int i = __ffsll((long long)kb) - 1;
+          kb &= kb - 1;
+          acc |= mask[(long long)(c * 64 + i) * nw + wv];
+        }
+        removed[wv] |= acc;
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) p.out_counts[b] = s_kept < p.max_keep ? s_kept : p.max_keep;
+}
+
+// rows of `mask` that nms_mask_kernel never writes must read as zero: words cb < rb are unused by the reduce (it only
+// reads words >= its chunk), words beyond n likewise; so no clearing pass is needed.
+int launch_nms(const NmsParams& p, int B, hipStream_t s) {
+  if (p.cap % 64 || p.cap > NMS_MAX_CAP || p.n_groups > NMS_MAX_GROUPS) return NUHTC_E_INVALID;
+  size_t lds = (size_t)p.cap_pow2 * sizeof(u64);
+  hipLaunchKernelGGL(nms_prepare_kernel, dim3(B), dim3(1024), lds, s, p);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(p.cap / 64, p.cap / 64, B), dim3(64), 0, s, p);
+  hipLaunchKernelGGL(nms_reduce_kernel, dim3(B), dim3(256), 0, s, p);
+  return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
+}
+
+int nms_set_attributes() {
+  // the sort image can exceed the default 64 KiB dynamic-LDS limit (gfx950 has 160 KiB per workgroup)
+  hipError_t e = hipFuncSetAttribute((const void*)nms_prepare_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NMS_MAX_CAP * 8);
+  return e == hipSuccess ? 0 : NUHTC_E_HIP;
+}
+
+// ------------------------------------------------------------------------------------------- connected-component proposals
+struct Gauss5 { float k[25]; };
+
+// semantic logits (h x w) -> bilinear x4 (align_corners=True) -> 5x5 Gaussian (reflect pad) -> > 0
+__global__ __launch_bounds__(256) void cc_mask_kernel(const float* __restrict__ pred, unsigned char* __restrict__ m, int h, int w, int H,
+                                                      int W, Gauss5 gk) {
+  __shared__ float up[20][20 + 1];
+  const int b = blockIdx.z;
+  const int X0 = blockIdx.x * 16, Y0 = blockIdx.y * 16;
+  const float* pb = pred + (long long)b * h * w;
+  const float sy = h > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
+  const float sx = w > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+  for (int e = threadIdx.x; e < 400; e += 256) {
+    int ly = e / 20, lx = e - ly * 20;
+    int Y = Y0 + ly - 2, X = X0 + lx - 2;
+    // reflect (no edge repeat): -1 -> 1, H -> H-2
+    if (Y < 0) Y = -Y; if (Y >= H) Y = 2 * H - 2 - Y;
+    if (X < 0) X = -X; if (X >= W) X = 2 * W - 2 - X;
+    float fy = sy * Y, fx = sx * X;
+    int y0 = (int)fy, x0 = (int)fx;
+    int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    float ly1 = fy - y0, lx1 = fx - x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+    up[ly][lx] = ly0 * (lx0 * pb[y0 * w + x0] + lx1 * pb[y0 * w + x1]) + ly1 * (lx0 * pb[y1 * w + x0] + lx1 * pb[y1 * w + x1]);
+  }
+  __syncthreads();
+  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+  const int Y = Y0 + ty, X = X0 + tx;
+  if (Y >= H || X >= W) return;
+  float acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) acc += gk.k[i * 5 + j] * up[ty + i][tx + j];
+  m[((long long)b * H + Y) * W + X] = acc > 0.f ? 1 : 0;
+}
+
+// 9-tap binary min (erode) / max (dilate) along x or y; outside the image counts as 0
+template <int DILATE, int VERT>
+__global__ void morph9_kernel(const unsigned char* __restrict__ in, unsigned char* __restrict__ out, int H, int W, long long total) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  int x = idx % W, y = (idx / W) % H;
+  const unsigned char* base = in + (idx - (long long)y * W - x);
+  int r = DILATE ? 0 : 1;
+#pragma unroll
+  for (int d = -4; d <= 4; ++d) {
+    int yy = VERT ? y + d : y, xx = VERT ? x : x + d;
+    int v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? base[(long long)yy * W + xx] : 0;
+    r = DILATE ? (r | v) : (r & v);
+  }
+  out[idx] = (unsigned char)r;
+}
+
+__device__ __forceinline__ int uf_find(int* lab, int a) {
+  int p = lab[a];
+  while (p != a) { a = p; p = lab[a]; }
+  return a;
+}
+__device__ __forceinline__ void uf_union(int* lab, int a, int b) {
+  while (true) {
+    a = uf_find(lab, a);
+    b = uf_find(lab, b);
+    if (a == b) return;
+    if (a < b) { int t = a; a = b; b = t; }   // a > b: hang a under b (roots are component minima)
+    int old = atomicMin(&lab[a], b);
+    if (old == a) return;
+    a = old;
+  }
+}
+
+// labels of the pixels whose mask value == target (4-connectivity); others -1.  lab is per image (H*W ints)
+__global__ void ccl_init_kernel(const unsigned char* __restrict__ m, int* __restrict__ lab, int target, int HW, long long total) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  lab[idx] = (m[idx] == target) ? (int)(idx % HW) : -1;
+}
+__global__ void ccl_merge_kernel(const unsigned char* __restrict__ m, int* __restrict__ lab, int target, int H, int W, long long total) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  if (m[idx] != target) return;
+  const int HW = H * W;
+  int p = idx % HW;
+  int* l = lab + (idx - p);
+  const unsigned char* mm = m + (idx - p);
+  int x = p % W, y = p / W;
+  if (x > 0 && mm[p - 1] == target) uf_union(l, p, p - 1);
+  if (y > 0 && mm[p - W] == target) uf_union(l, p, p - W);
+}
+__global__ void ccl_flatten_kernel(int* __restrict__ lab, int HW, long long total) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  if (lab[idx] < 0) return;
+  int p = idx % HW;
+  int* l = lab + (idx - p);
+  l[p] = uf_find(l, p);
+}
+// background components touching the image border are "outside"; flag their roots
+__global__ void cc_border_kernel(const int* __restrict__ lab, unsigned char* __restrict__ touch, int H, int W, int B) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  int per = 2 * (H + W);
+  if (idx >= B * per) return;
+  int b = idx / per, r = idx - b * per;
+  int x, y;
+  if (r < W) { y = 0; x = r; }
+  else if (r < 2 * W) { y = H - 1; x = r - W; }
+  else if (r < 2 * W + H) { x = 0; y = r - 2 * W; }
+  else { x = W - 1; y = r - 2 * W - H; }
+  long long base = (long long)b * H * W;
+  int l = lab[base + y * W + x];
+  if (l >= 0) touch[base + l] = 1;
+}
+// binary_fill_holes: background pixels whose component does not touch the border become foreground
+__global__ void cc_fill_kernel(const unsigned char* __restrict__ m, const int* __restrict__ lab, const unsigned char* __restrict__ touch,
+                               unsigned char* __restrict__ out, int HW, long long total) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  int v = m[idx];
+  if (!v) {
+    long long base = idx - (idx % HW);
+    v = touch[base + lab[idx]] ? 0 : 1;
+  }
+  out[idx] = (unsigned char)v;
+}
+// per-root statistics, addressed by the root's pixel index: area, min x, min y, max x, max y
+__global__ void cc_stats_kernel(const int* __restrict__ lab, int* __restrict__ stats, int H, int W, long long total) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  int l = lab[idx];
+  if (l < 0) return;
+  const int HW = H * W;
+  int p = idx % HW;
+  long long base = idx - p;
+  int* s = stats + (base + l) * 5;
+  int x = p % W, y = p / W;
+  atomicAdd(&s[0], 1);
+  atomicMin(&s[1], x); atomicMin(&s[2], y); atomicMax(&s[3], x); atomicMax(&s[4], y);
+}
+__global__ void cc_stats_init_kernel(int* __restrict__ stats, long long total) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  int* s = stats + idx * 5;
+  s[0] = 0; s[1] = 1 << 30; s[2] = 1 << 30; s[3] = -1; s[4] = -1;
+}
+// roots in raster order (== scipy.ndimage.label numbering), area filter, boxes [xmin, ymin, xmax+1, ymax+1]
+__global__ __launch_bounds__(1024) void cc_emit_kernel(const int* __restrict__ lab, const int* __restrict__ stats, float* __restrict__ boxes,
+                                                       int* __restrict__ counts, int* __restrict__ overflow, int H, int W, int min_area,
+                                                       int max_area, int cap) {
+  __shared__ int sc16[17];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int HW = H * W;
+  const int* l = lab + (long long)b * HW;
+  const int* st = stats + (long long)b * HW * 5;
+  const int per = (HW + 1023) / 1024;
+  const int p0 = tid * per, p1 = min(p0 + per, HW);
+  int cnt = 0;
+  for (int p = p0; p < p1; ++p)
+    if (l[p] == p) { int a = st[p * 5]; if (a > min_area && a < max_area) ++cnt; }
+  int tot;
+  int off = block_exscan_1024(cnt, sc16, &tot);
+  for (int p = p0; p < p1; ++p)
+    if (l[p] == p) {
+      const int* s = st + p * 5;
+      if (s[0] > min_area && s[0] < max_area) {
+        if (off < cap) {
+          float* o = boxes + ((long long)b * cap + off) * 4;
+          o[0] = (float)s[1]; o[1] = (float)s[2]; o[2] = (float)(s[3] + 1); o[3] = (float)(s[4] + 1);
+        }
+        ++off;
+      }
+    }
+  if (tid == 0) {
+    counts[b] = tot < cap ? tot : cap;
+    if (tot > cap) atomicAdd(&overflow[0], 1);
+  }
+}
+
+int launch_cc_proposals(const CcParams& p, int B, hipStream_t s) {
+  const int H = p.img_h, W = p.img_w, HW = H * W;
+  const long long total = (long long)B * HW;
+  const unsigned nb = (unsigned)((total + 255) / 256);
+  Gauss5 gk;
+  {   // torchvision gaussian_blur(kernel_size=5): sigma = 0.15*5+0.35 = 1.1, float32 like torch
+    float pdf[5], sum = 0.f;
+    for (int i = 0; i < 5; ++i) { float x = (float)(i - 2) / 1.1f; pdf[i] = expf(-0.5f * (x * x)); sum += pdf[i]; }
+    float k1[5];
+    for (int i = 0; i < 5; ++i) k1[i] = pdf[i] / sum;
+    for (int i = 0; i < 5; ++i)
+      for (int j = 0; j < 5; ++j) gk.k[i * 5 + j] = k1[i] * k1[j];
+  }
+  unsigned char *A = p.mask_a, *Bm = p.mask_b;
+  hipLaunchKernelGGL(cc_mask_kernel, dim3(cdiv(W, 16), cdiv(H, 16), B), dim3(256), 0, s, p.sem_pred, A, p.h, p.w, H, W, gk);
+  // open(5x5, 2) == erode 9x9 then dilate 9x9 (zero outside), separable
+  hipLaunchKernelGGL((morph9_kernel<0, 0>), dim3(nb), dim3(256), 0, s, A, Bm, H, W, total);
+  hipLaunchKernelGGL((morph9_kernel<0, 1>), dim3(nb), dim3(256), 0, s, Bm, A, H, W, total);
+  hipLaunchKernelGGL((morph9_kernel<1, 0>), dim3(nb), dim3(256), 0, s, A, Bm, H, W, total);
+  hipLaunchKernelGGL((morph9_kernel<1, 1>), dim3(nb), dim3(256), 0, s, Bm, A, H, W, total);
+  // hole fill: label background, keep only border-connected background
+  hipLaunchKernelGGL(ccl_init_kernel, dim3(nb), dim3(256), 0, s, A, p.labels, 0, HW, total);
+  hipLaunchKernelGGL(ccl_merge_kernel, dim3(nb), dim3(256), 0, s, A, p.labels, 0, H, W, total);
+  hipLaunchKernelGGL(ccl_flatten_kernel, dim3(nb), dim3(256), 0, s, p.labels, HW, total);
+  if (hipMemsetAsync(p.touch, 0, (size_t)total, s) != hipSuccess) return NUHTC_E_HIP;
+  hipLaunchKernelGGL(cc_border_kernel, dim3(cdiv(B * 2 * (H + W), 256)), dim3(256), 0, s, p.labels, p.touch, H, W, B);
+  hipLaunchKernelGGL(cc_fill_kernel, dim3(nb), dim3(256), 0, s, A, p.labels, p.touch, Bm, HW, total);
+  // label the filled foreground, collect per-component stats, emit boxes in raster order of first pixel
+  hipLaunchKernelGGL(ccl_init_kernel, dim3(nb), dim3(256), 0, s, Bm, p.labels, 1, HW, total);
+  hipLaunchKernelGGL(ccl_merge_kernel, dim3(nb), dim3(256), 0, s, Bm, p.labels, 1, H, W, total);
+  hipLaunchKernelGGL(ccl_flatten_kernel, dim3(nb), dim3(256), 0, s, p.labels, HW, total);
+  hipLaunchKernelGGL(cc_stats_init_kernel, dim3(nb), dim3(256), 0, s, p.stats, total);
+  hipLaunchKernelGGL(cc_stats_kernel, dim3(nb), dim3(256), 0, s, p.labels, p.stats, H, W, total);
+  hipLaunchKernelGGL(cc_emit_kernel, dim3(B), dim3(1024), 0, s, p.labels, p.stats, p.boxes, p.counts, p.overflow, H, W, p.min_area,
+                     HW / 4, p.cap);
+  return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
+}

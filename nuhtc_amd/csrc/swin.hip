@@ -1,0 +1,283 @@
+// Swin-T front-end and per-block non-GEMM kernels (gfx950, wave64).
+//   preproc       : uint8 x2 bilinear resize (cv2 INTER_LINEAR fixed point) + channel swap + normalise
+//                   (mmdet/datasets/pipelines/transforms.py:207-236,686-700)
+//   patch_embed   : conv4x4 s4 (3->96) + LayerNorm(96)          (mmdet/models/utils/transformer.py:236-257)
+//   layernorm     : LN with optional row gather (LN1 + pad + cyclic roll + window partition in one pass;
+//                   padding rows are zeros *after* the norm)    (mmdet/models/backbones/swin.py:182-226,360)
+//   merge_ln      : PatchMerging 2x2 gather + LN(4C)            (transformer.py:363-385)
+//   window_attn   : softmax(q·s·kᵀ + relpos_bias + shift_mask)·v per (window, head), N=49, d=32
+//                   (swin.py:79-117); one wave per (window, head), K/V staged in LDS, one query row per lane,
+//                   scores/softmax entirely in registers.
+#include "common.h"
+
+// ----------------------------------------------------------------------------- preproc
+struct NormConst { float mean[3]; float istd[3]; };
+
+__global__ void preproc_kernel(const uint8_t* __restrict__ tiles, float* __restrict__ img, int B, int th, int tw, int swap,
+                               NormConst nc) {
+  const int Hn = 2 * th, Wn = 2 * tw;
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long total = (long long)B * Hn * Wn;
+  if (idx >= total) return;
+  int x = idx % Wn;
+  int y = (idx / Wn) % Hn;
+  int b = idx / ((long long)Wn * Hn);
+  // even d: taps (d/2-1, d/2) weights (1,3)/4 ; odd d: (d/2, d/2+1) weights (3,1)/4 ; edge clamped
+  int y0 = (y & 1) ? (y >> 1) : (y >> 1) - 1, wy0 = (y & 1) ? 3 : 1;
+  int x0 = (x & 1) ? (x >> 1) : (x >> 1) - 1, wx0 = (x & 1) ? 3 : 1;
+  int y1 = min(y0 + 1, th - 1), x1 = min(x0 + 1, tw - 1);
+  y0 = max(y0, 0);
+  x0 = max(x0, 0);
+  const uint8_t* t = tiles + (long long)b * th * tw * 3;
+  const uint8_t* p00 = t + ((long long)y0 * tw + x0) * 3;
+  const uint8_t* p01 = t + ((long long)y0 * tw + x1) * 3;
+  const uint8_t* p10 = t + ((long long)y1 * tw + x0) * 3;
+  const uint8_t* p11 = t + ((long long)y1 * tw + x1) * 3;
+  float* o = img + idx * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    int sc = swap ? 2 - c : c;
+    int h0 = p00[sc] * wx0 + p01[sc] * (4 - wx0);
+    int h1 = p10[sc] * wx0 + p11[sc] * (4 - wx0);
+    int v = h0 * wy0 + h1 * (4 - wy0);   // 16 x value
+    int u = (((v >> 2) + 2) >> 2);
+    o[c] = ((float)u - nc.mean[c]) * nc.istd[c];
+  }
+}
+
+int launch_preproc(const uint8_t* tiles, float* img, int B, int th, int tw, int swap, const float* mean_istd, hipStream_t s) {
+  NormConst nc;
+  for (int i = 0; i < 3; ++i) { nc.mean[i] = mean_istd[i]; nc.istd[i] = mean_istd[3 + i]; }
+  long long total = (long long)B * 4 * th * tw;
+  hipLaunchKernelGGL(preproc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, tiles, img, B, th, tw, swap, nc);
+  return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
+}
+
+// ----------------------------------------------------------------------------- patch embed
+// w: [48][96] k-major with k = (kh*4+kw)*3 + c (NHWC pixel order); 32 tokens per block, 8 lanes x 12 channels per token
+__global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, const float* __restrict__ g,
+                                                          const float* __restrict__ beta, float* __restrict__ tok, int nTok,
+                                                          int Hn, int Wn) {
+  __shared__ float wl[48 * 96];
+  __shared__ float pl[32 * 49];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < 48 * 96; e += 256) wl[e] = w[e];
+  const int Wt = Wn >> 2, Ht = Hn >> 2;
+  const int t0 = blockIdx.x * 32;
+  for (int e = tid; e < 32 * 48; e += 256) {
+    int tl = e / 48, k = e - tl * 48;
+    int t = t0 + tl;
+    float v = 0.f;
+    if (t < nTok) {
+      int tx = t % Wt, ty = (t / Wt) % Ht, b = t / (Wt * Ht);
+      int kh = k / 12, r = k - kh * 12;   // r = kw*3 + c
+      v = img[(((long long)b * Hn + 4 * ty + kh) * Wn + 4 * tx) * 3 + r];
+    }
+    pl[tl * 49 + k] = v;
+  }
+  __syncthreads();
+  const int tl = tid >> 3, cg = tid & 7;
+  float acc[12];
+#pragma unroll
+  for (int j = 0; j < 12; ++j) acc[j] = 0.f;
+  for (int k = 0; k < 48; ++k) {
+    float x = pl[tl * 49 + k];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) acc[j] = fmaf(x, wl[k * 96 + cg + 8 * j], acc[j]);
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < 12; ++j) { acc[j] += bias[cg + 8 * j]; sum += acc[j]; }
+  sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
+  const float mean = sum * (1.0f / 96.0f);
+  float var = 0.f;
+#pragma unroll
+  for (int j = 0; j < 12; ++j) { float d = acc[j] - mean; var = fmaf(d, d, var); }
+  var += __shfl_xor(var, 1); var += __shfl_xor(var, 2); var += __shfl_xor(var, 4);
+  const float rstd = 1.0f / sqrtf(var * (1.0f / 96.0f) + 1e-5f);
+  const int t = t0 + tl;
+  if (t < nTok) {
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      int c = cg + 8 * j;
+      tok[(long long)t * 96 + c] = (acc[j] - mean) * rstd * g[c] + beta[c];
+    }
+  }
+}
+
+int launch_patch_embed(const float* img, const float* w, const float* b, const float* g, const float* beta, float* tok, int B,
+                       int Hn, int Wn, hipStream_t s) {
+  int nTok = B * (Hn / 4) * (Wn / 4);
+  hipLaunchKernelGGL(patch_embed_kernel, dim3(cdiv(nTok, 32)), dim3(256), 0, s, img, w, b, g, beta, tok, nTok, Hn, Wn);
+  return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
+}
+
+// ----------------------------------------------------------------------------- LayerNorm (+ row gather)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+template <int NV>   // NV = ceil(C/64) elements per lane
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const int* __restrict__ src_map,
+                                                        const float* __restrict__ g, const float* __restrict__ b,
+                                                        float* __restrict__ y, int rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  long long src = src_map ? src_map[row] : row;
+  float* yr = y + row * C;
+  if (src < 0) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) { int c = lane + 64 * j; if (c < C) yr[c] = 0.f; }
+    return;
+  }
+  const float* xr = x + src * C;
+  float v[NV];
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) { int c = lane + 64 * j; v[j] = c < C ? xr[c] : 0.f; sum += v[j]; }
+  const float mean = wave_sum(sum) / (float)C;
+  float var = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) { int c = lane + 64 * j; float d = c < C ? v[j] - mean : 0.f; var = fmaf(d, d, var); }
+  const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)C + 1e-5f);
+#pragma unroll
+  for (int j = 0; j < NV; ++j) { int c = lane + 64 * j; if (c < C) yr[c] = (v[j] - mean) * rstd * g[c] + b[c]; }
+}
+
+int launch_layernorm(const float* x, const int* src_map, const float* g, const float* b, float* y, int rows, int C, hipStream_t s) {
+  if (rows <= 0) return 0;
+  dim3 grid(cdiv(rows, 4)), blk(256);
+  int nv = cdiv(C, 64);
+  if (nv <= 2) hipLaunchKernelGGL(layernorm_kernel<2>, grid, blk, 0, s, x, src_map, g, b, y, rows, C);
+  else if (nv <= 3) hipLaunchKernelGGL(layernorm_kernel<3>, grid, blk, 0, s, x, src_map, g, b, y, rows, C);
+  else if (nv <= 6) hipLaunchKernelGGL(layernorm_kernel<6>, grid, blk, 0, s, x, src_map, g, b, y, rows, C);
+  else if (nv <= 12) hipLaunchKernelGGL(layernorm_kernel<12>, grid, blk, 0, s, x, src_map, g, b, y, rows, C);
+  else return NUHTC_E_INVALID;
+  return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
+}
+
+// ----------------------------------------------------------------------------- PatchMerging gather + LN(4C)
+template <int NV>   // NV = 4C/64
+__global__ __launch_bounds__(256) void merge_ln_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                       const float* __restrict__ b, float* __restrict__ y, int rows, int H, int W,
+                                                       int C) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int H2 = H >> 1, W2 = W >> 1;
+  int x2 = row % W2, y2 = (row / W2) % H2;
+  long long bb = row / ((long long)W2 * H2);
+  const int C4 = 4 * C;
+  float v[NV];
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    int k = lane + 64 * j;            // k = q*C + c, q = kh*2 + kw
+    int q = k / C, c = k - q * C;
+    v[j] = x[((bb * H + 2 * y2 + (q >> 1)) * W + 2 * x2 + (q & 1)) * C + c];
+    sum += v[j];
+  }
+  const float mean = wave_sum(sum) / (float)C4;
+  float var = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) { float d = v[j] - mean; var = fmaf(d, d, var); }
+  const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)C4 + 1e-5f);
+  float* yr = y + row * C4;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) { int k = lane + 64 * j; yr[k] = (v[j] - mean) * rstd * g[k] + b[k]; }
+}
+
+int launch_merge_ln(const float* x, const float* g, const float* b, float* y, int B, int H, int W, int C, hipStream_t s) {
+  int rows = B * (H / 2) * (W / 2);
+  dim3 grid(cdiv(rows, 4)), blk(256);
+  int nv = 4 * C / 64;
+  if (4 * C % 64) return NUHTC_E_INVALID;
+  if (nv == 6) hipLaunchKernelGGL(merge_ln_kernel<6>, grid, blk, 0, s, x, g, b, y, rows, H, W, C);
+  else if (nv == 12) hipLaunchKernelGGL(merge_ln_kernel<12>, grid, blk, 0, s, x, g, b, y, rows, H, W, C);
+  else if (nv == 24) hipLaunchKernelGGL(merge_ln_kernel<24>, grid, blk, 0, s, x, g, b, y, rows, H, W, C);
+  else return NUHTC_E_INVALID;
+  return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
+}
+
+// ----------------------------------------------------------------------------- window attention
+__global__ __launch_bounds__(256) void window_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ bias,
+                                                          const float* __restrict__ mask, float* __restrict__ out, int nPairs,
+                                                          int nWperImg, int C, int nH) {
+  __shared__ float4 kv[4][2][WS2 * 8];   // per wave: K then V, [49][32] as float4
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pair = blockIdx.x * 4 + wave;
+  if (pair >= nPairs) return;   // whole wave exits; no block-wide barrier below
+  const int win = pair / nH, head = pair - win * nH;
+  const float* base = qkv + (long long)win * WS2 * 3 * C + head * HEAD_DIM;
+  float4* Kl = kv[wave][0];
+  float4* Vl = kv[wave][1];
+  // stage K and V: 8 lanes per row, 8 rows per pass
+  for (int r = lane >> 3; r < WS2; r += 8) {
+    int c4 = lane & 7;
+    Kl[r * 8 + c4] = *reinterpret_cast<const float4*>(base + (long long)r * 3 * C + C + c4 * 4);
+    Vl[r * 8 + c4] = *reinterpret_cast<const float4*>(base + (long long)r * 3 * C + 2 * C + c4 * 4);
+  }
+  const int i = lane < WS2 ? lane : WS2 - 1;   // idle lanes shadow the last row (results discarded)
+  float q[HEAD_DIM];
+  {
+    const float scale = 0.17677669529663687f;   // 32^-0.5
+    const float4* qp = reinterpret_cast<const float4*>(base + (long long)i * 3 * C);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      float4 t = qp[d];
+      q[4 * d] = t.x * scale; q[4 * d + 1] = t.y * scale; q[4 * d + 2] = t.z * scale; q[4 * d + 3] = t.w * scale;
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0);   // LDS writes of this wave are complete before its reads (same wave: in order)
+  __builtin_amdgcn_wave_barrier();
+  const float* brow = bias + ((long long)head * WS2 + i) * WS2;
+  const float* mrow = mask ? mask + ((long long)(win % nWperImg) * WS2 + i) * WS2 : nullptr;
+  float sc[WS2];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int j = 0; j < WS2; ++j) {
+    float a = 0.f;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      float4 k4 = Kl[j * 8 + d];
+      a = fmaf(q[4 * d], k4.x, a); a = fmaf(q[4 * d + 1], k4.y, a); a = fmaf(q[4 * d + 2], k4.z, a); a = fmaf(q[4 * d + 3], k4.w, a);
+    }
+    a += brow[j];
+    if (mrow) a += mrow[j];
+    sc[j] = a;
+    mx = fmaxf(mx, a);
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < WS2; ++j) { sc[j] = expf(sc[j] - mx); sum += sc[j]; }
+  float o[HEAD_DIM];
+#pragma unroll
+  for (int d = 0; d < HEAD_DIM; ++d) o[d] = 0.f;
+#pragma unroll
+  for (int j = 0; j < WS2; ++j) {
+    const float pj = sc[j] / sum;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      float4 v4 = Vl[j * 8 + d];
+      o[4 * d] = fmaf(pj, v4.x, o[4 * d]); o[4 * d + 1] = fmaf(pj, v4.y, o[4 * d + 1]);
+      o[4 * d + 2] = fmaf(pj, v4.z, o[4 * d + 2]); o[4 * d + 3] = fmaf(pj, v4.w, o[4 * d + 3]);
+    }
+  }
+  if (lane < WS2) {
+    float4* op = reinterpret_cast<float4*>(out + ((long long)win * WS2 + lane) * C + head * HEAD_DIM);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) op[d] = make_float4(o[4 * d], o[4 * d + 1], o[4 * d + 2], o[4 * d + 3]);
+  }
+}
+
+int launch_window_attn(const float* qkv, const float* bias, const float* mask, float* out, int nWinTotal, int nWperImg, int C,
+                       int nH, hipStream_t s) {
+  int nPairs = nWinTotal * nH;
+  if (nPairs <= 0) return 0;
+  hipLaunchKernelGGL(window_attn_kernel, dim3(cdiv(nPairs, 4)), dim3(256), 0, s, qkv, bias, mask, out, nPairs, nWperImg, C, nH);
+  return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
+}

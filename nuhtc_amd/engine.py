@@ -1,0 +1,194 @@
+"""Host-side driver of one libnuhtc_hip engine (one per GPU / process).
+
+Plays the role of the reference's `HybridTaskCascade_Cus` module object (nuhtc/models/htc_cus.py): holds the
+weights on the device and turns a batch of uint8 tiles into `(bbox_results, segm_results)` per tile, in the
+exact format `inference_detector` returns (mmdet/apis/inference.py:90-153).  torch is used for
+device buffers and the current stream only; every computation happens inside the HIP library.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import hip
+
+
+class HipError(RuntimeError):
+    pass
+
+
+class _DevView:
+    """Zero-copy view of a raw device pointer for torch.as_tensor (CUDA array interface v2)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = dict(shape=tuple(int(s) for s in shape), typestr=typestr, data=(int(ptr), False),
+                                             version=2, strides=None)
+
+
+_TYPESTR = {0: '<f4', 1: '<i4', 2: '|u1', 3: '<u4'}
+_TORCH = {0: torch.float32, 1: torch.int32, 2: torch.uint8, 3: torch.int32}
+
+
+class Engine:
+    def __init__(self, state_dict, device=0, max_batch=16, tile=(256, 256), num_classes=5, **cfg_overrides):
+        if not torch.cuda.is_available():
+            raise HipError('no HIP device visible: nuhtc_amd has no CPU path (the CPU oracle lives under oracle/ and is test-only)')
+        self.lib = hip.load()
+        self.device = torch.device('cuda', device if isinstance(device, int) else torch.device(device).index or 0)
+        cfg = hip.default_config()
+        cfg.num_classes = num_classes
+        cfg.tile_h, cfg.tile_w = int(tile[0]), int(tile[1])
+        cfg.max_batch = int(max_batch)
+        for k, v in cfg_overrides.items():
+            if not hasattr(cfg, k):
+                raise KeyError(f'unknown engine option {k}')
+            if k == 'stage_stds':
+                for i in range(3):
+                    for j in range(4):
+                        cfg.stage_stds[i][j] = float(v[i][j])
+            elif k in ('mean', 'std'):
+                for i in range(3):
+                    getattr(cfg, k)[i] = float(v[i])
+            else:
+                setattr(cfg, k, v)
+        self.cfg = cfg
+        self.h = ctypes.c_void_p()
+        rc = self.lib.nuhtc_create(ctypes.byref(cfg), self.device.index, ctypes.byref(self.h))
+        if rc:
+            raise HipError(f'nuhtc_create failed ({rc}): {self.lib.nuhtc_last_error(None).decode()}')
+        for name, t in state_dict.items():
+            a = np.ascontiguousarray(t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else t, dtype=np.float32)
+            if a.ndim == 0:
+                a = a.reshape(1)
+            shape = (ctypes.c_int64 * a.ndim)(*a.shape)
+            self._check(self.lib.nuhtc_load_weight(self.h, name.encode(), a.ctypes.data_as(ctypes.c_void_p), shape, a.ndim))
+        self._check(self.lib.nuhtc_finalize(self.h))
+        B, K = cfg.max_batch, cfg.max_per_img
+        with torch.cuda.device(self.device):
+            self.boxes = torch.zeros(B, K, 5, dtype=torch.float32, device=self.device)
+            self.labels = torch.zeros(B, K, dtype=torch.int32, device=self.device)
+            self.counts = torch.zeros(B, dtype=torch.int32, device=self.device)
+            self.masks = torch.zeros(B, K, cfg.tile_h, cfg.tile_w // 32, dtype=torch.int32, device=self.device)
+            self.areas = torch.zeros(B, K, dtype=torch.int32, device=self.device)
+            self.keep = torch.zeros(B, K, dtype=torch.uint8, device=self.device)
+        self.dets = hip.Dets(self.boxes.data_ptr(), self.labels.data_ptr(), self.counts.data_ptr(), self.masks.data_ptr(),
+                             self.areas.data_ptr(), self.keep.data_ptr())
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, rc):
+        if rc:
+            raise HipError(f'libnuhtc_hip error {rc}: {self.lib.nuhtc_last_error(self.h).decode()}')
+
+    def close(self):
+        if getattr(self, 'h', None) and self.h.value:
+            self.lib.nuhtc_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def to_device(self, tiles):
+        """(B,H,W,3) uint8 ndarray / tensor -> contiguous device tensor."""
+        if isinstance(tiles, np.ndarray):
+            tiles = torch.from_numpy(np.ascontiguousarray(tiles))
+        if tiles.dtype != torch.uint8 or tiles.dim() != 4 or tiles.shape[-1] != 3:
+            raise ValueError('tiles must be uint8 (B,H,W,3)')
+        if tuple(tiles.shape[1:3]) != (self.cfg.tile_h, self.cfg.tile_w):
+            raise ValueError(f'tile size {tuple(tiles.shape[1:3])} != engine tile size {(self.cfg.tile_h, self.cfg.tile_w)}')
+        return tiles.to(self.device, non_blocking=True).contiguous()
+
+    # ------------------------------------------------------------------ hot path
+    def infer_async(self, tiles_dev, channel_mode=hip.CH_AS_IS):
+        """Enqueue the whole path for a device-resident batch; outputs land in self.boxes/labels/counts/masks/keep."""
+        B = tiles_dev.shape[0]
+        self._check(self.lib.nuhtc_infer(self.h, ctypes.c_void_p(tiles_dev.data_ptr()), B, channel_mode, self._stream(),
+                                         ctypes.byref(self.dets)))
+        return B
+
+    def infer_fixed_load_async(self, tiles_dev, rois_dev, n_dets, channel_mode=hip.CH_AS_IS):
+        B, n_rois = tiles_dev.shape[0], rois_dev.shape[1]
+        self._check(self.lib.nuhtc_infer_fixed_load(self.h, ctypes.c_void_p(tiles_dev.data_ptr()), B, channel_mode,
+                                                    ctypes.c_void_p(rois_dev.data_ptr()), n_rois, n_dets, self._stream(),
+                                                    ctypes.byref(self.dets)))
+        return B
+
+    def check(self):
+        self._check(self.lib.nuhtc_check(self.h, self._stream()))
+
+    def results(self, B, with_masks=True):
+        """Device outputs of the last infer -> list of (bbox_results, segm_results) exactly like the reference
+        (`bbox2result` mmdet/core/bbox/transforms.py:100-117; `get_seg_masks` list-of-bool-arrays per class)."""
+        self.check()
+        counts = self.counts[:B].cpu().numpy()
+        boxes = self.boxes[:B].cpu().numpy()
+        labels = self.labels[:B].cpu().numpy()
+        nc = self.cfg.num_classes
+        H, W = self.cfg.tile_h, self.cfg.tile_w
+        out = []
+        for b in range(B):
+            n = int(counts[b])
+            d, l = boxes[b, :n], labels[b, :n]
+            bbox_res = [d[l == c] for c in range(nc)]
+            if with_masks and n:
+                words = self.masks[b, :n].cpu().numpy().view(np.uint32)
+                bits = np.unpackbits(words.view(np.uint8).reshape(n, H, W // 8), axis=-1, bitorder='little').astype(bool)
+                segm_res = [[bits[j] for j in range(n) if l[j] == c] for c in range(nc)]
+            else:
+                segm_res = [[] for _ in range(nc)]
+            out.append((bbox_res, segm_res))
+        return out
+
+    def __call__(self, tiles, channel_mode=hip.CH_AS_IS):
+        t = self.to_device(tiles)
+        out = []
+        for i in range(0, t.shape[0], self.cfg.max_batch):
+            chunk = t[i:i + self.cfg.max_batch]
+            B = self.infer_async(chunk, channel_mode)
+            out.extend(self.results(B))
+        return out
+
+    # ------------------------------------------------------------------ parity-test access
+    def enable_token_dump(self):
+        p = ctypes.c_void_p()
+        self._check(self.lib.nuhtc_get_buffer(self.h, b'__enable_token_dump', ctypes.byref(p), None, None, None))
+
+    def buffer(self, name):
+        """Copy of an intermediate tensor of the last infer call (see nuhtc_get_buffer)."""
+        p = ctypes.c_void_p()
+        shape = (ctypes.c_int64 * 6)()
+        nd, dt = ctypes.c_int(), ctypes.c_int()
+        self._check(self.lib.nuhtc_get_buffer(self.h, name.encode(), ctypes.byref(p), shape, ctypes.byref(nd), ctypes.byref(dt)))
+        torch.cuda.current_stream(self.device).synchronize()
+        shp = [shape[i] for i in range(nd.value)]
+        view = torch.as_tensor(_DevView(p.value, shp, _TYPESTR[dt.value]), device=self.device)
+        return view.clone()
+
+    def op_gemm(self, A, W, bias=None, act=0):
+        M, K = A.shape
+        N = W.shape[0]
+        C = torch.empty(M, N, dtype=torch.float32, device=self.device)
+        self._check(self.lib.nuhtc_op_gemm(self.h, A.data_ptr(), W.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                           C.data_ptr(), M, N, K, act, self._stream()))
+        return C
+
+    def op_roi_align(self, feat_nhwc, rois, P, scale, sr):
+        N, H, W, C = feat_nhwc.shape
+        R = rois.shape[0]
+        out = torch.empty(R, P, P, C, dtype=torch.float32, device=self.device)
+        self._check(self.lib.nuhtc_op_roi_align(self.h, feat_nhwc.data_ptr(), N, H, W, rois.data_ptr(), R, P, float(scale), int(sr),
+                                                out.data_ptr(), self._stream()))
+        return out
+
+    def op_nms(self, boxes, scores, thr):
+        n = boxes.shape[0]
+        keep = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        cnt = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._check(self.lib.nuhtc_op_nms(self.h, boxes.data_ptr(), scores.data_ptr(), n, float(thr), keep.data_ptr(), cnt.data_ptr(),
+                                          self._stream()))
+        return keep[:int(cnt.item())].long()

@@ -1,0 +1,83 @@
+"""ctypes binding of libnuhtc_hip.so — the C ABI declared in include/nuhtc_hip.h.
+
+There is no fallback: if the shared library is missing or fails to load, importing callers get an
+ImportError/OSError that says how to build it (`python -m nuhtc_amd.build`).
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libnuhtc_hip.so')
+
+OK, E_INVALID, E_HIP, E_STATE, E_CAPACITY, E_NOTFOUND = 0, -1, -2, -3, -4, -5
+CH_AS_IS, CH_SWAP = 0, 1
+
+
+class Config(ctypes.Structure):
+    _fields_ = [
+        ('abi_version', ctypes.c_int32), ('num_classes', ctypes.c_int32),
+        ('tile_h', ctypes.c_int32), ('tile_w', ctypes.c_int32), ('max_batch', ctypes.c_int32),
+        ('scale_factor', ctypes.c_float), ('mean', ctypes.c_float * 3), ('std', ctypes.c_float * 3),
+        ('rpn_nms_pre', ctypes.c_int32), ('rpn_max_per_img', ctypes.c_int32),
+        ('rpn_nms_iou', ctypes.c_float), ('rpn_min_bbox_size', ctypes.c_float),
+        ('score_thr', ctypes.c_float), ('nms_iou', ctypes.c_float), ('max_per_img', ctypes.c_int32),
+        ('mask_thr_binary', ctypes.c_float), ('att_thres', ctypes.c_float),
+        ('watershed_proposal', ctypes.c_int32), ('max_cc_proposals', ctypes.c_int32),
+        ('stage_stds', (ctypes.c_float * 4) * 3),
+        ('margin', ctypes.c_int32), ('min_area', ctypes.c_int32), ('mask_nms_thr', ctypes.c_float),
+    ]
+
+
+class Dets(ctypes.Structure):
+    _fields_ = [('boxes', ctypes.c_void_p), ('labels', ctypes.c_void_p), ('counts', ctypes.c_void_p),
+                ('masks', ctypes.c_void_p), ('areas', ctypes.c_void_p), ('keep', ctypes.c_void_p)]
+
+
+EXPORTS = ['nuhtc_default_config', 'nuhtc_create', 'nuhtc_destroy', 'nuhtc_last_error', 'nuhtc_load_weight',
+           'nuhtc_finalize', 'nuhtc_infer', 'nuhtc_infer_fixed_load', 'nuhtc_check', 'nuhtc_get_buffer',
+           'nuhtc_op_gemm', 'nuhtc_op_roi_align', 'nuhtc_op_nms']
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f'{LIB_PATH} not found: the HIP extension is required (no CPU fallback exists). '
+                          'Build it with `python -m nuhtc_amd.build` (hipcc, --offload-arch=gfx950).')
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+    lib.nuhtc_default_config.argtypes = [ctypes.POINTER(Config)]
+    lib.nuhtc_default_config.restype = None
+    lib.nuhtc_create.argtypes = [ctypes.POINTER(Config), ci, ctypes.POINTER(vp)]
+    lib.nuhtc_destroy.argtypes = [vp]
+    lib.nuhtc_destroy.restype = None
+    lib.nuhtc_last_error.argtypes = [vp]
+    lib.nuhtc_last_error.restype = ctypes.c_char_p
+    lib.nuhtc_load_weight.argtypes = [vp, ctypes.c_char_p, vp, ctypes.POINTER(ctypes.c_int64), ci]
+    lib.nuhtc_finalize.argtypes = [vp]
+    lib.nuhtc_infer.argtypes = [vp, vp, ci, ci, vp, ctypes.POINTER(Dets)]
+    lib.nuhtc_infer_fixed_load.argtypes = [vp, vp, ci, ci, vp, ci, ci, vp, ctypes.POINTER(Dets)]
+    lib.nuhtc_check.argtypes = [vp, vp]
+    lib.nuhtc_get_buffer.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int64),
+                                     ctypes.POINTER(ci), ctypes.POINTER(ci)]
+    lib.nuhtc_op_gemm.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
+    lib.nuhtc_op_roi_align.argtypes = [vp, vp, ci, ci, ci, vp, ci, ci, cf, ci, vp, vp]
+    lib.nuhtc_op_nms.argtypes = [vp, vp, vp, ci, cf, vp, vp, vp]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if fn.restype is ctypes.c_int or name not in ('nuhtc_default_config', 'nuhtc_destroy', 'nuhtc_last_error'):
+            fn.restype = ci
+    lib.nuhtc_last_error.restype = ctypes.c_char_p
+    lib.nuhtc_default_config.restype = None
+    lib.nuhtc_destroy.restype = None
+    _lib = lib
+    return lib
+
+
+def default_config():
+    cfg = Config()
+    load().nuhtc_default_config(ctypes.byref(cfg))
+    return cfg

@@ -1,0 +1,97 @@
+"""GPU parity of the dense part of the path (pre-processing, Swin-T, FPN, RPN convs, semantic head) against
+the oracle and the committed reference goldens, through the C ABI (libnuhtc_hip.so)."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+# fp32 tolerance of this tier: |err| <= ATOL + RTOL*|ref| per element (accumulation order differs between the
+# MFMA k-ordered fma chain and the CPU's blocked sums); decisions downstream are compared by IoU, not by value.
+RTOL, ATOL = 2e-4, 2e-4
+
+
+def _engine(g, max_batch=None):
+    from nuhtc_amd.engine import Engine
+    sd = G.seeded_sd(g)
+    tiles = g['tiles']
+    return Engine(sd, device=0, max_batch=max_batch or len(tiles), tile=tiles.shape[1:3]), sd
+
+
+def _cmp(name, got, ref, errs, rtol=RTOL, atol=ATOL):
+    got = got.detach().cpu().float().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    ref = ref.detach().cpu().float().numpy() if isinstance(ref, torch.Tensor) else np.asarray(ref)
+    if got.shape != ref.shape:
+        errs.append(f'{name}: shape {got.shape} vs {ref.shape}')
+        return
+    err = np.abs(got - ref)
+    bad = err > atol + rtol * np.abs(ref)
+    msg = f'{name}: max_abs_err={err.max():.3e} ref_absmax={np.abs(ref).max():.3e} bad={int(bad.sum())}/{bad.size}'
+    print(msg)
+    if bad.any() or not np.isfinite(got).all():
+        errs.append(msg)
+
+
+def test_gemm_op_shapes(hip_device):
+    from nuhtc_amd.engine import Engine
+    from nuhtc_amd import weights
+    g = G.load('small_b2')
+    eng, _ = _engine(g)
+    errs = []
+    gen = torch.Generator().manual_seed(0)
+    for (M, N, K) in [(128, 96, 96), (200, 288, 96), (1, 32, 32), (49, 64, 64), (333, 128, 192), (130, 384, 96), (257, 96, 384),
+                      (64, 256, 3136), (500, 2304, 768), (77, 768, 3072)]:
+        A = torch.randn(M, K, generator=gen)
+        W = torch.randn(N, K, generator=gen) / K ** 0.5
+        b = torch.randn(N, generator=gen)
+        for act in (0, 1, 2):
+            ref = A.double() @ W.double().T + b.double()
+            ref = ref if act == 0 else (torch.relu(ref) if act == 1 else torch.nn.functional.gelu(ref))
+            out = eng.op_gemm(A.cuda(), W.cuda(), b.cuda(), act)
+            _cmp(f'gemm M{M} N{N} K{K} act{act}', out, ref.float(), errs, 1e-5, 2e-5)
+    # A = I with an asymmetric B catches transposed fragment/C layouts
+    I = torch.eye(96)
+    Wb = torch.arange(96 * 96, dtype=torch.float32).reshape(96, 96) / 97.0
+    _cmp('gemm identity', eng.op_gemm(I.cuda(), Wb.cuda(), None, 0), Wb.T.contiguous(), errs, 0, 1e-6)
+    assert not errs, '\n'.join(errs)
+
+
+@pytest.mark.parametrize('case', ['small_b2', 'small_wsi_b3', 'full_b1'])
+def test_dense_stages_vs_oracle_and_golden(hip_device, case):
+    from oracle import model as O
+    g = G.load(case)
+    eng, sd = _engine(g)
+    eng.enable_token_dump()
+    tiles = g['tiles']
+    B = len(tiles)
+    mode = int(g['channel_mode'])
+    eng.infer_async(eng.to_device(tiles), mode)
+    eng.check()
+    errs = []
+    img = O.preprocess(tiles, mode)
+    _cmp('img', eng.buffer('img')[:B].permute(0, 3, 1, 2), img, errs, 0, 1e-6)
+    with torch.no_grad():
+        c, toks = O.backbone(sd, img, return_tokens=True)
+        x = O.fpn(sd, c)
+        rcls, rreg = O.rpn_convs(sd, x)
+        sp, sf = O.semantic_head(sd, x)
+    for s in range(4):
+        for b in range(O.DEPTHS[s]):
+            t = eng.buffer(f'tok_s{s}b{b}')[:B]
+            _cmp(f'tok_s{s}b{b}', t, toks[f's{s}b{b}'], errs)
+            G.check_sub(g, f's{s}b{b}', t, RTOL * 5, ATOL * 5)
+    for i in range(4):
+        ci = eng.buffer(f'c{i}')[:B].permute(0, 3, 1, 2)
+        _cmp(f'c{i}', ci, c[i], errs)
+        xi = eng.buffer(f'x{i}')[:B].permute(0, 3, 1, 2)
+        _cmp(f'x{i}', xi, x[i], errs)
+        G.check_sub(g, f'x{i}', xi.contiguous(), RTOL * 5, ATOL * 5)
+        r = eng.buffer(f'rpn{i}')[:B].permute(0, 3, 1, 2)
+        _cmp(f'rpn_cls{i}', r[:, 0:3], rcls[i], errs)
+        _cmp(f'rpn_reg{i}', r[:, 3:15], rreg[i], errs)
+    _cmp('sem_pred', eng.buffer('sem_pred')[:B][:, None], sp, errs, 5e-4, 5e-4)
+    _cmp('sem_feat', eng.buffer('sem_feat')[:B].permute(0, 3, 1, 2), sf, errs, 5e-4, 5e-4)
+    G.check_sub(g, 'sem_feat', eng.buffer('sem_feat')[:B].permute(0, 3, 1, 2).contiguous(), 2e-3, 2e-3)
+    assert not errs, '\n'.join(errs)
