@@ -10,6 +10,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libnuhtc_hip.so')
+# box / IoU arithmetic must follow the reference's separate float32 mul and add steps (no fused multiply-add)
+NO_CONTRACT = ('proposals.hip', 'roi.hip')
 
 
 def sources():
@@ -36,6 +38,8 @@ def build(force=False, verbose=False):
         obj = os.path.join(objdir, os.path.basename(src) + '.o')
         objs.append(obj)
         cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-c', src, '-o', obj]
+        if os.path.basename(src) in NO_CONTRACT:
+            cmd.insert(4, '-ffp-contract=off')
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for cmd, p in procs:
         out, _ = p.communicate()

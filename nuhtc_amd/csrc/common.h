@@ -103,21 +103,6 @@ int launch_conv1x1_n1(const float* x, const float* w, const float* b, float* y, 
 int launch_rownorm_inv(const float* x, float* inv, int rows, int C, hipStream_t s);
 int launch_transpose(const float* x, float* y, int batch, int rows, int cols, hipStream_t s);
 
-// ----------------------------------------------------------------------------- proposals (proposals.hip)
-struct RpnLevel { const float* out; int h, w, stride; };   // out: [B, h*w, 16] (3 cls logits + 12 deltas + pad)
-int launch_rpn_topk(const RpnLevel* lv, int B, int nms_pre, float* cand_boxes, float* cand_scores, int* cand_level,
-                    int* cand_count, int cand_cap, int img_h, int img_w, float min_size, unsigned long long* scratch_keys,
-                    hipStream_t s);
-// generic per-image sorted NMS: n_i = counts[b] candidates at b*cap; optional ids -> coordinate offset trick.
-// Writes kept rows (x1,y1,x2,y2,score) + kept source index, at most max_keep per image.
-int launch_batched_nms(const float* boxes, const float* scores, const int* ids, const int* counts, int cap, int B,
-                       float iou_thr, int max_keep, float* out_dets, int* out_src, int* out_counts,
-                       unsigned long long* sort_keys, unsigned long long* mask_words, hipStream_t s);
-size_t nms_mask_words_per_image(int cap);
-int launch_cc_proposals(const float* sem_pred, int B, int h, int w, int img_h, int img_w, int min_area, float* boxes,
-                        int* counts, int cap, unsigned char* mask_a, unsigned char* mask_b, int* labels, int* stats,
-                        int* overflow, hipStream_t s);
-
 // ----------------------------------------------------------------------------- RoI path (roi.hip)
 int launch_roi_align(const float* feat, int N, int H, int W, int C, const float* rois, int R, const int* r_dev, int P,
                      float scale, int sr, float* out, int accumulate, hipStream_t s);

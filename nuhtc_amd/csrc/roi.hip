@@ -1,0 +1,548 @@
+// RoI path of the HTC-lite cascade on the device (gfx950, wave64; compiled with -ffp-contract=off so that box
+// arithmetic follows the reference's float32 mul/add sequence).
+//   attn_pool_kernel   : AttentionRoIExtractor levels 2,3 — similarity-weighted global mean for every possible
+//                        RoI centre of a level, computed once per image and shared by all cascade stages and
+//                        the mask branch (nuhtc/models/roi_extractors_cus.py:220-238)
+//   roi_feat_kernel    : fused RoI feature: RoIAlign(lvl0) + RoIAlign(lvl1) + G2 + G3 (+ semantic RoIAlign14,
+//                        2x2 average-pooled for the 7x7 box head) — one wave per RoI, lane = channel, NHWC maps
+//                        (roi_extractors_cus.py:194-259, nuhtc/models/htc_roi_head_cus.py:187-199,2322-2335;
+//                         mmcv RoIAlign avg/aligned semantics as in oracle/ops_c.c)
+//   bbox_tail_kernel   : NormedLinear cls + fc_reg + cascade refinement (normed_predictor.py:33-38,
+//                        convfc_bbox_head.py:190-196, bbox_head.py:459-496)
+//   det_candidates     : score ensemble, Seesaw activation, decode, threshold, (roi,class) expansion
+//                        (htc_roi_head_cus.py:2283-2303, seesaw_loss.py:157-175, nuhtc/models/bbox_head.py:12-102)
+//   paste_kernel       : _do_paste_mask / get_seg_masks (fcn_mask_head.py:229-307,344-412) -> bit-packed masks
+//   tile_post_kernel   : tools/infer_wsi.py:510-531,60-84 margin/min-area filter + greedy mask-NMS (popcount IoU)
+#include "roi.h"
+
+__device__ __forceinline__ float wsum64(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------- attention pooling table
+// G[b, q, c] = mean_p( F[b,p,c] * (relu(cos(F[b,q], F[b,p]) - tau) + tau) ),  F: [B, HW, 64] (NHWC level map)
+__global__ __launch_bounds__(256) void attn_pool_kernel(const float* __restrict__ F, float* __restrict__ G, int HW, float tau) {
+  __shared__ float part[4][64];
+  const int q = blockIdx.x, b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* Fb = F + (long long)b * HW * 64;
+  const float qv = Fb[(long long)q * 64 + lane];
+  const float qn = fmaxf(sqrtf(wsum64(qv * qv)), 1e-8f);
+  const float qh = qv / qn;
+  float acc = 0.f;
+  for (int p = wave; p < HW; p += 4) {
+    const float v = Fb[(long long)p * 64 + lane];
+    const float pn = fmaxf(sqrtf(wsum64(v * v)), 1e-8f);
+    const float cs = wsum64(qh * (v / pn));
+    const float sim = fmaxf(cs - tau, 0.f) + tau;
+    acc += v * sim;
+  }
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0) {
+    float s = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+    G[((long long)b * HW + q) * 64 + lane] = s / (float)HW;
+  }
+}
+
+int launch_attn_pool(const float* F, float* G, int B, int HW, float tau, hipStream_t s) {
+  hipLaunchKernelGGL(attn_pool_kernel, dim3(HW, B), dim3(256), 0, s, F, G, HW, tau);
+  return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
+}
+
+// ------------------------------------------------------------------------------------------- RoI list assembly
+// rois[b] = cat(cc_boxes[b], rpn_dets[b]) (htc_roi_head_cus.py:339), flattened over the batch (bbox2roi)
+__global__ __launch_bounds__(256) void build_rois_kernel(const float* __restrict__ cc_boxes, const int* __restrict__ cc_counts, int cc_cap,
+                                                         const float* __restrict__ rpn_dets, const int* __restrict__ rpn_counts, int rpn_cap,
+                                                         const float* __restrict__ fixed, int n_fixed, float* __restrict__ rois,
+                                                         int* __restrict__ roi_off, int* __restrict__ roi_cnt, int* __restrict__ total, int B) {
+  __shared__ int off[257];
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    int acc = 0;
+    for (int b = 0; b < B; ++b) {
+      int n = fixed ? n_fixed : (cc_boxes ? cc_counts[b] : 0) + rpn_counts[b];
+      off[b] = acc;
+      roi_off[b] = acc;
+      roi_cnt[b] = n;
+      acc += n;
+    }
+    off[B] = acc;
+    *total = acc;
+  }
+  __syncthreads();
+  for (int b = 0; b < B; ++b) {
+    const int o = off[b], n = off[b + 1] - off[b];
+    const int ncc = fixed ? 0 : (cc_boxes ? cc_counts[b] : 0);
+    for (int j = tid; j < n; j += 256) {
+      const float* src = fixed ? fixed + ((long long)b * n_fixed + j) * 4
+                               : (j < ncc ? cc_boxes + ((long long)b * cc_cap + j) * 4 : rpn_dets + ((long long)b * rpn_cap + (j - ncc)) * 5);
+      float* d = rois + (long long)(o + j) * 5;
+      d[0] = (float)b; d[1] = src[0]; d[2] = src[1]; d[3] = src[2]; d[4] = src[3];
+    }
+  }
+}
+
+int launch_build_rois(const float* cc_boxes, const int* cc_counts, int cc_cap, const float* rpn_dets, const int* rpn_counts, int rpn_cap,
+                      const float* fixed, int n_fixed, float* rois, int* roi_off, int* roi_cnt, int* total, int B, hipStream_t s) {
+  if (B > 256) return NUHTC_E_INVALID;
+  hipLaunchKernelGGL(build_rois_kernel, dim3(1), dim3(256), 0, s, cc_boxes, cc_counts, cc_cap, rpn_dets, rpn_counts, rpn_cap, fixed, n_fixed,
+                     rois, roi_off, roi_cnt, total, B);
+  return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
+}
+
+// ------------------------------------------------------------------------------------------- fused RoI features
+struct Tap { int o00, o01, o10, o11; float w1, w2, w3, w4; };   // offsets in units of 64-channel pixels; weight 0 when invalid
+
+// mmcv bilinear_interpolate pre-computation for one sample point (y, x) on an H x W map
+__device__ __forceinline__ Tap make_tap(float y, float x, int H, int W) {
+  Tap t;
+  if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) {
+    t.o00 = t.o01 = t.o10 = t.o11 = 0;
+    t.w1 = t.w2 = t.w3 = t.w4 = 0.f;
+    return t;
+  }
+  if (y <= 0.f) y = 0.f;
+  if (x <= 0.f) x = 0.f;
+  int yl = (int)y, xl = (int)x, yh, xh;
+  if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else yh = yl + 1;
+  if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
+  const float ly = y - (float)yl, lx = x - (float)xl, hy = 1.0f - ly, hx = 1.0f - lx;
+  t.o00 = yl * W + xl; t.o01 = yl * W + xh; t.o10 = yh * W + xl; t.o11 = yh * W + xh;
+  t.w1 = hy * hx; t.w2 = hy * lx; t.w3 = ly * hx; t.w4 = ly * lx;
+  return t;
+}
+
+// RoIAlign (avg, aligned) of one bin, all 64 channels of the wave; fb = map of image b (NHWC, 64 ch), lane = channel
+__device__ __forceinline__ float roi_bin(const float* __restrict__ fb, int H, int W, float x1, float y1, float bw, float bh, int gw, int gh,
+                                         int pw, int ph, int lane) {
+  float acc = 0.f;
+  for (int iy = 0; iy < gh; ++iy) {
+    const float y = y1 + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
+    for (int ix = 0; ix < gw; ++ix) {
+      const float x = x1 + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)gw;
+      const Tap t = make_tap(y, x, H, W);
+      const float v1 = fb[(long long)t.o00 * 64 + lane], v2 = fb[(long long)t.o01 * 64 + lane];
+      const float v3 = fb[(long long)t.o10 * 64 + lane], v4 = fb[(long long)t.o11 * 64 + lane];
+      acc += t.w1 * v1 + t.w2 * v2 + t.w3 * v3 + t.w4 * v4;
+    }
+  }
+  const int cnt = gh * gw;
+  return acc / (float)(cnt > 1 ? cnt : 1);
+}
+
+struct RoiGeom { float x1, y1, bw, bh; int gw, gh; };
+__device__ __forceinline__ RoiGeom roi_geom(const float* roi, float scale, int P, int sr) {
+  RoiGeom g;
+  g.x1 = roi[1] * scale - 0.5f;
+  g.y1 = roi[2] * scale - 0.5f;
+  const float x2 = roi[3] * scale - 0.5f, y2 = roi[4] * scale - 0.5f;
+  const float rw = x2 - g.x1, rh = y2 - g.y1;
+  g.bw = rw / (float)P;
+  g.bh = rh / (float)P;
+  g.gw = sr > 0 ? sr : (int)ceilf(rw / (float)P);
+  g.gh = sr > 0 ? sr : (int)ceilf(rh / (float)P);
+  return g;
+}
+
+// out[r][bin][c]; P=7: bbox head features (sr=2, semantic 14x14 -> 2x2 mean); P=14: mask features (sr=0, semantic added as is)
+template <int P>
+__global__ __launch_bounds__(256) void roi_feat_kernel(RoiFeatParams p) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int R = *p.r_dev;
+  if (r >= R) return;
+  const float* roi = p.rois + (long long)r * 5;
+  const int b = (int)roi[0];
+  const int sr = P == 7 ? 2 : 0;
+  const RoiGeom g0 = roi_geom(roi, 0.25f, P, sr), g1 = roi_geom(roi, 0.125f, P, sr);
+  const RoiGeom gs = roi_geom(roi, 0.25f, 14, 0);
+  const float* f0 = p.x0 + (long long)b * p.H0 * p.W0 * 64;
+  const float* f1 = p.x1 + (long long)b * p.H1 * p.W1 * 64;
+  const float* fs = p.sem + (long long)b * p.H0 * p.W0 * 64;
+  // attention-pooled global terms (levels 2, 3): centre cell of the RoI at stride 16 / 32
+  float gsum[2];
+#pragma unroll
+  for (int l = 0; l < 2; ++l) {
+    const int Hl = l ? p.H3 : p.H2, Wl = l ? p.W3 : p.W2;
+    const float st = l ? 32.f : 16.f;
+    float cx = floorf((roi[1] + roi[3]) / (2.0f * st)), cy = floorf((roi[2] + roi[4]) / (2.0f * st));
+    cx = fminf(fmaxf(cx, 0.f), (float)(Wl - 1));
+    cy = fminf(fmaxf(cy, 0.f), (float)(Hl - 1));
+    const float* G = l ? p.G3 : p.G2;
+    gsum[l] = G[(((long long)b * Hl + (int)cy) * Wl + (int)cx) * 64 + lane];
+  }
+  float* out = p.out + (long long)r * P * P * 64;
+  for (int ph = 0; ph < P; ++ph)
+    for (int pw = 0; pw < P; ++pw) {
+      float v = 0.f;
+      v += roi_bin(f0, p.H0, p.W0, g0.x1, g0.y1, g0.bw, g0.bh, g0.gw, g0.gh, pw, ph, lane);
+      v += roi_bin(f1, p.H1, p.W1, g1.x1, g1.y1, g1.bw, g1.bh, g1.gw, g1.gh, pw, ph, lane);
+      v += gsum[0];
+      v += gsum[1];
+      float sv;
+      if (P == 7) {
+        const float a = roi_bin(fs, p.H0, p.W0, gs.x1, gs.y1, gs.bw, gs.bh, gs.gw, gs.gh, 2 * pw, 2 * ph, lane);
+        const float bq = roi_bin(fs, p.H0, p.W0, gs.x1, gs.y1, gs.bw, gs.bh, gs.gw, gs.gh, 2 * pw + 1, 2 * ph, lane);
+        const float c = roi_bin(fs, p.H0, p.W0, gs.x1, gs.y1, gs.bw, gs.bh, gs.gw, gs.gh, 2 * pw, 2 * ph + 1, lane);
+        const float d = roi_bin(fs, p.H0, p.W0, gs.x1, gs.y1, gs.bw, gs.bh, gs.gw, gs.gh, 2 * pw + 1, 2 * ph + 1, lane);
+        sv = (((a + bq) + c) + d) * 0.25f;
+      } else {
+        sv = roi_bin(fs, p.H0, p.W0, gs.x1, gs.y1, gs.bw, gs.bh, gs.gw, gs.gh, pw, ph, lane);
+      }
+      out[(ph * P + pw) * 64 + lane] = v + sv;
+    }
+}
+
+int launch_roi_feat(const RoiFeatParams& p, int P, int r_cap, hipStream_t s) {
+  if (r_cap <= 0) return 0;
+  if (P == 7) hipLaunchKernelGGL(roi_feat_kernel<7>, dim3(cdiv(r_cap, 4)), dim3(256), 0, s, p);
+  else if (P == 14) hipLaunchKernelGGL(roi_feat_kernel<14>, dim3(cdiv(r_cap, 4)), dim3(256), 0, s, p);
+  else return NUHTC_E_INVALID;
+  return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
+}
+
+// stand-alone RoIAlign on an NHWC map (kernel-level parity test of the mmcv semantics)
+__global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict__ feat, int H, int W, const float* __restrict__ rois, int R, int P,
+                                                        float scale, int sr, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const float* roi = rois + (long long)r * 5;
+  const RoiGeom g = roi_geom(roi, scale, P, sr);
+  const float* fb = feat + (long long)((int)roi[0]) * H * W * 64;
+  for (int ph = 0; ph < P; ++ph)
+    for (int pw = 0; pw < P; ++pw)
+      out[((long long)r * P * P + ph * P + pw) * 64 + lane] = roi_bin(fb, H, W, g.x1, g.y1, g.bw, g.bh, g.gw, g.gh, pw, ph, lane);
+}
+
+int launch_roi_align(const float* feat, int N, int H, int W, int C, const float* rois, int R, const int* r_dev, int P, float scale, int sr,
+                     float* out, int accumulate, hipStream_t s) {
+  if (C != 64 || r_dev || accumulate) return NUHTC_E_INVALID;
+  if (R <= 0) return 0;
+  hipLaunchKernelGGL(roi_align_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, feat, H, W, rois, R, P, scale, sr, out);
+  return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
+}
+
+// ------------------------------------------------------------------------------------------- bbox head tail
+__device__ __forceinline__ void delta2bbox_dev(const float* roi4, const float* d, const float* stds, float img_w, float img_h, float* o) {
+  const float MR = 4.135166556742356f;
+  const float dx = d[0] * stds[0], dy = d[1] * stds[1];
+  float dw = d[2] * stds[2], dh = d[3] * stds[3];
+  dw = fminf(fmaxf(dw, -MR), MR);
+  dh = fminf(fmaxf(dh, -MR), MR);
+  const float pxc = (roi4[0] + roi4[2]) * 0.5f, pyc = (roi4[1] + roi4[3]) * 0.5f;
+  const float pw = roi4[2] - roi4[0], ph = roi4[3] - roi4[1];
+  const float gx = pxc + pw * dx, gy = pyc + ph * dy;
+  const float gw = pw * expf(dw), gh = ph * expf(dh);
+  o[0] = fminf(fmaxf(gx - gw * 0.5f, 0.f), img_w);
+  o[1] = fminf(fmaxf(gy - gh * 0.5f, 0.f), img_h);
+  o[2] = fminf(fmaxf(gx + gw * 0.5f, 0.f), img_w);
+  o[3] = fminf(fmaxf(gy + gh * 0.5f, 0.f), img_h);
+}
+
+// one wave per RoI: h [R][256] -> cls [R][16] (nc+2 used), reg [R][4]; optional in-place cascade refinement of the roi
+__global__ __launch_bounds__(256) void bbox_tail_kernel(BboxTailParams p) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= *p.r_dev) return;
+  const float4 hv = reinterpret_cast<const float4*>(p.h + (long long)r * 256)[lane];
+  const float nrm = sqrtf(wsum64(hv.x * hv.x + hv.y * hv.y + hv.z * hv.z + hv.w * hv.w));
+  const float den = nrm + 1e-6f;
+  const float4 xn = make_float4(hv.x / den * 20.f, hv.y / den * 20.f, hv.z / den * 20.f, hv.w / den * 20.f);
+  const int nout = p.nc + 2;
+  float keep = 0.f;
+  for (int n = 0; n < nout + 4; ++n) {
+    const float4 w = reinterpret_cast<const float4*>(p.w + (long long)n * 256)[lane];
+    const float4 x = n < nout ? xn : hv;
+    float d = wsum64(x.x * w.x + x.y * w.y + x.z * w.z + x.w * w.w) + p.b[n];
+    if (lane == n) keep = d;
+  }
+  if (lane < nout) p.cls[(long long)r * 16 + lane] = keep;
+  if (lane >= nout && lane < nout + 4) p.reg[(long long)r * 4 + (lane - nout)] = keep;
+  if (p.refine) {
+    float d[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d[j] = __shfl(keep, nout + j);
+    if (lane == 0) {
+      float* roi = p.rois + (long long)r * 5;
+      float o[4];
+      delta2bbox_dev(roi + 1, d, p.stds, p.img_w, p.img_h, o);
+      roi[1] = o[0]; roi[2] = o[1]; roi[3] = o[2]; roi[4] = o[3];
+    }
+  }
+}
+
+int launch_bbox_tail(const BboxTailParams& p, int r_cap, hipStream_t s) {
+  if (p.nc + 6 > 64) return NUHTC_E_INVALID;
+  hipLaunchKernelGGL(bbox_tail_kernel, dim3(cdiv(r_cap, 4)), dim3(256), 0, s, p);
+  return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
+}
+
+// ------------------------------------------------------------------------------------------- detection candidates
+__device__ int block_exscan(int v, int* lds, int* total) {   // blockDim.x == 1024
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+  if (lane == 63) lds[wave] = incl;
+  __syncthreads();
+  if (wave == 0) {
+    int w = lane < 16 ? lds[lane] : 0;
+    int wi = w;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { int t = __shfl_up(wi, o); if (lane >= o) wi += t; }
+    if (lane < 16) lds[lane] = wi - w;
+    if (lane == 15) lds[16] = wi;
+  }
+  __syncthreads();
+  int res = lds[wave] + incl - v;
+  *total = lds[16];
+  __syncthreads();
+  return res;
+}
+
+__global__ __launch_bounds__(1024) void det_candidates_kernel(DetCandParams p) {
+  __shared__ int sc[17];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int off = p.roi_off[b], n = p.roi_cnt[b];
+  const int nc = p.nc;
+  float* cb = p.cand_boxes + (long long)b * p.cap * 4;
+  float* cs = p.cand_scores + (long long)b * p.cap;
+  int* ci = p.cand_ids + (long long)b * p.cap;
+  int written = 0;
+  for (int base = 0; base < n; base += 1024) {
+    const int j = base + tid;
+    float sc_c[16];
+    float box[4] = {0, 0, 0, 0};
+    int cnt = 0;
+    if (j < n) {
+      const long long r = off + j;
+      float l[16];
+      float mx = -3.0e38f;
+      for (int c = 0; c < nc + 2; ++c) {
+        // sum(ms_scores) / 3.0  (htc_roi_head_cus.py:2283-2286): ((c0 + c1) + c2) / 3
+        l[c] = ((p.cls0[r * 16 + c] + p.cls1[r * 16 + c]) + p.cls2[r * 16 + c]) / 3.0f;
+      }
+      for (int c = 0; c < nc; ++c) mx = fmaxf(mx, l[c]);
+      float sum = 0.f;
+      float e[16];
+      for (int c = 0; c < nc; ++c) { e[c] = expf(l[c] - mx); sum += e[c]; }
+      const float mo = fmaxf(l[nc], l[nc + 1]);
+      const float e0 = expf(l[nc] - mo), e1 = expf(l[nc + 1] - mo);
+      const float pos = e0 / (e0 + e1);
+      delta2bbox_dev(p.rois + r * 5 + 1, p.reg2 + r * 4, p.stds, p.img_w, p.img_h, box);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) box[q] = box[q] / p.scale;
+      for (int c = 0; c < nc; ++c) {
+        sc_c[c] = (e[c] / sum) * pos;
+        if (sc_c[c] > p.score_thr) ++cnt;
+      }
+    }
+    int tot;
+    int o = block_exscan(cnt, sc, &tot) + written;
+    if (j < n) {
+      for (int c = 0; c < nc; ++c)
+        if (sc_c[c] > p.score_thr) {
+          if (o < p.cap) {
+            cb[o * 4 + 0] = box[0]; cb[o * 4 + 1] = box[1]; cb[o * 4 + 2] = box[2]; cb[o * 4 + 3] = box[3];
+            cs[o] = sc_c[c];
+            ci[o] = c;
+          }
+          ++o;
+        }
+    }
+    written += tot;
+  }
+  if (tid == 0) p.cand_count[b] = written < p.cap ? written : p.cap;
+}
+
+int launch_det_candidates(const DetCandParams& p, int B, hipStream_t s) {
+  if (p.nc + 2 > 16) return NUHTC_E_INVALID;
+  hipLaunchKernelGGL(det_candidates_kernel, dim3(B), dim3(1024), 0, s, p);
+  return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
+}
+
+// labels of the kept detections + mask-branch RoIs (det boxes back in network pixels), compacted over the batch
+__global__ __launch_bounds__(256) void det_finish_kernel(DetFinishParams p) {
+  __shared__ int off[257];
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    int acc = 0;
+    for (int b = 0; b < p.B; ++b) {
+      int n = p.det_counts[b] < p.limit ? p.det_counts[b] : p.limit;
+      p.det_counts[b] = n;
+      off[b] = acc; p.det_off[b] = acc; acc += n;
+    }
+    off[p.B] = acc;
+    *p.det_total = acc;
+  }
+  __syncthreads();
+  for (int b = 0; b < p.B; ++b) {
+    const int n = off[b + 1] - off[b];
+    for (int j = tid; j < n; j += 256) {
+      const int src = p.keep_src[(long long)b * p.max_keep + j];
+      p.labels[(long long)b * p.max_keep + j] = p.cand_ids[src];
+      const float* d = p.dets + ((long long)b * p.max_keep + j) * 5;
+      float* m = p.mask_rois + (long long)(off[b] + j) * 5;
+      m[0] = (float)b; m[1] = d[0] * p.scale; m[2] = d[1] * p.scale; m[3] = d[2] * p.scale; m[4] = d[3] * p.scale;
+    }
+  }
+}
+
+int launch_det_finish(const DetFinishParams& p, hipStream_t s) {
+  if (p.B > 256) return NUHTC_E_INVALID;
+  hipLaunchKernelGGL(det_finish_kernel, dim3(1), dim3(256), 0, s, p);
+  return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
+}
+
+// ------------------------------------------------------------------------------------------- mask paste
+// one block per (detection slot, tile); 28x28 probabilities -> bit-packed H x W mask (bit x&31 of word x>>5)
+__global__ __launch_bounds__(256) void paste_kernel(PasteParams p) {
+  __shared__ float pr[28 * 28];
+  __shared__ int s_area;
+  const int j = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int n = p.det_counts[b];
+  const int wpr = p.W >> 5;
+  unsigned* out = p.masks + ((long long)b * p.max_keep + j) * p.H * wpr;
+  if (j >= n) return;
+  const long long d = p.det_off[b] + j;
+  for (int e = tid; e < 784; e += 256) pr[e] = p.prob[d * 784 + e];
+  if (tid == 0) s_area = 0;
+  __syncthreads();
+  const float* box = p.mask_rois + d * 5 + 1;   // network pixels; get_seg_masks divides by scale_factor again
+  const float x0 = box[0] / p.scale, y0 = box[1] / p.scale, x1 = box[2] / p.scale, y1 = box[3] / p.scale;
+  // CPU semantics (skip_empty=True, one instance per chunk): only the integer hull of the box is sampled
+  const int hx0 = max((int)floorf(x0) - 1, 0), hy0 = max((int)floorf(y0) - 1, 0);
+  const int hx1 = min((int)ceilf(x1) + 1, p.W), hy1 = min((int)ceilf(y1) + 1, p.H);
+  int area = 0;
+  for (int wi = tid; wi < p.H * wpr; wi += 256) {
+    const int y = wi / wpr, wx = wi - y * wpr;
+    unsigned bits = 0;
+    if (y >= hy0 && y < hy1 && (wx << 5) < hx1 && ((wx << 5) + 32) > hx0) {
+      float gy = ((float)y + 0.5f - y0) / (y1 - y0) * 2.0f - 1.0f;
+      if (isinf(gy)) gy = 0.f;
+      const float iy = ((gy + 1.0f) * 28.0f - 1.0f) / 2.0f;
+      const float fy = floorf(iy);
+      const int iy0 = (int)fy, iy1 = iy0 + 1;
+      const float wy1 = iy - fy, wy0 = (fy + 1.0f) - iy;   // torch: nw = (ix_se - ix)*(iy_se - iy) with ix_se = ix_nw + 1
+      for (int k = 0; k < 32; ++k) {
+        const int x = (wx << 5) + k;
+        if (x < hx0 || x >= hx1) continue;
+        float gx = ((float)x + 0.5f - x0) / (x1 - x0) * 2.0f - 1.0f;
+        if (isinf(gx)) gx = 0.f;
+        const float ix = ((gx + 1.0f) * 28.0f - 1.0f) / 2.0f;
+        const float fx = floorf(ix);
+        const int ix0 = (int)fx, ix1 = ix0 + 1;
+        const float wx1 = ix - fx, wx0 = (fx + 1.0f) - ix;
+        float v = 0.f;
+        const bool okx0 = ix0 >= 0 && ix0 < 28, okx1 = ix1 >= 0 && ix1 < 28;
+        const bool oky0 = iy0 >= 0 && iy0 < 28, oky1 = iy1 >= 0 && iy1 < 28;
+        if (oky0 && okx0) v += pr[iy0 * 28 + ix0] * (wx0 * wy0);
+        if (oky0 && okx1) v += pr[iy0 * 28 + ix1] * (wx1 * wy0);
+        if (oky1 && okx0) v += pr[iy1 * 28 + ix0] * (wx0 * wy1);
+        if (oky1 && okx1) v += pr[iy1 * 28 + ix1] * (wx1 * wy1);
+        if (v >= p.thr) bits |= 1u << k;   // NaN compares false, like the reference
+      }
+    }
+    out[wi] = bits;
+    area += __popc(bits);
+  }
+  area = (int)wsum64((float)area);   // exact: counts <= 2^24
+  if ((tid & 63) == 0) atomicAdd(&s_area, area);
+  __syncthreads();
+  if (tid == 0 && p.areas) p.areas[(long long)b * p.max_keep + j] = s_area;
+}
+
+int launch_paste(const PasteParams& p, int B, hipStream_t s) {
+  hipLaunchKernelGGL(paste_kernel, dim3(p.max_keep, B), dim3(256), 0, s, p);
+  return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
+}
+
+// ------------------------------------------------------------------------------------------- per-tile filter + mask-NMS
+// tools/infer_wsi.py:486-531: detections are visited in class-major order (np.concatenate of the per-class lists),
+// filtered by margin / min_area, ordered by np.argsort(score)[::-1] and greedily suppressed at mask IoU > thr.
+__global__ __launch_bounds__(256) void tile_post_kernel(TilePostParams p) {
+  __shared__ unsigned long long okey[2048];   // sort keys
+  __shared__ unsigned char sup[2048];
+  __shared__ int s_inter;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n = p.det_counts[b];
+  const int K = p.max_keep;
+  const float* dets = p.dets + (long long)b * K * 5;
+  const int* labels = p.labels + (long long)b * K;
+  const int* areas = p.areas + (long long)b * K;
+  unsigned char* keep = p.keep + (long long)b * K;
+  const int wpr = p.W >> 5, words = p.H * wpr;
+  int npad = 2; while (npad < n) npad <<= 1;
+  // class-major position of detection j: (#dets with smaller label) + (#dets with equal label before j)
+  for (int j = tid; j < npad; j += 256) {
+    unsigned long long key = ~0ull;
+    if (j < n) {
+      int pos = 0;
+      for (int i = 0; i < n; ++i) pos += (labels[i] < labels[j]) || (labels[i] == labels[j] && i < j);
+      const float* d = dets + j * 5;
+      const bool ok = d[0] >= (float)p.margin && d[1] >= (float)p.margin && d[2] <= (float)(p.W - p.margin) &&
+                      d[3] <= (float)(p.H - p.margin) && areas[j] >= p.min_area;
+      // order: score desc, ties by class-major position desc (reverse of a stable ascending argsort)
+      if (ok) key = ((unsigned long long)(~__float_as_uint(d[4])) << 32) | ((unsigned)(0xFFFF - pos) << 16) | (unsigned)j;
+    }
+    okey[j] = key;
+    sup[j] = 0;
+    if (j < n) keep[j] = 0;
+  }
+  __syncthreads();
+  for (int k = 2; k <= npad; k <<= 1)
+    for (int jj = k >> 1; jj > 0; jj >>= 1) {
+      for (int t = tid; t < (npad >> 1); t += 256) {
+        int lo = ((t / jj) * (jj << 1)) + (t % jj), hi = lo + jj;
+        bool asc = ((lo & k) == 0);
+        unsigned long long a = okey[lo], c = okey[hi];
+        if ((a > c) == asc) { okey[lo] = c; okey[hi] = a; }
+      }
+      __syncthreads();
+    }
+  int m = 0;   // number of candidates that passed the filter (keys != ~0)
+  for (int j = 0; j < n; ++j) if (okey[j] != ~0ull) m = j + 1;
+  const unsigned* masks = p.masks + (long long)b * K * words;
+  for (int a = 0; a < m; ++a) {
+    __syncthreads();
+    if (sup[a]) continue;
+    const int i = (int)(okey[a] & 0xFFFF);
+    if (tid == 0) keep[i] = 1;
+    const float* di = dets + i * 5;
+    const unsigned* mi = masks + (long long)i * words;
+    // rows/words where mask i can be non-zero: hull of its box
+    const int y0 = max((int)floorf(di[1]) - 1, 0), y1 = min((int)ceilf(di[3]) + 1, p.H);
+    for (int c = a + 1; c < m; ++c) {
+      if (sup[c]) continue;   // uniform: sup[] only changes between barriers
+      const int j = (int)(okey[c] & 0xFFFF);
+      const float* dj = dets + j * 5;
+      // masks live inside their box hulls: no overlap of hulls -> IoU 0
+      const bool ov = fminf(di[2], dj[2]) + 2.f > fmaxf(di[0], dj[0]) - 2.f && fminf(di[3], dj[3]) + 2.f > fmaxf(di[1], dj[1]) - 2.f;
+      if (!ov) continue;
+      if (tid == 0) s_inter = 0;
+      __syncthreads();
+      const unsigned* mj = masks + (long long)j * words;
+      int cnt = 0;
+      for (int wv = y0 * wpr + tid; wv < y1 * wpr; wv += 256) cnt += __popc(mi[wv] & mj[wv]);
+      cnt = (int)wsum64((float)cnt);
+      if ((tid & 63) == 0 && cnt) atomicAdd(&s_inter, cnt);
+      __syncthreads();
+      if (tid == 0) {
+        const int inter = s_inter;
+        const int uni = areas[i] + areas[j] - inter;
+        if (uni > 0 && (double)inter / (double)uni > p.thr) sup[c] = 1;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+int launch_tile_post(const TilePostParams& p, int B, hipStream_t s) {
+  if (p.max_keep > 2048) return NUHTC_E_INVALID;
+  hipLaunchKernelGGL(tile_post_kernel, dim3(B), dim3(256), 0, s, p);
+  return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
+}

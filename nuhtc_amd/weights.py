@@ -126,6 +126,18 @@ def seeded_state_dict(seed=0, num_classes=5, gain=1.0):
             relu_stack = name.startswith(('neck.', 'rpn_head.', 'roi_head.'))
             g = 2.0 if relu_stack else 1.0
             v = v * (gain * (g / _fan_in(name, shape)) ** 0.5)
+        # keep box regression well-conditioned like a trained model (|delta| < ~1): otherwise proposals blow up to
+        # tile-sized boxes and fp32 rounding differences are amplified through the cascade
+        # (and keep objectness logits out of sigmoid saturation: exact score ties are ordered by an unstable sort
+        # in the reference, which no re-implementation can reproduce)
+        if name.endswith('rpn_cls.weight'):
+            v = v * 0.2
+        elif name.endswith('rpn_reg.weight'):
+            v = v * 0.03
+        elif name.endswith('rpn_reg.bias'):
+            v = v * 0.5
+        elif name.endswith('fc_reg.weight'):
+            v = v * 0.02
         sd[name] = v
     # make the synthetic model produce work for every stage: positive semantic logit bias (foreground
     # blobs for the connected-component proposals) is tuned in tests via `bias_overrides`

@@ -137,7 +137,7 @@ def run_case(name, tile_size, n_tiles, seed, channel_mode):
     if 'mask' in cap:
         inp, out = cap['mask'][0]
         put(g, 'mask_feats', inp[0])
-        g['mask_logits'] = out[0].numpy().astype(np.float32)
+        put(g, 'mask_logits', out[0])
     for i, (br, sr) in enumerate(results):
         g[f'det{i}'] = np.concatenate(br, 0).astype(np.float32)
         g[f'lab{i}'] = np.concatenate([np.full(len(b), c, np.int32) for c, b in enumerate(br)])

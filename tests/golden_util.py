@@ -44,3 +44,14 @@ def canon_rows(d):
         return d
     key = np.lexsort((d[:, 3], d[:, 2], d[:, 1], d[:, 0], -d[:, 4]))
     return d[key]
+
+
+def check_prob_vs_logits(g, name, prob, atol=1e-6):
+    """sigmoid(stored logit subsample) vs the same subsample of a probability tensor."""
+    a = prob.detach().cpu().numpy() if isinstance(prob, torch.Tensor) else np.asarray(prob)
+    assert tuple(a.shape) == tuple(g[name + '.shape']), (name, a.shape, g[name + '.shape'])
+    got = a.reshape(-1)[::int(g[name + '.stride'])]
+    ref = 1.0 / (1.0 + np.exp(-g[name + '.sample'].astype(np.float64)))
+    err = np.abs(got - ref).max() if got.size else 0.0
+    assert err <= atol, f'{name}: max prob err {err:.3e}'
+    return float(err)

@@ -61,8 +61,7 @@ def test_cascade(run):
 
 def test_detections_and_masks(run):
     g, res, it, _ = run
-    prob_ref = 1.0 / (1.0 + np.exp(-g['mask_logits'].astype(np.float64)))
-    np.testing.assert_allclose(it['mask_prob'].numpy(), prob_ref, rtol=0, atol=1e-6)
+    G.check_prob_vs_logits(g, 'mask_logits', it['mask_prob'], atol=1e-6)
     for i, (br, sr) in enumerate(res):
         det = np.concatenate(br, 0)
         lab = np.concatenate([np.full(len(b), c, np.int32) for c, b in enumerate(br)])
