@@ -1,0 +1,144 @@
+#!/usr/bin/env python
+"""Headline benchmark: 256x256 tiles/s of the htc_lite_swin tile-inference path (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 16]
+
+One step = one nuhtc_infer call on one batch of `--batch` synthetic 256x256x3 tiles already resident in HBM
+(the full path: pre-processing, Swin-T, FPN, RPN, proposals, 3-stage cascade, detection NMS, mask head, paste,
+per-tile mask-NMS).  Workload = BASELINE.json configs[1] ("PanNuke fold1 batch_size=16 256x256 tiles, 1xMI355X")
+with seeded synthetic weights (models/pannuke.pth is not distributed) and synthetic nuclei tiles.
+With N > 1 (launched by torch.distributed.run, one rank per GPU) tiles are sharded across ranks (weak scaling:
+every rank processes its own batches, no data-path collective); the per-tile detection records of the last step
+are all-gathered once over RCCL, as the WSI path does before the host-side merge.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+DOMINANT = 'gemm_kernel<3>'      # all Swin-T linears (N % 96 == 0): 96 % of the path's FLOPs
+
+
+def cpu_baseline(sd, tiles, n):
+    """Oracle (CPU restatement of the reference path, oracle/model.py) timed on the host cores: reported next to
+    the GPU number, never the thing shipped."""
+    from oracle import model as O
+    orc = O.Oracle(sd)
+    threads = torch.get_num_threads()
+    orc(tiles[:1], 1)  # warm-up (builds oracle/libnuhtc_oracle.so on first use)
+    t0 = time.perf_counter()
+    orc(tiles[:n], 1)
+    dt = time.perf_counter() - t0
+    return dict(value=n / dt, unit='tiles/s', cores=threads, kind='port',
+                sample=f'{n} synthetic nuclei tiles, one batch, oracle/model.py fp32 torch-cpu + C RoIAlign/NMS, {dt:.1f} s')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=16)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-tiles', type=int, default=8)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)')
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    from nuhtc_amd import hip, synth, weights
+    from nuhtc_amd.engine import Engine
+    torch.cuda.set_device(local_rank)
+    sd = weights.bench_state_dict()
+    eng = Engine(sd, device=local_rank, max_batch=args.batch, tile=(256, 256))
+    B = args.batch
+    # every rank gets its own tiles (tile index space sharded contiguously across ranks)
+    tiles_np = synth.nuclei_tiles(B, 256, start=rank * B)
+    tiles = eng.to_device(tiles_np)
+    mode = hip.CH_SWAP   # tools/infer_wsi.py channel handling
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.infer_async(tiles, mode)
+    eng.check()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.infer_async(tiles, mode)
+    if dist is not None:
+        # one gather of the per-tile detection records (boxes, labels, counts, keep flags) for the host-side merge
+        rec = torch.cat([eng.boxes.reshape(B, -1), eng.labels.float(), eng.keep.float(), eng.counts.float()[:, None]], 1)
+        gathered = [torch.empty_like(rec) for _ in range(world)]
+        dist.all_gather(gathered, rec)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    eng.check()
+    total_tiles = args.steps * B * world
+    counts = eng.counts[:B].cpu().numpy()
+    roi_counts = eng.buffer('roi_counts')[:B].cpu().numpy()
+
+    # live per-kernel timing (HIP events on the launch stream) over the same workload, separate steps so the
+    # event records do not perturb the headline number
+    hip.profile_enable(True)
+    prof_steps = max(2, min(5, args.steps))
+    for _ in range(prof_steps):
+        eng.infer_async(tiles, mode)
+    prof = hip.profile_read()
+    hip.profile_enable(False)
+    dom = prof[DOMINANT]
+    dur_ms = dom['ms'] / dom['launches']
+    achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
+    tot_ms = sum(v['ms'] for v in prof.values())
+    breakdown = {k: round(v['ms'] / prof_steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])}
+
+    if rank == 0:
+        out = {
+            'metric': 'tiles/sec (256x256) whole-node', 'value': total_tiles / dt, 'unit': 'tiles/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'htc_lite_swin PanNuke config, batch_size=16 256x256 tiles per GPU (BASELINE configs[1]), full path '
+                                   'incl. proposals, cascade, masks, per-tile mask-NMS', 'batch_per_gpu': B,
+                       'weights': 'seeded synthetic (weights.bench_state_dict); pannuke.pth not distributed',
+                       'tiles': 'synthetic nuclei tiles (nuhtc_amd.synth), resident in HBM',
+                       'mean_rois_per_tile': float(roi_counts.mean()), 'mean_dets_per_tile': float(counts.mean())},
+            'roofline': {'bound': 'mfma', 'kernel': DOMINANT + ' (Swin-T linears, fp32 v_mfma_f32_32x32x2_f32)', 'achieved': achieved,
+                         'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                         'avg_launch_ms': dur_ms, 'launches_per_step': dom['launches'] // prof_steps,
+                         'share_of_step_kernel_time': dom['ms'] / tot_ms},
+            'kernel_ms_per_step': breakdown,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(sd, tiles_np, min(args.cpu_tiles, B))
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -140,6 +140,12 @@ int nuhtc_op_roi_align(nuhtc_engine* e, const float* feat_nhwc, int N, int H, in
 int nuhtc_op_nms(nuhtc_engine* e, const float* boxes, const float* scores, int n, float iou_thr, int32_t* keep_idx,
                  int32_t* count_dev, void* stream);
 
+/* Per-kernel timing with HIP events recorded on the launch stream (process-wide switch; off by default).
+ * nuhtc_profile_read synchronises the device and writes one text line per kernel tag,
+ * "tag launches total_ms algorithmic_flops algorithmic_bytes", then resets the records. */
+int nuhtc_profile_enable(int on);
+int nuhtc_profile_read(char* buf, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,15 @@ struct EngineError {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// per-kernel HIP-event timing (prof.hip); `tag` must be a string literal
+struct ProfScope {
+  ProfScope(const char* tag, double flops, double bytes, hipStream_t s);
+  ~ProfScope();
+  hipStream_t s_;
+  int idx_;
+};
+bool prof_enabled();
+
 // ----------------------------------------------------------------------------- GEMM (gemm.hip)
 // C[row_map(m), n] = epilogue( sum_k A(m,k) * W[n,k] )      fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32
 enum AMode { A_PLAIN = 0, A_CONV3 = 1 };

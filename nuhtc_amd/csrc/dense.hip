@@ -44,6 +44,7 @@ __global__ void sem_fuse_kernel(const float* __restrict__ g0, const float* __res
 
 int launch_sem_fuse(const float* g0, const float* g1, const float* g2, const float* g3, float* out, int B, int H, int W,
                     hipStream_t s) {
+  ProfScope ps("sem_fuse", 0, 4.0 * 64 * B * H * W * 2.33, s);
   long long total = (long long)B * H * W * 16;
   hipLaunchKernelGGL(sem_fuse_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g0, g1, g2, g3, out, B, H, W);
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;

@@ -198,6 +198,10 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
   dim3 grid(cdiv(p.M, BM) * (p.N / bn), 1, p.batch > 0 ? p.batch : 1);
   GemmParams q = p;
   if (q.alpha == 0.f) q.alpha = 1.f;
+  static const char* tags[5] = {"", "gemm_kernel<1>", "gemm_kernel<2>", "gemm_kernel<3>", "gemm_kernel<4>"};
+  const double nb = p.batch > 0 ? p.batch : 1;
+  // algorithmic work of the launch (device-side row counts are not known here: the capacity M is an upper bound)
+  ProfScope ps(tags[nt], 2.0 * p.M * p.N * p.K * nb, 4.0 * nb * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N), s);
   switch (nt) {
     case 1: hipLaunchKernelGGL(gemm_kernel<1>, grid, dim3(256), 0, s, q); break;
     case 2: hipLaunchKernelGGL(gemm_kernel<2>, grid, dim3(256), 0, s, q); break;

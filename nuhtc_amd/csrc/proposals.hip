@@ -179,6 +179,7 @@ __global__ __launch_bounds__(1024) void rpn_level_kernel(RpnLevels lv, RpnSelPar
 }
 
 int launch_rpn_select(const RpnLevels& lv, const RpnSelParams& p, int B, hipStream_t s) {
+  ProfScope ps("rpn_select", 0, 0, s);
   if (p.nms_pre > 4096 || p.slot < p.nms_pre) return NUHTC_E_INVALID;
   hipLaunchKernelGGL(rpn_level_kernel, dim3(B, 4), dim3(1024), 0, s, lv, p);
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
@@ -331,6 +332,7 @@ __global__ __launch_bounds__(256) void nms_reduce_kernel(NmsParams p) {
 // rows of `mask` that nms_mask_kernel never writes must read as zero: words cb < rb are unused by the reduce (it only
 // reads words >= its chunk), words beyond n likewise; so no clearing pass is needed.
 int launch_nms(const NmsParams& p, int B, hipStream_t s) {
+  ProfScope ps("nms", 0, 0, s);
   if (p.cap % 64 || p.cap > NMS_MAX_CAP || p.n_groups > NMS_MAX_GROUPS) return NUHTC_E_INVALID;
   size_t lds = (size_t)p.cap_pow2 * sizeof(u64);
   hipLaunchKernelGGL(nms_prepare_kernel, dim3(B), dim3(1024), lds, s, p);
@@ -522,6 +524,7 @@ __global__ __launch_bounds__(1024) void cc_emit_kernel(const int* __restrict__ l
 }
 
 int launch_cc_proposals(const CcParams& p, int B, hipStream_t s) {
+  ProfScope ps("cc_proposals", 0, 0, s);
   const int H = p.img_h, W = p.img_w, HW = H * W;
   const long long total = (long long)B * HW;
   const unsigned nb = (unsigned)((total + 255) / 256);

@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256) void attn_pool_kernel(const float* __restrict_
 }
 
 int launch_attn_pool(const float* F, float* G, int B, int HW, float tau, hipStream_t s) {
+  ProfScope ps("attn_pool", 4.0 * 64 * (double)HW * HW * B, 0, s);
   hipLaunchKernelGGL(attn_pool_kernel, dim3(HW, B), dim3(256), 0, s, F, G, HW, tau);
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
 }
@@ -197,6 +198,7 @@ __global__ __launch_bounds__(256) void roi_feat_kernel(RoiFeatParams p) {
 }
 
 int launch_roi_feat(const RoiFeatParams& p, int P, int r_cap, hipStream_t s) {
+  ProfScope ps("roi_feat", 0, 0, s);
   if (r_cap <= 0) return 0;
   if (P == 7) hipLaunchKernelGGL(roi_feat_kernel<7>, dim3(cdiv(r_cap, 4)), dim3(256), 0, s, p);
   else if (P == 14) hipLaunchKernelGGL(roi_feat_kernel<14>, dim3(cdiv(r_cap, 4)), dim3(256), 0, s, p);
@@ -276,6 +278,7 @@ __global__ __launch_bounds__(256) void bbox_tail_kernel(BboxTailParams p) {
 }
 
 int launch_bbox_tail(const BboxTailParams& p, int r_cap, hipStream_t s) {
+  ProfScope ps("bbox_tail", 0, 0, s);
   if (p.nc + 6 > 64) return NUHTC_E_INVALID;
   hipLaunchKernelGGL(bbox_tail_kernel, dim3(cdiv(r_cap, 4)), dim3(256), 0, s, p);
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
@@ -360,6 +363,7 @@ __global__ __launch_bounds__(1024) void det_candidates_kernel(DetCandParams p) {
 }
 
 int launch_det_candidates(const DetCandParams& p, int B, hipStream_t s) {
+  ProfScope ps("det_candidates", 0, 0, s);
   if (p.nc + 2 > 16) return NUHTC_E_INVALID;
   hipLaunchKernelGGL(det_candidates_kernel, dim3(B), dim3(1024), 0, s, p);
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
@@ -457,6 +461,7 @@ __global__ __launch_bounds__(256) void paste_kernel(PasteParams p) {
 }
 
 int launch_paste(const PasteParams& p, int B, hipStream_t s) {
+  ProfScope ps("paste", 0, 0, s);
   hipLaunchKernelGGL(paste_kernel, dim3(p.max_keep, B), dim3(256), 0, s, p);
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
 }
@@ -542,6 +547,7 @@ __global__ __launch_bounds__(256) void tile_post_kernel(TilePostParams p) {
 }
 
 int launch_tile_post(const TilePostParams& p, int B, hipStream_t s) {
+  ProfScope ps("tile_post", 0, 0, s);
   if (p.max_keep > 2048) return NUHTC_E_INVALID;
   hipLaunchKernelGGL(tile_post_kernel, dim3(B), dim3(256), 0, s, p);
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;

@@ -46,6 +46,7 @@ __global__ void preproc_kernel(const uint8_t* __restrict__ tiles, float* __restr
 }
 
 int launch_preproc(const uint8_t* tiles, float* img, int B, int th, int tw, int swap, const float* mean_istd, hipStream_t s) {
+  ProfScope ps("preproc", 0, (double)B * th * tw * (3.0 + 48.0), s);
   NormConst nc;
   for (int i = 0; i < 3; ++i) { nc.mean[i] = mean_istd[i]; nc.istd[i] = mean_istd[3 + i]; }
   long long total = (long long)B * 4 * th * tw;
@@ -108,6 +109,7 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
 
 int launch_patch_embed(const float* img, const float* w, const float* b, const float* g, const float* beta, float* tok, int B,
                        int Hn, int Wn, hipStream_t s) {
+  ProfScope ps("patch_embed", 2.0 * 48 * 96 * B * (Hn / 4) * (Wn / 4), 4.0 * B * Hn * Wn * 3 + 4.0 * 96 * B * (Hn / 4) * (Wn / 4), s);
   int nTok = B * (Hn / 4) * (Wn / 4);
   hipLaunchKernelGGL(patch_embed_kernel, dim3(cdiv(nTok, 32)), dim3(256), 0, s, img, w, b, g, beta, tok, nTok, Hn, Wn);
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
@@ -149,6 +151,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 int launch_layernorm(const float* x, const int* src_map, const float* g, const float* b, float* y, int rows, int C, hipStream_t s) {
+  ProfScope ps("layernorm", 0, 8.0 * rows * C, s);
   if (rows <= 0) return 0;
   dim3 grid(cdiv(rows, 4)), blk(256);
   int nv = cdiv(C, 64);
@@ -192,6 +195,7 @@ __global__ __launch_bounds__(256) void merge_ln_kernel(const float* __restrict__
 }
 
 int launch_merge_ln(const float* x, const float* g, const float* b, float* y, int B, int H, int W, int C, hipStream_t s) {
+  ProfScope ps("merge_ln", 0, 8.0 * B * H * W * C, s);
   int rows = B * (H / 2) * (W / 2);
   dim3 grid(cdiv(rows, 4)), blk(256);
   int nv = 4 * C / 64;
@@ -276,6 +280,7 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const float* __restric
 
 int launch_window_attn(const float* qkv, const float* bias, const float* mask, float* out, int nWinTotal, int nWperImg, int C,
                        int nH, hipStream_t s) {
+  ProfScope ps("window_attn", 4.0 * 49 * 49 * 32 * nWinTotal * nH, 16.0 * 49 * C * nWinTotal, s);
   int nPairs = nWinTotal * nH;
   if (nPairs <= 0) return 0;
   hipLaunchKernelGGL(window_attn_kernel, dim3(cdiv(nPairs, 4)), dim3(256), 0, s, qkv, bias, mask, out, nPairs, nWperImg, C, nH);

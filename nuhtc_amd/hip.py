@@ -35,7 +35,7 @@ class Dets(ctypes.Structure):
 
 EXPORTS = ['nuhtc_default_config', 'nuhtc_create', 'nuhtc_destroy', 'nuhtc_last_error', 'nuhtc_load_weight',
            'nuhtc_finalize', 'nuhtc_infer', 'nuhtc_infer_fixed_load', 'nuhtc_check', 'nuhtc_get_buffer',
-           'nuhtc_op_gemm', 'nuhtc_op_roi_align', 'nuhtc_op_nms']
+           'nuhtc_op_gemm', 'nuhtc_op_roi_align', 'nuhtc_op_nms', 'nuhtc_profile_enable', 'nuhtc_profile_read']
 
 _lib = None
 
@@ -66,6 +66,8 @@ def load():
     lib.nuhtc_op_gemm.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
     lib.nuhtc_op_roi_align.argtypes = [vp, vp, ci, ci, ci, vp, ci, ci, cf, ci, vp, vp]
     lib.nuhtc_op_nms.argtypes = [vp, vp, vp, ci, cf, vp, vp, vp]
+    lib.nuhtc_profile_enable.argtypes = [ci]
+    lib.nuhtc_profile_read.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is ctypes.c_int or name not in ('nuhtc_default_config', 'nuhtc_destroy', 'nuhtc_last_error'):
@@ -81,3 +83,20 @@ def default_config():
     cfg = Config()
     load().nuhtc_default_config(ctypes.byref(cfg))
     return cfg
+
+
+def profile_enable(on=True):
+    load().nuhtc_profile_enable(1 if on else 0)
+
+
+def profile_read():
+    """{tag: dict(launches, ms, flops, bytes)} of the kernels launched since profile_enable / the last read."""
+    buf = ctypes.create_string_buffer(1 << 16)
+    rc = load().nuhtc_profile_read(buf, len(buf))
+    if rc:
+        raise RuntimeError(f'nuhtc_profile_read failed ({rc})')
+    out = {}
+    for line in buf.value.decode().splitlines():
+        tag, n, ms, fl, by = line.rsplit(' ', 4)
+        out[tag] = dict(launches=int(n), ms=float(ms), flops=float(fl), bytes=float(by))
+    return out

@@ -176,3 +176,15 @@ def load_checkpoint(path, num_classes=5):
             raise ValueError(f'{name}: checkpoint shape {tuple(t.shape)} != expected {tuple(shape)}')
         sd[name] = t
     return sd
+
+
+def bench_state_dict(seed=0, num_classes=5):
+    """Synthetic weights for bench.py / smoke(): seeded_state_dict plus fixed offsets that give every stage a
+    realistic load (two classes around the 0.35 score threshold, ~30 % semantic foreground), like the goldens."""
+    sd = seeded_state_dict(seed, num_classes)
+    add = torch.zeros(num_classes + 2)
+    add[:2] = 1.2
+    add[-2] = 3.0
+    for k in range(3):
+        sd[f'roi_head.bbox_head.{k}.fc_cls.bias'] = sd[f'roi_head.bbox_head.{k}.fc_cls.bias'] + add
+    return sd
