@@ -1,0 +1,133 @@
+"""Drop-in mirror of the reference's inference API:
+
+    init_detector(config, checkpoint=None, device='cuda:0', cfg_options=None)   nuhtc/apis/inference.py:11-57
+    inference_detector(model, imgs)                                             mmdet/apis/inference.py:90-153
+
+Same names, argument meaning and result format — `(bbox_results, segm_results)` per image with per-class (k,5) float32
+arrays in original-tile pixels and per-class lists of (H,W) bool masks.  Everything between the uint8 pixels and
+those results runs in libnuhtc_hip.so on the MI355X; there is no CPU path (device='cpu' is an error).
+"""
+import warnings
+
+import numpy as np
+
+from . import hip, weights
+from .config import Config, engine_options, patch_config
+
+
+class Detector:
+    """Stands in for the nn.Module `init_detector` returns: callers set `.CLASSES` and read `.cfg`
+    (tools/infer.py:49, tools/infer_wsi.py:424-428)."""
+
+    def __init__(self, cfg, state_dict, device, max_batch=16, max_cc_proposals=512):
+        self.cfg = cfg
+        self.state_dict = state_dict
+        self.device = device
+        self.max_batch = max_batch
+        self.max_cc_proposals = max_cc_proposals
+        self.opts = engine_options(cfg)
+        self.CLASSES = tuple(str(i) for i in range(self.opts['num_classes']))
+        self._engines = {}
+
+    def engine(self, tile_hw):
+        from .engine import Engine
+        key = (int(tile_hw[0]), int(tile_hw[1]))
+        if key not in self._engines:
+            opts = dict(self.opts)
+            nc = opts.pop('num_classes')
+            self._engines[key] = Engine(self.state_dict, device=self.device, max_batch=self.max_batch, tile=key, num_classes=nc,
+                                        max_cc_proposals=self.max_cc_proposals, **opts)
+        return self._engines[key]
+
+    def eval(self):
+        return self
+
+
+def _device_index(device):
+    d = str(device)
+    if d == 'cpu' or d.startswith('cpu'):
+        raise ValueError("nuhtc_amd has no CPU path: device must be 'cuda:N' (an MI355X). The CPU oracle under oracle/ is test infrastructure only.")
+    if d == 'cuda':
+        return 0
+    if d.startswith('cuda:'):
+        return int(d.split(':')[1])
+    raise ValueError(f'unsupported device {device!r}')
+
+
+def init_detector(config, checkpoint=None, device='cuda:0', cfg_options=None, max_batch=16):
+    if isinstance(config, str):
+        config = Config.fromfile(config)
+    elif not isinstance(config, dict):
+        raise TypeError(f'config must be a filename or Config object, but got {type(config)}')
+    if cfg_options is not None:
+        config.merge_from_dict(cfg_options)
+    config = patch_config(config)
+    if 'pretrained' in config.model:
+        config.model.pretrained = None
+    config.model.train_cfg = None
+    dev = _device_index(device)
+    opts = engine_options(config)   # validates the model description before touching the GPU
+    if checkpoint is not None:
+        sd = weights.load_checkpoint(checkpoint, opts['num_classes'])
+    else:
+        warnings.warn('init_detector called without a checkpoint: using seeded synthetic weights (the reference would keep its random init)')
+        sd = weights.seeded_state_dict(0, opts['num_classes'])
+    model = Detector(config, sd, dev, max_batch=max_batch)
+    return model
+
+
+def _load_image_rgb(path):
+    from PIL import Image
+    return np.asarray(Image.open(path).convert('RGB'))
+
+
+def inference_detector(model, imgs):
+    """imgs: str | ndarray | list of either.  File paths follow tools/infer.py (mmcv.imread BGR -> to_rgb: the network
+    sees true RGB); ndarrays follow the LoadImageFromWebcam branch (mmdet/apis/inference.py:112-115): the array is
+    taken as BGR and channel-swapped before normalisation, whatever it really holds."""
+    is_batch = isinstance(imgs, (list, tuple))
+    if not is_batch:
+        imgs = [imgs]
+    if len(imgs) == 0:
+        return []
+    if isinstance(imgs[0], np.ndarray):
+        arrs, mode = [np.asarray(i) for i in imgs], hip.CH_SWAP
+    else:
+        arrs, mode = [_load_image_rgb(p) for p in imgs], hip.CH_AS_IS
+    shapes = {a.shape for a in arrs}
+    if len(shapes) != 1:
+        raise ValueError(f'all images of one inference_detector call must share one size, got {sorted(shapes)}')
+    if arrs[0].ndim != 3 or arrs[0].shape[2] != 3 or arrs[0].dtype != np.uint8:
+        raise ValueError('images must be uint8 HxWx3')
+    eng = model.engine(arrs[0].shape[:2])
+    results = eng(np.stack(arrs), mode)
+    return results if is_batch else results[0]
+
+
+def concat_results(result):
+    """tools/infer_wsi.py:486-494: per-class lists -> flat arrays (class-major order)."""
+    bbox, segm = result
+    boxes = np.concatenate(bbox, 0) if len(bbox) else np.zeros((0, 5), np.float32)
+    labels = np.concatenate([np.full(len(b), c, np.int32) for c, b in enumerate(bbox)]) if len(bbox) else np.zeros(0, np.int32)
+    masks = [m for cl in segm for m in cl]
+    return boxes, labels, (np.stack(masks) if masks else np.zeros((0, 0, 0), bool))
+
+
+def save_result(model, img, result, score_thr=0.3, out_file=None, **kw):
+    """nuhtc/apis/inference.py:60-82 (matplotlib overlay in the reference): writes a plain mask/box overlay PNG."""
+    from PIL import Image, ImageDraw
+    arr = _load_image_rgb(img) if isinstance(img, str) else np.asarray(img)
+    boxes, labels, masks = concat_results(result)
+    out = arr.astype(np.float32).copy()
+    palette = np.array([[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 0], [255, 0, 255], [0, 255, 255]], np.float32)
+    for b, l, m in zip(boxes, labels, masks):
+        if b[4] >= score_thr:
+            out[m] = 0.5 * out[m] + 0.5 * palette[l % len(palette)]
+    im = Image.fromarray(out.clip(0, 255).astype(np.uint8))
+    dr = ImageDraw.Draw(im)
+    for b, l in zip(boxes, labels):
+        if b[4] >= score_thr:
+            dr.rectangle([float(b[0]), float(b[1]), float(b[2]), float(b[3])], outline=tuple(int(v) for v in palette[l % len(palette)]))
+    if out_file:
+        im.save(out_file)
+    return im

@@ -1,0 +1,110 @@
+"""Host side of the whole-slide path (tools/infer_wsi.py:460-531 + tools/nuclei_merge.py:62-174).
+
+Tile contract of the reference (`Whole_Slide_Bag_FP`, tools/wsi_core/WholeSlideImage.py:832-898): RGB uint8
+(patch, patch, 3) tiles with their level-0 (x, y) origin; grid = np.arange(start, stop, step) (:460-466).
+OpenSlide / h5py are not available offline, so tiles come from arrays (`tile_grid` over an in-memory image, or a
+.npz with `tiles` + `coords`)."""
+import numpy as np
+
+from . import hip
+
+
+def tile_grid(image, patch_size=256, step_size=192):
+    """Grid tiling with zero padding past the edge (use_padding=True, WholeSlideImage.py:419-421,463-464)."""
+    H, W = image.shape[:2]
+    xs = np.arange(0, W, step_size)
+    ys = np.arange(0, H, step_size)
+    tiles, coords = [], []
+    for y in ys:
+        for x in xs:
+            t = np.zeros((patch_size, patch_size, 3), np.uint8)
+            sub = image[y:y + patch_size, x:x + patch_size]
+            t[:sub.shape[0], :sub.shape[1]] = sub
+            tiles.append(t)
+            coords.append((x, y))
+    return np.stack(tiles), np.array(coords, np.int64)
+
+
+def infer_tiles(model, tiles, coords, batch_size=16):
+    """Run the engine over `tiles` (N,P,P,3) and return per-detection records that survive the per-tile margin /
+    min-area filter + mask-NMS (computed on the GPU, tools/infer_wsi.py:510-531), in slide coordinates.
+
+    Returns dict(tile, box (n,4) float64 slide px, score, label, mask (list of (bool crop, x0, y0)))."""
+    eng = model.engine(tiles.shape[1:3])
+    P = tiles.shape[1]
+    rec = dict(tile=[], box=[], score=[], label=[], mask=[])
+    for i in range(0, len(tiles), batch_size):
+        chunk = tiles[i:i + batch_size]
+        B = eng.infer_async(eng.to_device(chunk), hip.CH_SWAP)
+        eng.check()
+        counts = eng.counts[:B].cpu().numpy()
+        boxes = eng.boxes[:B].cpu().numpy()
+        labels = eng.labels[:B].cpu().numpy()
+        keep = eng.keep[:B].cpu().numpy()
+        for b in range(B):
+            n = int(counts[b])
+            idx = np.nonzero(keep[b, :n])[0]
+            if len(idx) == 0:
+                continue
+            # class-major order like np.concatenate(result[0]) in the reference, then score order from mask_nms
+            order = idx[np.lexsort((idx, labels[b, idx]))]
+            order = order[np.argsort(boxes[b, order, 4], kind='stable')[::-1]]
+            words = eng.masks[b, order].cpu().numpy().view(np.uint32)
+            bits = np.unpackbits(words.view(np.uint8).reshape(len(order), P, P // 8), axis=-1, bitorder='little').astype(bool)
+            ox, oy = int(coords[i + b][0]), int(coords[i + b][1])
+            for k, j in enumerate(order):
+                ys, xs = np.nonzero(bits[k])
+                if len(ys) == 0:
+                    continue
+                y0, y1, x0, x1 = ys.min(), ys.max() + 1, xs.min(), xs.max() + 1
+                rec['tile'].append(i + b)
+                rec['box'].append(boxes[b, j, :4].astype(np.float64) + np.array([ox, oy, ox, oy]))
+                rec['score'].append(float(boxes[b, j, 4]))
+                rec['label'].append(int(labels[b, j]))
+                rec['mask'].append((bits[k, y0:y1, x0:x1].copy(), ox + int(x0), oy + int(y0)))
+    return rec
+
+
+def merge_overlap(rec, overlap_threshold=0.05):
+    """Cross-tile duplicate removal, strategy 'probability' of tools/nuclei_merge.py:62-174: detections sorted by
+    score (descending), each still-alive one suppresses every later one it overlaps with IoU > threshold.
+    The reference intersects shapely polygons of the cv2 contours; here IoU is taken on the pixel masks the
+    polygons are traced from (same objects, pixel-area instead of polygon-area IoU).  Returns kept indices."""
+    n = len(rec['score'])
+    if n == 0:
+        return np.zeros(0, np.int64)
+    order = np.argsort(-np.asarray(rec['score']), kind='stable')
+    boxes = np.array([[m[1], m[2], m[1] + m[0].shape[1], m[2] + m[0].shape[0]] for m in rec['mask']], np.int64)
+    cell = 64
+    grid = {}
+    for i in range(n):
+        for cy in range(boxes[i, 1] // cell, (boxes[i, 3] - 1) // cell + 1):
+            for cx in range(boxes[i, 0] // cell, (boxes[i, 2] - 1) // cell + 1):
+                grid.setdefault((cx, cy), []).append(i)
+    alive = np.ones(n, bool)
+    visited = np.zeros(n, bool)
+    keep = []
+    for q in order:
+        if visited[q]:
+            continue
+        visited[q] = True
+        keep.append(q)
+        mq, qx, qy = rec['mask'][q]
+        cands = set()
+        for cy in range(boxes[q, 1] // cell, (boxes[q, 3] - 1) // cell + 1):
+            for cx in range(boxes[q, 0] // cell, (boxes[q, 2] - 1) // cell + 1):
+                cands.update(grid.get((cx, cy), ()))
+        for c in cands:
+            if visited[c]:
+                continue
+            x0, y0 = max(boxes[q, 0], boxes[c, 0]), max(boxes[q, 1], boxes[c, 1])
+            x1, y1 = min(boxes[q, 2], boxes[c, 2]), min(boxes[q, 3], boxes[c, 3])
+            if x1 <= x0 or y1 <= y0:
+                continue
+            mc, cx0, cy0 = rec['mask'][c]
+            inter = int(np.logical_and(mq[y0 - qy:y1 - qy, x0 - qx:x1 - qx], mc[y0 - cy0:y1 - cy0, x0 - cx0:x1 - cx0]).sum())
+            union = int(mq.sum()) + int(mc.sum()) - inter
+            if union > 0 and inter / union > overlap_threshold:
+                visited[c] = True
+                alive[c] = False
+    return np.array(sorted(keep), np.int64)

