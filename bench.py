@@ -109,8 +109,16 @@ def main():
     prof_steps = max(2, min(5, args.steps))
     for _ in range(prof_steps):
         eng.infer_async(tiles, mode)
-    prof = hip.profile_read()
+    prof_raw = hip.profile_read()
     hip.profile_enable(False)
+    prof, shapes = {}, {}
+    for tag, v in prof_raw.items():          # GEMM tags carry the shape: "gemm_kernel<3>|N288|K96"
+        k = tag.split('|')[0]
+        a = prof.setdefault(k, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+        for f in a:
+            a[f] += v[f]
+        if '|' in tag:
+            shapes[tag] = dict(ms_per_step=round(v['ms'] / prof_steps, 3), tflops=round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1))
     dom = prof[DOMINANT]
     dur_ms = dom['ms'] / dom['launches']
     achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
@@ -132,6 +140,7 @@ def main():
                          'avg_launch_ms': dur_ms, 'launches_per_step': dom['launches'] // prof_steps,
                          'share_of_step_kernel_time': dom['ms'] / tot_ms},
             'kernel_ms_per_step': breakdown,
+            'gemm_shapes': shapes,
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(sd, tiles_np, min(args.cpu_tiles, B))

@@ -198,10 +198,18 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
   dim3 grid(cdiv(p.M, BM) * (p.N / bn), 1, p.batch > 0 ? p.batch : 1);
   GemmParams q = p;
   if (q.alpha == 0.f) q.alpha = 1.f;
-  static const char* tags[5] = {"", "gemm_kernel<1>", "gemm_kernel<2>", "gemm_kernel<3>", "gemm_kernel<4>"};
   const double nb = p.batch > 0 ? p.batch : 1;
+  const char* tag = "gemm";
+  if (prof_enabled()) {   // per-shape tags, e.g. "gemm_kernel<3>|N288|K96" (strings live for the process lifetime)
+    static std::map<long long, std::string> names;
+    long long key = ((long long)nt << 40) | ((long long)p.N << 20) | p.K | ((long long)(p.amode == A_CONV3) << 44);
+    auto it = names.find(key);
+    if (it == names.end())
+      it = names.emplace(key, "gemm_kernel<" + std::to_string(nt) + ">|N" + std::to_string(p.N) + "|K" + std::to_string(p.K) + (p.amode == A_CONV3 ? "|conv3" : "")).first;
+    tag = it->second.c_str();
+  }
   // algorithmic work of the launch (device-side row counts are not known here: the capacity M is an upper bound)
-  ProfScope ps(tags[nt], 2.0 * p.M * p.N * p.K * nb, 4.0 * nb * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N), s);
+  ProfScope ps(tag, 2.0 * p.M * p.N * p.K * nb, 4.0 * nb * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N), s);
   switch (nt) {
     case 1: hipLaunchKernelGGL(gemm_kernel<1>, grid, dim3(256), 0, s, q); break;
     case 2: hipLaunchKernelGGL(gemm_kernel<2>, grid, dim3(256), 0, s, q); break;

@@ -470,17 +470,37 @@ __global__ void cc_fill_kernel(const unsigned char* __restrict__ m, const int* _
   }
   out[idx] = (unsigned char)v;
 }
-// per-root statistics, addressed by the root's pixel index: area, min x, min y, max x, max y
+// per-root statistics, addressed by the root's pixel index: area, min x, min y, max x, max y.
+// Pixels of one wave are 64 consecutive pixels of a row and mostly share one component: when every foreground lane
+// of the wave has the same root the wave reduces first and issues one set of atomics instead of 64.
 __global__ void cc_stats_kernel(const int* __restrict__ lab, int* __restrict__ stats, int H, int W, long long total) {
   long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
-  int l = lab[idx];
-  if (l < 0) return;
+  const int l = idx < total ? lab[idx] : -1;
   const int HW = H * W;
-  int p = idx % HW;
-  long long base = idx - p;
+  const int p = idx < total ? (int)(idx % HW) : 0;
+  const long long base = idx - p;
+  const int x = p % W, y = p / W;
+  const bool fg = l >= 0;
+  const unsigned long long fgmask = __ballot(fg);
+  if (fgmask == 0) return;
+  const int leader = __ffsll((long long)fgmask) - 1;
+  const int l0 = __shfl(l, leader);
+  const long long base0 = __shfl(base, leader);
+  const int y0 = __shfl(y, leader);
+  const bool same = !fg || (l == l0 && base == base0 && y == y0);
+  if (__all(same)) {
+    int mn = fg ? x : (1 << 30), mx = fg ? x : -1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mn = min(mn, __shfl_xor(mn, o)); mx = max(mx, __shfl_xor(mx, o)); }
+    if ((threadIdx.x & 63) == leader) {
+      int* s = stats + (base0 + l0) * 5;
+      atomicAdd(&s[0], __popcll(fgmask));
+      atomicMin(&s[1], mn); atomicMin(&s[2], y0); atomicMax(&s[3], mx); atomicMax(&s[4], y0);
+    }
+    return;
+  }
+  if (!fg) return;
   int* s = stats + (base + l) * 5;
-  int x = p % W, y = p / W;
   atomicAdd(&s[0], 1);
   atomicMin(&s[1], x); atomicMin(&s[2], y); atomicMax(&s[3], x); atomicMax(&s[4], y);
 }

@@ -10,6 +10,8 @@ struct RoiFeatParams {
   const float* sem;     // semantic embedding NHWC at stride 4
   int H0, W0, H1, W1, H2, W2, H3, W3;
   float* out;           // [R][P*P][64]
+  int* fb_count;        // P=7: RoIs that do not fit the LDS tiles (processed by the generic kernel)
+  int* fb_list;         // [R]
 };
 
 struct BboxTailParams {

@@ -148,22 +148,146 @@ __device__ __forceinline__ RoiGeom roi_geom(const float* roi, float scale, int P
   return g;
 }
 
-// out[r][bin][c]; P=7: bbox head features (sr=2, semantic 14x14 -> 2x2 mean); P=14: mask features (sr=0, semantic added as is)
-template <int P>
-__global__ __launch_bounds__(256) void roi_feat_kernel(RoiFeatParams p) {
-  const int lane = threadIdx.x & 63;
-  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int R = *p.r_dev;
-  if (r >= R) return;
+// ---- LDS-staged variant for the 7x7 box-head features ------------------------------------------------------------
+// Nuclei-sized RoIs touch at most an 8x8 pixel footprint on the stride-4 maps (5x5 on stride 8).  One wave per RoI
+// copies the three footprints (FPN level 0, semantic embedding, FPN level 1) into LDS with direct global->LDS loads
+// (one 256-byte pixel per instruction, no VGPR staging, all in flight at once), builds the per-axis bilinear tables
+// of the regular sampling grid once (14 sample columns + 14 sample rows per map, computed by 28 lanes in parallel), and
+// then evaluates the 49 bins from LDS with exactly the arithmetic of roi_bin() (same products, same summation order), so
+// both paths are bit-identical.  RoIs with a larger footprint fall back to the global-memory path.
+#define TP0 8
+#define TP1 5
+struct AxisEnt { int lo, hi; float l, h; };
+
+// per-axis part of mmcv's bilinear_interpolate for sample coordinate c on an axis of `size` pixels
+__device__ __forceinline__ AxisEnt axis_entry(float c, int size, bool& valid) {
+  AxisEnt e;
+  valid = !(c < -1.0f || c > (float)size);
+  if (!valid) { e.lo = e.hi = 0; e.l = e.h = 0.f; return e; }
+  if (c <= 0.f) c = 0.f;
+  int lo = (int)c, hi;
+  if (lo >= size - 1) { hi = lo = size - 1; c = (float)lo; } else hi = lo + 1;
+  e.lo = lo; e.hi = hi;
+  e.l = c - (float)lo;
+  e.h = 1.0f - e.l;
+  return e;
+}
+
+__device__ __forceinline__ int half_min(int v) {   // min over the 32-lane half this lane belongs to
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ int half_max(int v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  return v;
+}
+
+struct LevelPlan { AxisEnt ent; int fx0, fy0, fw, fh; bool ok, empty; };
+
+// lanes 0..n-1 build the x entries, lanes 32..32+n-1 the y entries of a P x P bin grid with g samples per bin and axis
+__device__ __forceinline__ LevelPlan plan_level(const RoiGeom& g, int P, int gsamp, int H, int W, int tp, int lane) {
+  LevelPlan lp;
+  const bool is_y = lane >= 32;
+  const int idx = lane & 31;
+  const int n = P * gsamp;
+  const bool active = idx < n;
+  const int pb = active ? idx / gsamp : 0, is = active ? idx - pb * gsamp : 0;
+  const float start = is_y ? g.y1 : g.x1, bs = is_y ? g.bh : g.bw;
+  const float c = start + (float)pb * bs + ((float)is + 0.5f) * bs / (float)gsamp;   // same expression as roi_bin()
+  bool valid;
+  lp.ent = axis_entry(c, is_y ? H : W, valid);
+  valid = valid && active;
+  const int lo = half_min(valid ? lp.ent.lo : (1 << 30));
+  const int hi = half_max(valid ? lp.ent.hi : -1);
+  const int x_lo = __shfl(lo, 0), x_hi = __shfl(hi, 0), y_lo = __shfl(lo, 32), y_hi = __shfl(hi, 32);
+  lp.empty = x_hi < 0 || y_hi < 0;
+  lp.fx0 = lp.empty ? 0 : x_lo; lp.fy0 = lp.empty ? 0 : y_lo;
+  lp.fw = lp.empty ? 0 : x_hi - x_lo + 1; lp.fh = lp.empty ? 0 : y_hi - y_lo + 1;
+  lp.ok = lp.fw <= tp && lp.fh <= tp;
+  const int f0 = is_y ? lp.fy0 : lp.fx0;
+  if (valid) { lp.ent.lo -= f0; lp.ent.hi -= f0; }   // invalid entries keep offset 0 with zero weights
+  return lp;
+}
+
+__device__ __forceinline__ void stage_tile(const float* __restrict__ map, int H, int W, int b, const LevelPlan& lp, float* tile, int lane) {
+  for (int yy = 0; yy < lp.fh; ++yy)
+    for (int xx = 0; xx < lp.fw; ++xx) {
+      const float* src = map + (((long long)b * H + lp.fy0 + yy) * W + lp.fx0 + xx) * 64 + lane;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(tile + (yy * lp.fw + xx) * 64), 4, 0, 0);
+    }
+}
+
+// one bin from the LDS image: identical arithmetic to roi_bin() (weights hy*hx.., sample sum iy-outer ix-inner, / count)
+template <int G>
+__device__ __forceinline__ float bin_lds(const float* tile, int fw, const AxisEnt* tx, const AxisEnt* ty, int pw, int ph, int lane) {
+  float acc = 0.f;
+#pragma unroll
+  for (int iy = 0; iy < G; ++iy) {
+    const AxisEnt ey = ty[ph * G + iy];
+#pragma unroll
+    for (int ix = 0; ix < G; ++ix) {
+      const AxisEnt ex = tx[pw * G + ix];
+      const float w1 = ey.h * ex.h, w2 = ey.h * ex.l, w3 = ey.l * ex.h, w4 = ey.l * ex.l;
+      const float v1 = tile[(ey.lo * fw + ex.lo) * 64 + lane], v2 = tile[(ey.lo * fw + ex.hi) * 64 + lane];
+      const float v3 = tile[(ey.hi * fw + ex.lo) * 64 + lane], v4 = tile[(ey.hi * fw + ex.hi) * 64 + lane];
+      acc += w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+    }
+  }
+  return acc / (float)(G * G);
+}
+
+// RoIs whose footprint does not fit the LDS tiles (large proposals): taken from the fallback list written by
+// roi_feat7_lds_kernel; one wave per output bin (block = bin row, 7 waves) so that a 300-px RoI with its 6x6 adaptive
+// semantic sampling grid does not serialise ~30k dependent loads in a single wave.
+__global__ __launch_bounds__(448) void roi_feat7_generic_kernel(RoiFeatParams p) {
+  const int lane = threadIdx.x & 63, pw = threadIdx.x >> 6, ph = blockIdx.y;
+  const int nfb = *p.fb_count;
+  for (int i = blockIdx.x; i < nfb; i += gridDim.x) {
+    const int r = p.fb_list[i];
+    const float* roi = p.rois + (long long)r * 5;
+    const int b = (int)roi[0];
+    float gs2[2];
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      const int Hl = l ? p.H3 : p.H2, Wl = l ? p.W3 : p.W2;
+      const float st = l ? 32.f : 16.f;
+      float cx = floorf((roi[1] + roi[3]) / (2.0f * st)), cy = floorf((roi[2] + roi[4]) / (2.0f * st));
+      cx = fminf(fmaxf(cx, 0.f), (float)(Wl - 1));
+      cy = fminf(fmaxf(cy, 0.f), (float)(Hl - 1));
+      const float* G = l ? p.G3 : p.G2;
+      gs2[l] = G[(((long long)b * Hl + (int)cy) * Wl + (int)cx) * 64 + lane];
+    }
+    float* out = p.out + (long long)r * 49 * 64;
+    const RoiGeom g0 = roi_geom(roi, 0.25f, 7, 2), g1 = roi_geom(roi, 0.125f, 7, 2), gs = roi_geom(roi, 0.25f, 14, 0);
+    const float* f0 = p.x0 + (long long)b * p.H0 * p.W0 * 64;
+    const float* f1 = p.x1 + (long long)b * p.H1 * p.W1 * 64;
+    const float* fs = p.sem + (long long)b * p.H0 * p.W0 * 64;
+    float v = 0.f;
+    v += roi_bin(f0, p.H0, p.W0, g0.x1, g0.y1, g0.bw, g0.bh, g0.gw, g0.gh, pw, ph, lane);
+    v += roi_bin(f1, p.H1, p.W1, g1.x1, g1.y1, g1.bw, g1.bh, g1.gw, g1.gh, pw, ph, lane);
+    v += gs2[0];
+    v += gs2[1];
+    const float a = roi_bin(fs, p.H0, p.W0, gs.x1, gs.y1, gs.bw, gs.bh, gs.gw, gs.gh, 2 * pw, 2 * ph, lane);
+    const float bq = roi_bin(fs, p.H0, p.W0, gs.x1, gs.y1, gs.bw, gs.bh, gs.gw, gs.gh, 2 * pw + 1, 2 * ph, lane);
+    const float c = roi_bin(fs, p.H0, p.W0, gs.x1, gs.y1, gs.bw, gs.bh, gs.gw, gs.gh, 2 * pw, 2 * ph + 1, lane);
+    const float d = roi_bin(fs, p.H0, p.W0, gs.x1, gs.y1, gs.bw, gs.bh, gs.gw, gs.gh, 2 * pw + 1, 2 * ph + 1, lane);
+    out[(ph * 7 + pw) * 64 + lane] = v + (((a + bq) + c) + d) * 0.25f;
+  }
+}
+
+__global__ __launch_bounds__(64) void roi_feat7_lds_kernel(RoiFeatParams p) {
+  __shared__ float tile0[TP0 * TP0 * 64];
+  __shared__ float tileS[TP0 * TP0 * 64];
+  __shared__ float tile1[TP1 * TP1 * 64];
+  __shared__ AxisEnt tab[3][2][16];
+  const int lane = threadIdx.x;
+  const int r = blockIdx.x;
+  if (r >= *p.r_dev) return;
   const float* roi = p.rois + (long long)r * 5;
   const int b = (int)roi[0];
-  const int sr = P == 7 ? 2 : 0;
-  const RoiGeom g0 = roi_geom(roi, 0.25f, P, sr), g1 = roi_geom(roi, 0.125f, P, sr);
-  const RoiGeom gs = roi_geom(roi, 0.25f, 14, 0);
-  const float* f0 = p.x0 + (long long)b * p.H0 * p.W0 * 64;
-  const float* f1 = p.x1 + (long long)b * p.H1 * p.W1 * 64;
-  const float* fs = p.sem + (long long)b * p.H0 * p.W0 * 64;
-  // attention-pooled global terms (levels 2, 3): centre cell of the RoI at stride 16 / 32
   float gsum[2];
 #pragma unroll
   for (int l = 0; l < 2; ++l) {
@@ -175,33 +299,88 @@ __global__ __launch_bounds__(256) void roi_feat_kernel(RoiFeatParams p) {
     const float* G = l ? p.G3 : p.G2;
     gsum[l] = G[(((long long)b * Hl + (int)cy) * Wl + (int)cx) * 64 + lane];
   }
-  float* out = p.out + (long long)r * P * P * 64;
-  for (int ph = 0; ph < P; ++ph)
-    for (int pw = 0; pw < P; ++pw) {
+  float* out = p.out + (long long)r * 49 * 64;
+  const RoiGeom g0 = roi_geom(roi, 0.25f, 7, 2), g1 = roi_geom(roi, 0.125f, 7, 2), gs = roi_geom(roi, 0.25f, 14, 0);
+  const bool sem_g1 = gs.gw == 1 && gs.gh == 1;
+  const LevelPlan l0 = plan_level(g0, 7, 2, p.H0, p.W0, TP0, lane);
+  const LevelPlan l1 = plan_level(g1, 7, 2, p.H1, p.W1, TP1, lane);
+  const LevelPlan ls = plan_level(gs, 14, 1, p.H0, p.W0, TP0, lane);
+  if (!(sem_g1 && l0.ok && l1.ok && ls.ok)) {
+    if (lane == 0) p.fb_list[atomicAdd(p.fb_count, 1)] = r;
+    return;
+  }
+  {
+    const int ax = lane >> 5, idx = lane & 31;
+    if (idx < 14) { tab[0][ax][idx] = l0.ent; tab[1][ax][idx] = l1.ent; tab[2][ax][idx] = ls.ent; }
+  }
+  stage_tile(p.x0, p.H0, p.W0, b, l0, tile0, lane);
+  stage_tile(p.x1, p.H1, p.W1, b, l1, tile1, lane);
+  stage_tile(p.sem, p.H0, p.W0, b, ls, tileS, lane);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  for (int ph = 0; ph < 7; ++ph)
+    for (int pw = 0; pw < 7; ++pw) {
       float v = 0.f;
-      v += roi_bin(f0, p.H0, p.W0, g0.x1, g0.y1, g0.bw, g0.bh, g0.gw, g0.gh, pw, ph, lane);
-      v += roi_bin(f1, p.H1, p.W1, g1.x1, g1.y1, g1.bw, g1.bh, g1.gw, g1.gh, pw, ph, lane);
+      v += l0.empty ? 0.f : bin_lds<2>(tile0, l0.fw, tab[0][0], tab[0][1], pw, ph, lane);
+      v += l1.empty ? 0.f : bin_lds<2>(tile1, l1.fw, tab[1][0], tab[1][1], pw, ph, lane);
       v += gsum[0];
       v += gsum[1];
-      float sv;
-      if (P == 7) {
-        const float a = roi_bin(fs, p.H0, p.W0, gs.x1, gs.y1, gs.bw, gs.bh, gs.gw, gs.gh, 2 * pw, 2 * ph, lane);
-        const float bq = roi_bin(fs, p.H0, p.W0, gs.x1, gs.y1, gs.bw, gs.bh, gs.gw, gs.gh, 2 * pw + 1, 2 * ph, lane);
-        const float c = roi_bin(fs, p.H0, p.W0, gs.x1, gs.y1, gs.bw, gs.bh, gs.gw, gs.gh, 2 * pw, 2 * ph + 1, lane);
-        const float d = roi_bin(fs, p.H0, p.W0, gs.x1, gs.y1, gs.bw, gs.bh, gs.gw, gs.gh, 2 * pw + 1, 2 * ph + 1, lane);
+      float sv = 0.f;
+      if (!ls.empty) {
+        const float a = bin_lds<1>(tileS, ls.fw, tab[2][0], tab[2][1], 2 * pw, 2 * ph, lane);
+        const float bq = bin_lds<1>(tileS, ls.fw, tab[2][0], tab[2][1], 2 * pw + 1, 2 * ph, lane);
+        const float c = bin_lds<1>(tileS, ls.fw, tab[2][0], tab[2][1], 2 * pw, 2 * ph + 1, lane);
+        const float d = bin_lds<1>(tileS, ls.fw, tab[2][0], tab[2][1], 2 * pw + 1, 2 * ph + 1, lane);
         sv = (((a + bq) + c) + d) * 0.25f;
-      } else {
-        sv = roi_bin(fs, p.H0, p.W0, gs.x1, gs.y1, gs.bw, gs.bh, gs.gw, gs.gh, pw, ph, lane);
       }
-      out[(ph * P + pw) * 64 + lane] = v + sv;
+      out[(ph * 7 + pw) * 64 + lane] = v + sv;
     }
 }
 
+// 14x14 mask features: 4 waves per RoI, bins interleaved across the waves
+__global__ __launch_bounds__(256) void roi_feat14_kernel(RoiFeatParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = blockIdx.x;
+  if (r >= *p.r_dev) return;
+  const float* roi = p.rois + (long long)r * 5;
+  const int b = (int)roi[0];
+  const RoiGeom g0 = roi_geom(roi, 0.25f, 14, 0), g1 = roi_geom(roi, 0.125f, 14, 0);
+  const float* f0 = p.x0 + (long long)b * p.H0 * p.W0 * 64;
+  const float* f1 = p.x1 + (long long)b * p.H1 * p.W1 * 64;
+  const float* fs = p.sem + (long long)b * p.H0 * p.W0 * 64;
+  float gsum[2];
+#pragma unroll
+  for (int l = 0; l < 2; ++l) {
+    const int Hl = l ? p.H3 : p.H2, Wl = l ? p.W3 : p.W2;
+    const float st = l ? 32.f : 16.f;
+    float cx = floorf((roi[1] + roi[3]) / (2.0f * st)), cy = floorf((roi[2] + roi[4]) / (2.0f * st));
+    cx = fminf(fmaxf(cx, 0.f), (float)(Wl - 1));
+    cy = fminf(fmaxf(cy, 0.f), (float)(Hl - 1));
+    const float* G = l ? p.G3 : p.G2;
+    gsum[l] = G[(((long long)b * Hl + (int)cy) * Wl + (int)cx) * 64 + lane];
+  }
+  float* out = p.out + (long long)r * 196 * 64;
+  for (int bin = wave; bin < 196; bin += 4) {
+    const int ph = bin / 14, pw = bin - ph * 14;
+    float v = 0.f;
+    v += roi_bin(f0, p.H0, p.W0, g0.x1, g0.y1, g0.bw, g0.bh, g0.gw, g0.gh, pw, ph, lane);
+    v += roi_bin(f1, p.H1, p.W1, g1.x1, g1.y1, g1.bw, g1.bh, g1.gw, g1.gh, pw, ph, lane);
+    v += gsum[0];
+    v += gsum[1];
+    const float sv = roi_bin(fs, p.H0, p.W0, g0.x1, g0.y1, g0.bw, g0.bh, g0.gw, g0.gh, pw, ph, lane);
+    out[bin * 64 + lane] = v + sv;
+  }
+}
+
 int launch_roi_feat(const RoiFeatParams& p, int P, int r_cap, hipStream_t s) {
-  ProfScope ps("roi_feat", 0, 0, s);
+  ProfScope ps(P == 7 ? "roi_feat7" : "roi_feat14", 0, 0, s);
   if (r_cap <= 0) return 0;
-  if (P == 7) hipLaunchKernelGGL(roi_feat_kernel<7>, dim3(cdiv(r_cap, 4)), dim3(256), 0, s, p);
-  else if (P == 14) hipLaunchKernelGGL(roi_feat_kernel<14>, dim3(cdiv(r_cap, 4)), dim3(256), 0, s, p);
+  if (P == 7) {
+    if (hipMemsetAsync(p.fb_count, 0, sizeof(int), s) != hipSuccess) return NUHTC_E_HIP;
+    hipLaunchKernelGGL(roi_feat7_lds_kernel, dim3(r_cap), dim3(64), 0, s, p);
+    ProfScope ps2("roi_feat7_generic", 0, 0, s);
+    hipLaunchKernelGGL(roi_feat7_generic_kernel, dim3(r_cap < 1024 ? r_cap : 1024, 7), dim3(448), 0, s, p);
+  } else if (P == 14) hipLaunchKernelGGL(roi_feat14_kernel, dim3(r_cap), dim3(256), 0, s, p);
   else return NUHTC_E_INVALID;
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
 }

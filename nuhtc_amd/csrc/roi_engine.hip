@@ -25,8 +25,9 @@ struct RoiWs {
   // rois + cascade
   float* rois;
   int *roi_off, *roi_cnt, *roi_total;
-  float *G2, *G3;
+  float *G2, *G3, *ap_inv, *ap_S, *ap_Ft;
   float *feats, *h1, *h2;
+  int *fb_count, *fb_list;
   float *cls[3], *reg[3];
   int total_cap;
   // detections
@@ -180,7 +181,11 @@ int alloc_roi_workspace(nuhtc_engine* e) {
   if ((rc = wsa(e, &w->rois, "rois", {T, 5}, 0)) || (rc = wsa(e, &w->roi_off, "roi_off", {B}, 1)) || (rc = wsa(e, &w->roi_cnt, "roi_counts", {B}, 1)) ||
       (rc = wsa(e, &w->roi_total, "roi_total", {1}, 1)) || (rc = wsa(e, &w->G2, "G2", {B, e->st[2].H * e->st[2].W, 64}, 0)) ||
       (rc = wsa(e, &w->G3, "G3", {B, e->st[3].H * e->st[3].W, 64}, 0)) || (rc = wsa(e, &w->feats, "bbox_feats", {T, 49, 64}, 0)) ||
-      (rc = wsa(e, &w->h1, nullptr, {T, 256}, 0)) || (rc = wsa(e, &w->h2, nullptr, {T, 256}, 0)))
+      (rc = wsa(e, &w->h1, nullptr, {T, 256}, 0)) || (rc = wsa(e, &w->h2, nullptr, {T, 256}, 0)) ||
+      (rc = wsa(e, &w->ap_inv, nullptr, {B, e->st[2].H * e->st[2].W}, 0)) ||
+      (rc = wsa(e, &w->ap_S, nullptr, {B, (int64_t)e->st[2].H * e->st[2].W, (int64_t)e->st[2].H * e->st[2].W}, 0)) ||
+      (rc = wsa(e, &w->ap_Ft, nullptr, {B, 64, e->st[2].H * e->st[2].W}, 0)) ||
+      (rc = wsa(e, &w->fb_count, "roi_fallback_count", {1}, 1)) || (rc = wsa(e, &w->fb_list, nullptr, {T}, 1)))
     return rc;
   for (int k = 0; k < 3; ++k) {
     std::string n = std::to_string(k);
@@ -254,13 +259,30 @@ int run_roi_path(nuhtc_engine* e, int B, const float* rois_fixed, int n_rois, in
   const int Rcap = fixed ? B * n_rois : B * e->roi_cap;
 
   // ---- attention-pool tables for levels 2, 3 (roi_extractors_cus.py:220-238)
-  RUN(launch_attn_pool(e->x[2], w->G2, B, e->st[2].H * e->st[2].W, c.att_thres, s));
-  RUN(launch_attn_pool(e->x[3], w->G3, B, e->st[3].H * e->st[3].W, c.att_thres, s));
+  for (int l = 2; l < 4; ++l) {
+    const int HW = e->st[l].H * e->st[l].W;
+    float* G = l == 2 ? w->G2 : w->G3;
+    if (HW % 32 == 0) {
+      // S = relu(cos(F_q, F_p) - tau) + tau as one batched GEMM F·Fᵀ with the cosine epilogue, then G = S·F / HW
+      RUN(launch_rownorm_inv(e->x[l], w->ap_inv, B * HW, 64, s));
+      GemmParams p1 = gpr(e->x[l], e->x[l], nullptr, w->ap_S, HW, HW, 64);
+      p1.act = ACT_COS; p1.cos_ri = w->ap_inv; p1.cos_rj = w->ap_inv; p1.cos_tau = c.att_thres;
+      p1.batch = B; p1.sA = (long long)HW * 64; p1.sW = (long long)HW * 64; p1.sC = (long long)HW * HW; p1.sRi = HW; p1.sRj = HW;
+      RUN(launch_gemm(p1, s));
+      RUN(launch_transpose(e->x[l], w->ap_Ft, B, HW, 64, s));
+      GemmParams p2 = gpr(w->ap_S, w->ap_Ft, nullptr, G, HW, 64, HW);
+      p2.alpha = 1.0f / (float)HW;
+      p2.batch = B; p2.sA = (long long)HW * HW; p2.sW = (long long)HW * 64; p2.sC = (long long)HW * 64;
+      RUN(launch_gemm(p2, s));
+    } else {
+      RUN(launch_attn_pool(e->x[l], G, B, HW, c.att_thres, s));
+    }
+  }
 
   RoiFeatParams fp;
   fp.rois = w->rois; fp.r_dev = w->roi_total; fp.x0 = e->x[0]; fp.x1 = e->x[1]; fp.G2 = w->G2; fp.G3 = w->G3; fp.sem = e->sem_feat;
   fp.H0 = e->st[0].H; fp.W0 = e->st[0].W; fp.H1 = e->st[1].H; fp.W1 = e->st[1].W; fp.H2 = e->st[2].H; fp.W2 = e->st[2].W; fp.H3 = e->st[3].H; fp.W3 = e->st[3].W;
-  fp.out = w->feats;
+  fp.out = w->feats; fp.fb_count = w->fb_count; fp.fb_list = w->fb_list;
   // ---- 3-stage cascade (htc_roi_head_cus.py:2255-2280)
   for (int k = 0; k < 3; ++k) {
     auto it = e->bufs.find("rois_stage" + std::to_string(k));
