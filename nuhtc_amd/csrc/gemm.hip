@@ -6,18 +6,23 @@
 // (fpn.py:152-179, rpn_head.py:62-68, fused_semantic_head.py:97-111, htc_mask_head.py:22-39), the bbox-head
 // FCs (convfc_bbox_head.py:158-196) and the attention-pool similarity / aggregation products
 // (nuhtc/models/roi_extractors_cus.py:228-235).
+#include <cstdlib>
+
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define BM 128
-#define BK 32
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
-template <int NT>
+template <int NT, int BK>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   constexpr int BN = 32 * NT;
+  constexpr int KC = BK / 4;          // float4 chunks per tile row
+  constexpr int RPP = 256 / KC;       // rows staged per pass of the 256 threads
+  constexpr int NA = BM / RPP;        // passes for the A tile
+  constexpr int NB = (BN + RPP - 1) / RPP;   // passes for the W tile (last one may be partial)
   __shared__ float lds[2 * BK * (BM + BN)];
   float* As = lds;                 // [2][BK][BM]
   float* Bs = lds + 2 * BK * BM;   // [2][BK][BN]
@@ -42,14 +47,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   float* __restrict__ C = p.C + (long long)z * p.sC;
 
   // ---- per-thread staging assignment: float4 slots idx = tid + 256*j -> (row = idx/8, kc = idx%8)
-  const int kc = tid & 7;
-  const int rbase = tid >> 3;   // 0..31
-  const float* a_ptr[4];
-  int a_y[4], a_x[4];
-  bool a_ok[4];
+  const int kc = tid % KC;
+  const int rbase = tid / KC;   // 0..RPP-1
+  const float* a_ptr[NA];
+  int a_y[NA], a_x[NA];
+  bool a_ok[NA];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    int m = m0 + rbase + 32 * j;
+  for (int j = 0; j < NA; ++j) {
+    int m = m0 + rbase + RPP * j;
     a_ok[j] = m < Meff;
     if (p.amode == A_PLAIN) {
       a_ptr[j] = A + (long long)(a_ok[j] ? m : 0) * p.lda + kc * 4;
@@ -64,22 +69,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
       a_ptr[j] = A + ((long long)(b * p.cH + y) * p.cW + x) * p.cC + kc * 4;
     }
   }
-  const float* w_ptr[NT];
+  const float* w_ptr[NB];
+  bool w_ok[NB];
 #pragma unroll
-  for (int j = 0; j < NT; ++j) w_ptr[j] = Wt + (long long)(n0 + rbase + 32 * j) * p.K + kc * 4;
+  for (int j = 0; j < NB; ++j) {
+    w_ok[j] = rbase + RPP * j < BN;
+    w_ptr[j] = Wt + (long long)(n0 + (w_ok[j] ? rbase + RPP * j : 0)) * p.K + kc * 4;
+  }
 
-  float4 ra[4], rb[NT];
+  float4 ra[NA], rb[NB];
   auto load_tile = [&](int kt) {
     if (p.amode == A_PLAIN) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < NA; ++j)
         ra[j] = a_ok[j] ? *reinterpret_cast<const float4*>(a_ptr[j] + kt * BK) : make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
       int kk = kt * BK;
       int tap = kk / p.cC, c0 = kk - tap * p.cC;
       int ky = tap / 3 - 1, kx = tap - (tap / 3) * 3 - 1;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NA; ++j) {
         int yy = a_y[j] + ky, xx = a_x[j] + kx;
         bool ok = a_ok[j] && yy >= 0 && yy < p.cH && xx >= 0 && xx < p.cW;
         ra[j] = ok ? *reinterpret_cast<const float4*>(a_ptr[j] + (long long)(ky * p.cW + kx) * p.cC + c0)
@@ -87,23 +96,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
       }
     }
 #pragma unroll
-    for (int j = 0; j < NT; ++j) rb[j] = *reinterpret_cast<const float4*>(w_ptr[j] + kt * BK);
+    for (int j = 0; j < NB; ++j)
+      if (w_ok[j]) rb[j] = *reinterpret_cast<const float4*>(w_ptr[j] + kt * BK);
   };
   auto store_tile = [&](int buf) {
     float* as = As + buf * BK * BM;
     float* bs = Bs + buf * BK * BN;
     const int sw = kc << 2;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int r = (rbase + 32 * j) ^ sw;
+    for (int j = 0; j < NA; ++j) {
+      int r = (rbase + RPP * j) ^ sw;
       as[(kc * 4 + 0) * BM + r] = ra[j].x;
       as[(kc * 4 + 1) * BM + r] = ra[j].y;
       as[(kc * 4 + 2) * BM + r] = ra[j].z;
       as[(kc * 4 + 3) * BM + r] = ra[j].w;
     }
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      int r = (rbase + 32 * j) ^ sw;
+    for (int j = 0; j < NB; ++j) {
+      if (!w_ok[j]) continue;
+      int r = (rbase + RPP * j) ^ sw;
       bs[(kc * 4 + 0) * BN + r] = rb[j].x;
       bs[(kc * 4 + 1) * BN + r] = rb[j].y;
       bs[(kc * 4 + 2) * BN + r] = rb[j].z;
@@ -189,10 +200,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   }
 }
 
+static int g_bk = 0;
 int launch_gemm(const GemmParams& p, hipStream_t s) {
   if (p.M <= 0) return 0;
-  if (p.K % BK != 0 || p.N % 32 != 0) return NUHTC_E_INVALID;
-  if (p.amode == A_CONV3 && (p.cC % BK != 0 || p.K != 9 * p.cC)) return NUHTC_E_INVALID;
+  if (g_bk == 0) { const char* e = getenv("NUHTC_GEMM_BK"); g_bk = e ? atoi(e) : 16; if (g_bk != 32) g_bk = 16; }
+  if (p.K % 32 != 0 || p.N % 32 != 0) return NUHTC_E_INVALID;
+  if (p.amode == A_CONV3 && (p.cC % 32 != 0 || p.K != 9 * p.cC)) return NUHTC_E_INVALID;
   int nt = (p.N % 96 == 0) ? 3 : (p.N % 128 == 0) ? 4 : (p.N % 64 == 0) ? 2 : 1;
   int bn = 32 * nt;
   dim3 grid(cdiv(p.M, BM) * (p.N / bn), 1, p.batch > 0 ? p.batch : 1);
@@ -210,11 +223,20 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
   }
   // algorithmic work of the launch (device-side row counts are not known here: the capacity M is an upper bound)
   ProfScope ps(tag, 2.0 * p.M * p.N * p.K * nb, 4.0 * nb * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N), s);
-  switch (nt) {
-    case 1: hipLaunchKernelGGL(gemm_kernel<1>, grid, dim3(256), 0, s, q); break;
-    case 2: hipLaunchKernelGGL(gemm_kernel<2>, grid, dim3(256), 0, s, q); break;
-    case 3: hipLaunchKernelGGL(gemm_kernel<3>, grid, dim3(256), 0, s, q); break;
-    default: hipLaunchKernelGGL(gemm_kernel<4>, grid, dim3(256), 0, s, q); break;
+  if (g_bk == 16) {
+    switch (nt) {
+      case 1: hipLaunchKernelGGL((gemm_kernel<1, 16>), grid, dim3(256), 0, s, q); break;
+      case 2: hipLaunchKernelGGL((gemm_kernel<2, 16>), grid, dim3(256), 0, s, q); break;
+      case 3: hipLaunchKernelGGL((gemm_kernel<3, 16>), grid, dim3(256), 0, s, q); break;
+      default: hipLaunchKernelGGL((gemm_kernel<4, 16>), grid, dim3(256), 0, s, q); break;
+    }
+  } else {
+    switch (nt) {
+      case 1: hipLaunchKernelGGL((gemm_kernel<1, 32>), grid, dim3(256), 0, s, q); break;
+      case 2: hipLaunchKernelGGL((gemm_kernel<2, 32>), grid, dim3(256), 0, s, q); break;
+      case 3: hipLaunchKernelGGL((gemm_kernel<3, 32>), grid, dim3(256), 0, s, q); break;
+      default: hipLaunchKernelGGL((gemm_kernel<4, 32>), grid, dim3(256), 0, s, q); break;
+    }
   }
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
 }

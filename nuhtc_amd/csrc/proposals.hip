@@ -417,11 +417,26 @@ __device__ __forceinline__ void uf_union(int* lab, int a, int b) {
   }
 }
 
-// labels of the pixels whose mask value == target (4-connectivity); others -1.  lab is per image (H*W ints)
-__global__ void ccl_init_kernel(const unsigned char* __restrict__ m, int* __restrict__ lab, int target, int HW, long long total) {
+// labels of the pixels whose mask value == target (4-connectivity); others -1.  lab is per image (H*W ints).
+// Initial label = first pixel of the horizontal run inside the wave's 64-pixel chunk (one ballot per wave), so that
+// only chunk-boundary pixels need a union with their left neighbour, and a union with the pixel above is needed only
+// where a new overlap of two runs begins (left or upper-left neighbour not in the set).
+__global__ void ccl_init_kernel(const unsigned char* __restrict__ m, int* __restrict__ lab, int target, int HW, int W, long long total) {
   long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool t = idx < total && m[idx] == target;
+  const unsigned long long bits = __ballot(t);
   if (idx >= total) return;
-  lab[idx] = (m[idx] == target) ? (int)(idx % HW) : -1;
+  const int L = threadIdx.x & 63;
+  const int p = (int)(idx % HW);
+  const int x = p % W;
+  int out = -1;
+  if (t) {
+    const unsigned long long zeros_left = ~bits & ((1ull << L) - 1ull);
+    int start = zeros_left ? 64 - __clzll((long long)zeros_left) : 0;   // lane after the nearest 0 to the left
+    start = max(start, L - x);                                            // runs do not cross the row start
+    out = p - (L - start);
+  }
+  lab[idx] = out;
 }
 __global__ void ccl_merge_kernel(const unsigned char* __restrict__ m, int* __restrict__ lab, int target, int H, int W, long long total) {
   long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -432,8 +447,9 @@ __global__ void ccl_merge_kernel(const unsigned char* __restrict__ m, int* __res
   int* l = lab + (idx - p);
   const unsigned char* mm = m + (idx - p);
   int x = p % W, y = p / W;
-  if (x > 0 && mm[p - 1] == target) uf_union(l, p, p - 1);
-  if (y > 0 && mm[p - W] == target) uf_union(l, p, p - W);
+  const bool left = x > 0 && mm[p - 1] == target;
+  if (left && (threadIdx.x & 63) == 0) uf_union(l, p, p - 1);          // run continues from the previous chunk
+  if (y > 0 && mm[p - W] == target && !(left && mm[p - W - 1] == target)) uf_union(l, p, p - W);
 }
 __global__ void ccl_flatten_kernel(int* __restrict__ lab, int HW, long long total) {
   long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -565,14 +581,14 @@ int launch_cc_proposals(const CcParams& p, int B, hipStream_t s) {
   hipLaunchKernelGGL((morph9_kernel<1, 0>), dim3(nb), dim3(256), 0, s, A, Bm, H, W, total);
   hipLaunchKernelGGL((morph9_kernel<1, 1>), dim3(nb), dim3(256), 0, s, Bm, A, H, W, total);
   // hole fill: label background, keep only border-connected background
-  hipLaunchKernelGGL(ccl_init_kernel, dim3(nb), dim3(256), 0, s, A, p.labels, 0, HW, total);
+  hipLaunchKernelGGL(ccl_init_kernel, dim3(nb), dim3(256), 0, s, A, p.labels, 0, HW, W, total);
   hipLaunchKernelGGL(ccl_merge_kernel, dim3(nb), dim3(256), 0, s, A, p.labels, 0, H, W, total);
   hipLaunchKernelGGL(ccl_flatten_kernel, dim3(nb), dim3(256), 0, s, p.labels, HW, total);
   if (hipMemsetAsync(p.touch, 0, (size_t)total, s) != hipSuccess) return NUHTC_E_HIP;
   hipLaunchKernelGGL(cc_border_kernel, dim3(cdiv(B * 2 * (H + W), 256)), dim3(256), 0, s, p.labels, p.touch, H, W, B);
   hipLaunchKernelGGL(cc_fill_kernel, dim3(nb), dim3(256), 0, s, A, p.labels, p.touch, Bm, HW, total);
   // label the filled foreground, collect per-component stats, emit boxes in raster order of first pixel
-  hipLaunchKernelGGL(ccl_init_kernel, dim3(nb), dim3(256), 0, s, Bm, p.labels, 1, HW, total);
+  hipLaunchKernelGGL(ccl_init_kernel, dim3(nb), dim3(256), 0, s, Bm, p.labels, 1, HW, W, total);
   hipLaunchKernelGGL(ccl_merge_kernel, dim3(nb), dim3(256), 0, s, Bm, p.labels, 1, H, W, total);
   hipLaunchKernelGGL(ccl_flatten_kernel, dim3(nb), dim3(256), 0, s, p.labels, HW, total);
   hipLaunchKernelGGL(cc_stats_init_kernel, dim3(nb), dim3(256), 0, s, p.stats, total);
