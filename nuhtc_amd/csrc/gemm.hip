@@ -1,37 +1,45 @@
-// fp32 GEMM on the CDNA4 matrix cores: C = epilogue(A · Wᵀ), v_mfma_f32_32x32x2_f32 (exact f32, k-ordered fma
-// chain), 128 x (32·NT) x 32 block tile, 4 waves (each 32 rows x 32·NT cols), double-buffered LDS with a
-// k-major XOR-swizzled image (conflict-free transposing writes and fragment reads), register prefetch of the
-// next k-tile.  Serves every dense layer of the path: Swin QKV/proj/FFN/merge linears (mmdet swin.py:88,115,
-// mmcv FFN, transformer.py:384), FPN / RPN / semantic / mask-head convolutions as NHWC implicit GEMM
-// (fpn.py:152-179, rpn_head.py:62-68, fused_semantic_head.py:97-111, htc_mask_head.py:22-39), the bbox-head
-// FCs (convfc_bbox_head.py:158-196) and the attention-pool similarity / aggregation products
-// (nuhtc/models/roi_extractors_cus.py:228-235).
+// fp32 GEMM on the CDNA4 matrix cores: C = epilogue(A · Wᵀ), v_mfma_f32_32x32x2_f32 (exact f32 fma chain).
+// Block = 4 waves arranged WM x WN, each wave owns MT x NT sub-tiles of 32x32 (block tile BM x BN = 32·MT·WM x 32·NT·WN),
+// k-tile BK (16 or 32), double-buffered LDS image in row-major [row][BK+4] (128-bit conflict-free staging writes and
+// fragment reads), register prefetch of the next k-tile issued ahead of the MFMAs.  Serves every dense layer of the
+// path: Swin QKV/proj/FFN/merge linears (mmdet swin.py:88,115, mmcv FFN, transformer.py:384), FPN / RPN / semantic /
+// mask-head convolutions as NHWC implicit GEMM (fpn.py:152-179, rpn_head.py:62-68, fused_semantic_head.py:97-111,
+// htc_mask_head.py:22-39), the bbox-head FCs (convfc_bbox_head.py:158-196) and the attention-pool similarity /
+// aggregation products (nuhtc/models/roi_extractors_cus.py:228-235).
 #include <cstdlib>
 
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-#define BM 128
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
-template <int NT, int BK>
+template <int MT, int NT, int WM, int WN, int BK, int AMODE>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
-  constexpr int BN = 32 * NT;
+  static_assert(WM * WN == 4, "4 waves per block");
+  constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
   constexpr int KC = BK / 4;          // float4 chunks per tile row
   constexpr int RPP = 256 / KC;       // rows staged per pass of the 256 threads
-  constexpr int NA = BM / RPP;        // passes for the A tile
-  constexpr int NB = (BN + RPP - 1) / RPP;   // passes for the W tile (last one may be partial)
-  __shared__ float lds[2 * BK * (BM + BN)];
-  float* As = lds;                 // [2][BK][BM]
-  float* Bs = lds + 2 * BK * BM;   // [2][BK][BN]
+  constexpr int NA = (BM + RPP - 1) / RPP, NB = (BN + RPP - 1) / RPP;   // staging passes (the last may be partial)
+  // LDS image: row-major [row][BK + 4] for both operands (the +4 pad makes the 128-bit fragment reads and the 128-bit
+  // staging writes bank-conflict free).  MFMA k-step s of a tile multiplies k = s (lanes 0-31) and k = s + BK/2 (lanes
+  // 32-63), so each lane's fragments of a whole tile are BK/2 contiguous floats = BK/8 ds_read_b128.
+  constexpr int LDK = BK + 4;
+  constexpr int KH = BK / 2;
+  __shared__ __attribute__((aligned(16))) float lds[2 * LDK * (BM + BN)];
+  float* As = lds;                  // [2][BM][LDK]
+  float* Bs = lds + 2 * LDK * BM;   // [2][BN][LDK]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
   const int i32 = lane & 31, half = lane >> 5;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (ids with equal id % 8 share an L2), so all
+  // n-tiles of one m-tile get ids of the same residue, adjacent in time
   const int nTilesN = p.N / BN;
-  const int tile_m = blockIdx.x / nTilesN, tile_n = blockIdx.x % nTilesN;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tile_m = (slot / nTilesN) * 8 + xcd, tile_n = slot % nTilesN;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int z = blockIdx.z;
 
@@ -46,169 +54,224 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   const float* __restrict__ Wt = p.W + (long long)z * p.sW;
   float* __restrict__ C = p.C + (long long)z * p.sC;
 
-  // ---- per-thread staging assignment: float4 slots idx = tid + 256*j -> (row = idx/8, kc = idx%8)
+  // ---- per-thread staging assignment: float4 slot (row = tid/KC + RPP*j, kc = tid%KC)
+  // Rows past Meff are clamped to the last valid row (their results are never stored) and out-of-image conv taps are
+  // loaded from a clamped address and zeroed by a select: every staging load is unconditional, so the loads of tile
+  // kt+1 stay in flight across the MFMAs of tile kt instead of being fenced by exec-mask branches.
   const int kc = tid % KC;
-  const int rbase = tid / KC;   // 0..RPP-1
+  const int rbase = tid / KC;
   const float* a_ptr[NA];
   int a_y[NA], a_x[NA];
-  bool a_ok[NA];
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
-    int m = m0 + rbase + RPP * j;
-    a_ok[j] = m < Meff;
-    if (p.amode == A_PLAIN) {
-      a_ptr[j] = A + (long long)(a_ok[j] ? m : 0) * p.lda + kc * 4;
+    int r = rbase + RPP * j;
+    r = r < BM ? r : BM - 1;
+    int m = m0 + r;
+    m = m < Meff ? m : Meff - 1;
+    if (AMODE == A_PLAIN) {
+      a_ptr[j] = A + (long long)m * p.lda + kc * 4;
       a_y[j] = a_x[j] = 0;
     } else {
-      int mm = a_ok[j] ? m : 0;
       int hw = p.cH * p.cW;
-      int b = mm / hw, r = mm - b * hw;
-      int y = r / p.cW, x = r - y * p.cW;
+      int b = m / hw, rr = m - b * hw;
+      int y = rr / p.cW, x = rr - y * p.cW;
       a_y[j] = y;
       a_x[j] = x;
       a_ptr[j] = A + ((long long)(b * p.cH + y) * p.cW + x) * p.cC + kc * 4;
     }
   }
   const float* w_ptr[NB];
-  bool w_ok[NB];
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
-    w_ok[j] = rbase + RPP * j < BN;
-    w_ptr[j] = Wt + (long long)(n0 + (w_ok[j] ? rbase + RPP * j : 0)) * p.K + kc * 4;
+    int r = rbase + RPP * j;
+    r = r < BN ? r : BN - 1;
+    w_ptr[j] = Wt + (long long)(n0 + r) * p.K + kc * 4;
   }
+  // a partial last staging pass (e.g. BN = 96 rows with 64 rows per pass) is clamped to the tile's last row on both the
+  // load and the LDS store side: the surplus threads rewrite that row with identical data, so nothing is conditional
+  int a_srow[NA], w_srow[NB];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) { int r = rbase + RPP * j; a_srow[j] = r < BM ? r : BM - 1; }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) { int r = rbase + RPP * j; w_srow[j] = r < BN ? r : BN - 1; }
 
-  float4 ra[NA], rb[NB];
-  auto load_tile = [&](int kt) {
-    if (p.amode == A_PLAIN) {
+  v4f ra[NA], rb[NB];
+  // (macros rather than lambdas: arrays captured by reference were being demoted to scratch memory)
+#define LOAD_TILE(kt_)                                                                                          \
+  {                                                                                                             \
+    const int kt__ = (kt_);                                                                                     \
+    if (AMODE == A_PLAIN) {                                                                                     \
+      _Pragma("unroll") for (int j = 0; j < NA; ++j) ra[j] = *reinterpret_cast<const v4f*>(a_ptr[j] + kt__ * BK); \
+    } else {                                                                                                    \
+      const int kk = kt__ * BK;                                                                                 \
+      const int tap = kk / p.cC, c0 = kk - tap * p.cC;                                                          \
+      const int ky = tap / 3 - 1, kx = tap - (tap / 3) * 3 - 1;                                                 \
+      _Pragma("unroll") for (int j = 0; j < NA; ++j) {                                                          \
+        const int yy = a_y[j] + ky, xx = a_x[j] + kx;                                                           \
+        const bool ok = yy >= 0 && yy < p.cH && xx >= 0 && xx < p.cW;                                           \
+        const int dy = ok ? ky : 0, dx = ok ? kx : 0;                                                           \
+        const v4f v = *reinterpret_cast<const v4f*>(a_ptr[j] + (long long)(dy * p.cW + dx) * p.cC + c0);        \
+        const float zm = ok ? 1.0f : 0.0f;                                                                      \
+        ra[j] = v;                                                                                              \
+        a_zero[j] = zm;                                                                                         \
+      }                                                                                                         \
+    }                                                                                                           \
+    _Pragma("unroll") for (int j = 0; j < NB; ++j) rb[j] = *reinterpret_cast<const v4f*>(w_ptr[j] + kt__ * BK); \
+  }
+  // out-of-image conv taps are zeroed when the tile is written to LDS (a multiply by 0/1 kept beside the data), so the
+  // load itself has no consumer until then
+#define STORE_TILE(buf_)                                                                                        \
+  {                                                                                                             \
+    float* as = As + (buf_) * LDK * BM;                                                                         \
+    float* bs = Bs + (buf_) * LDK * BN;                                                                         \
+    _Pragma("unroll") for (int j = 0; j < NA; ++j) {                                                            \
+      v4f v = ra[j];                                                                                            \
+      if (AMODE != A_PLAIN) v = v * a_zero[j];                                                                  \
+      *reinterpret_cast<v4f*>(as + a_srow[j] * LDK + kc * 4) = v;                                               \
+    }                                                                                                           \
+    _Pragma("unroll") for (int j = 0; j < NB; ++j)                                                              \
+      *reinterpret_cast<v4f*>(bs + w_srow[j] * LDK + kc * 4) = rb[j];                                           \
+  }
+  float a_zero[NA];
 #pragma unroll
-      for (int j = 0; j < NA; ++j)
-        ra[j] = a_ok[j] ? *reinterpret_cast<const float4*>(a_ptr[j] + kt * BK) : make_float4(0.f, 0.f, 0.f, 0.f);
-    } else {
-      int kk = kt * BK;
-      int tap = kk / p.cC, c0 = kk - tap * p.cC;
-      int ky = tap / 3 - 1, kx = tap - (tap / 3) * 3 - 1;
-#pragma unroll
-      for (int j = 0; j < NA; ++j) {
-        int yy = a_y[j] + ky, xx = a_x[j] + kx;
-        bool ok = a_ok[j] && yy >= 0 && yy < p.cH && xx >= 0 && xx < p.cW;
-        ra[j] = ok ? *reinterpret_cast<const float4*>(a_ptr[j] + (long long)(ky * p.cW + kx) * p.cC + c0)
-                   : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < NB; ++j)
-      if (w_ok[j]) rb[j] = *reinterpret_cast<const float4*>(w_ptr[j] + kt * BK);
-  };
-  auto store_tile = [&](int buf) {
-    float* as = As + buf * BK * BM;
-    float* bs = Bs + buf * BK * BN;
-    const int sw = kc << 2;
-#pragma unroll
-    for (int j = 0; j < NA; ++j) {
-      int r = (rbase + RPP * j) ^ sw;
-      as[(kc * 4 + 0) * BM + r] = ra[j].x;
-      as[(kc * 4 + 1) * BM + r] = ra[j].y;
-      as[(kc * 4 + 2) * BM + r] = ra[j].z;
-      as[(kc * 4 + 3) * BM + r] = ra[j].w;
-    }
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      if (!w_ok[j]) continue;
-      int r = (rbase + RPP * j) ^ sw;
-      bs[(kc * 4 + 0) * BN + r] = rb[j].x;
-      bs[(kc * 4 + 1) * BN + r] = rb[j].y;
-      bs[(kc * 4 + 2) * BN + r] = rb[j].z;
-      bs[(kc * 4 + 3) * BN + r] = rb[j].w;
-    }
-  };
+  for (int j = 0; j < NA; ++j) a_zero[j] = 1.0f;
 
-  f32x16 acc[NT];
+  f32x16 acc[MT][NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][t][r] = 0.f;
+
+  // ---- main loop, software-pipelined at half-tile granularity (BK = 16: two groups of 4 k-steps):
+  //   FB <- LDS frags(t, half 1) | MFMA(FA) | wait + store regs(t+1) -> LDS | barrier | global loads(t+2) -> regs |
+  //   FA <- LDS frags(t+1, half 0) | MFMA(FB)
+  // so the MFMAs after a barrier never wait for LDS (their operands were read before it), the LDS latency of the next
+  // fragments and the HBM/L2 latency of the staging loads both sit behind 12-24 MFMAs, and there is one barrier per k-tile.
+  static_assert(BK == 16, "pipelined main loop is written for BK = 16");
+  v4f fa_a[MT], fa_b[NT], fb_a[MT], fb_b[NT];
+  const float* arow0 = As + (wm * MT * 32 + i32) * LDK + half * KH;
+  const float* brow0 = Bs + (wn * NT * 32 + i32) * LDK + half * KH;
+#define READ_FRAGS(buf_, q_, FA_, FB_)                                                                         \
+  {                                                                                                            \
+    _Pragma("unroll") for (int mi = 0; mi < MT; ++mi)                                                          \
+        FA_[mi] = *reinterpret_cast<const v4f*>(arow0 + (buf_) * LDK * BM + 32 * mi * LDK + 4 * (q_));      \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                             \
+        FB_[t] = *reinterpret_cast<const v4f*>(brow0 + (buf_) * LDK * BN + 32 * t * LDK + 4 * (q_));        \
+  }
+#define MFMA_STEP(E_, FA_, FB_)                                                                                \
+  _Pragma("unroll") for (int mi = 0; mi < MT; ++mi) _Pragma("unroll") for (int t = 0; t < NT; ++t)             \
+      acc[mi][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA_[mi].E_, FB_[t].E_, acc[mi][t], 0, 0, 0);
+#define MFMA_GROUP(FA_, FB_) { MFMA_STEP(x, FA_, FB_) MFMA_STEP(y, FA_, FB_) MFMA_STEP(z, FA_, FB_) MFMA_STEP(w, FA_, FB_) }
 
   const int nk = p.K / BK;
-  load_tile(0);
-  store_tile(0);
+  LOAD_TILE(0)
+  STORE_TILE(0)
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
+  LOAD_TILE(nk > 1 ? 1 : 0)
+  READ_FRAGS(0, 0, fa_a, fa_b)
+  int kt = 0;
+  for (; kt + 1 < nk; ++kt) {       // every iteration here has a successor tile: no conditional inside the body
     const int buf = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);
-    const float* as = As + buf * BK * BM + wave * 32;
-    const float* bs = Bs + buf * BK * BN;
-#pragma unroll
-    for (int ks = 0; ks < BK / 2; ++ks) {
-      const int k = 2 * ks + half;
-      const int sw = (k >> 2) << 2;
-      const float a = as[k * BM + (i32 ^ sw)];
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const float b = bs[k * BN + ((32 * t + i32) ^ sw)];
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
-      }
-    }
-    if (kt + 1 < nk) store_tile(buf ^ 1);
-    __syncthreads();
+    READ_FRAGS(buf, 1, fb_a, fb_b)
+    __builtin_amdgcn_sched_barrier(0);
+    MFMA_GROUP(fa_a, fa_b)
+    __builtin_amdgcn_sched_barrier(0);
+    STORE_TILE(buf ^ 1)                          // waits for the staging loads issued one iteration ago
+    __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): this wave's LDS writes have landed
+    __builtin_amdgcn_s_barrier();                // raw barrier: no vmcnt(0) (nothing is in flight here anyway)
+    __builtin_amdgcn_sched_barrier(0);
+    LOAD_TILE(kt + 2 < nk ? kt + 2 : nk - 1)     // the clamped reload at the end is never used
+    READ_FRAGS(buf ^ 1, 0, fa_a, fa_b)
+    __builtin_amdgcn_sched_barrier(0);
+    MFMA_GROUP(fb_a, fb_b)
+    __builtin_amdgcn_sched_barrier(0);
   }
+  READ_FRAGS(kt & 1, 1, fb_a, fb_b)
+  MFMA_GROUP(fa_a, fa_b)
+  MFMA_GROUP(fb_a, fb_b)
+#undef LOAD_TILE
+#undef STORE_TILE
+#undef READ_FRAGS
+#undef MFMA_STEP
+#undef MFMA_GROUP
 
-  // ---- epilogue: lane holds column n = n0 + 32t + i32 and rows (r&3) + 8(r>>2) + 4·half of the wave's 32
+  // ---- epilogue: lane holds column n = .. + i32 and rows (r&3) + 8(r>>2) + 4·half of each 32x32 sub-tile
   const float* ri = p.cos_ri ? p.cos_ri + (long long)z * p.sRi : nullptr;
   const float* rj = p.cos_rj ? p.cos_rj + (long long)z * p.sRj : nullptr;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-    if (m >= Meff) continue;
-    long long drow = m;
-    if (p.store == ST_ROWMAP) {
-      int d = p.row_map[m];
-      if (d < 0) continue;
-      drow = d;
-    }
-    long long uprow = 0;
-    if (p.up) {
-      int hw = p.upH * p.upW;
-      int b = m / hw, rr = m - b * hw;
-      int y = rr / p.upW, x = rr - y * p.upW;
-      uprow = ((long long)b * (p.upH >> 1) + (y >> 1)) * (p.upW >> 1) + (x >> 1);
-    }
-    long long dbase = 0;
-    if (p.store == ST_DECONV2) {
-      // rows m = (d, y, x) on a cH x cW grid; columns n = (kh*2+kw)*ldc + oc -> out[(d, 2y+kh, 2x+kw), oc]
-      int hw = p.cH * p.cW;
-      int b = m / hw, rr = m - b * hw;
-      int y = rr / p.cW, x = rr - y * p.cW;
-      dbase = ((long long)b * (2 * p.cH) + 2 * y) * (2 * p.cW) + 2 * x;
-    }
+  for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int n = n0 + 32 * t + i32;
-      float v = acc[t][r] * p.alpha;
-      if (p.bias) v += p.bias[n];
-      if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
-      else if (p.act == ACT_GELU) v = gelu_erf(v);
-      else if (p.act == ACT_COS) v = fmaxf(v * ri[m] * rj[n] - p.cos_tau, 0.f) + p.cos_tau;
-      if (p.up) v += p.up[uprow * p.N + n];
-      if (p.res) v += p.res[drow * p.ldr + n];
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + (wm * MT + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (m >= Meff) continue;
+      long long drow = m;
+      if (p.store == ST_ROWMAP) {
+        int d = p.row_map[m];
+        if (d < 0) continue;
+        drow = d;
+      }
+      long long uprow = 0;
+      if (p.up) {
+        int hw = p.upH * p.upW;
+        int b = m / hw, rr = m - b * hw;
+        int y = rr / p.upW, x = rr - y * p.upW;
+        uprow = ((long long)b * (p.upH >> 1) + (y >> 1)) * (p.upW >> 1) + (x >> 1);
+      }
+      long long dbase = 0;
       if (p.store == ST_DECONV2) {
-        int tap = n / p.ldc, oc = n - tap * p.ldc;
-        C[(dbase + (tap >> 1) * (2 * p.cW) + (tap & 1)) * p.ldc + oc] = v;
-      } else {
-        C[drow * p.ldc + n] = v;
+        // rows m = (d, y, x) on a cH x cW grid; columns n = (kh*2+kw)*ldc + oc -> out[(d, 2y+kh, 2x+kw), oc]
+        int hw = p.cH * p.cW;
+        int b = m / hw, rr = m - b * hw;
+        int y = rr / p.cW, x = rr - y * p.cW;
+        dbase = ((long long)b * (2 * p.cH) + 2 * y) * (2 * p.cW) + 2 * x;
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int n = n0 + (wn * NT + t) * 32 + i32;
+        float v = acc[mi][t][r] * p.alpha;
+        if (p.bias) v += p.bias[n];
+        if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+        else if (p.act == ACT_GELU) v = gelu_erf(v);
+        else if (p.act == ACT_COS) v = fmaxf(v * ri[m] * rj[n] - p.cos_tau, 0.f) + p.cos_tau;
+        if (p.up) v += p.up[uprow * p.N + n];
+        if (p.res) v += p.res[drow * p.ldr + n];
+        if (p.store == ST_DECONV2) {
+          int tap = n / p.ldc, oc = n - tap * p.ldc;
+          C[(dbase + (tap >> 1) * (2 * p.cW) + (tap & 1)) * p.ldc + oc] = v;
+        } else {
+          C[drow * p.ldc + n] = v;
+        }
       }
     }
-  }
 }
 
-static int g_bk = 0;
+// geometry ids: 0 = 128x(32·nt) tiles, one 32-row strip per wave (nt = 1,2,3,4); 1 = 128x128 tiles, 64x64 per wave (2x2);
+//               2 = 256x64 tiles, 64x64 per wave (4x1 waves)
+template <int MT, int NT, int WM, int WN>
+static void launch_cfg(const GemmParams& q, int bk, int mtiles, hipStream_t s) {
+  constexpr int BN = 32 * NT * WN;
+  dim3 grid(cdiv(mtiles, 8) * 8 * (q.N / BN), 1, q.batch > 0 ? q.batch : 1);
+  (void)bk;
+  if (q.amode == A_CONV3) hipLaunchKernelGGL((gemm_kernel<MT, NT, WM, WN, 16, A_CONV3>), grid, dim3(256), 0, s, q);
+  else hipLaunchKernelGGL((gemm_kernel<MT, NT, WM, WN, 16, A_PLAIN>), grid, dim3(256), 0, s, q);
+}
+
+static int g_bk = 0, g_geo128 = 0, g_geo256 = 0;
 int launch_gemm(const GemmParams& p, hipStream_t s) {
   if (p.M <= 0) return 0;
-  if (g_bk == 0) { const char* e = getenv("NUHTC_GEMM_BK"); g_bk = e ? atoi(e) : 16; if (g_bk != 32) g_bk = 16; }
+  if (g_bk == 0) {
+    const char* e = getenv("NUHTC_GEMM_BK"); g_bk = e ? atoi(e) : 16; if (g_bk != 32) g_bk = 16;
+    e = getenv("NUHTC_GEMM_G128"); g_geo128 = e ? atoi(e) : 0;
+    e = getenv("NUHTC_GEMM_G256"); g_geo256 = e ? atoi(e) : 0;
+  }
   if (p.K % 32 != 0 || p.N % 32 != 0) return NUHTC_E_INVALID;
   if (p.amode == A_CONV3 && (p.cC % 32 != 0 || p.K != 9 * p.cC)) return NUHTC_E_INVALID;
   int nt = (p.N % 96 == 0) ? 3 : (p.N % 128 == 0) ? 4 : (p.N % 64 == 0) ? 2 : 1;
-  int bn = 32 * nt;
-  dim3 grid(cdiv(p.M, BM) * (p.N / bn), 1, p.batch > 0 ? p.batch : 1);
+  int geo = 0;
+  if (g_geo128 && p.N % 128 == 0) geo = 1;
+  if (g_geo256 && p.N == 64) geo = 2;
   GemmParams q = p;
   if (q.alpha == 0.f) q.alpha = 1.f;
   const double nb = p.batch > 0 ? p.batch : 1;
@@ -223,20 +286,11 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
   }
   // algorithmic work of the launch (device-side row counts are not known here: the capacity M is an upper bound)
   ProfScope ps(tag, 2.0 * p.M * p.N * p.K * nb, 4.0 * nb * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N), s);
-  if (g_bk == 16) {
-    switch (nt) {
-      case 1: hipLaunchKernelGGL((gemm_kernel<1, 16>), grid, dim3(256), 0, s, q); break;
-      case 2: hipLaunchKernelGGL((gemm_kernel<2, 16>), grid, dim3(256), 0, s, q); break;
-      case 3: hipLaunchKernelGGL((gemm_kernel<3, 16>), grid, dim3(256), 0, s, q); break;
-      default: hipLaunchKernelGGL((gemm_kernel<4, 16>), grid, dim3(256), 0, s, q); break;
-    }
-  } else {
-    switch (nt) {
-      case 1: hipLaunchKernelGGL((gemm_kernel<1, 32>), grid, dim3(256), 0, s, q); break;
-      case 2: hipLaunchKernelGGL((gemm_kernel<2, 32>), grid, dim3(256), 0, s, q); break;
-      case 3: hipLaunchKernelGGL((gemm_kernel<3, 32>), grid, dim3(256), 0, s, q); break;
-      default: hipLaunchKernelGGL((gemm_kernel<4, 32>), grid, dim3(256), 0, s, q); break;
-    }
-  }
+  if (geo == 1) launch_cfg<2, 2, 2, 2>(q, g_bk, cdiv(p.M, 128), s);
+  else if (geo == 2) launch_cfg<2, 2, 4, 1>(q, g_bk, cdiv(p.M, 256), s);
+  else if (nt == 1) launch_cfg<1, 1, 4, 1>(q, g_bk, cdiv(p.M, 128), s);
+  else if (nt == 2) launch_cfg<1, 2, 4, 1>(q, g_bk, cdiv(p.M, 128), s);
+  else if (nt == 3) launch_cfg<1, 3, 4, 1>(q, g_bk, cdiv(p.M, 128), s);
+  else launch_cfg<1, 4, 4, 1>(q, g_bk, cdiv(p.M, 128), s);
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
 }
