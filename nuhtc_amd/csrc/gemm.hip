@@ -174,18 +174,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   int kt = 0;
   for (; kt + 1 < nk; ++kt) {       // every iteration here has a successor tile: no conditional inside the body
     const int buf = kt & 1;
+    // the LDS reads of the other fragment set are issued one MFMA step into the group, so the lgkmcnt wait in front of
+    // the group only covers reads issued half a tile ago
+    MFMA_STEP(x, fa_a, fa_b)
+    __builtin_amdgcn_sched_barrier(0);
     READ_FRAGS(buf, 1, fb_a, fb_b)
     __builtin_amdgcn_sched_barrier(0);
-    MFMA_GROUP(fa_a, fa_b)
+    MFMA_STEP(y, fa_a, fa_b) MFMA_STEP(z, fa_a, fa_b) MFMA_STEP(w, fa_a, fa_b)
     __builtin_amdgcn_sched_barrier(0);
     STORE_TILE(buf ^ 1)                          // waits for the staging loads issued one iteration ago
     __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): this wave's LDS writes have landed
     __builtin_amdgcn_s_barrier();                // raw barrier: no vmcnt(0) (nothing is in flight here anyway)
     __builtin_amdgcn_sched_barrier(0);
     LOAD_TILE(kt + 2 < nk ? kt + 2 : nk - 1)     // the clamped reload at the end is never used
+    __builtin_amdgcn_sched_barrier(0);
+    MFMA_STEP(x, fb_a, fb_b)
+    __builtin_amdgcn_sched_barrier(0);
     READ_FRAGS(buf ^ 1, 0, fa_a, fa_b)
     __builtin_amdgcn_sched_barrier(0);
-    MFMA_GROUP(fb_a, fb_b)
+    MFMA_STEP(y, fb_a, fb_b) MFMA_STEP(z, fb_a, fb_b) MFMA_STEP(w, fb_a, fb_b)
     __builtin_amdgcn_sched_barrier(0);
   }
   READ_FRAGS(kt & 1, 1, fb_a, fb_b)
