@@ -102,8 +102,8 @@ int launch_layernorm(const float* x, const int* src_map, const float* g, const f
 // PatchMerging gather + LN(4C): out[(b,y2,x2), (kh*2+kw)*C + c] (weights pre-permuted to this order)
 int launch_merge_ln(const float* x, const float* g, const float* b, float* y, int B, int H, int W, int C, hipStream_t s);
 // window attention: qkv [nWin*49, 3C] -> out [nWin*49, C]; bias [nH,49,49]; mask [nW,49,49] or null
-int launch_window_attn(const float* qkv, const float* bias, const float* mask, float* out, int nWinTotal, int nWperImg, int C,
-                       int nH, hipStream_t s);
+int launch_window_attn(const float* qkv, const float* bias, const float* biasT, const float* mask, float* out, int nWinTotal,
+                       int nWperImg, int C, int nH, hipStream_t s);
 
 // ----------------------------------------------------------------------------- dense heads (dense.hip)
 int launch_sem_fuse(const float* g0, const float* g1, const float* g2, const float* g3, float* out, int B, int H, int W,

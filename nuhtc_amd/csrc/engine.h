@@ -10,7 +10,7 @@ struct StageGeom {
 };
 
 struct BlockW {
-  float *n1g, *n1b, *relb, *qkv_w, *qkv_b, *proj_w, *proj_b, *n2g, *n2b, *f1_w, *f1_b, *f2_w, *f2_b;
+  float *n1g, *n1b, *relb, *relbT, *qkv_w, *qkv_b, *proj_w, *proj_b, *n2g, *n2b, *f1_w, *f1_b, *f2_w, *f2_b;
 };
 
 struct nuhtc_engine {
@@ -47,6 +47,8 @@ struct nuhtc_engine {
   int roi_cap = 0;          // rois per tile: max_cc_proposals + rpn_max_per_img
   int cand_cap = 0;         // rpn candidates per tile (<= 4 * nms_pre), det candidates per tile
   int* overflow = nullptr;  // dev int[4]
+  hipStream_t side = nullptr;       // proposal selection / NMS run here, concurrently with the semantic head on the caller's stream
+  hipEvent_t ev_rpn = nullptr, ev_side = nullptr;
   struct RoiWs* rw = nullptr;
 };
 

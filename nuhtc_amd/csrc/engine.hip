@@ -60,6 +60,10 @@ int nuhtc_create(const nuhtc_config* cfg, int device, nuhtc_engine** out) {
 void nuhtc_destroy(nuhtc_engine* e) {
   if (!e) return;
   hipSetDevice(e->device);
+  hipDeviceSynchronize();
+  if (e->side) hipStreamDestroy(e->side);
+  if (e->ev_rpn) hipEventDestroy(e->ev_rpn);
+  if (e->ev_side) hipEventDestroy(e->ev_side);
   for (void* p : e->allocs) hipFree(p);
   delete e;
 }
@@ -220,6 +224,11 @@ int nuhtc_finalize(nuhtc_engine* e) {
       std::vector<float> rb((size_t)nH * WS2 * WS2);
       for (int h = 0; h < nH; ++h)
         for (int i = 0; i < WS2 * WS2; ++i) rb[(size_t)h * WS2 * WS2 + i] = tab->data[(size_t)rel[i] * nH + h];
+      std::vector<float> rbT((size_t)nH * WS2 * WS2);   // [head][key][query] for the MFMA attention kernel
+      for (int h = 0; h < nH; ++h)
+        for (int qi = 0; qi < WS2; ++qi)
+          for (int kj = 0; kj < WS2; ++kj) rbT[((size_t)h * WS2 + kj) * WS2 + qi] = rb[((size_t)h * WS2 + qi) * WS2 + kj];
+      if ((rc = upload(e, &bw.relbT, rbT))) return rc;
       if ((rc = upload(e, &bw.n1g, n1w->data)) || (rc = upload(e, &bw.n1b, n1b->data)) || (rc = upload(e, &bw.relb, rb)) ||
           (rc = upload(e, &bw.qkv_w, qw->data)) || (rc = upload(e, &bw.qkv_b, qb->data)) || (rc = upload(e, &bw.proj_w, pw->data)) ||
           (rc = upload(e, &bw.proj_b, pb->data)) || (rc = upload(e, &bw.n2g, n2w->data)) || (rc = upload(e, &bw.n2b, n2b->data)) ||
@@ -317,6 +326,9 @@ int nuhtc_finalize(nuhtc_engine* e) {
       (rc = ws(e, &e->sem_feat, "sem_feat", {B, g0.H, g0.W, 64}, 0)) || (rc = ws(e, &e->sem_pred, "sem_pred", {B, g0.H, g0.W}, 0)))
     return rc;
   if ((rc = alloc_roi_workspace(e))) return rc;
+  HIP_CHECK(e, hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+  HIP_CHECK(e, hipEventCreateWithFlags(&e->ev_rpn, hipEventDisableTiming));
+  HIP_CHECK(e, hipEventCreateWithFlags(&e->ev_side, hipEventDisableTiming));
   HIP_CHECK(e, hipDeviceSynchronize());
   e->raw.clear();
   e->finalized = true;
@@ -358,7 +370,7 @@ int run_backbone(nuhtc_engine* e, int B, hipStream_t s) {
       // x += proj(attn(LN1(x)))      (mmdet swin.py:356-363)
       RUN(launch_layernorm(x, g.map[sh], w.n1g, w.n1b, e->xw, Mw, C, s));
       RUN(launch_gemm(gp(e->xw, w.qkv_w, w.qkv_b, e->qkv, Mw, 3 * C, C), s));
-      RUN(launch_window_attn(e->qkv, w.relb, sh ? g.mask : nullptr, e->att, B * g.nW, g.nW, C, g.nH, s));
+      RUN(launch_window_attn(e->qkv, w.relb, w.relbT, sh ? g.mask : nullptr, e->att, B * g.nW, g.nW, C, g.nH, s));
       {
         GemmParams p = gp(e->att, w.proj_w, w.proj_b, x, Mw, C, C);
         p.store = ST_ROWMAP; p.row_map = g.map[sh]; p.res = x; p.ldr = C;
@@ -409,6 +421,7 @@ int run_neck_heads(nuhtc_engine* e, int B, hipStream_t s) {
     RUN(conv3x3(e, e->x[i], e->rpn_w, e->rpn_b, e->tmpA, B, g.H, g.W, ACT_RELU, nullptr, 1, s));
     RUN(launch_gemm(gp(e->tmpA, e->rpn_hw, e->rpn_hb, e->rpn[i], B * g.H * g.W, 32, 64), s));
   }
+  if (hipEventRecord(e->ev_rpn, s) != hipSuccess) FAIL(e, NUHTC_E_HIP, "hipEventRecord failed");   // RPN maps ready: side stream may start
   // FusedSemanticHead (fused_semantic_head.py:97-111)
   for (int i = 0; i < 4; ++i) {
     const StageGeom& g = e->st[i];

@@ -236,14 +236,19 @@ int run_roi_path(nuhtc_engine* e, int B, const float* rois_fixed, int n_rois, in
     RpnSelParams sp;
     sp.nms_pre = c.rpn_nms_pre; sp.slot = w->rpn_slot; sp.cand_boxes = w->cand_boxes; sp.cand_scores = w->cand_scores; sp.cand_count = w->cand_count;
     sp.img_h = Hn; sp.img_w = Wn; sp.min_size = c.rpn_min_bbox_size;
-    RUN(launch_rpn_select(lv, sp, B, s));
+    // RPN selection + NMS depend only on the RPN maps: they run on the side stream, overlapping the semantic head /
+    // connected-component kernels the caller's stream is still working through (fork at ev_rpn, join before build_rois)
+    hipStream_t s2 = e->side;
+    if (hipStreamWaitEvent(s2, e->ev_rpn, 0) != hipSuccess) FAIL(e, NUHTC_E_HIP, "hipStreamWaitEvent failed");
+    RUN(launch_rpn_select(lv, sp, B, s2));
     NmsParams np;
     memset(&np, 0, sizeof(np));
     np.boxes = w->cand_boxes; np.scores = w->cand_scores; np.ids = nullptr; np.group_count = w->cand_count; np.n_groups = 4; np.slot = w->rpn_slot;
     np.cap = w->rpn_cap; np.cap_pow2 = w->rpn_pow2; np.iou_thr = c.rpn_nms_iou; np.max_keep = c.rpn_max_per_img;
     np.sorted_boxes = w->nms_sboxes; np.sorted_src = w->nms_src; np.n_total = w->nms_ntotal; np.mask = w->nms_mask;
     np.out_dets = w->rpn_dets; np.out_src = w->rpn_src; np.out_counts = w->rpn_counts;
-    RUN(launch_nms(np, B, s));
+    RUN(launch_nms(np, B, s2));
+    if (hipEventRecord(e->ev_side, s2) != hipSuccess) FAIL(e, NUHTC_E_HIP, "hipEventRecord failed");
     // ---- connected-component ("watershed") proposals (htc_roi_head_cus.py:283-342)
     if (c.watershed_proposal && c.max_cc_proposals > 0) {
       CcParams cp;
@@ -254,11 +259,7 @@ int run_roi_path(nuhtc_engine* e, int B, const float* rois_fixed, int n_rois, in
     }
   }
   const bool use_cc = !fixed && c.watershed_proposal && c.max_cc_proposals > 0;
-  RUN(launch_build_rois(use_cc ? w->cc_boxes : nullptr, w->cc_counts, std::max(c.max_cc_proposals, 1), w->rpn_dets, w->rpn_counts, c.rpn_max_per_img,
-                        rois_fixed, n_rois, w->rois, w->roi_off, w->roi_cnt, w->roi_total, B, s));
-  const int Rcap = fixed ? B * n_rois : B * e->roi_cap;
-
-  // ---- attention-pool tables for levels 2, 3 (roi_extractors_cus.py:220-238)
+  // ---- attention-pool tables for levels 2, 3 (roi_extractors_cus.py:220-238): independent of the proposals
   for (int l = 2; l < 4; ++l) {
     const int HW = e->st[l].H * e->st[l].W;
     float* G = l == 2 ? w->G2 : w->G3;
@@ -278,6 +279,10 @@ int run_roi_path(nuhtc_engine* e, int B, const float* rois_fixed, int n_rois, in
       RUN(launch_attn_pool(e->x[l], G, B, HW, c.att_thres, s));
     }
   }
+  if (!fixed && hipStreamWaitEvent(s, e->ev_side, 0) != hipSuccess) FAIL(e, NUHTC_E_HIP, "hipStreamWaitEvent failed");   // join
+  RUN(launch_build_rois(use_cc ? w->cc_boxes : nullptr, w->cc_counts, std::max(c.max_cc_proposals, 1), w->rpn_dets, w->rpn_counts, c.rpn_max_per_img,
+                        rois_fixed, n_rois, w->rois, w->roi_off, w->roi_cnt, w->roi_total, B, s));
+  const int Rcap = fixed ? B * n_rois : B * e->roi_cap;
 
   RoiFeatParams fp;
   fp.rois = w->rois; fp.r_dev = w->roi_total; fp.x0 = e->x[0]; fp.x1 = e->x[1]; fp.G2 = w->G2; fp.G3 = w->G3; fp.sem = e->sem_feat;

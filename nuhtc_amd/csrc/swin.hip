@@ -8,6 +8,8 @@
 //   window_attn   : softmax(q·s·kᵀ + relpos_bias + shift_mask)·v per (window, head), N=49, d=32
 //                   (swin.py:79-117); one wave per (window, head), K/V staged in LDS, one query row per lane,
 //                   scores/softmax entirely in registers.
+#include <cstdlib>
+
 #include "common.h"
 
 // ----------------------------------------------------------------------------- preproc
@@ -278,11 +280,118 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const float* __restric
   }
 }
 
-int launch_window_attn(const float* qkv, const float* bias, const float* mask, float* out, int nWinTotal, int nWperImg, int C,
-                       int nH, hipStream_t s) {
+// ---- MFMA variant: one wave per (window, head), no LDS, no barriers ---------------------------------------------------
+// Sᵀ = K·(s·Q)ᵀ and Oᵀ = Vᵀ·Pᵀ on v_mfma_f32_32x32x2_f32 with the 49 tokens padded to 2 x 32.  Computing the transposed
+// products puts the query on the lane and the keys in the accumulator registers, so (a) the softmax over keys is a
+// within-lane reduction plus one lane^32 exchange, and (b) the probability tile is already in B-operand position for the
+// second product (it sums over the accumulator's row index): no data movement between the two GEMMs.  Q/K fragments are
+// 64 contiguous bytes per lane read straight from the qkv rows; V is read one dword per MFMA step (a full 128-byte row per
+// half-wave).  biasT is the relative-position bias transposed to [head][key][query] so lanes read it contiguously.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void window_attn_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ biasT,
+                                                               const float* __restrict__ mask, float* __restrict__ out, int nPairs,
+                                                               int nWperImg, int C, int nH) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pair = blockIdx.x * 4 + wave;
+  if (pair >= nPairs) return;
+  const int win = pair / nH, head = pair - win * nH;
+  const int l32 = lane & 31, half = lane >> 5;
+  const long long ld = 3LL * C;
+  const float* base = qkv + (long long)win * WS2 * ld + head * HEAD_DIM;
+  const float* bT = biasT + (long long)head * WS2 * WS2;
+  const float* mk = mask ? mask + (long long)(win % nWperImg) * WS2 * WS2 : nullptr;
+  const float scale = 0.17677669529663687f;   // 32^-0.5
+
+  // K fragments of both key tiles: lane (j, half) holds K[tj*32 + j][half*16 .. +16)
+  v4f kf[2][4];
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj) {
+    const int j = min(tj * 32 + l32, WS2 - 1);
+    const v4f* kp = reinterpret_cast<const v4f*>(base + j * ld + C + half * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) kf[tj][q] = kp[q];
+  }
+#pragma unroll 1
+  for (int ti = 0; ti < 2; ++ti) {
+    const int i = min(ti * 32 + l32, WS2 - 1);
+    v4f qf[4];
+    {
+      const v4f* qp = reinterpret_cast<const v4f*>(base + i * ld + half * 16);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) qf[q] = qp[q] * scale;
+    }
+    f32x16 st[2];
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[tj][r] = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        st[tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[tj][q].x, qf[q].x, st[tj], 0, 0, 0);
+        st[tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[tj][q].y, qf[q].y, st[tj], 0, 0, 0);
+        st[tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[tj][q].z, qf[q].z, st[tj], 0, 0, 0);
+        st[tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[tj][q].w, qf[q].w, st[tj], 0, 0, 0);
+      }
+    }
+    // + relative-position bias (+ shift mask), keys >= 49 masked out; softmax over the keys of query i
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = tj * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int jc = min(j, WS2 - 1);
+        float v = st[tj][r] + bT[jc * WS2 + i];
+        if (mk) v += mk[jc * WS2 + i];
+        v = j < WS2 ? v : -3.0e38f;
+        st[tj][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __expf(st[tj][r] - mx);
+        st[tj][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 32);
+    const float rsum = 1.0f / sum;
+    // Oᵀ[d][i] = sum_j V[j][d] * P[i][j]: A = V rows (lane = d), B = the probability registers themselves
+    f32x16 ot;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[r] = 0.f;
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = min(tj * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, WS2 - 1);
+        const float vv = base[j * ld + 2 * C + l32];
+        ot = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, st[tj][r] * rsum, ot, 0, 0, 0);
+      }
+    if (ti * 32 + l32 < WS2) {
+      float* op = out + ((long long)win * WS2 + ti * 32 + l32) * C + head * HEAD_DIM + 4 * half;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)   // registers 4g..4g+3 are d = 8g + 4*half + 0..3
+        *reinterpret_cast<v4f*>(op + 8 * g) = (v4f){ot[4 * g], ot[4 * g + 1], ot[4 * g + 2], ot[4 * g + 3]};
+    }
+  }
+}
+
+int launch_window_attn(const float* qkv, const float* bias, const float* biasT, const float* mask, float* out, int nWinTotal,
+                       int nWperImg, int C, int nH, hipStream_t s) {
   ProfScope ps("window_attn", 4.0 * 49 * 49 * 32 * nWinTotal * nH, 16.0 * 49 * C * nWinTotal, s);
   int nPairs = nWinTotal * nH;
   if (nPairs <= 0) return 0;
-  hipLaunchKernelGGL(window_attn_kernel, dim3(cdiv(nPairs, 4)), dim3(256), 0, s, qkv, bias, mask, out, nPairs, nWperImg, C, nH);
+  static int use_mfma = -1;
+  if (use_mfma < 0) { const char* e = getenv("NUHTC_ATTN_VALU"); use_mfma = (e && atoi(e)) ? 0 : 1; }
+  if (use_mfma && biasT)
+    hipLaunchKernelGGL(window_attn_mfma_kernel, dim3(cdiv(nPairs, 4)), dim3(256), 0, s, qkv, biasT, mask, out, nPairs, nWperImg, C, nH);
+  else
+    hipLaunchKernelGGL(window_attn_kernel, dim3(cdiv(nPairs, 4)), dim3(256), 0, s, qkv, bias, mask, out, nPairs, nWperImg, C, nH);
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
 }
