@@ -211,13 +211,15 @@ __device__ __forceinline__ LevelPlan plan_level(const RoiGeom& g, int P, int gsa
   return lp;
 }
 
-__device__ __forceinline__ void stage_tile(const float* __restrict__ map, int H, int W, int b, const LevelPlan& lp, float* tile, int lane) {
-  for (int yy = 0; yy < lp.fh; ++yy)
-    for (int xx = 0; xx < lp.fw; ++xx) {
-      const float* src = map + (((long long)b * H + lp.fy0 + yy) * W + lp.fx0 + xx) * 64 + lane;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(tile + (yy * lp.fw + xx) * 64), 4, 0, 0);
-    }
+// the block's 4 waves copy the footprint pixel by pixel (one 256-byte pixel per global->LDS instruction)
+__device__ __forceinline__ void stage_tile(const float* __restrict__ map, int H, int W, int b, const LevelPlan& lp, float* tile, int lane, int wave) {
+  const int npx = lp.fh * lp.fw;
+  for (int pp = wave; pp < npx; pp += 4) {
+    const int yy = pp / lp.fw, xx = pp - yy * lp.fw;
+    const float* src = map + (((long long)b * H + lp.fy0 + yy) * W + lp.fx0 + xx) * 64 + lane;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(tile + pp * 64), 4, 0, 0);
+  }
 }
 
 // one bin from the LDS image: identical arithmetic to roi_bin() (weights hy*hx.., sample sum iy-outer ix-inner, / count)
@@ -278,12 +280,14 @@ __global__ __launch_bounds__(448) void roi_feat7_generic_kernel(RoiFeatParams p)
   }
 }
 
-__global__ __launch_bounds__(64) void roi_feat7_lds_kernel(RoiFeatParams p) {
+__global__ __launch_bounds__(256) void roi_feat7_lds_kernel(RoiFeatParams p) {
   __shared__ float tile0[TP0 * TP0 * 64];
   __shared__ float tileS[TP0 * TP0 * 64];
   __shared__ float tile1[TP1 * TP1 * 64];
   __shared__ AxisEnt tab[3][2][16];
-  const int lane = threadIdx.x;
+  // one RoI per block: the 4 waves share the staged footprints and split the 49 bins, so each SIMD holds 4 waves of
+  // 4 different RoIs (LDS allows 4 blocks per CU) and the LDS / global latencies of one hide behind the others
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = blockIdx.x;
   if (r >= *p.r_dev) return;
   const float* roi = p.rois + (long long)r * 5;
@@ -302,39 +306,39 @@ __global__ __launch_bounds__(64) void roi_feat7_lds_kernel(RoiFeatParams p) {
   float* out = p.out + (long long)r * 49 * 64;
   const RoiGeom g0 = roi_geom(roi, 0.25f, 7, 2), g1 = roi_geom(roi, 0.125f, 7, 2), gs = roi_geom(roi, 0.25f, 14, 0);
   const bool sem_g1 = gs.gw == 1 && gs.gh == 1;
-  const LevelPlan l0 = plan_level(g0, 7, 2, p.H0, p.W0, TP0, lane);
+  const LevelPlan l0 = plan_level(g0, 7, 2, p.H0, p.W0, TP0, lane);   // every wave computes the same plan
   const LevelPlan l1 = plan_level(g1, 7, 2, p.H1, p.W1, TP1, lane);
   const LevelPlan ls = plan_level(gs, 14, 1, p.H0, p.W0, TP0, lane);
-  if (!(sem_g1 && l0.ok && l1.ok && ls.ok)) {
-    if (lane == 0) p.fb_list[atomicAdd(p.fb_count, 1)] = r;
+  if (!(sem_g1 && l0.ok && l1.ok && ls.ok)) {   // block-uniform
+    if (threadIdx.x == 0) p.fb_list[atomicAdd(p.fb_count, 1)] = r;
     return;
   }
-  {
+  if (wave == 0) {
     const int ax = lane >> 5, idx = lane & 31;
     if (idx < 14) { tab[0][ax][idx] = l0.ent; tab[1][ax][idx] = l1.ent; tab[2][ax][idx] = ls.ent; }
   }
-  stage_tile(p.x0, p.H0, p.W0, b, l0, tile0, lane);
-  stage_tile(p.x1, p.H1, p.W1, b, l1, tile1, lane);
-  stage_tile(p.sem, p.H0, p.W0, b, ls, tileS, lane);
+  stage_tile(p.x0, p.H0, p.W0, b, l0, tile0, lane, wave);
+  stage_tile(p.x1, p.H1, p.W1, b, l1, tile1, lane, wave);
+  stage_tile(p.sem, p.H0, p.W0, b, ls, tileS, lane, wave);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-  for (int ph = 0; ph < 7; ++ph)
-    for (int pw = 0; pw < 7; ++pw) {
-      float v = 0.f;
-      v += l0.empty ? 0.f : bin_lds<2>(tile0, l0.fw, tab[0][0], tab[0][1], pw, ph, lane);
-      v += l1.empty ? 0.f : bin_lds<2>(tile1, l1.fw, tab[1][0], tab[1][1], pw, ph, lane);
-      v += gsum[0];
-      v += gsum[1];
-      float sv = 0.f;
-      if (!ls.empty) {
-        const float a = bin_lds<1>(tileS, ls.fw, tab[2][0], tab[2][1], 2 * pw, 2 * ph, lane);
-        const float bq = bin_lds<1>(tileS, ls.fw, tab[2][0], tab[2][1], 2 * pw + 1, 2 * ph, lane);
-        const float c = bin_lds<1>(tileS, ls.fw, tab[2][0], tab[2][1], 2 * pw, 2 * ph + 1, lane);
-        const float d = bin_lds<1>(tileS, ls.fw, tab[2][0], tab[2][1], 2 * pw + 1, 2 * ph + 1, lane);
-        sv = (((a + bq) + c) + d) * 0.25f;
-      }
-      out[(ph * 7 + pw) * 64 + lane] = v + sv;
+  __syncthreads();
+  for (int bin = wave; bin < 49; bin += 4) {
+    const int ph = bin / 7, pw = bin - ph * 7;
+    float v = 0.f;
+    v += l0.empty ? 0.f : bin_lds<2>(tile0, l0.fw, tab[0][0], tab[0][1], pw, ph, lane);
+    v += l1.empty ? 0.f : bin_lds<2>(tile1, l1.fw, tab[1][0], tab[1][1], pw, ph, lane);
+    v += gsum[0];
+    v += gsum[1];
+    float sv = 0.f;
+    if (!ls.empty) {
+      const float a = bin_lds<1>(tileS, ls.fw, tab[2][0], tab[2][1], 2 * pw, 2 * ph, lane);
+      const float bq = bin_lds<1>(tileS, ls.fw, tab[2][0], tab[2][1], 2 * pw + 1, 2 * ph, lane);
+      const float c = bin_lds<1>(tileS, ls.fw, tab[2][0], tab[2][1], 2 * pw, 2 * ph + 1, lane);
+      const float d = bin_lds<1>(tileS, ls.fw, tab[2][0], tab[2][1], 2 * pw + 1, 2 * ph + 1, lane);
+      sv = (((a + bq) + c) + d) * 0.25f;
     }
+    out[bin * 64 + lane] = v + sv;
+  }
 }
 
 // 14x14 mask features: 4 waves per RoI, bins interleaved across the waves
@@ -377,7 +381,7 @@ int launch_roi_feat(const RoiFeatParams& p, int P, int r_cap, hipStream_t s) {
   if (r_cap <= 0) return 0;
   if (P == 7) {
     if (hipMemsetAsync(p.fb_count, 0, sizeof(int), s) != hipSuccess) return NUHTC_E_HIP;
-    hipLaunchKernelGGL(roi_feat7_lds_kernel, dim3(r_cap), dim3(64), 0, s, p);
+    hipLaunchKernelGGL(roi_feat7_lds_kernel, dim3(r_cap), dim3(256), 0, s, p);
     ProfScope ps2("roi_feat7_generic", 0, 0, s);
     hipLaunchKernelGGL(roi_feat7_generic_kernel, dim3(r_cap < 1024 ? r_cap : 1024, 7), dim3(448), 0, s, p);
   } else if (P == 14) hipLaunchKernelGGL(roi_feat14_kernel, dim3(r_cap), dim3(256), 0, s, p);
