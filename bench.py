@@ -125,6 +125,10 @@ def main():
     tot_ms = sum(v['ms'] for v in prof.values())
     breakdown = {k: round(v['ms'] / prof_steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])}
 
+    traffic = None
+    tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_traffic.json')
+    if os.path.exists(tf):   # HBM bytes per launch from separate rocprofv3 --pmc passes of this same command (committed summary)
+        traffic = json.load(open(tf))['hbm_bytes_per_launch']
     if rank == 0:
         out = {
             'metric': 'tiles/sec (256x256) whole-node', 'value': total_tiles / dt, 'unit': 'tiles/s', 'n_gpus': world,
@@ -136,7 +140,8 @@ def main():
                        'tiles': 'synthetic nuclei tiles (nuhtc_amd.synth), resident in HBM',
                        'mean_rois_per_tile': float(roi_counts.mean()), 'mean_dets_per_tile': float(counts.mean())},
             'roofline': {'bound': 'mfma', 'kernel': DOMINANT + ' (Swin-T linears, fp32 v_mfma_f32_32x32x2_f32)', 'achieved': achieved,
-                         'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                         'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
+                         'algorithmic_bytes_per_launch': dom['bytes'] / dom['launches'],
                          'avg_launch_ms': dur_ms, 'launches_per_step': dom['launches'] // prof_steps,
                          'share_of_step_kernel_time': dom['ms'] / tot_ms},
             'kernel_ms_per_step': breakdown,
