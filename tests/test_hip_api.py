@@ -64,3 +64,25 @@ def test_wsi_host_path_single_rank(hip_device, model):
     # kept detections do not overlap each other above the threshold
     sub = {k: [rec[k][i] for i in keep] for k in rec}
     assert len(wsi.merge_overlap(sub, 0.05)) == len(keep)
+
+
+def test_infer_wsi_cli_writes_qupath_geojson(hip_device, tmp_path):
+    import json
+    import subprocess
+    import sys
+    import torch
+    from nuhtc_amd import synth, weights
+    img = np.concatenate([np.concatenate([synth.nuclei_tile(30 + 2 * r + c, 128) for c in range(2)], 1) for r in range(2)], 0)
+    src = tmp_path / 'slide.npy'
+    np.save(src, img)
+    ck = tmp_path / 'w.pth'
+    torch.save(dict(state_dict=weights.bench_state_dict(0, obj_bias=0.0)), ck)
+    subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools/infer_wsi.py'), str(src), CFG, str(ck), '--patch_size', '64', '--step_size', '48',
+                           '--batch_size', '4', '--save_dir', str(tmp_path / 'out'), '--merge'])
+    feats = json.load(open(tmp_path / 'out/nuclei/slide/slide.geojson'))
+    merged = json.load(open(tmp_path / 'out/nuclei/slide/slide_merged.geojson'))
+    pts = json.load(open(tmp_path / 'out/nuclei/slide/slide_point.geojson'))
+    assert len(feats) == len(pts) > 0 and 0 < len(merged) <= len(feats)
+    f0 = feats[0]
+    assert f0['geometry']['type'] == 'Polygon' and f0['geometry']['coordinates'][0][0] == f0['geometry']['coordinates'][0][-1]
+    assert set(f0['properties']) >= {'objectType', 'label', 'score', 'classification', 'isLocked'}

@@ -237,3 +237,34 @@ def test_capacity_overflow_is_reported(hip_device):
     from nuhtc_amd.engine import HipError
     with pytest.raises(HipError):
         eng.check()
+
+
+def test_consep_classes_and_batch_independence(hip_device):
+    """CoNSeP-style head (num_classes=4, max_per_img=300) at full tile size, B=6 in a max_batch=16 engine: every tile
+    must equal the oracle, and a tile's result must not depend on its position in the batch or on its neighbours."""
+    from nuhtc_amd import synth, weights
+    from nuhtc_amd.engine import Engine
+    from oracle import model as O
+    sd = weights.bench_state_dict(5, num_classes=4, obj_bias=0.5)
+    eng = Engine(sd, device=0, max_batch=16, tile=(256, 256), num_classes=4, max_per_img=300)
+    base = synth.nuclei_tiles(3, 256, start=40)
+    tiles = np.stack([base[0], base[1], base[2], base[0], base[2], base[1]])
+    got = eng(tiles, 1)
+    ref = O.Oracle(sd, num_classes=4, max_per_img=300)(base, 1)
+    msgs = []
+    for i, r in zip((0, 1, 2), ref):
+        nr, ng, nm, miou, low = match_instances_nc(r, got[i], 4)
+        print(f'consep tile {i}: ref {nr} hip {ng} matched {nm} masks below 0.999: {low} (min {miou:.5f})')
+        assert ng <= 300
+        if nm < 0.98 * max(nr, ng) or low > 0.01 * max(nm, 1) + 1:
+            msgs.append(f'tile {i}: {nr}/{ng}/{nm}, {low} low-IoU masks')
+    for a, b in ((0, 3), (2, 4), (1, 5)):   # same tile at different batch positions -> bit-identical outputs
+        for c in range(4):
+            if not np.array_equal(got[a][0][c], got[b][0][c]) or any(not np.array_equal(x, y) for x, y in zip(got[a][1][c], got[b][1][c])):
+                msgs.append(f'tiles {a} and {b} differ in class {c}')
+    assert not msgs, '\n'.join(msgs)
+
+
+def match_instances_nc(ref, got, nc):
+    pad = lambda r: ([*r[0]] + [np.zeros((0, 5), np.float32)] * (5 - nc), [*r[1]] + [[]] * (5 - nc))
+    return match_instances(pad(ref), pad(got))

@@ -1,0 +1,43 @@
+#!/usr/bin/env python
+"""Same command line as the reference's tools/nuclei_merge.py:221-230: cross-tile duplicate removal on a GeoJSON list.
+
+    python tools/nuclei_merge.py --geojson slide.geojson [--overlap_threshold 0.01] [--merge_strategy probability|area]
+                                 [--output_name NAME] [--uniform_classification]
+"""
+import json
+import os
+import sys
+from argparse import ArgumentParser
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nuhtc_amd.contours import merge_features  # noqa: E402
+
+
+def parse_args():
+    p = ArgumentParser()
+    p.add_argument('--geojson', help='geojson file name')
+    p.add_argument('--output_name', default=None, type=str, help='output geojson file name')
+    p.add_argument('--overlap_threshold', type=float, default=0.01, help='area overlap percentage threshold to be removed')
+    p.add_argument('--merge_strategy', default='probability', help="'probability' or 'area'")
+    p.add_argument('--uniform_classification', action='store_true')
+    return p.parse_args()
+
+
+def main():
+    args = parse_args()
+    datadir = os.path.dirname(args.geojson) or '.'
+    name = os.path.basename(args.geojson).split('.geojson')[0]
+    with open(os.path.join(datadir, name + '.geojson')) as f:
+        data = json.load(f)
+    feats = merge_features(data, args.overlap_threshold, args.merge_strategy)
+    if args.uniform_classification:
+        for ft in feats:
+            ft['properties']['classification'] = {'name': 'uniform', 'color': [255, 255, 0]}
+    out = os.path.join(datadir, (args.output_name or name + '_merged') + '.geojson')
+    with open(out, 'w') as f:
+        json.dump(feats, f)
+    print(f'{len(data)} features -> {len(feats)} after merge; wrote {out}')
+
+
+if __name__ == '__main__':
+    main()
