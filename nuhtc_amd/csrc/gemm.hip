@@ -16,7 +16,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
 template <int MT, int NT, int WM, int WN, int BK, int AMODE>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+__global__ __launch_bounds__(256, (MT * NT <= 3 ? 4 : 3)) void gemm_kernel(GemmParams p) {   // 4 (3) blocks per CU: <= 128 (168) registers
   static_assert(WM * WN == 4, "4 waves per block");
   constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
   constexpr int KC = BK / 4;          // float4 chunks per tile row
@@ -204,52 +204,86 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 #undef MFMA_STEP
 #undef MFMA_GROUP
 
-  // ---- epilogue: lane holds column n = .. + i32 and rows (r&3) + 8(r>>2) + 4·half of each 32x32 sub-tile
+  // ---- epilogue: lane holds column n = .. + i32 and rows (r&3) + 8(r>>2) + 4·half of each 32x32 sub-tile.
+  // Row bookkeeping (validity, scatter map, FPN parent row) is resolved for all 16 rows first and every read the epilogue
+  // needs (map entries, residual, top-down term) is issued unconditionally from clamped addresses, so the loads of all
+  // rows are in flight together instead of forming 16 dependent map -> residual -> store chains.
   const float* ri = p.cos_ri ? p.cos_ri + (long long)z * p.sRi : nullptr;
   const float* rj = p.cos_rj ? p.cos_rj + (long long)z * p.sRj : nullptr;
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + (wm * MT + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (m >= Meff) continue;
-      long long drow = m;
+    for (int rg = 0; rg < 4; ++rg) {   // 4 rows (registers 4rg..4rg+3) at a time: stays inside the main loop's register budget
+      int mrow[4], drow[4], aux[4];    // aux: FPN parent row or deconv base row (mutually exclusive epilogues)
+      unsigned okmask = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = m0 + (wm * MT + mi) * 32 + q + 8 * rg + 4 * half;
+        if (m < Meff) okmask |= 1u << q;
+        mrow[q] = m < Meff ? m : Meff - 1;
+        drow[q] = mrow[q];
+        aux[q] = 0;
+      }
       if (p.store == ST_ROWMAP) {
-        int d = p.row_map[m];
-        if (d < 0) continue;
-        drow = d;
+        int d[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[q] = p.row_map[mrow[q]];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { if (d[q] < 0) okmask &= ~(1u << q); drow[q] = d[q] >= 0 ? d[q] : 0; }
       }
-      long long uprow = 0;
       if (p.up) {
-        int hw = p.upH * p.upW;
-        int b = m / hw, rr = m - b * hw;
-        int y = rr / p.upW, x = rr - y * p.upW;
-        uprow = ((long long)b * (p.upH >> 1) + (y >> 1)) * (p.upW >> 1) + (x >> 1);
-      }
-      long long dbase = 0;
-      if (p.store == ST_DECONV2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int hw = p.upH * p.upW;
+          const int b = mrow[q] / hw, rr = mrow[q] - b * hw;
+          const int y = rr / p.upW, x = rr - y * p.upW;
+          aux[q] = (b * (p.upH >> 1) + (y >> 1)) * (p.upW >> 1) + (x >> 1);
+        }
+      } else if (p.store == ST_DECONV2) {
         // rows m = (d, y, x) on a cH x cW grid; columns n = (kh*2+kw)*ldc + oc -> out[(d, 2y+kh, 2x+kw), oc]
-        int hw = p.cH * p.cW;
-        int b = m / hw, rr = m - b * hw;
-        int y = rr / p.cW, x = rr - y * p.cW;
-        dbase = ((long long)b * (2 * p.cH) + 2 * y) * (2 * p.cW) + 2 * x;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int hw = p.cH * p.cW;
+          const int b = mrow[q] / hw, rr = mrow[q] - b * hw;
+          const int y = rr / p.cW, x = rr - y * p.cW;
+          aux[q] = (b * (2 * p.cH) + 2 * y) * (2 * p.cW) + 2 * x;
+        }
       }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int n = n0 + (wn * NT + t) * 32 + i32;
-        float v = acc[mi][t][r] * p.alpha;
-        if (p.bias) v += p.bias[n];
-        if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
-        else if (p.act == ACT_GELU) v = gelu_erf(v);
-        else if (p.act == ACT_COS) v = fmaxf(v * ri[m] * rj[n] - p.cos_tau, 0.f) + p.cos_tau;
-        if (p.up) v += p.up[uprow * p.N + n];
-        if (p.res) v += p.res[drow * p.ldr + n];
-        if (p.store == ST_DECONV2) {
-          int tap = n / p.ldc, oc = n - tap * p.ldc;
-          C[(dbase + (tap >> 1) * (2 * p.cW) + (tap & 1)) * p.ldc + oc] = v;
-        } else {
-          C[drow * p.ldc + n] = v;
+        float addv[4];                 // residual + top-down term, fetched for the 4 rows before any is consumed
+#pragma unroll
+        for (int q = 0; q < 4; ++q) addv[q] = 0.f;
+        if (p.res) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) addv[q] = p.res[(long long)drow[q] * p.ldr + n];
         }
+        float upv[4];
+        if (p.up) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) upv[q] = p.up[(long long)aux[q] * p.N + n];
+        }
+        const float bias = p.bias ? p.bias[n] : 0.f;
+        const float rjn = rj ? rj[n] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v = acc[mi][t][rg * 4 + q] * p.alpha;
+          if (p.bias) v += bias;
+          if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+          else if (p.act == ACT_GELU) v = gelu_erf(v);
+          else if (p.act == ACT_COS) v = fmaxf(v * ri[mrow[q]] * rjn - p.cos_tau, 0.f) + p.cos_tau;
+          if (p.up) v += upv[q];
+          if (p.res) v += addv[q];
+          if (!((okmask >> q) & 1u)) continue;
+          if (p.store == ST_DECONV2) {
+            const int tap = n / p.ldc, oc = n - tap * p.ldc;
+            C[((long long)aux[q] + (tap >> 1) * (2 * p.cW) + (tap & 1)) * p.ldc + oc] = v;
+          } else {
+            C[(long long)drow[q] * p.ldc + n] = v;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the live ranges of one column tile from overlapping the next
       }
     }
 }
