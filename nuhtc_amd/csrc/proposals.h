@@ -4,6 +4,7 @@
 
 #define NMS_MAX_CAP 16384     // candidates per image the sort + mask matrix can take (128 KiB of LDS keys)
 #define NMS_MAX_GROUPS 16
+#define CC_LIST_CAP 4096      // components per tile that can pass the area filter before the ordered emit (opened masks: <= ~2600)
 
 struct RpnLevels {
   const float* out[4];   // [B, h*w, 32]: cols 0-2 objectness logits, 3.. deltas (anchor-major)
@@ -47,6 +48,8 @@ struct CcParams {
   unsigned char *mask_a, *mask_b, *touch;   // [B][img_h*img_w]
   int* labels;            // [B][img_h*img_w]
   int* stats;             // [B][img_h*img_w][5]
+  int* list;              // [B][CC_LIST_CAP] roots passing the area filter (unordered)
+  int* nlist;             // [B]
   float* boxes;           // [B][cap][4]
   int* counts;            // [B]
   int* overflow;          // int[4]

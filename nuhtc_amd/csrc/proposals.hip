@@ -487,8 +487,9 @@ __global__ void cc_fill_kernel(const unsigned char* __restrict__ m, const int* _
   out[idx] = (unsigned char)v;
 }
 // per-root statistics, addressed by the root's pixel index: area, min x, min y, max x, max y.
-// Pixels of one wave are 64 consecutive pixels of a row and mostly share one component: when every foreground lane
-// of the wave has the same root the wave reduces first and issues one set of atomics instead of 64.
+// A wave covers 64 consecutive pixels; when they lie in one row (W % 64 == 0) the lanes of each distinct root are reduced
+// with ballots (count = popcount, min/max x = first/last lane of the group) and one lane issues the 5 atomics, so a row
+// segment crossing k components costs 5k atomics instead of 5 per pixel.
 __global__ void cc_stats_kernel(const int* __restrict__ lab, int* __restrict__ stats, int H, int W, long long total) {
   long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int l = idx < total ? lab[idx] : -1;
@@ -496,26 +497,27 @@ __global__ void cc_stats_kernel(const int* __restrict__ lab, int* __restrict__ s
   const int p = idx < total ? (int)(idx % HW) : 0;
   const long long base = idx - p;
   const int x = p % W, y = p / W;
-  const bool fg = l >= 0;
-  const unsigned long long fgmask = __ballot(fg);
-  if (fgmask == 0) return;
-  const int leader = __ffsll((long long)fgmask) - 1;
-  const int l0 = __shfl(l, leader);
-  const long long base0 = __shfl(base, leader);
-  const int y0 = __shfl(y, leader);
-  const bool same = !fg || (l == l0 && base == base0 && y == y0);
-  if (__all(same)) {
-    int mn = fg ? x : (1 << 30), mx = fg ? x : -1;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { mn = min(mn, __shfl_xor(mn, o)); mx = max(mx, __shfl_xor(mx, o)); }
-    if ((threadIdx.x & 63) == leader) {
-      int* s = stats + (base0 + l0) * 5;
-      atomicAdd(&s[0], __popcll(fgmask));
-      atomicMin(&s[1], mn); atomicMin(&s[2], y0); atomicMax(&s[3], mx); atomicMax(&s[4], y0);
+  const int lane = threadIdx.x & 63;
+  unsigned long long todo = __ballot(l >= 0);
+  if (todo == 0) return;
+  if ((W & 63) == 0) {
+    const long long base0 = __shfl(base, __ffsll((long long)todo) - 1);   // all lanes of a wave share image and row here
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int l0 = __shfl(l, leader);
+      const unsigned long long grp = __ballot(l == l0) & todo;
+      if (lane == leader) {
+        const int first = leader, last = 63 - __clzll((long long)grp);
+        const int x0 = x, x1 = x + (last - first);
+        int* s = stats + (base0 + l0) * 5;
+        atomicAdd(&s[0], __popcll(grp));
+        atomicMin(&s[1], x0); atomicMin(&s[2], y); atomicMax(&s[3], x1); atomicMax(&s[4], y);
+      }
+      todo &= ~grp;
     }
     return;
   }
-  if (!fg) return;
+  if (l < 0) return;
   int* s = stats + (base + l) * 5;
   atomicAdd(&s[0], 1);
   atomicMin(&s[1], x); atomicMin(&s[2], y); atomicMax(&s[3], x); atomicMax(&s[4], y);
@@ -526,36 +528,40 @@ __global__ void cc_stats_init_kernel(int* __restrict__ stats, long long total) {
   int* s = stats + idx * 5;
   s[0] = 0; s[1] = 1 << 30; s[2] = 1 << 30; s[3] = -1; s[4] = -1;
 }
-// roots in raster order (== scipy.ndimage.label numbering), area filter, boxes [xmin, ymin, xmax+1, ymax+1]
-__global__ __launch_bounds__(1024) void cc_emit_kernel(const int* __restrict__ lab, const int* __restrict__ stats, float* __restrict__ boxes,
-                                                       int* __restrict__ counts, int* __restrict__ overflow, int H, int W, int min_area,
-                                                       int max_area, int cap) {
-  __shared__ int sc16[17];
+// roots that pass the area filter are appended (unordered) to a per-image list by all pixels in parallel ...
+__global__ void cc_collect_kernel(const int* __restrict__ lab, const int* __restrict__ stats, int* __restrict__ list, int* __restrict__ nlist,
+                                  int HW, int min_area, int max_area, long long total) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int p = (int)(idx % HW);
+  if (lab[idx] != p) return;
+  const int a = stats[idx * 5];
+  if (!(a > min_area && a < max_area)) return;
+  const int b = (int)(idx / HW);
+  const int k = atomicAdd(&nlist[b], 1);
+  if (k < CC_LIST_CAP) list[(long long)b * CC_LIST_CAP + k] = p;
+}
+// ... and one block per image sorts the list: ascending root index == raster order of first pixel == scipy.ndimage.label
+// numbering; boxes [xmin, ymin, xmax+1, ymax+1]
+__global__ __launch_bounds__(1024) void cc_emit_kernel(const int* __restrict__ stats, const int* __restrict__ list, const int* __restrict__ nlist,
+                                                       float* __restrict__ boxes, int* __restrict__ counts, int* __restrict__ overflow, int HW, int cap) {
+  __shared__ u64 keys[CC_LIST_CAP];
   const int b = blockIdx.x, tid = threadIdx.x;
-  const int HW = H * W;
-  const int* l = lab + (long long)b * HW;
+  const int n_all = nlist[b];
+  const int n = n_all < CC_LIST_CAP ? n_all : CC_LIST_CAP;
+  const int npad = next_pow2(n < 2 ? 2 : n);
+  for (int i = tid; i < npad; i += 1024) keys[i] = i < n ? (u64)(unsigned)list[(long long)b * CC_LIST_CAP + i] : ~0ull;
+  __syncthreads();
+  bitonic_sort_lds(keys, npad);
   const int* st = stats + (long long)b * HW * 5;
-  const int per = (HW + 1023) / 1024;
-  const int p0 = tid * per, p1 = min(p0 + per, HW);
-  int cnt = 0;
-  for (int p = p0; p < p1; ++p)
-    if (l[p] == p) { int a = st[p * 5]; if (a > min_area && a < max_area) ++cnt; }
-  int tot;
-  int off = block_exscan_1024(cnt, sc16, &tot);
-  for (int p = p0; p < p1; ++p)
-    if (l[p] == p) {
-      const int* s = st + p * 5;
-      if (s[0] > min_area && s[0] < max_area) {
-        if (off < cap) {
-          float* o = boxes + ((long long)b * cap + off) * 4;
-          o[0] = (float)s[1]; o[1] = (float)s[2]; o[2] = (float)(s[3] + 1); o[3] = (float)(s[4] + 1);
-        }
-        ++off;
-      }
-    }
+  for (int i = tid; i < n && i < cap; i += 1024) {
+    const int* s = st + (long long)(int)keys[i] * 5;
+    float* o = boxes + ((long long)b * cap + i) * 4;
+    o[0] = (float)s[1]; o[1] = (float)s[2]; o[2] = (float)(s[3] + 1); o[3] = (float)(s[4] + 1);
+  }
   if (tid == 0) {
-    counts[b] = tot < cap ? tot : cap;
-    if (tot > cap) atomicAdd(&overflow[0], 1);
+    counts[b] = n < cap ? n : cap;
+    if (n_all > cap) atomicAdd(&overflow[0], 1);
   }
 }
 
@@ -593,7 +599,8 @@ int launch_cc_proposals(const CcParams& p, int B, hipStream_t s) {
   hipLaunchKernelGGL(ccl_flatten_kernel, dim3(nb), dim3(256), 0, s, p.labels, HW, total);
   hipLaunchKernelGGL(cc_stats_init_kernel, dim3(nb), dim3(256), 0, s, p.stats, total);
   hipLaunchKernelGGL(cc_stats_kernel, dim3(nb), dim3(256), 0, s, p.labels, p.stats, H, W, total);
-  hipLaunchKernelGGL(cc_emit_kernel, dim3(B), dim3(1024), 0, s, p.labels, p.stats, p.boxes, p.counts, p.overflow, H, W, p.min_area,
-                     HW / 4, p.cap);
+  if (hipMemsetAsync(p.nlist, 0, sizeof(int) * B, s) != hipSuccess) return NUHTC_E_HIP;
+  hipLaunchKernelGGL(cc_collect_kernel, dim3(nb), dim3(256), 0, s, p.labels, p.stats, p.list, p.nlist, HW, p.min_area, HW / 4, total);
+  hipLaunchKernelGGL(cc_emit_kernel, dim3(B), dim3(1024), 0, s, p.stats, p.list, p.nlist, p.boxes, p.counts, p.overflow, HW, p.cap);
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
 }

@@ -20,7 +20,7 @@ struct RoiWs {
   int rpn_slot, rpn_cap, rpn_pow2;
   // connected-component proposals
   unsigned char *cc_a, *cc_b, *cc_touch;
-  int *cc_labels, *cc_stats, *cc_counts;
+  int *cc_labels, *cc_stats, *cc_counts, *cc_list, *cc_nlist;
   float* cc_boxes;
   // rois + cascade
   float* rois;
@@ -173,6 +173,7 @@ int alloc_roi_workspace(nuhtc_engine* e) {
   const int ccc = std::max(c.max_cc_proposals, 1);
   if ((rc = wsa(e, &w->cc_a, nullptr, {B, HW}, 2)) || (rc = wsa(e, &w->cc_b, "cc_mask", {B, Hn, Wn}, 2)) || (rc = wsa(e, &w->cc_touch, nullptr, {B, HW}, 2)) ||
       (rc = wsa(e, &w->cc_labels, "cc_labels", {B, Hn, Wn}, 1)) || (rc = wsa(e, &w->cc_stats, nullptr, {B, HW, 5}, 1)) ||
+      (rc = wsa(e, &w->cc_list, nullptr, {B, CC_LIST_CAP}, 1)) || (rc = wsa(e, &w->cc_nlist, nullptr, {B}, 1)) ||
       (rc = wsa(e, &w->cc_boxes, "cc_props", {B, ccc, 4}, 0)) || (rc = wsa(e, &w->cc_counts, "cc_counts", {B}, 1)) ||
       (rc = wsa(e, &e->overflow, nullptr, {4}, 1)))
     return rc;
@@ -254,7 +255,7 @@ int run_roi_path(nuhtc_engine* e, int B, const float* rois_fixed, int n_rois, in
       CcParams cp;
       cp.sem_pred = e->sem_pred; cp.h = e->st[0].H; cp.w = e->st[0].W; cp.img_h = Hn; cp.img_w = Wn; cp.min_area = 10; cp.cap = c.max_cc_proposals;
       cp.mask_a = w->cc_a; cp.mask_b = w->cc_b; cp.touch = w->cc_touch; cp.labels = w->cc_labels; cp.stats = w->cc_stats; cp.boxes = w->cc_boxes;
-      cp.counts = w->cc_counts; cp.overflow = e->overflow;
+      cp.counts = w->cc_counts; cp.overflow = e->overflow; cp.list = w->cc_list; cp.nlist = w->cc_nlist;
       RUN(launch_cc_proposals(cp, B, s));
     }
   }

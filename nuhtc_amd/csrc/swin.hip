@@ -152,9 +152,44 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   for (int j = 0; j < NV; ++j) { int c = lane + 64 * j; if (c < C) yr[c] = (v[j] - mean) * rstd * g[c] + b[c]; }
 }
 
+// C = 96 (stage 0, the most rows): one row per 32-lane half-wave, 24 lanes x one 16-byte load each
+__global__ __launch_bounds__(256) void layernorm96_kernel(const float* __restrict__ x, const int* __restrict__ src_map,
+                                                          const float* __restrict__ g, const float* __restrict__ b,
+                                                          float* __restrict__ y, int rows) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const int l = threadIdx.x & 31;
+  const long long row = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (row >= rows) return;
+  const long long src = src_map ? src_map[row] : row;
+  const bool act = l < 24;
+  v4f* yr = reinterpret_cast<v4f*>(y + row * 96);
+  if (src < 0) {
+    if (act) yr[l] = (v4f){0.f, 0.f, 0.f, 0.f};
+    return;
+  }
+  v4f v = act ? reinterpret_cast<const v4f*>(x + src * 96)[l] : (v4f){0.f, 0.f, 0.f, 0.f};
+  float sum = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float mean = sum / 96.0f;
+  v4f d = act ? v - mean : (v4f){0.f, 0.f, 0.f, 0.f};
+  float var = fmaf(d.x, d.x, fmaf(d.y, d.y, fmaf(d.z, d.z, d.w * d.w)));
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) var += __shfl_xor(var, o);
+  const float rstd = 1.0f / sqrtf(var / 96.0f + 1e-5f);
+  if (act) {
+    const v4f gg = reinterpret_cast<const v4f*>(g)[l], bb = reinterpret_cast<const v4f*>(b)[l];
+    yr[l] = d * rstd * gg + bb;
+  }
+}
+
 int launch_layernorm(const float* x, const int* src_map, const float* g, const float* b, float* y, int rows, int C, hipStream_t s) {
   ProfScope ps("layernorm", 0, 8.0 * rows * C, s);
   if (rows <= 0) return 0;
+  if (C == 96) {
+    hipLaunchKernelGGL(layernorm96_kernel, dim3(cdiv(rows, 8)), dim3(256), 0, s, x, src_map, g, b, y, rows);
+    return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
+  }
   dim3 grid(cdiv(rows, 4)), blk(256);
   int nv = cdiv(C, 64);
   if (nv <= 2) hipLaunchKernelGGL(layernorm_kernel<2>, grid, blk, 0, s, x, src_map, g, b, y, rows, C);
