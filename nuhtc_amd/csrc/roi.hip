@@ -654,6 +654,9 @@ int launch_paste(const PasteParams& p, int B, hipStream_t s) {
 // filtered by margin / min_area, ordered by np.argsort(score)[::-1] and greedily suppressed at mask IoU > thr.
 __global__ __launch_bounds__(256) void tile_post_kernel(TilePostParams p) {
   __shared__ unsigned long long okey[2048];   // sort keys
+  __shared__ float4 sbox[2048];               // boxes of the candidates in visiting order (LDS: the pair loop is latency-bound)
+  __shared__ int sarea[2048];
+  __shared__ short sidx[2048];
   __shared__ unsigned char sup[2048];
   __shared__ int s_inter;
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -692,28 +695,34 @@ __global__ __launch_bounds__(256) void tile_post_kernel(TilePostParams p) {
       }
       __syncthreads();
     }
-  int m = 0;   // number of candidates that passed the filter (keys != ~0)
-  for (int j = 0; j < n; ++j) if (okey[j] != ~0ull) m = j + 1;
+  for (int j = tid; j < n; j += 256) {
+    const bool valid = okey[j] != ~0ull;
+    const int i = valid ? (int)(okey[j] & 0xFFFF) : 0;
+    const float* d = dets + i * 5;
+    sbox[j] = make_float4(d[0], d[1], d[2], d[3]);
+    sarea[j] = areas[i];
+    sidx[j] = valid ? (short)i : (short)-1;
+  }
+  __syncthreads();
+  int m = 0;   // candidates that passed the filter sort first
+  while (m < n && sidx[m] >= 0) ++m;
   const unsigned* masks = p.masks + (long long)b * K * words;
   for (int a = 0; a < m; ++a) {
-    __syncthreads();
-    if (sup[a]) continue;
-    const int i = (int)(okey[a] & 0xFFFF);
+    if (sup[a]) continue;   // uniform: sup[] only changes between barriers
+    const int i = sidx[a];
     if (tid == 0) keep[i] = 1;
-    const float* di = dets + i * 5;
+    const float4 di = sbox[a];
     const unsigned* mi = masks + (long long)i * words;
-    // rows/words where mask i can be non-zero: hull of its box
-    const int y0 = max((int)floorf(di[1]) - 1, 0), y1 = min((int)ceilf(di[3]) + 1, p.H);
+    const int y0 = max((int)floorf(di.y) - 1, 0), y1 = min((int)ceilf(di.w) + 1, p.H);   // rows of mask i's hull
     for (int c = a + 1; c < m; ++c) {
-      if (sup[c]) continue;   // uniform: sup[] only changes between barriers
-      const int j = (int)(okey[c] & 0xFFFF);
-      const float* dj = dets + j * 5;
+      if (sup[c]) continue;
+      const float4 dj = sbox[c];
       // masks live inside their box hulls: no overlap of hulls -> IoU 0
-      const bool ov = fminf(di[2], dj[2]) + 2.f > fmaxf(di[0], dj[0]) - 2.f && fminf(di[3], dj[3]) + 2.f > fmaxf(di[1], dj[1]) - 2.f;
+      const bool ov = fminf(di.z, dj.z) + 2.f > fmaxf(di.x, dj.x) - 2.f && fminf(di.w, dj.w) + 2.f > fmaxf(di.y, dj.y) - 2.f;
       if (!ov) continue;
       if (tid == 0) s_inter = 0;
       __syncthreads();
-      const unsigned* mj = masks + (long long)j * words;
+      const unsigned* mj = masks + (long long)sidx[c] * words;
       int cnt = 0;
       for (int wv = y0 * wpr + tid; wv < y1 * wpr; wv += 256) cnt += __popc(mi[wv] & mj[wv]);
       cnt = (int)wsum64((float)cnt);
@@ -721,7 +730,7 @@ __global__ __launch_bounds__(256) void tile_post_kernel(TilePostParams p) {
       __syncthreads();
       if (tid == 0) {
         const int inter = s_inter;
-        const int uni = areas[i] + areas[j] - inter;
+        const int uni = sarea[a] + sarea[c] - inter;
         if (uni > 0 && (double)inter / (double)uni > p.thr) sup[c] = 1;
       }
       __syncthreads();
