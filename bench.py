@@ -49,6 +49,7 @@ def main():
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-tiles', type=int, default=8)
+    ap.add_argument('--gemm-shapes', action='store_true', help='add the per-shape GEMM timings to the JSON line')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -145,8 +146,9 @@ def main():
                          'avg_launch_ms': dur_ms, 'launches_per_step': dom['launches'] // prof_steps,
                          'share_of_step_kernel_time': dom['ms'] / tot_ms},
             'kernel_ms_per_step': breakdown,
-            'gemm_shapes': shapes,
         }
+        if args.gemm_shapes:
+            out['gemm_shapes'] = shapes
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(sd, tiles_np, min(args.cpu_tiles, B))
         print(json.dumps(out))
