@@ -15,7 +15,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
-template <int MT, int NT, int WM, int WN, int BK, int AMODE>
+template <int MT, int NT, int WM, int WN, int BK, int AMODE, int ABL = 0>   // ABL: timing-only ablation mask (dev builds)
 __global__ __launch_bounds__(256, (MT * NT <= 3 ? 4 : 3)) void gemm_kernel(GemmParams p) {   // 4 (3) blocks per CU: <= 128 (168) registers
   static_assert(WM * WN == 4, "4 waves per block");
   constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
@@ -178,19 +178,19 @@ __global__ __launch_bounds__(256, (MT * NT <= 3 ? 4 : 3)) void gemm_kernel(GemmP
     // the group only covers reads issued half a tile ago
     MFMA_STEP(x, fa_a, fa_b)
     __builtin_amdgcn_sched_barrier(0);
-    READ_FRAGS(buf, 1, fb_a, fb_b)
+    if (!(ABL & 8)) READ_FRAGS(buf, 1, fb_a, fb_b)
     __builtin_amdgcn_sched_barrier(0);
     MFMA_STEP(y, fa_a, fa_b) MFMA_STEP(z, fa_a, fa_b) MFMA_STEP(w, fa_a, fa_b)
     __builtin_amdgcn_sched_barrier(0);
-    STORE_TILE(buf ^ 1)                          // waits for the staging loads issued one iteration ago
+    if (!(ABL & 4)) STORE_TILE(buf ^ 1)          // waits for the staging loads issued one iteration ago
     __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): this wave's LDS writes have landed
-    __builtin_amdgcn_s_barrier();                // raw barrier: no vmcnt(0) (nothing is in flight here anyway)
+    if (!(ABL & 1)) __builtin_amdgcn_s_barrier();   // raw barrier: no vmcnt(0) (nothing is in flight here anyway)
     __builtin_amdgcn_sched_barrier(0);
-    LOAD_TILE(kt + 2 < nk ? kt + 2 : nk - 1)     // the clamped reload at the end is never used
+    if (!(ABL & 2)) LOAD_TILE(kt + 2 < nk ? kt + 2 : nk - 1)     // the clamped reload at the end is never used
     __builtin_amdgcn_sched_barrier(0);
     MFMA_STEP(x, fb_a, fb_b)
     __builtin_amdgcn_sched_barrier(0);
-    READ_FRAGS(buf ^ 1, 0, fa_a, fa_b)
+    if (!(ABL & 8)) READ_FRAGS(buf ^ 1, 0, fa_a, fa_b)
     __builtin_amdgcn_sched_barrier(0);
     MFMA_STEP(y, fb_a, fb_b) MFMA_STEP(z, fb_a, fb_b) MFMA_STEP(w, fb_a, fb_b)
     __builtin_amdgcn_sched_barrier(0);
@@ -327,6 +327,20 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
   }
   // algorithmic work of the launch (device-side row counts are not known here: the capacity M is an upper bound)
   ProfScope ps(tag, 2.0 * p.M * p.N * p.K * nb, 4.0 * nb * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N), s);
+  static int abl = -1;
+  if (abl < 0) { const char* e = getenv("NUHTC_GEMM_ABL"); abl = e ? atoi(e) : 0; }
+  if (abl && nt == 3 && p.amode == A_PLAIN) {   // timing-only ablations of the main loop (results are wrong by construction)
+    dim3 grid(cdiv(cdiv(p.M, 128), 8) * 8 * (q.N / 96), 1, q.batch > 0 ? q.batch : 1);
+    switch (abl) {
+      case 1: hipLaunchKernelGGL((gemm_kernel<1, 3, 4, 1, 16, A_PLAIN, 1>), grid, dim3(256), 0, s, q); break;
+      case 2: hipLaunchKernelGGL((gemm_kernel<1, 3, 4, 1, 16, A_PLAIN, 2>), grid, dim3(256), 0, s, q); break;
+      case 4: hipLaunchKernelGGL((gemm_kernel<1, 3, 4, 1, 16, A_PLAIN, 4>), grid, dim3(256), 0, s, q); break;
+      case 8: hipLaunchKernelGGL((gemm_kernel<1, 3, 4, 1, 16, A_PLAIN, 8>), grid, dim3(256), 0, s, q); break;
+      case 6: hipLaunchKernelGGL((gemm_kernel<1, 3, 4, 1, 16, A_PLAIN, 6>), grid, dim3(256), 0, s, q); break;
+      default: hipLaunchKernelGGL((gemm_kernel<1, 3, 4, 1, 16, A_PLAIN, 15>), grid, dim3(256), 0, s, q); break;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
+  }
   if (geo == 1) launch_cfg<2, 2, 2, 2>(q, g_bk, cdiv(p.M, 128), s);
   else if (geo == 2) launch_cfg<2, 2, 4, 1>(q, g_bk, cdiv(p.M, 256), s);
   else if (nt == 1) launch_cfg<1, 1, 4, 1>(q, g_bk, cdiv(p.M, 128), s);
