@@ -99,11 +99,16 @@ int launch_patch_embed(const float* img, const float* w, const float* b, const f
                        int B, int Hn, int Wn, hipStream_t s);
 // LayerNorm of `rows` rows of C channels: dst row m reads src row src_map[m] (or m when src_map==null); src_map[m]<0 -> zeros
 int launch_layernorm(const float* x, const int* src_map, const float* g, const float* b, float* y, int rows, int C, hipStream_t s);
+// LN1 of a Swin block over the `rows` window rows: row r with src_map[r] >= 0 is normalised into y[dst_map[r]] (the compact,
+// padding-free window order); a padding row writes pad_val[0..3C) (the QKV bias) into pad_dst[r] (the window QKV image).
+int launch_layernorm_windows(const float* x, const int* src_map, const int* dst_map, const float* g, const float* b, float* y,
+                             float* pad_dst, const float* pad_val, int rows, int C, hipStream_t s);
 // PatchMerging gather + LN(4C): out[(b,y2,x2), (kh*2+kw)*C + c] (weights pre-permuted to this order)
 int launch_merge_ln(const float* x, const float* g, const float* b, float* y, int B, int H, int W, int C, hipStream_t s);
-// window attention: qkv [nWin*49, 3C] -> out [nWin*49, C]; bias [nH,49,49]; mask [nW,49,49] or null
-int launch_window_attn(const float* qkv, const float* bias, const float* biasT, const float* mask, float* out, int nWinTotal,
-                       int nWperImg, int C, int nH, hipStream_t s);
+// window attention: qkv [nWin*49, 3C] -> out rows of C; bias [nH,49,49]; mask [nW,49,49] or null; window row r is written to
+// out row out_map[r] (skipped when negative), or to row r when out_map is null
+int launch_window_attn(const float* qkv, const float* bias, const float* biasT, const float* mask, const int* out_map, float* out,
+                       int nWinTotal, int nWperImg, int C, int nH, hipStream_t s);
 
 // ----------------------------------------------------------------------------- dense heads (dense.hip)
 int launch_sem_fuse(const float* g0, const float* g1, const float* g2, const float* g3, float* out, int B, int H, int W,

@@ -6,6 +6,9 @@ struct StageGeom {
   int H, W, C, nH;     // token grid, channels, heads
   int Hp, Wp, nW;      // padded grid (multiple of 7) and windows per image
   int* map[2];         // dev: window-row -> token index (-1 = padding), [max_batch*nW*49], un-shifted / shifted
+  int* cidx[2];        // dev: window-row -> index among the non-padding window rows (-1 = padding); tile b's rows are [b*H*W, (b+1)*H*W)
+  int* ctok[2];        // dev: that compact index -> token index, [max_batch*H*W]
+  int* vrow[2];        // dev: that compact index -> window row
   float* mask;         // dev: shift mask [nW][49][49]
 };
 

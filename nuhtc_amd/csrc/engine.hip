@@ -153,6 +153,21 @@ static int build_stage_maps(nuhtc_engine* e, int s) {
             }
     int rc = upload_i(e, &g.map[sh], m);
     if (rc) return rc;
+    // the non-padding window rows in window order: the QKV / proj GEMMs run on these only (padding rows of the window
+    // image hold the QKV bias, see launch_layernorm_windows)
+    std::vector<int> ci(m.size()), ct, vr;
+    ct.reserve((size_t)B * g.H * g.W);
+    vr.reserve((size_t)B * g.H * g.W);
+    for (size_t r = 0; r < m.size(); ++r) {
+      ci[r] = m[r] >= 0 ? (int)ct.size() : -1;
+      if (m[r] >= 0) { ct.push_back(m[r]); vr.push_back((int)r); }
+    }
+    rc = upload_i(e, &g.cidx[sh], ci);
+    if (rc) return rc;
+    rc = upload_i(e, &g.ctok[sh], ct);
+    if (rc) return rc;
+    rc = upload_i(e, &g.vrow[sh], vr);
+    if (rc) return rc;
   }
   // shift mask on the padded grid (swin.py:197-218)
   std::vector<int> ids((size_t)g.Hp * g.Wp);
@@ -368,12 +383,20 @@ int run_backbone(nuhtc_engine* e, int B, hipStream_t s) {
       const BlockW& w = e->blocks[st][b];
       const int sh = (int)(b & 1);
       // x += proj(attn(LN1(x)))      (mmdet swin.py:356-363)
-      RUN(launch_layernorm(x, g.map[sh], w.n1g, w.n1b, e->xw, Mw, C, s));
-      RUN(launch_gemm(gp(e->xw, w.qkv_w, w.qkv_b, e->qkv, Mw, 3 * C, C), s));
-      RUN(launch_window_attn(e->qkv, w.relb, w.relbT, sh ? g.mask : nullptr, e->att, B * g.nW, g.nW, C, g.nH, s));
+      // Only the T real tokens go through the two linears: LN1 writes them in window order without the padding rows
+      // (xw, T rows), the QKV GEMM scatters its rows into the window image, whose padding rows are the QKV bias
+      // (LN of a zero-padded token is 0 after swin.py:341-343's F.pad, so its qkv is the bias), attention writes the
+      // non-padding rows of its output compactly again and proj scatters them back to token order.
+      RUN(launch_layernorm_windows(x, g.map[sh], g.cidx[sh], w.n1g, w.n1b, e->xw, e->qkv, w.qkv_b, Mw, C, s));
       {
-        GemmParams p = gp(e->att, w.proj_w, w.proj_b, x, Mw, C, C);
-        p.store = ST_ROWMAP; p.row_map = g.map[sh]; p.res = x; p.ldr = C;
+        GemmParams p = gp(e->xw, w.qkv_w, w.qkv_b, e->qkv, T, 3 * C, C);
+        p.store = ST_ROWMAP; p.row_map = g.vrow[sh];
+        RUN(launch_gemm(p, s));
+      }
+      RUN(launch_window_attn(e->qkv, w.relb, w.relbT, sh ? g.mask : nullptr, g.cidx[sh], e->att, B * g.nW, g.nW, C, g.nH, s));
+      {
+        GemmParams p = gp(e->att, w.proj_w, w.proj_b, x, T, C, C);
+        p.store = ST_ROWMAP; p.row_map = g.ctok[sh]; p.res = x; p.ldr = C;
         RUN(launch_gemm(p, s));
       }
       // x += W2·gelu(W1·LN2(x))      (swin.py:365-367, mmcv FFN)

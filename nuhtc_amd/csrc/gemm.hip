@@ -310,6 +310,18 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
   if (p.K % 32 != 0 || p.N % 32 != 0) return NUHTC_E_INVALID;
   if (p.amode == A_CONV3 && (p.cC % 32 != 0 || p.K != 9 * p.cC)) return NUHTC_E_INVALID;
   int nt = (p.N % 96 == 0) ? 3 : (p.N % 128 == 0) ? 4 : (p.N % 64 == 0) ? 2 : 1;
+  {
+    // small problems: narrower column tiles until the launch has enough workgroups for the 256 CUs (a 128x96 tile
+    // grid of a few hundred blocks leaves most SIMDs with one wave or none).  Launches whose row count lives on the
+    // device (RoI / detection lists) are sized by capacity; about half of it is populated at the bench load.
+    static int fill = -1;
+    if (fill < 0) { const char* e = getenv("NUHTC_GEMM_FILL"); fill = e ? atoi(e) : 500; }
+    long long mt = cdiv(p.M, 128) * (long long)(p.batch > 0 ? p.batch : 1);
+    if (p.m_dev) mt = (mt + 1) / 2;
+    while (nt > 1 && mt * (p.N / (32 * nt)) < fill) {
+      if (nt > 2 && p.N % 64 == 0) nt = 2; else nt = 1;
+    }
+  }
   int geo = 0;
   if (g_geo128 && p.N % 128 == 0) geo = 1;
   if (g_geo256 && p.N == 64) geo = 2;

@@ -126,18 +126,26 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 template <int NV>   // NV = ceil(C/64) elements per lane
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const int* __restrict__ src_map,
-                                                        const float* __restrict__ g, const float* __restrict__ b,
-                                                        float* __restrict__ y, int rows, int C) {
+                                                        const int* __restrict__ dst_map, const float* __restrict__ g,
+                                                        const float* __restrict__ b, float* __restrict__ y,
+                                                        float* __restrict__ pad_dst, const float* __restrict__ pad_val,
+                                                        int rows, int C) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   long long src = src_map ? src_map[row] : row;
-  float* yr = y + row * C;
   if (src < 0) {
+    if (pad_dst) {   // padding row of a window: its QKV row is the bias
+      float* pr = pad_dst + row * 3 * C;
+      for (int c = lane; c < 3 * C; c += 64) pr[c] = pad_val[c];
+    } else {
+      float* yr = y + row * C;
 #pragma unroll
-    for (int j = 0; j < NV; ++j) { int c = lane + 64 * j; if (c < C) yr[c] = 0.f; }
+      for (int j = 0; j < NV; ++j) { int c = lane + 64 * j; if (c < C) yr[c] = 0.f; }
+    }
     return;
   }
+  float* yr = y + (dst_map ? (long long)dst_map[row] : row) * C;
   const float* xr = x + src * C;
   float v[NV];
   float sum = 0.f;
@@ -154,19 +162,27 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 
 // C = 96 (stage 0, the most rows): one row per 32-lane half-wave, 24 lanes x one 16-byte load each
 __global__ __launch_bounds__(256) void layernorm96_kernel(const float* __restrict__ x, const int* __restrict__ src_map,
-                                                          const float* __restrict__ g, const float* __restrict__ b,
-                                                          float* __restrict__ y, int rows) {
+                                                          const int* __restrict__ dst_map, const float* __restrict__ g,
+                                                          const float* __restrict__ b, float* __restrict__ y,
+                                                          float* __restrict__ pad_dst, const float* __restrict__ pad_val,
+                                                          int rows) {
   typedef float v4f __attribute__((ext_vector_type(4)));
   const int l = threadIdx.x & 31;
   const long long row = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);
   if (row >= rows) return;
   const long long src = src_map ? src_map[row] : row;
   const bool act = l < 24;
-  v4f* yr = reinterpret_cast<v4f*>(y + row * 96);
   if (src < 0) {
-    if (act) yr[l] = (v4f){0.f, 0.f, 0.f, 0.f};
+    if (pad_dst) {   // padding row of a window: its QKV row (288 floats) is the bias
+      v4f* pr = reinterpret_cast<v4f*>(pad_dst + row * 288);
+      const v4f* pv = reinterpret_cast<const v4f*>(pad_val);
+      for (int c = l; c < 72; c += 32) pr[c] = pv[c];
+    } else if (act) {
+      reinterpret_cast<v4f*>(y + row * 96)[l] = (v4f){0.f, 0.f, 0.f, 0.f};
+    }
     return;
   }
+  v4f* yr = reinterpret_cast<v4f*>(y + (dst_map ? (long long)dst_map[row] : row) * 96);
   v4f v = act ? reinterpret_cast<const v4f*>(x + src * 96)[l] : (v4f){0.f, 0.f, 0.f, 0.f};
   float sum = (v.x + v.y) + (v.z + v.w);
 #pragma unroll
@@ -183,21 +199,33 @@ __global__ __launch_bounds__(256) void layernorm96_kernel(const float* __restric
   }
 }
 
-int launch_layernorm(const float* x, const int* src_map, const float* g, const float* b, float* y, int rows, int C, hipStream_t s) {
-  ProfScope ps("layernorm", 0, 8.0 * rows * C, s);
+static int layernorm_any(const float* x, const int* src_map, const int* dst_map, const float* g, const float* b, float* y,
+                         float* pad_dst, const float* pad_val, int rows, int C, hipStream_t s) {
   if (rows <= 0) return 0;
   if (C == 96) {
-    hipLaunchKernelGGL(layernorm96_kernel, dim3(cdiv(rows, 8)), dim3(256), 0, s, x, src_map, g, b, y, rows);
+    hipLaunchKernelGGL(layernorm96_kernel, dim3(cdiv(rows, 8)), dim3(256), 0, s, x, src_map, dst_map, g, b, y, pad_dst, pad_val, rows);
     return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
   }
   dim3 grid(cdiv(rows, 4)), blk(256);
   int nv = cdiv(C, 64);
-  if (nv <= 2) hipLaunchKernelGGL(layernorm_kernel<2>, grid, blk, 0, s, x, src_map, g, b, y, rows, C);
-  else if (nv <= 3) hipLaunchKernelGGL(layernorm_kernel<3>, grid, blk, 0, s, x, src_map, g, b, y, rows, C);
-  else if (nv <= 6) hipLaunchKernelGGL(layernorm_kernel<6>, grid, blk, 0, s, x, src_map, g, b, y, rows, C);
-  else if (nv <= 12) hipLaunchKernelGGL(layernorm_kernel<12>, grid, blk, 0, s, x, src_map, g, b, y, rows, C);
+  if (nv <= 2) hipLaunchKernelGGL(layernorm_kernel<2>, grid, blk, 0, s, x, src_map, dst_map, g, b, y, pad_dst, pad_val, rows, C);
+  else if (nv <= 3) hipLaunchKernelGGL(layernorm_kernel<3>, grid, blk, 0, s, x, src_map, dst_map, g, b, y, pad_dst, pad_val, rows, C);
+  else if (nv <= 6) hipLaunchKernelGGL(layernorm_kernel<6>, grid, blk, 0, s, x, src_map, dst_map, g, b, y, pad_dst, pad_val, rows, C);
+  else if (nv <= 12) hipLaunchKernelGGL(layernorm_kernel<12>, grid, blk, 0, s, x, src_map, dst_map, g, b, y, pad_dst, pad_val, rows, C);
   else return NUHTC_E_INVALID;
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
+}
+
+int launch_layernorm(const float* x, const int* src_map, const float* g, const float* b, float* y, int rows, int C, hipStream_t s) {
+  ProfScope ps("layernorm", 0, 8.0 * rows * C, s);
+  return layernorm_any(x, src_map, nullptr, g, b, y, nullptr, nullptr, rows, C, s);
+}
+
+int launch_layernorm_windows(const float* x, const int* src_map, const int* dst_map, const float* g, const float* b, float* y,
+                             float* pad_dst, const float* pad_val, int rows, int C, hipStream_t s) {
+  ProfScope ps("layernorm", 0, 8.0 * rows * C, s);
+  if (!src_map || !dst_map || !pad_dst || !pad_val) return NUHTC_E_INVALID;
+  return layernorm_any(x, src_map, dst_map, g, b, y, pad_dst, pad_val, rows, C, s);
 }
 
 // ----------------------------------------------------------------------------- PatchMerging gather + LN(4C)
@@ -246,7 +274,7 @@ int launch_merge_ln(const float* x, const float* g, const float* b, float* y, in
 
 // ----------------------------------------------------------------------------- window attention
 __global__ __launch_bounds__(256) void window_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ bias,
-                                                          const float* __restrict__ mask, float* __restrict__ out, int nPairs,
+                                                          const float* __restrict__ mask, const int* __restrict__ out_map, float* __restrict__ out, int nPairs,
                                                           int nWperImg, int C, int nH) {
   __shared__ float4 kv[4][2][WS2 * 8];   // per wave: K then V, [49][32] as float4
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -308,8 +336,10 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const float* __restric
       o[4 * d + 2] = fmaf(pj, v4.z, o[4 * d + 2]); o[4 * d + 3] = fmaf(pj, v4.w, o[4 * d + 3]);
     }
   }
-  if (lane < WS2) {
-    float4* op = reinterpret_cast<float4*>(out + ((long long)win * WS2 + lane) * C + head * HEAD_DIM);
+  long long orow = (long long)win * WS2 + lane;
+  if (lane < WS2 && out_map) orow = out_map[orow];
+  if (lane < WS2 && orow >= 0) {
+    float4* op = reinterpret_cast<float4*>(out + orow * C + head * HEAD_DIM);
 #pragma unroll
     for (int d = 0; d < 8; ++d) op[d] = make_float4(o[4 * d], o[4 * d + 1], o[4 * d + 2], o[4 * d + 3]);
   }
@@ -326,7 +356,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void window_attn_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ biasT,
-                                                               const float* __restrict__ mask, float* __restrict__ out, int nPairs,
+                                                               const float* __restrict__ mask, const int* __restrict__ out_map, float* __restrict__ out, int nPairs,
                                                                int nWperImg, int C, int nH) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int pair = blockIdx.x * 4 + wave;
@@ -408,8 +438,10 @@ __global__ __launch_bounds__(256) void window_attn_mfma_kernel(const float* __re
         const float vv = base[j * ld + 2 * C + l32];
         ot = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, st[tj][r] * rsum, ot, 0, 0, 0);
       }
-    if (ti * 32 + l32 < WS2) {
-      float* op = out + ((long long)win * WS2 + ti * 32 + l32) * C + head * HEAD_DIM + 4 * half;
+    long long orow = (long long)win * WS2 + ti * 32 + l32;
+    if (ti * 32 + l32 < WS2 && out_map) orow = out_map[orow];
+    if (ti * 32 + l32 < WS2 && orow >= 0) {
+      float* op = out + orow * C + head * HEAD_DIM + 4 * half;
 #pragma unroll
       for (int g = 0; g < 4; ++g)   // registers 4g..4g+3 are d = 8g + 4*half + 0..3
         *reinterpret_cast<v4f*>(op + 8 * g) = (v4f){ot[4 * g], ot[4 * g + 1], ot[4 * g + 2], ot[4 * g + 3]};
@@ -417,16 +449,16 @@ __global__ __launch_bounds__(256) void window_attn_mfma_kernel(const float* __re
   }
 }
 
-int launch_window_attn(const float* qkv, const float* bias, const float* biasT, const float* mask, float* out, int nWinTotal,
-                       int nWperImg, int C, int nH, hipStream_t s) {
+int launch_window_attn(const float* qkv, const float* bias, const float* biasT, const float* mask, const int* out_map, float* out,
+                       int nWinTotal, int nWperImg, int C, int nH, hipStream_t s) {
   ProfScope ps("window_attn", 4.0 * 49 * 49 * 32 * nWinTotal * nH, 16.0 * 49 * C * nWinTotal, s);
   int nPairs = nWinTotal * nH;
   if (nPairs <= 0) return 0;
   static int use_mfma = -1;
   if (use_mfma < 0) { const char* e = getenv("NUHTC_ATTN_VALU"); use_mfma = (e && atoi(e)) ? 0 : 1; }
   if (use_mfma && biasT)
-    hipLaunchKernelGGL(window_attn_mfma_kernel, dim3(cdiv(nPairs, 4)), dim3(256), 0, s, qkv, biasT, mask, out, nPairs, nWperImg, C, nH);
+    hipLaunchKernelGGL(window_attn_mfma_kernel, dim3(cdiv(nPairs, 4)), dim3(256), 0, s, qkv, biasT, mask, out_map, out, nPairs, nWperImg, C, nH);
   else
-    hipLaunchKernelGGL(window_attn_kernel, dim3(cdiv(nPairs, 4)), dim3(256), 0, s, qkv, bias, mask, out, nPairs, nWperImg, C, nH);
+    hipLaunchKernelGGL(window_attn_kernel, dim3(cdiv(nPairs, 4)), dim3(256), 0, s, qkv, bias, mask, out_map, out, nPairs, nWperImg, C, nH);
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
 }
