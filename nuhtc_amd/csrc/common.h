@@ -76,6 +76,7 @@ struct GemmParams {
   int m_mul;
   int amode;
   int cH, cW, cC;      // A_CONV3: NHWC image geometry (rows = b*cH*cW + y*cW + x), K = 9*cC
+  const float* zeros;  // A_CONV3: >= 16 bytes of zeros that out-of-image taps read (launch_gemm supplies one when null)
   int act;
   float alpha;         // multiplies the accumulated sum before bias (1.0 default)
   const float* res;    // optional residual, added after activation: res[rmap(m)*ldr + n]

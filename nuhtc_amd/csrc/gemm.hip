@@ -15,7 +15,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
-template <int MT, int NT, int WM, int WN, int BK, int AMODE, int ABL = 0>   // ABL: timing-only ablation mask (dev builds)
+template <int MT, int NT, int WM, int WN, int BK, int AMODE>
 __global__ __launch_bounds__(256, (MT * NT <= 3 ? 4 : 3)) void gemm_kernel(GemmParams p) {   // 4 (3) blocks per CU: <= 128 (168) registers
   static_assert(WM * WN == 4, "4 waves per block");
   constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
@@ -56,12 +56,12 @@ __global__ __launch_bounds__(256, (MT * NT <= 3 ? 4 : 3)) void gemm_kernel(GemmP
 
   // ---- per-thread staging assignment: float4 slot (row = tid/KC + RPP*j, kc = tid%KC)
   // Rows past Meff are clamped to the last valid row (their results are never stored) and out-of-image conv taps are
-  // loaded from a clamped address and zeroed by a select: every staging load is unconditional, so the loads of tile
-  // kt+1 stay in flight across the MFMAs of tile kt instead of being fenced by exec-mask branches.
+  // redirected to a page of zeros: every staging load is unconditional, so the loads of tile kt+1 stay in flight across
+  // the MFMAs of tile kt instead of being fenced by exec-mask branches.
   const int kc = tid % KC;
   const int rbase = tid / KC;
   const float* a_ptr[NA];
-  int a_y[NA], a_x[NA];
+  unsigned a_ok[NA];   // A_CONV3: bit t set = tap t (ky = t/3 - 1, kx = t%3 - 1) of this row's pixel lies inside the image
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
     int r = rbase + RPP * j;
@@ -70,14 +70,19 @@ __global__ __launch_bounds__(256, (MT * NT <= 3 ? 4 : 3)) void gemm_kernel(GemmP
     m = m < Meff ? m : Meff - 1;
     if (AMODE == A_PLAIN) {
       a_ptr[j] = A + (long long)m * p.lda + kc * 4;
-      a_y[j] = a_x[j] = 0;
+      a_ok[j] = 0;
     } else {
-      int hw = p.cH * p.cW;
-      int b = m / hw, rr = m - b * hw;
-      int y = rr / p.cW, x = rr - y * p.cW;
-      a_y[j] = y;
-      a_x[j] = x;
-      a_ptr[j] = A + ((long long)(b * p.cH + y) * p.cW + x) * p.cC + kc * 4;
+      const int hw = p.cH * p.cW;
+      const int rr = m - (m / hw) * hw;
+      const int y = rr / p.cW, x = rr - y * p.cW;
+      unsigned bits = 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        if (yy >= 0 && yy < p.cH && xx >= 0 && xx < p.cW) bits |= 1u << t;
+      }
+      a_ok[j] = bits;
+      a_ptr[j] = A + (long long)m * p.cC + kc * 4;   // NHWC: row m is pixel m
     }
   }
   const float* w_ptr[NB];
@@ -96,45 +101,53 @@ __global__ __launch_bounds__(256, (MT * NT <= 3 ? 4 : 3)) void gemm_kernel(GemmP
   for (int j = 0; j < NB; ++j) { int r = rbase + RPP * j; w_srow[j] = r < BN ? r : BN - 1; }
 
   v4f ra[NA], rb[NB];
-  // (macros rather than lambdas: arrays captured by reference were being demoted to scratch memory)
+  int cv_tap = 0, cv_c0 = 0;   // A_CONV3: tap and channel offset of the next k-tile to load (k-tiles are visited in order)
+  long long cv_off = 0;
+  // One staging load / LDS store / fragment read per call, so the main loop can place them one by one between MFMAs
+  // (macros rather than lambdas: arrays captured by reference were being demoted to scratch memory).
+#define CONV_BEGIN()                                                                                            \
+  if (AMODE != A_PLAIN) {                                                                                       \
+    const int ky = cv_tap / 3 - 1, kx = cv_tap - (cv_tap / 3) * 3 - 1;                                          \
+    cv_off = (long long)(ky * p.cW + kx) * p.cC + cv_c0;                                                        \
+  }
+#define CONV_END()                                                                                              \
+  if (AMODE != A_PLAIN) {                                                                                       \
+    cv_c0 += BK;                                                                                                \
+    if (cv_c0 == p.cC) { cv_c0 = 0; cv_tap = cv_tap < 8 ? cv_tap + 1 : 8; }   /* (the clamped tail reload is unused) */ \
+  }
+#define LOAD_ONE(f_, kt_)                                                                                       \
+  {                                                                                                             \
+    if ((f_) < NA) {                                                                                            \
+      const int j = (f_) < NA ? (f_) : 0;                                                                       \
+      if (AMODE == A_PLAIN) {                                                                                   \
+        ra[j] = *reinterpret_cast<const v4f*>(a_ptr[j] + (kt_) * BK);                                           \
+      } else {                                                                                                  \
+        const bool ok = (a_ok[j] >> cv_tap) & 1u;                                                               \
+        const float* src = ok ? a_ptr[j] + cv_off : p.zeros;   /* out-of-image taps read a page of zeros */      \
+        ra[j] = *reinterpret_cast<const v4f*>(src);                                                             \
+      }                                                                                                         \
+    } else if ((f_) < NA + NB) {                                                                                \
+      const int j = (f_) >= NA && (f_) < NA + NB ? (f_) - NA : 0;                                               \
+      rb[j] = *reinterpret_cast<const v4f*>(w_ptr[j] + (kt_) * BK);                                             \
+    }                                                                                                           \
+  }
+#define STORE_ONE(f_, buf_)                                                                                     \
+  {                                                                                                             \
+    if ((f_) < NA) {                                                                                            \
+      const int j = (f_) < NA ? (f_) : 0;                                                                       \
+      *reinterpret_cast<v4f*>(As + (buf_) * LDK * BM + a_srow[j] * LDK + kc * 4) = ra[j];                        \
+    } else if ((f_) < NA + NB) {                                                                                \
+      const int j = (f_) >= NA && (f_) < NA + NB ? (f_) - NA : 0;                                               \
+      *reinterpret_cast<v4f*>(Bs + (buf_) * LDK * BN + w_srow[j] * LDK + kc * 4) = rb[j];                        \
+    }                                                                                                           \
+  }
 #define LOAD_TILE(kt_)                                                                                          \
   {                                                                                                             \
-    const int kt__ = (kt_);                                                                                     \
-    if (AMODE == A_PLAIN) {                                                                                     \
-      _Pragma("unroll") for (int j = 0; j < NA; ++j) ra[j] = *reinterpret_cast<const v4f*>(a_ptr[j] + kt__ * BK); \
-    } else {                                                                                                    \
-      const int kk = kt__ * BK;                                                                                 \
-      const int tap = kk / p.cC, c0 = kk - tap * p.cC;                                                          \
-      const int ky = tap / 3 - 1, kx = tap - (tap / 3) * 3 - 1;                                                 \
-      _Pragma("unroll") for (int j = 0; j < NA; ++j) {                                                          \
-        const int yy = a_y[j] + ky, xx = a_x[j] + kx;                                                           \
-        const bool ok = yy >= 0 && yy < p.cH && xx >= 0 && xx < p.cW;                                           \
-        const int dy = ok ? ky : 0, dx = ok ? kx : 0;                                                           \
-        const v4f v = *reinterpret_cast<const v4f*>(a_ptr[j] + (long long)(dy * p.cW + dx) * p.cC + c0);        \
-        const float zm = ok ? 1.0f : 0.0f;                                                                      \
-        ra[j] = v;                                                                                              \
-        a_zero[j] = zm;                                                                                         \
-      }                                                                                                         \
-    }                                                                                                           \
-    _Pragma("unroll") for (int j = 0; j < NB; ++j) rb[j] = *reinterpret_cast<const v4f*>(w_ptr[j] + kt__ * BK); \
+    CONV_BEGIN()                                                                                                \
+    _Pragma("unroll") for (int f = 0; f < NA + NB; ++f) LOAD_ONE(f, kt_)                                        \
+    CONV_END()                                                                                                  \
   }
-  // out-of-image conv taps are zeroed when the tile is written to LDS (a multiply by 0/1 kept beside the data), so the
-  // load itself has no consumer until then
-#define STORE_TILE(buf_)                                                                                        \
-  {                                                                                                             \
-    float* as = As + (buf_) * LDK * BM;                                                                         \
-    float* bs = Bs + (buf_) * LDK * BN;                                                                         \
-    _Pragma("unroll") for (int j = 0; j < NA; ++j) {                                                            \
-      v4f v = ra[j];                                                                                            \
-      if (AMODE != A_PLAIN) v = v * a_zero[j];                                                                  \
-      *reinterpret_cast<v4f*>(as + a_srow[j] * LDK + kc * 4) = v;                                               \
-    }                                                                                                           \
-    _Pragma("unroll") for (int j = 0; j < NB; ++j)                                                              \
-      *reinterpret_cast<v4f*>(bs + w_srow[j] * LDK + kc * 4) = rb[j];                                           \
-  }
-  float a_zero[NA];
-#pragma unroll
-  for (int j = 0; j < NA; ++j) a_zero[j] = 1.0f;
+#define STORE_TILE(buf_) { _Pragma("unroll") for (int f = 0; f < NA + NB; ++f) STORE_ONE(f, buf_) }
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -144,26 +157,39 @@ __global__ __launch_bounds__(256, (MT * NT <= 3 ? 4 : 3)) void gemm_kernel(GemmP
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][t][r] = 0.f;
 
-  // ---- main loop, software-pipelined at half-tile granularity (BK = 16: two groups of 4 k-steps):
-  //   FB <- LDS frags(t, half 1) | MFMA(FA) | wait + store regs(t+1) -> LDS | barrier | global loads(t+2) -> regs |
-  //   FA <- LDS frags(t+1, half 0) | MFMA(FB)
-  // so the MFMAs after a barrier never wait for LDS (their operands were read before it), the LDS latency of the next
-  // fragments and the HBM/L2 latency of the staging loads both sit behind 12-24 MFMAs, and there is one barrier per k-tile.
+  // ---- main loop, software-pipelined at half-tile granularity (BK = 16: two groups of 4 k-steps = 4·MT·NT MFMAs each).
+  // Every non-MFMA instruction of the k-tile is a "filler" placed alone in the gap after one MFMA, because a wave-wide
+  // LDS write (13 cycles), global load (~12) or LDS read (4) occupies the SIMD's issue port: bunched together at the
+  // barrier they open a gap no co-resident wave reliably covers, one per MFMA they fit inside the MFMA's own 64 cycles.
+  //   group A: MFMAs on fragments FA (tile t, half 0) | fillers: read FB <- LDS(t, half 1), then write regs(t+1) -> LDS
+  //   lgkmcnt(0) + one barrier
+  //   group B: MFMAs on FB                            | fillers: global loads(t+2) -> regs, then read FA <- LDS(t+1, half 0)
+  // so no MFMA waits for LDS (its operands were requested half a tile earlier) and the staging loads have a whole tile
+  // (>= 1500 cycles) to land before the LDS writes need them.
   static_assert(BK == 16, "pipelined main loop is written for BK = 16");
   v4f fa_a[MT], fa_b[NT], fb_a[MT], fb_b[NT];
   const float* arow0 = As + (wm * MT * 32 + i32) * LDK + half * KH;
   const float* brow0 = Bs + (wn * NT * 32 + i32) * LDK + half * KH;
-#define READ_FRAGS(buf_, q_, FA_, FB_)                                                                         \
+  constexpr int NMF = 4 * MT * NT;                  // MFMAs per group
+  constexpr int NRD = MT + NT, NST = NA + NB;       // fragment reads per half tile; staging loads (= LDS writes) per tile
+  constexpr int FPG = (NRD + NST + NMF - 1) / NMF;  // fillers per MFMA gap (1 except for the smallest wave tile)
+#define READ_ONE(f_, buf_, q_, FA_, FB_)                                                                       \
   {                                                                                                            \
-    _Pragma("unroll") for (int mi = 0; mi < MT; ++mi)                                                          \
-        FA_[mi] = *reinterpret_cast<const v4f*>(arow0 + (buf_) * LDK * BM + 32 * mi * LDK + 4 * (q_));      \
-    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                             \
-        FB_[t] = *reinterpret_cast<const v4f*>(brow0 + (buf_) * LDK * BN + 32 * t * LDK + 4 * (q_));        \
+    if ((f_) < MT) {                                                                                           \
+      const int mi = (f_) < MT ? (f_) : 0;                                                                     \
+      FA_[mi] = *reinterpret_cast<const v4f*>(arow0 + (buf_) * LDK * BM + 32 * mi * LDK + 4 * (q_));           \
+    } else if ((f_) < MT + NT) {                                                                               \
+      const int t = (f_) >= MT && (f_) < MT + NT ? (f_) - MT : 0;                                              \
+      FB_[t] = *reinterpret_cast<const v4f*>(brow0 + (buf_) * LDK * BN + 32 * t * LDK + 4 * (q_));             \
+    }                                                                                                          \
   }
-#define MFMA_STEP(E_, FA_, FB_)                                                                                \
-  _Pragma("unroll") for (int mi = 0; mi < MT; ++mi) _Pragma("unroll") for (int t = 0; t < NT; ++t)             \
-      acc[mi][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA_[mi].E_, FB_[t].E_, acc[mi][t], 0, 0, 0);
-#define MFMA_GROUP(FA_, FB_) { MFMA_STEP(x, FA_, FB_) MFMA_STEP(y, FA_, FB_) MFMA_STEP(z, FA_, FB_) MFMA_STEP(w, FA_, FB_) }
+#define READ_FRAGS(buf_, q_, FA_, FB_) { _Pragma("unroll") for (int f = 0; f < NRD; ++f) READ_ONE(f, buf_, q_, FA_, FB_) }
+#define MFMA_AT(i_, FA_, FB_)                                                                                  \
+  {                                                                                                            \
+    const int e = (i_) / (MT * NT), mi = ((i_) % (MT * NT)) / NT, t = (i_) % NT;                               \
+    acc[mi][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA_[mi][e], FB_[t][e], acc[mi][t], 0, 0, 0);             \
+  }
+#define MFMA_GROUP(FA_, FB_) { _Pragma("unroll") for (int i = 0; i < NMF; ++i) MFMA_AT(i, FA_, FB_) }
 
   const int nk = p.K / BK;
   LOAD_TILE(0)
@@ -174,34 +200,49 @@ __global__ __launch_bounds__(256, (MT * NT <= 3 ? 4 : 3)) void gemm_kernel(GemmP
   int kt = 0;
   for (; kt + 1 < nk; ++kt) {       // every iteration here has a successor tile: no conditional inside the body
     const int buf = kt & 1;
-    // the LDS reads of the other fragment set are issued one MFMA step into the group, so the lgkmcnt wait in front of
-    // the group only covers reads issued half a tile ago
-    MFMA_STEP(x, fa_a, fa_b)
-    __builtin_amdgcn_sched_barrier(0);
-    if (!(ABL & 8)) READ_FRAGS(buf, 1, fb_a, fb_b)
-    __builtin_amdgcn_sched_barrier(0);
-    MFMA_STEP(y, fa_a, fa_b) MFMA_STEP(z, fa_a, fa_b) MFMA_STEP(w, fa_a, fa_b)
-    __builtin_amdgcn_sched_barrier(0);
-    if (!(ABL & 4)) STORE_TILE(buf ^ 1)          // waits for the staging loads issued one iteration ago
+#pragma unroll
+    for (int i = 0; i < NMF; ++i) {
+      MFMA_AT(i, fa_a, fa_b)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < FPG; ++u) {
+        const int f = i * FPG + u;
+        if (f < NRD) READ_ONE(f, buf, 1, fb_a, fb_b)
+        else STORE_ONE(f - NRD, buf ^ 1)        // waits (vmcnt) for that staging load, issued a whole k-tile ago
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
     __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): this wave's LDS writes have landed
-    if (!(ABL & 1)) __builtin_amdgcn_s_barrier();   // raw barrier: no vmcnt(0) (nothing is in flight here anyway)
+    __builtin_amdgcn_s_barrier();                // raw barrier: no vmcnt(0) (nothing is in flight here anyway)
     __builtin_amdgcn_sched_barrier(0);
-    if (!(ABL & 2)) LOAD_TILE(kt + 2 < nk ? kt + 2 : nk - 1)     // the clamped reload at the end is never used
-    __builtin_amdgcn_sched_barrier(0);
-    MFMA_STEP(x, fb_a, fb_b)
-    __builtin_amdgcn_sched_barrier(0);
-    if (!(ABL & 8)) READ_FRAGS(buf ^ 1, 0, fa_a, fa_b)
-    __builtin_amdgcn_sched_barrier(0);
-    MFMA_STEP(y, fb_a, fb_b) MFMA_STEP(z, fb_a, fb_b) MFMA_STEP(w, fb_a, fb_b)
-    __builtin_amdgcn_sched_barrier(0);
+    const int ktn = kt + 2 < nk ? kt + 2 : nk - 1;   // the clamped reload at the end is never used
+    CONV_BEGIN()
+#pragma unroll
+    for (int i = 0; i < NMF; ++i) {
+      MFMA_AT(i, fb_a, fb_b)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < FPG; ++u) {
+        const int f = i * FPG + u;
+        if (f < NST) LOAD_ONE(f, ktn)
+        else READ_ONE(f - NST, buf ^ 1, 0, fa_a, fa_b)
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    CONV_END()
   }
   READ_FRAGS(kt & 1, 1, fb_a, fb_b)
   MFMA_GROUP(fa_a, fa_b)
   MFMA_GROUP(fb_a, fb_b)
+#undef CONV_BEGIN
+#undef CONV_END
+#undef LOAD_ONE
+#undef STORE_ONE
 #undef LOAD_TILE
 #undef STORE_TILE
+#undef READ_ONE
 #undef READ_FRAGS
-#undef MFMA_STEP
+#undef MFMA_AT
 #undef MFMA_GROUP
 
   // ---- epilogue: lane holds column n = .. + i32 and rows (r&3) + 8(r>>2) + 4·half of each 32x32 sub-tile.
@@ -299,6 +340,19 @@ static void launch_cfg(const GemmParams& q, int bk, int mtiles, hipStream_t s) {
   else hipLaunchKernelGGL((gemm_kernel<MT, NT, WM, WN, 16, A_PLAIN>), grid, dim3(256), 0, s, q);
 }
 
+// per-device page of zeros for the out-of-image taps of the implicit-GEMM convolutions (allocated on first use)
+static const float* zero_page() {
+  static std::map<int, float*> pages;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  auto it = pages.find(dev);
+  if (it != pages.end()) return it->second;
+  float* z = nullptr;
+  if (hipMalloc(&z, 256) != hipSuccess || hipMemset(z, 0, 256) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
+  pages[dev] = z;
+  return z;
+}
+
 static int g_bk = 0, g_geo128 = 0, g_geo256 = 0;
 int launch_gemm(const GemmParams& p, hipStream_t s) {
   if (p.M <= 0) return 0;
@@ -327,6 +381,10 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
   if (g_geo256 && p.N == 64) geo = 2;
   GemmParams q = p;
   if (q.alpha == 0.f) q.alpha = 1.f;
+  if (q.amode == A_CONV3 && !q.zeros) {
+    q.zeros = zero_page();
+    if (!q.zeros) return NUHTC_E_HIP;
+  }
   const double nb = p.batch > 0 ? p.batch : 1;
   const char* tag = "gemm";
   if (prof_enabled()) {   // per-shape tags, e.g. "gemm_kernel<3>|N288|K96" (strings live for the process lifetime)
@@ -339,20 +397,6 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
   }
   // algorithmic work of the launch (device-side row counts are not known here: the capacity M is an upper bound)
   ProfScope ps(tag, 2.0 * p.M * p.N * p.K * nb, 4.0 * nb * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N), s);
-  static int abl = -1;
-  if (abl < 0) { const char* e = getenv("NUHTC_GEMM_ABL"); abl = e ? atoi(e) : 0; }
-  if (abl && nt == 3 && p.amode == A_PLAIN) {   // timing-only ablations of the main loop (results are wrong by construction)
-    dim3 grid(cdiv(cdiv(p.M, 128), 8) * 8 * (q.N / 96), 1, q.batch > 0 ? q.batch : 1);
-    switch (abl) {
-      case 1: hipLaunchKernelGGL((gemm_kernel<1, 3, 4, 1, 16, A_PLAIN, 1>), grid, dim3(256), 0, s, q); break;
-      case 2: hipLaunchKernelGGL((gemm_kernel<1, 3, 4, 1, 16, A_PLAIN, 2>), grid, dim3(256), 0, s, q); break;
-      case 4: hipLaunchKernelGGL((gemm_kernel<1, 3, 4, 1, 16, A_PLAIN, 4>), grid, dim3(256), 0, s, q); break;
-      case 8: hipLaunchKernelGGL((gemm_kernel<1, 3, 4, 1, 16, A_PLAIN, 8>), grid, dim3(256), 0, s, q); break;
-      case 6: hipLaunchKernelGGL((gemm_kernel<1, 3, 4, 1, 16, A_PLAIN, 6>), grid, dim3(256), 0, s, q); break;
-      default: hipLaunchKernelGGL((gemm_kernel<1, 3, 4, 1, 16, A_PLAIN, 15>), grid, dim3(256), 0, s, q); break;
-    }
-    return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
-  }
   if (geo == 1) launch_cfg<2, 2, 2, 2>(q, g_bk, cdiv(p.M, 128), s);
   else if (geo == 2) launch_cfg<2, 2, 4, 1>(q, g_bk, cdiv(p.M, 256), s);
   else if (nt == 1) launch_cfg<1, 1, 4, 1>(q, g_bk, cdiv(p.M, 128), s);
