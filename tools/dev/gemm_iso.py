@@ -1,6 +1,6 @@
 """Dev helper: time nuhtc_op_gemm on isolated shapes."""
 import sys, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 from nuhtc_amd import weights
 from nuhtc_amd.engine import Engine
 eng = Engine(weights.seeded_state_dict(0), device=0, max_batch=1, tile=(64, 64))
