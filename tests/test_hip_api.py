@@ -78,7 +78,7 @@ def test_infer_wsi_cli_writes_qupath_geojson(hip_device, tmp_path):
     ck = tmp_path / 'w.pth'
     torch.save(dict(state_dict=weights.bench_state_dict(0, obj_bias=0.0)), ck)
     subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools/infer_wsi.py'), str(src), CFG, str(ck), '--patch_size', '64', '--step_size', '48',
-                           '--batch_size', '4', '--save_dir', str(tmp_path / 'out'), '--merge'])
+                           '--batch_size', '4', '--save_dir', str(tmp_path / 'out'), '--merge', '--mode', 'all'])
     feats = json.load(open(tmp_path / 'out/nuclei/slide/slide.geojson'))
     merged = json.load(open(tmp_path / 'out/nuclei/slide/slide_merged.geojson'))
     pts = json.load(open(tmp_path / 'out/nuclei/slide/slide_point.geojson'))
@@ -86,6 +86,53 @@ def test_infer_wsi_cli_writes_qupath_geojson(hip_device, tmp_path):
     f0 = feats[0]
     assert f0['geometry']['type'] == 'Polygon' and f0['geometry']['coordinates'][0][0] == f0['geometry']['coordinates'][0][-1]
     assert set(f0['properties']) >= {'objectType', 'label', 'score', 'classification', 'isLocked'}
+    # the other output modes describe the same detections
+    import sqlite3
+    from nuhtc_amd import cocomask
+    dsa = json.load(open(tmp_path / 'out/nuclei/slide/slide_dsa.json'))
+    assert len(dsa['elements']) == len(feats) and dsa['elements'][0]['points'][0][:2] == f0['geometry']['coordinates'][0][0]
+    coco = json.load(open(tmp_path / 'out/nuclei/slide/coco_nuclei.json'))
+    assert len(coco['annotations']) == len(feats) and sum(i['n_objects'] for i in coco['images']) == len(feats)
+    a0 = coco['annotations'][0]
+    m0 = cocomask.decode(a0['segmentation'])
+    assert m0.shape == (64, 64) and m0.sum() >= 10 and os.path.exists(tmp_path / 'out/imgs/slide' / f"{a0['image_id']}.png")
+    n_sql = sqlite3.connect(str(tmp_path / 'out/nuclei/slide/slide_dql.db')).execute('SELECT COUNT(*) FROM contour').fetchone()[0]
+    assert n_sql == len(feats)
+
+
+def test_infer_patch_cli_writes_coco(hip_device, tmp_path):
+    import json
+    import subprocess
+    import sys
+    import torch
+    from PIL import Image
+    from nuhtc_amd import cocomask, synth, weights
+    tiles = synth.nuclei_tiles(5, 64, start=60)
+    with open(tmp_path / 'labels.csv', 'w') as f:
+        f.write('image_path,other\n')
+        for i, t in enumerate(tiles):
+            Image.fromarray(t).save(tmp_path / f'im{i}.png')
+            f.write(f"{tmp_path / f'im{i}.png'},x\n")
+    ck = tmp_path / 'w.pth'
+    torch.save(dict(state_dict=weights.bench_state_dict(0, obj_bias=0.0)), ck)
+    subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools/infer_patch.py'), '--csv', str(tmp_path / 'labels.csv'), '--config', CFG,
+                           '--checkpoint', str(ck), '--output', str(tmp_path / 'o/nuclei_coco.json'), '--batch-size', '4'])
+    doc = json.load(open(tmp_path / 'o/nuclei_coco.json'))
+    assert [im['id'] for im in doc['images']] == [1, 2, 3, 4, 5] and doc['images'][0]['height'] == 64
+    assert len(doc['annotations']) > 0 and doc['categories'][0]['name'] == 'nucleus'
+    ids = [a['id'] for a in doc['annotations']]
+    assert ids == list(range(len(ids)))
+    for a in doc['annotations'][:5]:
+        m = cocomask.decode(a['segmentation'])
+        ys, xs = np.nonzero(m)
+        assert a['bbox'] == [xs.min(), ys.min(), xs.max() - xs.min() + 1, ys.max() - ys.min() + 1] and 0.35 <= a['score'] <= 1
+    # per image, kept instances do not overlap above the mask-NMS threshold
+    by_img = {}
+    for a in doc['annotations']:
+        by_img.setdefault(a['image_id'], []).append(a['segmentation'])
+    for rl in by_img.values():
+        iou = cocomask.iou(rl, rl)
+        assert (iou - np.eye(len(rl))).max() <= 0.05
 
 
 def test_pannuke_dataset_cli_exports_and_scores(hip_device, tmp_path):

@@ -6,11 +6,14 @@
     python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/infer_wsi.py ...   (one rank per GPU)
 
 <source>: .npy image (H,W,3) uint8 that is tiled on a grid (np.arange(0, size, step), zero padded), or .npz with
-`tiles` (N,P,P,3) and `coords` (N,2).  OpenSlide reading, tissue segmentation and the DSA/SQL/COCO writers of the
-reference are out of scope.
-Output (like the reference, :659-664): <save_dir>/nuclei/<name>/<name>.geojson and <name>_point.geojson — flat lists of
-QuPath features of every detection that survives the per-tile filter + mask-NMS; run tools/nuclei_merge.py on the
-.geojson for the cross-tile merge (or pass --merge to do it here on rank 0)."""
+`tiles` (N,P,P,3) and `coords` (N,2).  OpenSlide reading is out of scope (no openslide offline).
+Output (like the reference, :659-693), for every detection that survives the per-tile filter + mask-NMS:
+  --mode qupath : <save_dir>/nuclei/<name>/<name>.geojson and <name>_point.geojson (flat lists of QuPath features); run
+                  tools/nuclei_merge.py on the .geojson for the cross-tile merge (or pass --merge to do it here on rank 0)
+  --mode dsa    : <name>_dsa.json (HistomicsUI polyline elements)
+  --mode coco   : coco_nuclei.json (per-tile images + RLE annotations) and <save_dir>/imgs/<name>/<annidx>.png
+  --mode sql    : <name>_dql.db (contour table + R-tree)
+  --mode all    : everything."""
 import argparse
 import json
 import os
@@ -34,7 +37,7 @@ def parse_args():
     p.add_argument('--margin', type=int, default=2)
     p.add_argument('--min_area', type=int, default=10)
     p.add_argument('--mag', type=int, default=40)
-    p.add_argument('--mode', default='qupath', choices=['qupath'])
+    p.add_argument('--mode', default='qupath', choices=['qupath', 'dsa', 'coco', 'sql', 'all'])
     p.add_argument('--merge', action='store_true', help='also run the cross-tile merge (nuclei_merge.py) on rank 0')
     p.add_argument('--overlap_threshold', type=float, default=0.05)
     p.add_argument('--save_dir', default='wsi_out')
@@ -63,38 +66,82 @@ def main():
     rings = [contours.mask_to_ring(m, origin=(x0, y0)) for (m, x0, y0) in rec['mask']]
     keep = [i for i, r in enumerate(rings) if len(r) >= 4]          # reference drops contours with < 3 points (:536)
     n = len(keep)
-    head = torch.zeros((n, 7), dtype=torch.float64)
+    want = lambda m: args.mode in (m, 'all')
+    P = tiles.shape[1]
+    rles = []
+    if want('coco'):                                                  # RLE of the instance inside its tile (:611-613)
+        from nuhtc_amd import cocomask
+        for i in keep:
+            crop, x0, y0 = rec['mask'][i]
+            ox, oy = (int(v) for v in coords[lo + rec['tile'][i]])
+            full = np.zeros((P, P), np.uint8)
+            full[y0 - oy:y0 - oy + crop.shape[0], x0 - ox:x0 - ox + crop.shape[1]] = crop
+            rles.append(cocomask.encode(full)['counts'].encode('ascii'))
+    head = torch.zeros((n, 9), dtype=torch.float64)
     for k, i in enumerate(keep):
         head[k, :4] = torch.from_numpy(rec['box'][i])
         head[k, 4], head[k, 5], head[k, 6] = rec['score'][i], rec['label'][i], len(rings[i])
+        head[k, 7] = lo + rec['tile'][i]                              # annidx: the tile's position in the slide's tile list
+        head[k, 8] = len(rles[k]) if rles else 0
     verts = torch.from_numpy(np.concatenate([rings[i] for i in keep], 0).astype(np.float64)) if n else torch.zeros((0, 2), dtype=torch.float64)
+    blob = torch.from_numpy(np.frombuffer(b''.join(rles), np.uint8).copy()) if rles else torch.zeros(0, dtype=torch.uint8)
     dev = torch.device('cuda', local_rank) if world > 1 and torch.cuda.is_available() else torch.device('cpu')
     heads = parallel.gather_records(head.to(dev))
     vparts = parallel.gather_records(verts.to(dev))
+    bparts = parallel.gather_records(blob.to(dev)) if want('coco') else [None] * len(heads)
     if rank == 0:
-        feats, points = [], []
-        for h, v in zip(heads, vparts):
-            h, v = h.cpu().numpy(), v.cpu().numpy()
-            off = 0
-            for row in h:
-                nv = int(row[6])
-                ring = v[off:off + nv].astype(np.int64)
-                off += nv
-                feats.append(contours.feature(ring, int(row[5]), float(row[4]), model.CLASSES))
-                points.append(contours.point_feature(row[:4], int(row[5]), float(row[4]), model.CLASSES))
+        from nuhtc_amd import outputs
         name = os.path.splitext(os.path.basename(args.source))[0]
         out_dir = os.path.join(args.save_dir, 'nuclei', name)
         os.makedirs(out_dir, exist_ok=True)
-        with open(os.path.join(out_dir, name + '.geojson'), 'w') as f:
-            json.dump(feats, f)
-        with open(os.path.join(out_dir, name + '_point.geojson'), 'w') as f:
-            json.dump(points, f)
-        msg = f'{len(tiles)} tiles on {world} rank(s): {len(feats)} nuclei after per-tile mask-NMS'
-        if args.merge:
-            merged = contours.merge_features(feats, args.overlap_threshold, 'probability')
-            with open(os.path.join(out_dir, name + '_merged.geojson'), 'w') as f:
-                json.dump(merged, f)
-            msg += f', {len(merged)} after the cross-tile merge'
+        feats, points, dsa, annts, per_tile = [], [], [], [], {}
+        sql = outputs.SqlContourWriter(os.path.join(out_dir, name + '_dql.db')) if want('sql') else None
+        for h, v, bl in zip(heads, vparts, bparts):
+            h, v = h.cpu().numpy(), v.cpu().numpy()
+            bl = bl.cpu().numpy().tobytes() if bl is not None else b''
+            off = boff = 0
+            for row in h:
+                nv, annidx, nb = int(row[6]), int(row[7]), int(row[8])
+                ring = v[off:off + nv].astype(np.int64)
+                off += nv
+                label, score = int(row[5]), float(row[4])
+                elementidx = len(per_tile.setdefault(annidx, []))
+                per_tile[annidx].append(label)
+                if want('qupath'):
+                    feats.append(contours.feature(ring, label, score, model.CLASSES))
+                    points.append(contours.point_feature(row[:4], label, score, model.CLASSES))
+                if want('dsa'):
+                    dsa.append(outputs.dsa_element(ring, label, model.CLASSES))
+                if want('coco'):
+                    rle = {'size': [P, P], 'counts': bl[boff:boff + nb].decode('ascii')}
+                    boff += nb
+                    bbox = cocomask.to_bbox(rle)
+                    annts.append({'bbox': bbox, 'area': bbox[2] * bbox[3], 'image_id': annidx, 'category_id': label, 'id': len(annts),
+                                  'iscrowd': 0, 'segmentation': rle})
+                if sql:
+                    sql.add(annidx, elementidx, ring, label, score, model.CLASSES)
+        msg = f'{len(tiles)} tiles on {world} rank(s): {sum(len(v) for v in per_tile.values())} nuclei after per-tile mask-NMS'
+        if want('qupath'):
+            outputs.write_json(os.path.join(out_dir, name + '.geojson'), feats)
+            outputs.write_json(os.path.join(out_dir, name + '_point.geojson'), points)
+            if args.merge:
+                merged = contours.merge_features(feats, args.overlap_threshold, 'probability')
+                outputs.write_json(os.path.join(out_dir, name + '_merged.geojson'), merged)
+                msg += f', {len(merged)} after the cross-tile merge'
+        if want('dsa'):
+            outputs.write_json(os.path.join(out_dir, name + '_dsa.json'), outputs.dsa_document(dsa))
+        if want('coco'):
+            from PIL import Image
+            img_dir = os.path.join(args.save_dir, 'imgs', name)
+            os.makedirs(img_dir, exist_ok=True)
+            imgs = []
+            for annidx in sorted(per_tile):
+                imgs.append(outputs.coco_tile_image(annidx, P, P, per_tile[annidx], model.CLASSES))
+                Image.fromarray(tiles[annidx]).save(os.path.join(img_dir, f'{annidx}.png'))
+            outputs.write_json(os.path.join(out_dir, 'coco_nuclei.json'),
+                               {'images': imgs, 'annotations': annts, 'categories': outputs.coco_categories(model.CLASSES)})
+        if sql:
+            sql.close()
         print(msg)
 
 
