@@ -118,6 +118,16 @@ int nuhtc_infer(nuhtc_engine* e, const uint8_t* tiles_dev, int B, int channel_mo
 int nuhtc_infer_fixed_load(nuhtc_engine* e, const uint8_t* tiles_dev, int B, int channel_mode, const float* rois_dev,
                            int n_rois, int n_dets, void* stream, const nuhtc_dets* out);
 
+/* Outer contours of the instance masks of a finished nuhtc_infer, traced on the device so that only vertex lists leave it.
+ * Replaces `mask2inst` (tools/infer_wsi.py:51-54: cv2.findContours(mask, RETR_TREE, CHAIN_APPROX_SIMPLE)[0][0]) applied
+ * to every detection that survived the per-tile filter + mask-NMS (:533-539).  For detection slot s = b*max_per_img + r
+ * with r < dets->counts[b] and (dets->keep == NULL or dets->keep[s]):  n_dev[s] = number of vertices written to
+ * xy_dev[s*cap*2 ..] as (x, y) int16 pairs in tile pixels, open ring (the caller repeats the first point and adds the
+ * tile origin); n_dev[s] = -1 if the contour has more than `cap` vertices or more than 2048 border pixels (trace that
+ * one on the host); n_dev[s] = 0 for slots that are not traced.  dets->masks and dets->counts must be non-NULL.
+ * Enqueues on `stream`; does not synchronise. */
+int nuhtc_mask_contours(nuhtc_engine* e, const nuhtc_dets* dets, int B, int cap, int16_t* xy_dev, int32_t* n_dev, void* stream);
+
 /* Synchronises `stream` and reports whether the last nuhtc_infer overflowed a capacity
  * (returns NUHTC_E_CAPACITY) — call before trusting the results. */
 int nuhtc_check(nuhtc_engine* e, void* stream);

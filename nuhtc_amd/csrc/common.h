@@ -94,6 +94,11 @@ struct GemmParams {
 };
 int launch_gemm(const GemmParams& p, hipStream_t s);
 
+// ----------------------------------------------------------------------------- contours (contour.hip)
+// outer contour (cv2 RETR first contour, CHAIN_APPROX_SIMPLE) of every kept instance mask; n: 0 = none, -1 = overflow
+int launch_contours(const uint32_t* masks, const uint8_t* keep, const int32_t* counts, int B, int max_per_img, int H, int W,
+                    int cap, int16_t* xy, int32_t* n, hipStream_t s);
+
 // ----------------------------------------------------------------------------- Swin kernels (swin.hip)
 int launch_preproc(const uint8_t* tiles, float* img, int B, int th, int tw, int swap, const float* mean_istd, hipStream_t s);
 int launch_patch_embed(const float* img, const float* w, const float* b, const float* g, const float* beta, float* tok,

@@ -507,6 +507,17 @@ int nuhtc_infer_fixed_load(nuhtc_engine* e, const uint8_t* tiles, int B, int cha
   return 0;
 }
 
+int nuhtc_mask_contours(nuhtc_engine* e, const nuhtc_dets* dets, int B, int cap, int16_t* xy, int32_t* n, void* stream) {
+  if (!e) return NUHTC_E_INVALID;
+  if (!dets || !dets->masks || !dets->counts || !xy || !n || B < 1 || B > e->cfg.max_batch || cap < 1)
+    FAIL(e, NUHTC_E_INVALID, "bad nuhtc_mask_contours arguments");
+  HIP_CHECK(e, hipSetDevice(e->device));
+  int rc = launch_contours(dets->masks, dets->keep, dets->counts, B, e->cfg.max_per_img, e->cfg.tile_h, e->cfg.tile_w, cap, xy, n,
+                           (hipStream_t)stream);
+  if (rc) FAIL(e, rc, "contour launch failed (tile width must be a multiple of 32)");
+  return 0;
+}
+
 int nuhtc_check(nuhtc_engine* e, void* stream) {
   if (!e) return NUHTC_E_INVALID;
   HIP_CHECK(e, hipSetDevice(e->device));

@@ -121,6 +121,40 @@ class Engine:
     def check(self):
         self._check(self.lib.nuhtc_check(self.h, self._stream()))
 
+    def contours_async(self, B, cap=256, kept_only=True):
+        """Enqueue the outer-contour trace (cv2.findContours(...)[0][0] of tools/infer_wsi.py:51-54) of the last infer's
+        masks on the device; results in self.contour_xy (B,K,cap,2) int16 / self.contour_n (B,K) int32."""
+        K = self.cfg.max_per_img
+        if getattr(self, 'contour_xy', None) is None or self.contour_xy.shape[2] != cap:
+            self.contour_xy = torch.zeros(self.cfg.max_batch, K, cap, 2, dtype=torch.int16, device=self.device)
+            self.contour_n = torch.zeros(self.cfg.max_batch, K, dtype=torch.int32, device=self.device)
+        dets = self.dets if kept_only else hip.Dets(self.boxes.data_ptr(), self.labels.data_ptr(), self.counts.data_ptr(),
+                                                    self.masks.data_ptr(), self.areas.data_ptr(), None)
+        self._check(self.lib.nuhtc_mask_contours(self.h, ctypes.byref(dets), B, cap, ctypes.c_void_p(self.contour_xy.data_ptr()),
+                                                 ctypes.c_void_p(self.contour_n.data_ptr()), self._stream()))
+
+    def contours(self, B, cap=256, kept_only=True):
+        """-> per tile, dict slot -> (n,2) int64 open contour in tile pixels.  Contours that overflow the device
+        capacities are traced by the host mirror (nuhtc_amd.contours) from the mask."""
+        from . import contours as host
+        self.contours_async(B, cap, kept_only)
+        n = self.contour_n[:B].cpu().numpy()
+        out = []
+        for b in range(B):
+            d = {}
+            slots = np.nonzero(n[b])[0]
+            if len(slots):
+                xy = self.contour_xy[b, torch.from_numpy(slots).to(self.device)].cpu().numpy()
+                for k, sl in enumerate(slots):
+                    if n[b, sl] > 0:
+                        d[int(sl)] = xy[k, :n[b, sl]].astype(np.int64)
+                    else:
+                        words = self.masks[b, sl].cpu().numpy().view(np.uint32)
+                        bits = np.unpackbits(words.view(np.uint8).reshape(self.cfg.tile_h, self.cfg.tile_w // 8), axis=-1, bitorder='little')
+                        d[int(sl)] = host.trace_outer_contour(bits.astype(bool))
+            out.append(d)
+        return out
+
     def results(self, B, with_masks=True):
         """Device outputs of the last infer -> list of (bbox_results, segm_results) exactly like the reference
         (`bbox2result` mmdet/core/bbox/transforms.py:100-117; `get_seg_masks` list-of-bool-arrays per class)."""

@@ -29,14 +29,16 @@ def infer_tiles(model, tiles, coords, batch_size=16):
     """Run the engine over `tiles` (N,P,P,3) and return per-detection records that survive the per-tile margin /
     min-area filter + mask-NMS (computed on the GPU, tools/infer_wsi.py:510-531), in slide coordinates.
 
-    Returns dict(tile, box (n,4) float64 slide px, score, label, mask (list of (bool crop, x0, y0)))."""
+    Returns dict(tile, box (n,4) float64 slide px, score, label, mask (list of (bool crop, x0, y0)), ring (closed
+    (n+1,2) int64 contour in slide px, traced on the GPU: nuhtc_mask_contours))."""
     eng = model.engine(tiles.shape[1:3])
     P = tiles.shape[1]
-    rec = dict(tile=[], box=[], score=[], label=[], mask=[])
+    rec = dict(tile=[], box=[], score=[], label=[], mask=[], ring=[])
     for i in range(0, len(tiles), batch_size):
         chunk = tiles[i:i + batch_size]
         B = eng.infer_async(eng.to_device(chunk), hip.CH_SWAP)
         eng.check()
+        rings = eng.contours(B)             # slot -> open contour in tile pixels, kept detections only
         counts = eng.counts[:B].cpu().numpy()
         boxes = eng.boxes[:B].cpu().numpy()
         labels = eng.labels[:B].cpu().numpy()
@@ -62,6 +64,8 @@ def infer_tiles(model, tiles, coords, batch_size=16):
                 rec['score'].append(float(boxes[b, j, 4]))
                 rec['label'].append(int(labels[b, j]))
                 rec['mask'].append((bits[k, y0:y1, x0:x1].copy(), ox + int(x0), oy + int(y0)))
+                c = rings[b][int(j)]
+                rec['ring'].append(np.concatenate([c, c[:1]], 0) + np.array([ox, oy], np.int64))   # mask2inst + contour_map
     return rec
 
 

@@ -58,7 +58,10 @@ def test_wsi_host_path_single_rank(hip_device, model):
     tiles, coords = wsi.tile_grid(rng_img, 64, 48)
     rec = wsi.infer_tiles(model, tiles, coords, batch_size=4)
     n = len(rec['score'])
-    assert n > 0 and len(rec['mask']) == n
+    assert n > 0 and len(rec['mask']) == n == len(rec['ring'])
+    from nuhtc_amd import contours
+    for (m, x0, y0), ring in zip(rec['mask'], rec['ring']):      # GPU-traced ring == host trace of the same mask
+        assert np.array_equal(ring, contours.mask_to_ring(m, origin=(x0, y0)))
     keep = wsi.merge_overlap(rec, 0.05)
     assert 0 < len(keep) <= n
     # kept detections do not overlap each other above the threshold
@@ -162,3 +165,57 @@ def test_pannuke_dataset_cli_exports_and_scores(hip_device, tmp_path):
     # drop slightly below 1 while every surviving pair matches exactly
     assert s['sq'] > 0.97 and s['dq'] > 0.9 and s['bPQ'] > 0.85 and max(s[f'multi_pq+_{c}'] for c in range(5)) > 0.85
     assert os.path.exists(tmp_path / 'b' / 'class_stats.csv') and os.path.exists(tmp_path / 'b' / 'tissue_stats.csv')
+
+
+def test_device_contours_match_host_mirror(hip_device, model):
+    """nuhtc_mask_contours against nuhtc_amd.contours.trace_outer_contour, vertex by vertex (integer work: exact), on the
+    engine's own masks and on hand-made shapes written into the mask buffer (thin lines, holes, single pixels, blobs that
+    touch the tile border, a contour longer than the device capacity)."""
+    import torch
+    from nuhtc_amd import contours as host
+    from nuhtc_amd import synth
+    eng = model.engine((64, 64))
+    tiles = synth.nuclei_tiles(4, 64, start=70)
+    B = eng.infer_async(eng.to_device(tiles), 1)
+    eng.check()
+    got = eng.contours(B, cap=256, kept_only=True)
+    keep = eng.keep[:B].cpu().numpy()
+    counts = eng.counts[:B].cpu().numpy()
+    n_checked = 0
+    for b in range(B):
+        assert sorted(got[b]) == [int(i) for i in np.nonzero(keep[b, :counts[b]])[0]]
+        for sl, ring in got[b].items():
+            words = eng.masks[b, sl].cpu().numpy().view(np.uint32)
+            bits = np.unpackbits(words.view(np.uint8).reshape(64, 8), axis=-1, bitorder='little').astype(bool)
+            assert np.array_equal(ring, host.trace_outer_contour(bits))
+            n_checked += 1
+    assert n_checked > 10
+    # hand-made masks in slots 0.. of tile 0
+    shapes = []
+    m = np.zeros((64, 64), bool); m[10, 5:40] = True; shapes.append(m)                       # horizontal line
+    m = np.zeros((64, 64), bool); m[5:50, 7] = True; shapes.append(m)                        # vertical line
+    m = np.zeros((64, 64), bool); m[20, 20] = True; shapes.append(m)                         # single pixel
+    m = np.zeros((64, 64), bool); m[20, 20] = m[21, 21] = True; shapes.append(m)             # two diagonal pixels
+    m = np.zeros((64, 64), bool); m[8:30, 8:30] = True; m[14:20, 14:20] = False; shapes.append(m)   # hole
+    m = np.zeros((64, 64), bool); m[0:12, 0:9] = True; m[55:64, 50:64] = True; shapes.append(m)      # two blobs on the border
+    m = np.ones((64, 64), bool); shapes.append(m)                                            # full tile
+    yy, xx = np.mgrid[0:64, 0:64]
+    m = ((yy - 30) ** 2 / 400 + (xx - 28) ** 2 / 150) <= 1; shapes.append(m)                 # ellipse
+    m = (xx + yy) % 2 == 0; m[:, 40:] = False; shapes.append(m)                              # checkerboard: long 8-connected border
+    rng = np.random.default_rng(3)
+    m = rng.uniform(size=(64, 64)) < 0.55; shapes.append(m)                                  # noise
+    masks = eng.masks.clone()
+    for i, m in enumerate(shapes):
+        packed = np.packbits(m.reshape(64, 8, 8), axis=-1, bitorder='little').reshape(64, 8).view(np.uint32).reshape(64, 2)
+        masks[0, i] = torch.from_numpy(packed.view(np.int32)).to(masks.device)
+    eng.masks.copy_(masks)
+    eng.counts[0] = len(shapes)
+    got = eng.contours(1, cap=32, kept_only=False)[0]          # small cap: the checkerboard / noise overflow to the host path
+    raw_n = eng.contour_n[0, :len(shapes)].cpu().numpy()
+    assert (raw_n == -1).sum() >= 1 and (raw_n > 0).sum() >= 7
+    for i, m in enumerate(shapes):
+        assert np.array_equal(got[i], host.trace_outer_contour(m)), i
+    got = eng.contours(1, cap=1024, kept_only=False)[0]
+    assert (eng.contour_n[0, :len(shapes)].cpu().numpy() > 0).all()
+    for i, m in enumerate(shapes):
+        assert np.array_equal(got[i], host.trace_outer_contour(m)), i

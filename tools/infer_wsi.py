@@ -63,7 +63,7 @@ def main():
     model.opts.update(margin=args.margin, min_area=args.min_area, mask_nms_thr=0.05)
     rec = wsi.infer_tiles(model, tiles[lo:hi], coords[lo:hi], args.batch_size)
     # contours are traced on the rank that owns the tile; two variable-length gathers: records, then ring vertices
-    rings = [contours.mask_to_ring(m, origin=(x0, y0)) for (m, x0, y0) in rec['mask']]
+    rings = rec['ring']                                              # traced on the GPU (nuhtc_mask_contours)
     keep = [i for i, r in enumerate(rings) if len(r) >= 4]          # reference drops contours with < 3 points (:536)
     n = len(keep)
     want = lambda m: args.mode in (m, 'all')
