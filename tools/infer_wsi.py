@@ -5,7 +5,8 @@
                                --margin 2 --min_area 10 --save_dir out --mode qupath]
     python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/infer_wsi.py ...   (one rank per GPU)
 
-<source>: .npy image (H,W,3) uint8 that is tiled on a grid (np.arange(0, size, step), zero padded), or .npz with
+<source>: .npy image (H,W,3) uint8 that is tiled on a grid (np.arange(0, size, step), zero padded; with --seg only the
+tissue found by nuhtc_amd.tissue is tiled, as the reference's seg_and_patch does), or .npz with
 `tiles` (N,P,P,3) and `coords` (N,2).  OpenSlide reading is out of scope (no openslide offline).
 Output (like the reference, :659-693), for every detection that survives the per-tile filter + mask-NMS:
   --mode qupath : <save_dir>/nuclei/<name>/<name>.geojson and <name>_point.geojson (flat lists of QuPath features); run
@@ -38,6 +39,8 @@ def parse_args():
     p.add_argument('--min_area', type=int, default=10)
     p.add_argument('--mag', type=int, default=40)
     p.add_argument('--mode', default='qupath', choices=['qupath', 'dsa', 'coco', 'sql', 'all'])
+    p.add_argument('--seg', action='store_true', help='segment tissue first and tile only the tissue contours (reference --seg --patch)')
+    p.add_argument('--seg_downsample', type=int, default=64, help='downsample factor of the segmentation level (reference: pyramid level nearest 64x)')
     p.add_argument('--merge', action='store_true', help='also run the cross-tile merge (nuclei_merge.py) on rank 0')
     p.add_argument('--overlap_threshold', type=float, default=0.05)
     p.add_argument('--save_dir', default='wsi_out')
@@ -55,6 +58,13 @@ def main():
     if args.source.endswith('.npz'):
         z = np.load(args.source)
         tiles, coords = z['tiles'], z['coords']
+    elif args.seg:
+        from nuhtc_amd import tissue
+        slide = np.load(args.source)
+        coords, conts, _ = tissue.tissue_tile_coords(slide, args.patch_size, args.step_size, scale=args.seg_downsample)
+        tiles = tissue.read_tiles(slide, coords, args.patch_size)
+        if rank == 0:
+            print(f'tissue segmentation: {len(conts)} contour(s), {len(coords)} tiles')
     else:
         tiles, coords = wsi.tile_grid(np.load(args.source), args.patch_size, args.step_size)
     lo, hi = parallel.shard_range(len(tiles), rank, world)
