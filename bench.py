@@ -49,6 +49,7 @@ def main():
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-tiles', type=int, default=8)
+    ap.add_argument('--in-flight', type=int, default=3, help='also report the streaming rate with this many batches in flight (0/1 = skip)')
     ap.add_argument('--gemm-shapes', action='store_true', help='add the per-shape GEMM timings to the JSON line')
     args = ap.parse_args()
 
@@ -104,6 +105,35 @@ def main():
     counts = eng.counts[:B].cpu().numpy()
     roi_counts = eng.buffer('roi_counts')[:B].cpu().numpy()
 
+    # streaming rate: the same K steps with `--in-flight` batches on the GPU at once (one engine + HIP stream each, as the WSI
+    # path runs: nuhtc_amd.pipeline).  Reported beside `value`, which stays the one-batch-at-a-time rate the per-kernel
+    # numbers above belong to.
+    pipelined = None
+    if args.in_flight > 1:
+        engs = [eng] + [Engine(sd, device=local_rank, max_batch=args.batch, tile=(256, 256)) for _ in range(args.in_flight - 1)]
+        streams = [torch.cuda.Stream() for _ in engs]
+
+        def run(k):
+            for i in range(k):
+                with torch.cuda.stream(streams[i % len(engs)]):
+                    engs[i % len(engs)].infer_async(tiles, mode)
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream())
+        run(args.warmup * len(engs))
+        sync_all()
+        t0 = time.perf_counter()
+        run(args.steps)
+        sync_all()
+        dtp = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dtp], device='cuda')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtp = float(t.item())
+        for e in engs:
+            e.check()
+        pipelined = {'in_flight': len(engs), 'value': total_tiles / dtp, 'unit': 'tiles/s', 'ms_per_step': dtp / args.steps * 1e3,
+                     'note': 'same K steps, consecutive batches overlapped on separate HIP streams (one engine each)'}
+
     # live per-kernel timing (HIP events on the launch stream) over the same workload, separate steps so the
     # event records do not perturb the headline number
     hip.profile_enable(True)
@@ -147,6 +177,8 @@ def main():
                          'share_of_step_kernel_time': dom['ms'] / tot_ms},
             'kernel_ms_per_step': breakdown,
         }
+        if pipelined:
+            out['pipelined'] = pipelined
         if args.gemm_shapes:
             out['gemm_shapes'] = shapes
         if world == 1 and not args.no_cpu_baseline:

@@ -39,6 +39,17 @@ class Detector:
                                         max_cc_proposals=self.max_cc_proposals, **opts)
         return self._engines[key]
 
+    def pipeline(self, tile_hw, depth=3):
+        """`depth` engines on their own streams for the streaming (WSI) path: nuhtc_amd.pipeline.EnginePipeline."""
+        from .pipeline import EnginePipeline
+        key = (int(tile_hw[0]), int(tile_hw[1]), int(depth))
+        if key not in self._engines:
+            opts = dict(self.opts)
+            nc = opts.pop('num_classes')
+            self._engines[key] = EnginePipeline(self.state_dict, device=self.device, depth=depth, max_batch=self.max_batch, tile=key[:2],
+                                                num_classes=nc, max_cc_proposals=self.max_cc_proposals, **opts)
+        return self._engines[key]
+
     def eval(self):
         return self
 

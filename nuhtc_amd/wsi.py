@@ -25,47 +25,67 @@ def tile_grid(image, patch_size=256, step_size=192):
     return np.stack(tiles), np.array(coords, np.int64)
 
 
-def infer_tiles(model, tiles, coords, batch_size=16):
+def _unpack(eng, B, i0, coords, P, rec):
+    """Device outputs of one finished batch -> detection records (kept detections only), in slide coordinates."""
+    rings = eng.contours(B)             # slot -> open contour in tile pixels, traced on the GPU
+    counts = eng.counts[:B].cpu().numpy()
+    boxes = eng.boxes[:B].cpu().numpy()
+    labels = eng.labels[:B].cpu().numpy()
+    keep = eng.keep[:B].cpu().numpy()
+    for b in range(B):
+        n = int(counts[b])
+        idx = np.nonzero(keep[b, :n])[0]
+        if len(idx) == 0:
+            continue
+        # class-major order like np.concatenate(result[0]) in the reference, then score order from mask_nms
+        order = idx[np.lexsort((idx, labels[b, idx]))]
+        order = order[np.argsort(boxes[b, order, 4], kind='stable')[::-1]]
+        words = eng.masks[b, torch_index(order, eng)].cpu().numpy().view(np.uint32)
+        bits = np.unpackbits(words.view(np.uint8).reshape(len(order), P, P // 8), axis=-1, bitorder='little').astype(bool)
+        ox, oy = int(coords[i0 + b][0]), int(coords[i0 + b][1])
+        for k, j in enumerate(order):
+            ys, xs = np.nonzero(bits[k])
+            if len(ys) == 0:
+                continue
+            y0, y1, x0, x1 = ys.min(), ys.max() + 1, xs.min(), xs.max() + 1
+            rec['tile'].append(i0 + b)
+            rec['box'].append(boxes[b, j, :4].astype(np.float64) + np.array([ox, oy, ox, oy]))
+            rec['score'].append(float(boxes[b, j, 4]))
+            rec['label'].append(int(labels[b, j]))
+            rec['mask'].append((bits[k, y0:y1, x0:x1].copy(), ox + int(x0), oy + int(y0)))
+            c = rings[b][int(j)]
+            rec['ring'].append(np.concatenate([c, c[:1]], 0) + np.array([ox, oy], np.int64))   # mask2inst + contour_map
+
+
+def torch_index(order, eng):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(order)).to(eng.device)
+
+
+def infer_tiles(model, tiles, coords, batch_size=16, depth=3):
     """Run the engine over `tiles` (N,P,P,3) and return per-detection records that survive the per-tile margin /
-    min-area filter + mask-NMS (computed on the GPU, tools/infer_wsi.py:510-531), in slide coordinates.
+    min-area filter + mask-NMS (computed on the GPU, tools/infer_wsi.py:510-531), in slide coordinates.  `depth` batches
+    are kept in flight (nuhtc_amd.pipeline): the host unpacks batch i while the GPU runs batch i+1.
 
     Returns dict(tile, box (n,4) float64 slide px, score, label, mask (list of (bool crop, x0, y0)), ring (closed
     (n+1,2) int64 contour in slide px, traced on the GPU: nuhtc_mask_contours))."""
-    eng = model.engine(tiles.shape[1:3])
+    import torch
     P = tiles.shape[1]
     rec = dict(tile=[], box=[], score=[], label=[], mask=[], ring=[])
+    pipe = model.pipeline(tiles.shape[1:3], depth)
+
+    def finish():
+        eng, B, stream, i0 = pipe.collect()
+        with torch.cuda.stream(stream):
+            _unpack(eng, B, i0, coords, P, rec)
+            stream.synchronize()
+
     for i in range(0, len(tiles), batch_size):
-        chunk = tiles[i:i + batch_size]
-        B = eng.infer_async(eng.to_device(chunk), hip.CH_SWAP)
-        eng.check()
-        rings = eng.contours(B)             # slot -> open contour in tile pixels, kept detections only
-        counts = eng.counts[:B].cpu().numpy()
-        boxes = eng.boxes[:B].cpu().numpy()
-        labels = eng.labels[:B].cpu().numpy()
-        keep = eng.keep[:B].cpu().numpy()
-        for b in range(B):
-            n = int(counts[b])
-            idx = np.nonzero(keep[b, :n])[0]
-            if len(idx) == 0:
-                continue
-            # class-major order like np.concatenate(result[0]) in the reference, then score order from mask_nms
-            order = idx[np.lexsort((idx, labels[b, idx]))]
-            order = order[np.argsort(boxes[b, order, 4], kind='stable')[::-1]]
-            words = eng.masks[b, order].cpu().numpy().view(np.uint32)
-            bits = np.unpackbits(words.view(np.uint8).reshape(len(order), P, P // 8), axis=-1, bitorder='little').astype(bool)
-            ox, oy = int(coords[i + b][0]), int(coords[i + b][1])
-            for k, j in enumerate(order):
-                ys, xs = np.nonzero(bits[k])
-                if len(ys) == 0:
-                    continue
-                y0, y1, x0, x1 = ys.min(), ys.max() + 1, xs.min(), xs.max() + 1
-                rec['tile'].append(i + b)
-                rec['box'].append(boxes[b, j, :4].astype(np.float64) + np.array([ox, oy, ox, oy]))
-                rec['score'].append(float(boxes[b, j, 4]))
-                rec['label'].append(int(labels[b, j]))
-                rec['mask'].append((bits[k, y0:y1, x0:x1].copy(), ox + int(x0), oy + int(y0)))
-                c = rings[b][int(j)]
-                rec['ring'].append(np.concatenate([c, c[:1]], 0) + np.array([ox, oy], np.int64))   # mask2inst + contour_map
+        if pipe.full():
+            finish()
+        pipe.submit(tiles[i:i + batch_size], hip.CH_SWAP, tag=i)
+    while pipe.pending:
+        finish()
     return rec
 
 

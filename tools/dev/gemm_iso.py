@@ -4,7 +4,8 @@ import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__fil
 from nuhtc_amd import weights
 from nuhtc_amd.engine import Engine
 eng = Engine(weights.seeded_state_dict(0), device=0, max_batch=1, tile=(64, 64))
-for (M, N, K) in [(16384, 3072, 3072), (8192, 3072, 768), (262144, 384, 96), (262144, 96, 384), (283024, 288, 96), (16384, 1536, 384), (4096, 768, 3072), (65536, 768, 192)]:
+shapes = [tuple(int(v) for v in a.split('x')) for a in sys.argv[1:]]
+for (M, N, K) in shapes or [(16384, 3072, 3072), (8192, 3072, 768), (262144, 384, 96), (262144, 96, 384), (283024, 288, 96), (16384, 1536, 384), (4096, 768, 3072), (65536, 768, 192)]:
     A = torch.randn(M, K, device='cuda'); W = torch.randn(N, K, device='cuda') / K ** 0.5; b = torch.randn(N, device='cuda')
     for _ in range(3): eng.op_gemm(A, W, b, 0)
     torch.cuda.synchronize()
