@@ -1,0 +1,156 @@
+"""GPU edge cases and full-size properties of the tile path (through the C ABI).
+
+Edge cases the reference's own surface implies: tiles without any detection, constant / noise tiles, a batch of one, a
+non-square tile, a detection cap that truncates, a score threshold nothing passes.  Full-size properties at BASELINE
+configs[1] (B=16, 256x256), which the CPU oracle cannot cover in seconds: determinism, batch-permutation equivariance,
+idempotence of the per-tile mask-NMS keep set, structural invariants of the outputs."""
+import numpy as np
+import pytest
+
+from test_hip_full import match_instances
+
+pytestmark = pytest.mark.gpu
+
+
+def _pad5(r, nc=5):
+    return r
+
+
+def _flat(res):
+    b = np.concatenate(res[0], 0)
+    m = [x for cl in res[1] for x in cl]
+    return b, m
+
+
+def test_blank_noise_and_single_tile_batches(hip_device):
+    from nuhtc_amd import synth, weights
+    from nuhtc_amd.engine import Engine
+    from oracle import model as O
+    sd = weights.bench_state_dict(3, obj_bias=0.0)
+    rng = np.random.default_rng(5)
+    tiles = np.stack([np.full((64, 64, 3), 255, np.uint8), np.zeros((64, 64, 3), np.uint8), synth.nuclei_tiles(1, 64, start=9)[0],
+                      rng.integers(0, 256, (64, 64, 3), dtype=np.uint8), np.full((64, 64, 3), 127, np.uint8)])
+    eng = Engine(sd, device=0, max_batch=8, tile=(64, 64))
+    got = eng(tiles, 1)
+    ref = O.Oracle(sd)(tiles, 1)
+    for i, (g, r) in enumerate(zip(got, ref)):
+        nr, ng, nm, miou, low = match_instances(r, g)
+        assert nm >= 0.98 * max(nr, ng) and low <= 1, (i, nr, ng, nm, low)
+    # a batch of one gives the same answer as the same tile inside a batch
+    for i in (0, 2, 3):
+        one = eng(tiles[i:i + 1], 1)[0]
+        assert all(np.array_equal(a, b) for a, b in zip(one[0], got[i][0]))
+        assert all(len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b)) for a, b in zip(one[1], got[i][1]))
+    # contours / keep flags cope with tiles that have no detections
+    B = eng.infer_async(eng.to_device(tiles), 1)
+    eng.check()
+    rings = eng.contours(B)
+    counts = eng.counts[:B].cpu().numpy()
+    keep = eng.keep[:B].cpu().numpy()
+    for b in range(B):
+        assert len(rings[b]) <= counts[b] and not keep[b, counts[b]:].any()
+
+
+def test_nothing_passes_the_score_threshold(hip_device):
+    from nuhtc_amd import synth, weights
+    from nuhtc_amd.engine import Engine
+    sd = weights.bench_state_dict(3, obj_bias=0.0)
+    eng = Engine(sd, device=0, max_batch=4, tile=(64, 64), score_thr=0.9999)
+    got = eng(synth.nuclei_tiles(3, 64, start=2), 1)
+    for bbox, segm in got:
+        assert all(b.shape == (0, 5) for b in bbox) and all(len(s) == 0 for s in segm)
+    assert eng.counts[:3].cpu().numpy().tolist() == [0, 0, 0]
+    assert all(len(r) == 0 for r in eng.contours(3))
+
+
+def test_non_square_tile_and_detection_cap(hip_device):
+    from nuhtc_amd import synth, weights
+    from nuhtc_amd.engine import Engine
+    from oracle import model as O
+    sd = weights.bench_state_dict(4, obj_bias=0.5)
+    base = synth.nuclei_tiles(2, 128, start=21)
+    tiles = np.ascontiguousarray(base[:, :64, :96])               # 64 x 96 tiles
+    eng = Engine(sd, device=0, max_batch=2, tile=(64, 96))
+    got = eng(tiles, 0)
+    ref = O.Oracle(sd)(tiles, 0)
+    for g, r in zip(got, ref):
+        nr, ng, nm, miou, low = match_instances(r, g)
+        assert ng > 0 and nm >= 0.98 * max(nr, ng) and low <= 1, (nr, ng, nm, low)
+        assert all(m.shape == (64, 96) for cl in g[1] for m in cl)
+    # max_per_img truncates to the best-scoring detections of the uncapped run
+    cap = 7
+    engc = Engine(sd, device=0, max_batch=2, tile=(64, 96), max_per_img=cap)
+    gotc = engc(tiles, 0)
+    for g, gc in zip(got, gotc):
+        b, _ = _flat(g)
+        bc, _ = _flat(gc)
+        assert len(bc) == min(cap, len(b))
+        top = b[np.argsort(-b[:, 4], kind='stable')[:len(bc)]]
+        assert np.allclose(np.sort(bc[:, 4]), np.sort(top[:, 4]), atol=1e-6)
+
+
+def test_full_size_properties_b16(hip_device):
+    """BASELINE configs[1] size: B=16 tiles of 256x256."""
+    import torch
+    from nuhtc_amd import hip, synth, weights
+    from nuhtc_amd.engine import Engine
+    sd = weights.bench_state_dict(0)
+    eng = Engine(sd, device=0, max_batch=16)
+    tiles = synth.nuclei_tiles(16, 256, start=0)
+    dev = eng.to_device(tiles)
+
+    def snapshot():
+        B = eng.infer_async(dev, hip.CH_SWAP)
+        eng.check()
+        return [t[:B].clone() for t in (eng.counts, eng.boxes, eng.labels, eng.masks, eng.areas, eng.keep)]
+    a = snapshot()
+    b = snapshot()
+    counts = a[0].cpu().numpy()
+    assert counts.min() > 0 and counts.max() <= 500
+    # determinism: a second run is bit-identical in every output buffer (valid rows)
+    for x, y in zip(a, b):
+        for t in range(16):
+            n = counts[t]
+            assert torch.equal(x[t][:n] if x[t].dim() else x[t], y[t][:n] if y[t].dim() else y[t])
+    # permutation equivariance: reversing the batch reverses the results
+    perm = torch.arange(15, -1, -1, device=dev.device)
+    B = eng.infer_async(dev[perm].contiguous(), hip.CH_SWAP)
+    eng.check()
+    c = [t[:B].clone() for t in (eng.counts, eng.boxes, eng.labels, eng.masks, eng.areas, eng.keep)]
+    for x, y in zip(a, c):
+        for t in range(16):
+            n = counts[t]
+            assert torch.equal(x[t][:n] if x[t].dim() else x[t], y[15 - t][:n] if y[15 - t].dim() else y[15 - t])
+    # structural invariants
+    boxes, labels, masks, areas, keep = (t.cpu().numpy() for t in a[1:])
+    for t in range(16):
+        n = counts[t]
+        bx = boxes[t, :n]
+        assert (bx[:, 4] >= 0.35).all() and (bx[:, 4] <= 1).all() and (np.diff(bx[:, 4]) <= 1e-7).all()     # NMS order: score descending
+        assert (bx[:, 0] >= 0).all() and (bx[:, 1] >= 0).all() and (bx[:, 2] <= 256).all() and (bx[:, 3] <= 256).all()
+        assert ((labels[t, :n] >= 0) & (labels[t, :n] < 5)).all()
+        bits = np.unpackbits(masks[t, :n].view(np.uint8).reshape(n, 256, 32), axis=-1, bitorder='little')
+        assert np.array_equal(bits.reshape(n, -1).sum(1), areas[t, :n])                                    # popcount areas
+        # mask pixels lie inside the (integer-expanded) box
+        ys, xs = np.nonzero(bits.any(0))
+        k = np.nonzero(keep[t, :n])[0]
+        # keep set: margin / min-area filter holds, and mask-NMS at 0.05 over the kept set suppresses nothing more
+        assert (areas[t, k] >= 10).all()
+        assert (bx[k, 0] >= 2).all() and (bx[k, 1] >= 2).all() and (bx[k, 2] <= 254).all() and (bx[k, 3] <= 254).all()
+        if len(k) > 1:
+            f = bits[k].reshape(len(k), -1).astype(np.float32)
+            inter = f @ f.T
+            ar = f.sum(1)
+            iou = inter / (ar[:, None] + ar[None, :] - inter)
+            np.fill_diagonal(iou, 0)
+            assert iou.max() <= 0.05
+        # and every dropped-but-eligible detection is overlapped by a better kept one (greedy NMS completeness)
+        elig = np.array([j for j in range(n) if j not in set(k.tolist()) and areas[t, j] >= 10 and bx[j, 0] >= 2 and bx[j, 1] >= 2
+                         and bx[j, 2] <= 254 and bx[j, 3] <= 254], dtype=int)
+        for j in elig:
+            fj = bits[j].reshape(-1).astype(np.float32)
+            better = [q for q in k if bx[q, 4] >= bx[j, 4]]
+            fk = bits[better].reshape(len(better), -1).astype(np.float32)
+            inter = fk @ fj
+            iou = inter / (fk.sum(1) + fj.sum() - inter)
+            assert iou.max() > 0.05
