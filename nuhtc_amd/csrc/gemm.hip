@@ -245,88 +245,107 @@ __global__ __launch_bounds__(256, (MT * NT <= 3 ? 4 : 3)) void gemm_kernel(GemmP
 #undef MFMA_AT
 #undef MFMA_GROUP
 
-  // ---- epilogue: lane holds column n = .. + i32 and rows (r&3) + 8(r>>2) + 4·half of each 32x32 sub-tile.
-  // Row bookkeeping (validity, scatter map, FPN parent row) is resolved for all 16 rows first and every read the epilogue
-  // needs (map entries, residual, top-down term) is issued unconditionally from clamped addresses, so the loads of all
-  // rows are in flight together instead of forming 16 dependent map -> residual -> store chains.
+  // ---- epilogue.  The accumulators hold a 32x32 sub-tile with the column on the lane and 16 rows in the registers, which
+  // would mean 16 single-dword stores (and residual loads) per lane per sub-tile: at K = 96..384 that store / load issue
+  // costs as much as the whole k-loop.  Each wave therefore transposes its sub-tile through a private 4 KB slice of the
+  // (now idle) staging LDS -- 16 conflict-free ds_write_b32, 4 ds_read_b128 -- so that a lane owns 4 consecutive columns
+  // of 4 rows: every global access of the epilogue (bias, residual, FPN top-down term, the store) is one 16-byte
+  // instruction covering 8 full 128-byte row segments per wave.
   const float* ri = p.cos_ri ? p.cos_ri + (long long)z * p.sRi : nullptr;
   const float* rj = p.cos_rj ? p.cos_rj + (long long)z * p.sRj : nullptr;
+  __syncthreads();                              // every wave is done reading the k-loop's LDS tiles
+  float* tb = lds + wave * (32 * 32);           // this wave's transpose tile [row][col]
+  const int rr = lane >> 3, c4 = (lane & 7) * 4;
 #pragma unroll
-  for (int mi = 0; mi < MT; ++mi)
+  for (int mi = 0; mi < MT; ++mi) {
+    // bookkeeping of the 4 rows this lane stores (rows 8j + rr of the sub-tile): validity, scatter map, FPN parent /
+    // deconv base row; all map reads are issued together from clamped addresses
+    int mrow[4], drow[4], aux[4];
+    unsigned okmask = 0;
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {   // 4 rows (registers 4rg..4rg+3) at a time: stays inside the main loop's register budget
-      int mrow[4], drow[4], aux[4];    // aux: FPN parent row or deconv base row (mutually exclusive epilogues)
-      unsigned okmask = 0;
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + (wm * MT + mi) * 32 + 8 * j + rr;
+      if (m < Meff) okmask |= 1u << j;
+      mrow[j] = m < Meff ? m : Meff - 1;
+      drow[j] = mrow[j];
+      aux[j] = 0;
+    }
+    if (p.store == ST_ROWMAP) {
+      int d[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int m = m0 + (wm * MT + mi) * 32 + q + 8 * rg + 4 * half;
-        if (m < Meff) okmask |= 1u << q;
-        mrow[q] = m < Meff ? m : Meff - 1;
-        drow[q] = mrow[q];
-        aux[q] = 0;
+      for (int j = 0; j < 4; ++j) d[j] = p.row_map[mrow[j]];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { if (d[j] < 0) okmask &= ~(1u << j); drow[j] = d[j] >= 0 ? d[j] : 0; }
+    }
+    if (p.up) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int hw = p.upH * p.upW;
+        const int b = mrow[j] / hw, q = mrow[j] - b * hw;
+        const int y = q / p.upW, x = q - y * p.upW;
+        aux[j] = (b * (p.upH >> 1) + (y >> 1)) * (p.upW >> 1) + (x >> 1);
       }
-      if (p.store == ST_ROWMAP) {
-        int d[4];
+    } else if (p.store == ST_DECONV2) {
+      // rows m = (d, y, x) on a cH x cW grid; columns n = (kh*2+kw)*ldc + oc -> out[(d, 2y+kh, 2x+kw), oc]
 #pragma unroll
-        for (int q = 0; q < 4; ++q) d[q] = p.row_map[mrow[q]];
+      for (int j = 0; j < 4; ++j) {
+        const int hw = p.cH * p.cW;
+        const int b = mrow[j] / hw, q = mrow[j] - b * hw;
+        const int y = q / p.cW, x = q - y * p.cW;
+        aux[j] = (b * (2 * p.cH) + 2 * y) * (2 * p.cW) + 2 * x;
+      }
+    }
+    float riv[4];
+    if (p.act == ACT_COS) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { if (d[q] < 0) okmask &= ~(1u << q); drow[q] = d[q] >= 0 ? d[q] : 0; }
+      for (int j = 0; j < 4; ++j) riv[j] = ri[mrow[j]];
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tb[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + i32] = acc[mi][t][r];
+      const int n = n0 + (wn * NT + t) * 32 + c4;            // this lane's 4 columns
+      v4f addv[4], upv[4];
+      if (p.res) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) addv[j] = *reinterpret_cast<const v4f*>(p.res + (long long)drow[j] * p.ldr + n);
       }
       if (p.up) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int hw = p.upH * p.upW;
-          const int b = mrow[q] / hw, rr = mrow[q] - b * hw;
-          const int y = rr / p.upW, x = rr - y * p.upW;
-          aux[q] = (b * (p.upH >> 1) + (y >> 1)) * (p.upW >> 1) + (x >> 1);
-        }
-      } else if (p.store == ST_DECONV2) {
-        // rows m = (d, y, x) on a cH x cW grid; columns n = (kh*2+kw)*ldc + oc -> out[(d, 2y+kh, 2x+kw), oc]
+        for (int j = 0; j < 4; ++j) upv[j] = *reinterpret_cast<const v4f*>(p.up + (long long)aux[j] * p.N + n);
+      }
+      v4f bias4 = {0.f, 0.f, 0.f, 0.f}, rj4 = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bias4 = *reinterpret_cast<const v4f*>(p.bias + n);
+      if (rj) rj4 = *reinterpret_cast<const v4f*>(rj + n);
+      // (DS operations of one wave execute in order: the reads below see the writes above, and the next sub-tile's writes
+      // cannot overtake these reads)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int hw = p.cH * p.cW;
-          const int b = mrow[q] / hw, rr = mrow[q] - b * hw;
-          const int y = rr / p.cW, x = rr - y * p.cW;
-          aux[q] = (b * (2 * p.cH) + 2 * y) * (2 * p.cW) + 2 * x;
+      for (int j = 0; j < 4; ++j) {
+        v4f v = *reinterpret_cast<const v4f*>(tb + (8 * j + rr) * 32 + c4) * p.alpha;
+        if (p.bias) v += bias4;
+        if (p.act == ACT_RELU) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        } else if (p.act == ACT_GELU) {
+          v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+        } else if (p.act == ACT_COS) {
+          v.x = fmaxf(v.x * riv[j] * rj4.x - p.cos_tau, 0.f) + p.cos_tau;
+          v.y = fmaxf(v.y * riv[j] * rj4.y - p.cos_tau, 0.f) + p.cos_tau;
+          v.z = fmaxf(v.z * riv[j] * rj4.z - p.cos_tau, 0.f) + p.cos_tau;
+          v.w = fmaxf(v.w * riv[j] * rj4.w - p.cos_tau, 0.f) + p.cos_tau;
+        }
+        if (p.up) v += upv[j];
+        if (p.res) v += addv[j];
+        if (!((okmask >> j) & 1u)) continue;
+        if (p.store == ST_DECONV2) {
+          const int tap = n / p.ldc, oc = n - tap * p.ldc;     // ldc % 4 == 0: the 4 columns share one tap
+          *reinterpret_cast<v4f*>(C + ((long long)aux[j] + (tap >> 1) * (2 * p.cW) + (tap & 1)) * p.ldc + oc) = v;
+        } else {
+          *reinterpret_cast<v4f*>(C + (long long)drow[j] * p.ldc + n) = v;
         }
       }
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int n = n0 + (wn * NT + t) * 32 + i32;
-        float addv[4];                 // residual + top-down term, fetched for the 4 rows before any is consumed
-#pragma unroll
-        for (int q = 0; q < 4; ++q) addv[q] = 0.f;
-        if (p.res) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) addv[q] = p.res[(long long)drow[q] * p.ldr + n];
-        }
-        float upv[4];
-        if (p.up) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) upv[q] = p.up[(long long)aux[q] * p.N + n];
-        }
-        const float bias = p.bias ? p.bias[n] : 0.f;
-        const float rjn = rj ? rj[n] : 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float v = acc[mi][t][rg * 4 + q] * p.alpha;
-          if (p.bias) v += bias;
-          if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
-          else if (p.act == ACT_GELU) v = gelu_erf(v);
-          else if (p.act == ACT_COS) v = fmaxf(v * ri[mrow[q]] * rjn - p.cos_tau, 0.f) + p.cos_tau;
-          if (p.up) v += upv[q];
-          if (p.res) v += addv[q];
-          if (!((okmask >> q) & 1u)) continue;
-          if (p.store == ST_DECONV2) {
-            const int tap = n / p.ldc, oc = n - tap * p.ldc;
-            C[((long long)aux[q] + (tap >> 1) * (2 * p.cW) + (tap & 1)) * p.ldc + oc] = v;
-          } else {
-            C[(long long)drow[q] * p.ldc + n] = v;
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);   // keep the live ranges of one column tile from overlapping the next
-      }
+      __builtin_amdgcn_sched_barrier(0);   // keep the live ranges of one column tile from overlapping the next
     }
+  }
 }
 
 // geometry ids: 0 = 128x(32·nt) tiles, one 32-row strip per wave (nt = 1,2,3,4); 1 = 128x128 tiles, 64x64 per wave (2x2);
