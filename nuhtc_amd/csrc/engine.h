@@ -45,7 +45,7 @@ struct nuhtc_engine {
   // workspace
   float *img, *tokA, *tokB, *xw, *qkv, *att, *hid;
   float *c[4], *lat[4], *x[4], *rpn[4], *semg[4];
-  float *tmpA, *tmpB, *sem_feat, *sem_pred;
+  float *tmpA, *tmpB, *sem_feat, *sem_pred, *x0sem;
   // proposals / roi path
   int roi_cap = 0;          // rois per tile: max_cc_proposals + rpn_max_per_img
   int cand_cap = 0;         // rpn candidates per tile (<= 4 * nms_pre), det candidates per tile

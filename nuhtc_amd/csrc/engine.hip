@@ -338,7 +338,7 @@ int nuhtc_finalize(nuhtc_engine* e) {
       return rc;
   }
   if ((rc = ws(e, &e->tmpA, nullptr, {B, g0.H, g0.W, 64}, 0)) || (rc = ws(e, &e->tmpB, nullptr, {B, g0.H, g0.W, 64}, 0)) ||
-      (rc = ws(e, &e->sem_feat, "sem_feat", {B, g0.H, g0.W, 64}, 0)) || (rc = ws(e, &e->sem_pred, "sem_pred", {B, g0.H, g0.W}, 0)))
+      (rc = ws(e, &e->sem_feat, "sem_feat", {B, g0.H, g0.W, 64}, 0)) || (rc = ws(e, &e->x0sem, "x0sem", {B, g0.H, g0.W, 64}, 0)) || (rc = ws(e, &e->sem_pred, "sem_pred", {B, g0.H, g0.W}, 0)))
     return rc;
   if ((rc = alloc_roi_workspace(e))) return rc;
   HIP_CHECK(e, hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
@@ -462,6 +462,9 @@ int run_neck_heads(nuhtc_engine* e, int B, hipStream_t s) {
   {
     GemmParams p = gp(a, e->sem_ew, e->sem_eb, e->sem_feat, B * g0.H * g0.W, 64, 64);
     p.act = ACT_RELU;
+    RUN(launch_gemm(p, s));
+    // x0 + sem for the 7x7 RoI features (roi.hip: one interpolation serves the FPN level-0 and the semantic term)
+    p.C = e->x0sem; p.res = e->x[0]; p.ldr = 64;
     RUN(launch_gemm(p, s));
   }
   return 0;

@@ -8,6 +8,7 @@ struct RoiFeatParams {
   const float *x0, *x1; // FPN levels 0,1 NHWC (stride 4, 8)
   const float *G2, *G3; // attention-pool tables [B][H*W][64] of levels 2,3
   const float* sem;     // semantic embedding NHWC at stride 4
+  const float* x0sem;   // x0 + sem (P = 7 LDS path: both are sampled at the same points, so one interpolation serves both)
   int H0, W0, H1, W1, H2, W2, H3, W3;
   float* out;           // [R][P*P][64]
   int* fb_count;        // P=7: RoIs that do not fit the LDS tiles (processed by the generic kernel)

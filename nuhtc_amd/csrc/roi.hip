@@ -241,6 +241,32 @@ __device__ __forceinline__ float bin_lds(const float* tile, int fw, const AxisEn
   return acc / (float)(G * G);
 }
 
+// Two channels per lane (packed fp32: v_pk_mul_f32 / v_pk_add_f32, ds_read_b64): the same operations in the same order as
+// bin_lds() on each channel, at half the instruction count -- the RoI kernels are bound by VALU issue (address and weight
+// arithmetic per tap), not by LDS or memory.  `cp2` = 2 * (lane & 31) is the lane's first channel; the two half-waves
+// work on different bins, so the axis tables are read per lane.
+typedef float v2f __attribute__((ext_vector_type(2)));
+template <int G>
+__device__ __forceinline__ v2f bin_lds2(const float* tile, const AxisEnt* tx, const AxisEnt* ty, int pw, int ph) {
+  v2f acc = {0.f, 0.f};
+#pragma unroll
+  for (int iy = 0; iy < G; ++iy) {
+    const AxisEnt ey = ty[ph * G + iy];
+#pragma unroll
+    for (int ix = 0; ix < G; ++ix) {
+      const AxisEnt ex = tx[pw * G + ix];
+      const float w1 = ey.h * ex.h, w2 = ey.h * ex.l, w3 = ey.l * ex.h, w4 = ey.l * ex.l;
+      // (the tables of this path hold element offsets: x entries * 64, y entries * fw * 64; `tile` already includes cp2)
+      const v2f v1 = *reinterpret_cast<const v2f*>(tile + (ey.lo + ex.lo));
+      const v2f v2 = *reinterpret_cast<const v2f*>(tile + (ey.lo + ex.hi));
+      const v2f v3 = *reinterpret_cast<const v2f*>(tile + (ey.hi + ex.lo));
+      const v2f v4 = *reinterpret_cast<const v2f*>(tile + (ey.hi + ex.hi));
+      acc += w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+    }
+  }
+  return acc / (float)(G * G);
+}
+
 // RoIs whose footprint does not fit the LDS tiles (large proposals): taken from the fallback list written by
 // roi_feat7_lds_kernel; one wave per output bin (block = bin row, 7 waves) so that a 300-px RoI with its 6x6 adaptive
 // semantic sampling grid does not serialise ~30k dependent loads in a single wave.
@@ -282,9 +308,8 @@ __global__ __launch_bounds__(448) void roi_feat7_generic_kernel(RoiFeatParams p)
 
 __global__ __launch_bounds__(256) void roi_feat7_lds_kernel(RoiFeatParams p) {
   __shared__ float tile0[TP0 * TP0 * 64];
-  __shared__ float tileS[TP0 * TP0 * 64];
   __shared__ float tile1[TP1 * TP1 * 64];
-  __shared__ AxisEnt tab[3][2][16];
+  __shared__ AxisEnt tab[2][2][16];
   // one RoI per block: the 4 waves share the staged footprints and split the 49 bins, so each SIMD holds 4 waves of
   // 4 different RoIs (LDS allows 4 blocks per CU) and the LDS / global latencies of one hide behind the others
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -292,7 +317,8 @@ __global__ __launch_bounds__(256) void roi_feat7_lds_kernel(RoiFeatParams p) {
   if (r >= *p.r_dev) return;
   const float* roi = p.rois + (long long)r * 5;
   const int b = (int)roi[0];
-  float gsum[2];
+  const int cp2 = 2 * (lane & 31), hw = lane >> 5;     // bin loop: 2 channels per lane, one bin per half-wave
+  v2f gsum[2];
 #pragma unroll
   for (int l = 0; l < 2; ++l) {
     const int Hl = l ? p.H3 : p.H2, Wl = l ? p.W3 : p.W2;
@@ -301,43 +327,45 @@ __global__ __launch_bounds__(256) void roi_feat7_lds_kernel(RoiFeatParams p) {
     cx = fminf(fmaxf(cx, 0.f), (float)(Wl - 1));
     cy = fminf(fmaxf(cy, 0.f), (float)(Hl - 1));
     const float* G = l ? p.G3 : p.G2;
-    gsum[l] = G[(((long long)b * Hl + (int)cy) * Wl + (int)cx) * 64 + lane];
+    gsum[l] = *reinterpret_cast<const v2f*>(G + (((long long)b * Hl + (int)cy) * Wl + (int)cx) * 64 + cp2);
   }
   float* out = p.out + (long long)r * 49 * 64;
   const RoiGeom g0 = roi_geom(roi, 0.25f, 7, 2), g1 = roi_geom(roi, 0.125f, 7, 2), gs = roi_geom(roi, 0.25f, 14, 0);
   const bool sem_g1 = gs.gw == 1 && gs.gh == 1;
   const LevelPlan l0 = plan_level(g0, 7, 2, p.H0, p.W0, TP0, lane);   // every wave computes the same plan
   const LevelPlan l1 = plan_level(g1, 7, 2, p.H1, p.W1, TP1, lane);
-  const LevelPlan ls = plan_level(gs, 14, 1, p.H0, p.W0, TP0, lane);
-  if (!(sem_g1 && l0.ok && l1.ok && ls.ok)) {   // block-uniform
+  // With one sample per bin the 14x14 semantic grid (fused_semantic_head -> adaptive_avg_pool2d to 7x7,
+  // htc_roi_head_cus.py) samples exactly the 2x2-per-bin points of the 7x7 grid on the same stride-4 geometry, and both
+  // results are averaged over the same 4 samples: by linearity one interpolation of the pre-added map x0 + sem serves both.
+  if (!(sem_g1 && l0.ok && l1.ok)) {   // block-uniform
     if (threadIdx.x == 0) p.fb_list[atomicAdd(p.fb_count, 1)] = r;
     return;
   }
   if (wave == 0) {
     const int ax = lane >> 5, idx = lane & 31;
-    if (idx < 14) { tab[0][ax][idx] = l0.ent; tab[1][ax][idx] = l1.ent; tab[2][ax][idx] = ls.ent; }
+    if (idx < 14) {      // pixel indices -> element offsets inside the staged tile (x: * 64 channels, y: * row pitch)
+      AxisEnt e0 = l0.ent, e1 = l1.ent;
+      const int m0 = ax ? l0.fw * 64 : 64, m1 = ax ? l1.fw * 64 : 64;
+      e0.lo *= m0; e0.hi *= m0; e1.lo *= m1; e1.hi *= m1;
+      tab[0][ax][idx] = e0; tab[1][ax][idx] = e1;
+    }
   }
-  stage_tile(p.x0, p.H0, p.W0, b, l0, tile0, lane, wave);
+  stage_tile(p.x0sem, p.H0, p.W0, b, l0, tile0, lane, wave);
   stage_tile(p.x1, p.H1, p.W1, b, l1, tile1, lane, wave);
-  stage_tile(p.sem, p.H0, p.W0, b, ls, tileS, lane, wave);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
-  for (int bin = wave; bin < 49; bin += 4) {
-    const int ph = bin / 7, pw = bin - ph * 7;
-    float v = 0.f;
-    v += l0.empty ? 0.f : bin_lds<2>(tile0, l0.fw, tab[0][0], tab[0][1], pw, ph, lane);
-    v += l1.empty ? 0.f : bin_lds<2>(tile1, l1.fw, tab[1][0], tab[1][1], pw, ph, lane);
+  const v2f zero2 = {0.f, 0.f};
+  for (int pair = wave; pair < 25; pair += 4) {         // bins 2*pair and 2*pair + 1 (bin 49 does not exist)
+    const int bin = 2 * pair + hw;
+    const bool live = bin < 49;
+    const int bc = live ? bin : 48;
+    const int ph = bc / 7, pw = bc - ph * 7;
+    v2f v = zero2;
+    v += l0.empty ? zero2 : bin_lds2<2>(tile0 + cp2, tab[0][0], tab[0][1], pw, ph);
+    v += l1.empty ? zero2 : bin_lds2<2>(tile1 + cp2, tab[1][0], tab[1][1], pw, ph);
     v += gsum[0];
     v += gsum[1];
-    float sv = 0.f;
-    if (!ls.empty) {
-      const float a = bin_lds<1>(tileS, ls.fw, tab[2][0], tab[2][1], 2 * pw, 2 * ph, lane);
-      const float bq = bin_lds<1>(tileS, ls.fw, tab[2][0], tab[2][1], 2 * pw + 1, 2 * ph, lane);
-      const float c = bin_lds<1>(tileS, ls.fw, tab[2][0], tab[2][1], 2 * pw, 2 * ph + 1, lane);
-      const float d = bin_lds<1>(tileS, ls.fw, tab[2][0], tab[2][1], 2 * pw + 1, 2 * ph + 1, lane);
-      sv = (((a + bq) + c) + d) * 0.25f;
-    }
-    out[bin * 64 + lane] = v + sv;
+    if (live) *reinterpret_cast<v2f*>(out + bin * 64 + cp2) = v;
   }
 }
 

@@ -286,7 +286,7 @@ int run_roi_path(nuhtc_engine* e, int B, const float* rois_fixed, int n_rois, in
   const int Rcap = fixed ? B * n_rois : B * e->roi_cap;
 
   RoiFeatParams fp;
-  fp.rois = w->rois; fp.r_dev = w->roi_total; fp.x0 = e->x[0]; fp.x1 = e->x[1]; fp.G2 = w->G2; fp.G3 = w->G3; fp.sem = e->sem_feat;
+  fp.rois = w->rois; fp.r_dev = w->roi_total; fp.x0 = e->x[0]; fp.x1 = e->x[1]; fp.G2 = w->G2; fp.G3 = w->G3; fp.sem = e->sem_feat; fp.x0sem = e->x0sem;
   fp.H0 = e->st[0].H; fp.W0 = e->st[0].W; fp.H1 = e->st[1].H; fp.W1 = e->st[1].W; fp.H2 = e->st[2].H; fp.W2 = e->st[2].W; fp.H3 = e->st[3].H; fp.W3 = e->st[3].W;
   fp.out = w->feats; fp.fb_count = w->fb_count; fp.fb_list = w->fb_list;
   // ---- 3-stage cascade (htc_roi_head_cus.py:2255-2280)
