@@ -13,6 +13,7 @@ struct RoiFeatParams {
   float* out;           // [R][P*P][64]
   int* fb_count;        // P=7: RoIs that do not fit the LDS tiles (processed by the generic kernel)
   int* fb_list;         // [R]
+  unsigned char* fb_flag; // [R] 1 = handled by the generic path
 };
 
 struct BboxTailParams {

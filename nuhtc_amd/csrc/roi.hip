@@ -268,12 +268,18 @@ __device__ __forceinline__ v2f bin_lds2(const float* tile, const AxisEnt* tx, co
 }
 
 // RoIs whose footprint does not fit the LDS tiles (large proposals): taken from the fallback list written by
-// roi_feat7_lds_kernel; one wave per output bin (block = bin row, 7 waves) so that a 300-px RoI with its 6x6 adaptive
-// semantic sampling grid does not serialise ~30k dependent loads in a single wave.
-__global__ __launch_bounds__(448) void roi_feat7_generic_kernel(RoiFeatParams p) {
-  const int lane = threadIdx.x & 63, pw = threadIdx.x >> 6, ph = blockIdx.y;
+// roi_classify_kernel; one wave per output bin so that a 300-px RoI with its 6x6 adaptive semantic sampling grid does not
+// serialise ~30k dependent loads in a single wave.  These blocks are the FIRST FB_SLOTS * FB_QUADS blocks of the one
+// roi_feat7 launch: the few long chains of big RoIs start at once and run beside the stream of LDS-path blocks.
+#define FB_SLOTS 1024   // fallback RoIs processed concurrently (more are looped over)
+#define FB_QUADS 13     // 49 bins / 4 waves
+__device__ __forceinline__ void roi_feat7_generic_block(const RoiFeatParams& p, int slot, int quad) {
+  const int lane = threadIdx.x & 63;
+  const int bin = quad * 4 + (threadIdx.x >> 6);
+  if (bin >= 49) return;
+  const int ph = bin / 7, pw = bin - ph * 7;
   const int nfb = *p.fb_count;
-  for (int i = blockIdx.x; i < nfb; i += gridDim.x) {
+  for (int i = slot; i < nfb; i += FB_SLOTS) {
     const int r = p.fb_list[i];
     const float* roi = p.rois + (long long)r * 5;
     const int b = (int)roi[0];
@@ -306,6 +312,23 @@ __global__ __launch_bounds__(448) void roi_feat7_generic_kernel(RoiFeatParams p)
   }
 }
 
+// pre-pass: which RoIs fit the LDS tiles (one wave per RoI, the same plan code as the main kernel)
+__global__ __launch_bounds__(256) void roi_classify_kernel(RoiFeatParams p) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= *p.r_dev) return;
+  const float* roi = p.rois + (long long)r * 5;
+  const RoiGeom g0 = roi_geom(roi, 0.25f, 7, 2), g1 = roi_geom(roi, 0.125f, 7, 2), gs = roi_geom(roi, 0.25f, 14, 0);
+  const bool sem_g1 = gs.gw == 1 && gs.gh == 1;
+  const LevelPlan l0 = plan_level(g0, 7, 2, p.H0, p.W0, TP0, lane);
+  const LevelPlan l1 = plan_level(g1, 7, 2, p.H1, p.W1, TP1, lane);
+  const bool fb = !(sem_g1 && l0.ok && l1.ok);
+  if (lane == 0) {
+    p.fb_flag[r] = fb ? 1 : 0;
+    if (fb) p.fb_list[atomicAdd(p.fb_count, 1)] = r;
+  }
+}
+
 __global__ __launch_bounds__(256) void roi_feat7_lds_kernel(RoiFeatParams p) {
   __shared__ float tile0[TP0 * TP0 * 64];
   __shared__ float tile1[TP1 * TP1 * 64];
@@ -313,8 +336,12 @@ __global__ __launch_bounds__(256) void roi_feat7_lds_kernel(RoiFeatParams p) {
   // one RoI per block: the 4 waves share the staged footprints and split the 49 bins, so each SIMD holds 4 waves of
   // 4 different RoIs (LDS allows 4 blocks per CU) and the LDS / global latencies of one hide behind the others
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r = blockIdx.x;
-  if (r >= *p.r_dev) return;
+  if (blockIdx.x < FB_SLOTS * FB_QUADS) {               // fallback blocks first (see roi_feat7_generic_block)
+    roi_feat7_generic_block(p, blockIdx.x / FB_QUADS, blockIdx.x % FB_QUADS);
+    return;
+  }
+  const int r = blockIdx.x - FB_SLOTS * FB_QUADS;
+  if (r >= *p.r_dev || p.fb_flag[r]) return;
   const float* roi = p.rois + (long long)r * 5;
   const int b = (int)roi[0];
   const int cp2 = 2 * (lane & 31), hw = lane >> 5;     // bin loop: 2 channels per lane, one bin per half-wave
@@ -337,10 +364,7 @@ __global__ __launch_bounds__(256) void roi_feat7_lds_kernel(RoiFeatParams p) {
   // With one sample per bin the 14x14 semantic grid (fused_semantic_head -> adaptive_avg_pool2d to 7x7,
   // htc_roi_head_cus.py) samples exactly the 2x2-per-bin points of the 7x7 grid on the same stride-4 geometry, and both
   // results are averaged over the same 4 samples: by linearity one interpolation of the pre-added map x0 + sem serves both.
-  if (!(sem_g1 && l0.ok && l1.ok)) {   // block-uniform
-    if (threadIdx.x == 0) p.fb_list[atomicAdd(p.fb_count, 1)] = r;
-    return;
-  }
+  if (!(sem_g1 && l0.ok && l1.ok)) return;   // (cannot happen: roi_classify_kernel ran the same test)
   if (wave == 0) {
     const int ax = lane >> 5, idx = lane & 31;
     if (idx < 14) {      // pixel indices -> element offsets inside the staged tile (x: * 64 channels, y: * row pitch)
@@ -409,9 +433,8 @@ int launch_roi_feat(const RoiFeatParams& p, int P, int r_cap, hipStream_t s) {
   if (r_cap <= 0) return 0;
   if (P == 7) {
     if (hipMemsetAsync(p.fb_count, 0, sizeof(int), s) != hipSuccess) return NUHTC_E_HIP;
-    hipLaunchKernelGGL(roi_feat7_lds_kernel, dim3(r_cap), dim3(256), 0, s, p);
-    ProfScope ps2("roi_feat7_generic", 0, 0, s);
-    hipLaunchKernelGGL(roi_feat7_generic_kernel, dim3(r_cap < 1024 ? r_cap : 1024, 7), dim3(448), 0, s, p);
+    hipLaunchKernelGGL(roi_classify_kernel, dim3(cdiv(r_cap, 4)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(roi_feat7_lds_kernel, dim3(FB_SLOTS * FB_QUADS + r_cap), dim3(256), 0, s, p);
   } else if (P == 14) hipLaunchKernelGGL(roi_feat14_kernel, dim3(r_cap), dim3(256), 0, s, p);
   else return NUHTC_E_INVALID;
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;

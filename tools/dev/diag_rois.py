@@ -1,5 +1,5 @@
 import numpy as np, torch, sys
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 from nuhtc_amd import hip, synth, weights
 from nuhtc_amd.engine import Engine
 sd = weights.bench_state_dict()
