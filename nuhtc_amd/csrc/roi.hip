@@ -401,9 +401,10 @@ __global__ __launch_bounds__(256) void roi_feat14_kernel(RoiFeatParams p) {
   const float* roi = p.rois + (long long)r * 5;
   const int b = (int)roi[0];
   const RoiGeom g0 = roi_geom(roi, 0.25f, 14, 0), g1 = roi_geom(roi, 0.125f, 14, 0);
-  const float* f0 = p.x0 + (long long)b * p.H0 * p.W0 * 64;
+  // the semantic term is sampled on the same grid as FPN level 0 (same scale, bins and adaptive sample count): the
+  // pre-added map x0 + sem gives both in one interpolation
+  const float* f0 = p.x0sem + (long long)b * p.H0 * p.W0 * 64;
   const float* f1 = p.x1 + (long long)b * p.H1 * p.W1 * 64;
-  const float* fs = p.sem + (long long)b * p.H0 * p.W0 * 64;
   float gsum[2];
 #pragma unroll
   for (int l = 0; l < 2; ++l) {
@@ -423,8 +424,7 @@ __global__ __launch_bounds__(256) void roi_feat14_kernel(RoiFeatParams p) {
     v += roi_bin(f1, p.H1, p.W1, g1.x1, g1.y1, g1.bw, g1.bh, g1.gw, g1.gh, pw, ph, lane);
     v += gsum[0];
     v += gsum[1];
-    const float sv = roi_bin(fs, p.H0, p.W0, g0.x1, g0.y1, g0.bw, g0.bh, g0.gw, g0.gh, pw, ph, lane);
-    out[bin * 64 + lane] = v + sv;
+    out[bin * 64 + lane] = v;
   }
 }
 
