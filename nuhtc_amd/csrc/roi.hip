@@ -709,7 +709,6 @@ __global__ __launch_bounds__(256) void tile_post_kernel(TilePostParams p) {
   __shared__ int sarea[2048];
   __shared__ short sidx[2048];
   __shared__ unsigned char sup[2048];
-  __shared__ int s_inter;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int n = p.det_counts[b];
   const int K = p.max_keep;
@@ -758,6 +757,10 @@ __global__ __launch_bounds__(256) void tile_post_kernel(TilePostParams p) {
   int m = 0;   // candidates that passed the filter sort first
   while (m < n && sidx[m] >= 0) ++m;
   const unsigned* masks = p.masks + (long long)b * K * words;
+  // Greedy suppression: for a kept candidate a, the pairs (a, c > a) are independent of each other, so every wave takes its
+  // own c (popcount of the AND over the rows of a's hull, 64 lanes wide) and there is one barrier per kept candidate
+  // instead of three per overlapping pair.
+  const int lane = tid & 63, wave = tid >> 6;
   for (int a = 0; a < m; ++a) {
     if (sup[a]) continue;   // uniform: sup[] only changes between barriers
     const int i = sidx[a];
@@ -765,27 +768,23 @@ __global__ __launch_bounds__(256) void tile_post_kernel(TilePostParams p) {
     const float4 di = sbox[a];
     const unsigned* mi = masks + (long long)i * words;
     const int y0 = max((int)floorf(di.y) - 1, 0), y1 = min((int)ceilf(di.w) + 1, p.H);   // rows of mask i's hull
-    for (int c = a + 1; c < m; ++c) {
+    for (int c = a + 1 + wave; c < m; c += 4) {
       if (sup[c]) continue;
       const float4 dj = sbox[c];
       // masks live inside their box hulls: no overlap of hulls -> IoU 0
       const bool ov = fminf(di.z, dj.z) + 2.f > fmaxf(di.x, dj.x) - 2.f && fminf(di.w, dj.w) + 2.f > fmaxf(di.y, dj.y) - 2.f;
       if (!ov) continue;
-      if (tid == 0) s_inter = 0;
-      __syncthreads();
       const unsigned* mj = masks + (long long)sidx[c] * words;
       int cnt = 0;
-      for (int wv = y0 * wpr + tid; wv < y1 * wpr; wv += 256) cnt += __popc(mi[wv] & mj[wv]);
-      cnt = (int)wsum64((float)cnt);
-      if ((tid & 63) == 0 && cnt) atomicAdd(&s_inter, cnt);
-      __syncthreads();
-      if (tid == 0) {
-        const int inter = s_inter;
-        const int uni = sarea[a] + sarea[c] - inter;
-        if (uni > 0 && (double)inter / (double)uni > p.thr) sup[c] = 1;
+      for (int wv = y0 * wpr + lane; wv < y1 * wpr; wv += 64) cnt += __popc(mi[wv] & mj[wv]);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+      if (lane == 0) {
+        const int uni = sarea[a] + sarea[c] - cnt;
+        if (uni > 0 && (double)cnt / (double)uni > p.thr) sup[c] = 1;
       }
-      __syncthreads();
     }
+    __syncthreads();
   }
 }
 
