@@ -49,7 +49,9 @@ def main():
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-tiles', type=int, default=8)
-    ap.add_argument('--in-flight', type=int, default=3, help='also report the streaming rate with this many batches in flight (0/1 = skip)')
+    ap.add_argument('--in-flight', type=int, default=0,
+                    help='also report the streaming rate with this many batches in flight (e.g. 3; off by default so that the '
+                         'rocprofv3 summary of the default command sees every kernel without co-running kernels)')
     ap.add_argument('--gemm-shapes', action='store_true', help='add the per-shape GEMM timings to the JSON line')
     args = ap.parse_args()
 
