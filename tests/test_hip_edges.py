@@ -154,3 +154,43 @@ def test_full_size_properties_b16(hip_device):
             inter = fk @ fj
             iou = inter / (fk.sum(1) + fj.sum() - inter)
             assert iou.max() > 0.05
+
+
+def test_pipeline_matches_single_engine(hip_device):
+    """Three batches in flight on their own engines / streams give bit-identical outputs to one engine run batch by batch,
+    in submission order, including a ragged last batch."""
+    import torch
+    from nuhtc_amd import hip, synth, weights
+    from nuhtc_amd.engine import Engine
+    from nuhtc_amd.pipeline import EnginePipeline
+    sd = weights.bench_state_dict(2, obj_bias=0.0)
+    tiles = synth.nuclei_tiles(14, 64, start=11)
+    eng = Engine(sd, device=0, max_batch=4, tile=(64, 64))
+    ref = []
+    for i in range(0, 14, 4):
+        B = eng.infer_async(eng.to_device(tiles[i:i + 4]), hip.CH_SWAP)
+        eng.check()
+        ref.append([t[:B].clone().cpu() for t in (eng.counts, eng.boxes, eng.labels, eng.masks, eng.keep)])
+    pipe = EnginePipeline(sd, device=0, depth=3, max_batch=4, tile=(64, 64))
+    got = []
+
+    def collect():
+        e, B, stream, tag = pipe.collect()
+        with torch.cuda.stream(stream):
+            got.append((tag, [t[:B].clone().cpu() for t in (e.counts, e.boxes, e.labels, e.masks, e.keep)]))
+    for i in range(0, 14, 4):
+        if pipe.full():
+            collect()
+        pipe.submit(tiles[i:i + 4], hip.CH_SWAP, tag=i)
+    while pipe.pending:
+        collect()
+    assert [t for t, _ in got] == [0, 4, 8, 12]
+    for (_, g), r in zip(got, ref):
+        counts = r[0].numpy()
+        for x, y in zip(g, r):
+            for b in range(len(counts)):
+                n = counts[b]
+                assert torch.equal(x[b][:n] if x[b].dim() else x[b], y[b][:n] if y[b].dim() else y[b])
+    with pytest.raises(RuntimeError):
+        for _ in range(4):
+            pipe.submit(tiles[:4], hip.CH_SWAP)
