@@ -39,6 +39,11 @@ struct NmsParams {
   float* out_dets;        // [B][max_keep][5]
   int* out_src;           // [B][max_keep]
   int* out_counts;        // [B]
+  // level-wise variant (launch_nms_levels): groups never suppress each other, so each runs its own NMS
+  int* seg_start;         // [B][n_groups] first row of the group's 64-aligned segment in the sorted arrays
+  int* seg_n;             // [B][n_groups] candidates of the group
+  int* sorted_pos;        // [B][cap] group-major position of the sorted row (tie-break of the reference's global sort)
+  unsigned long long* keepbits;   // [B][cap/64] survivors per 64-row chunk
 };
 
 struct CcParams {
@@ -57,5 +62,8 @@ struct CcParams {
 
 int launch_rpn_select(const RpnLevels& lv, const RpnSelParams& p, int B, hipStream_t s);
 int launch_nms(const NmsParams& p, int B, hipStream_t s);
+// same result as launch_nms for ids == null (id = group): per-group NMS in parallel, then the survivors merged by score;
+// needs cap >= sum(round_up(group counts, 64)) and n_groups * max_keep <= 8192
+int launch_nms_levels(const NmsParams& p, int B, hipStream_t s);
 int nms_set_attributes();
 int launch_cc_proposals(const CcParams& p, int B, hipStream_t s);

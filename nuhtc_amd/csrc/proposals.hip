@@ -341,9 +341,212 @@ int launch_nms(const NmsParams& p, int B, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
 }
 
+// ---- level-wise variant ------------------------------------------------------------------------------------------------
+// mmcv batched_nms offsets the boxes of each group (RPN level) so that groups never overlap: the greedy pass over the
+// global score order is exactly one independent greedy pass per group, followed by a merge of the survivors by score.
+// Running the groups separately cuts the pair tests from n^2/2 to sum(n_g^2)/2 (3.5x for 3000+3000+3000+768), runs the
+// serial reduce chains of the groups side by side, and keeps the result identical (same offset boxes, same IoU test, same
+// (score desc, position asc) order, same first max_keep survivors).
+__global__ __launch_bounds__(1024) void nms_prepare_levels_kernel(NmsParams p) {
+  extern __shared__ u64 keys[];      // pow2 >= slot entries: one group per block
+  __shared__ float red[16];
+  __shared__ float s_max;
+  const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+  int goff[NMS_MAX_GROUPS + 1], astart[NMS_MAX_GROUPS + 1];
+  goff[0] = astart[0] = 0;
+  for (int h = 0; h < p.n_groups; ++h) {
+    const int c = p.group_count[b * p.n_groups + h];
+    goff[h + 1] = goff[h] + c;
+    astart[h + 1] = astart[h] + ((c + 63) & ~63);
+  }
+  const int n = goff[p.n_groups];
+  // max coordinate over the candidate boxes of ALL groups (boxes.max() of mmcv batched_nms)
+  float mx = -3.0e38f;
+  for (int i = tid; i < n; i += 1024) {
+    int h = 0;
+    while (i >= goff[h + 1]) ++h;
+    const float* bx = p.boxes + ((long long)(b * p.n_groups + h) * p.slot + (i - goff[h])) * 4;
+    mx = fmaxf(mx, fmaxf(fmaxf(bx[0], bx[1]), fmaxf(bx[2], bx[3])));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  if (tid == 0) { float m = red[0]; for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]); s_max = m; }
+  __syncthreads();
+  const float off = (float)g * (s_max + 1.0f);
+  // this group's candidates by (score desc, position asc)
+  const int cnt = goff[g + 1] - goff[g];
+  const int npad = next_pow2(cnt < 2 ? 2 : cnt);
+  const long long base = (long long)(b * p.n_groups + g) * p.slot;
+  for (int i = tid; i < npad; i += 1024) keys[i] = i < cnt ? (((u64)(~f2key(p.scores[base + i]))) << 32 | (unsigned)i) : ~0ull;
+  __syncthreads();
+  bitonic_sort_lds(keys, npad);
+  for (int r = tid; r < cnt; r += 1024) {
+    const int i = (int)(keys[r] & 0xFFFFFFFFu);
+    const long long src = base + i;
+    const float* bx = p.boxes + src * 4;
+    const long long a = (long long)b * p.cap + astart[g] + r;
+    float* sb = p.sorted_boxes + a * 4;
+    sb[0] = bx[0] + off; sb[1] = bx[1] + off; sb[2] = bx[2] + off; sb[3] = bx[3] + off;
+    p.sorted_src[a] = (int)src;
+    p.sorted_pos[a] = goff[g] + i;      // group-major position: the tie-break of the reference's single global sort
+  }
+  if (tid == 0) {
+    p.seg_start[b * p.n_groups + g] = astart[g];
+    p.seg_n[b * p.n_groups + g] = cnt;
+    if (g == 0) p.n_total[b] = astart[p.n_groups];
+  }
+}
+
+__device__ __forceinline__ int seg_of_chunk(const NmsParams& p, int b, int chunk, int& start, int& cnt) {
+  for (int g = 0; g < p.n_groups; ++g) {
+    start = p.seg_start[b * p.n_groups + g];
+    cnt = p.seg_n[b * p.n_groups + g];
+    if (chunk * 64 >= start && chunk * 64 < start + ((cnt + 63) & ~63)) return g;
+  }
+  return -1;
+}
+
+__global__ __launch_bounds__(64) void nms_mask_levels_kernel(NmsParams p) {
+  const int b = blockIdx.z, rb = blockIdx.y, cb = blockIdx.x;
+  if (cb < rb || cb * 64 >= p.n_total[b]) return;
+  int rs, rn, cs, cn;
+  const int gr = seg_of_chunk(p, b, rb, rs, rn);
+  if (gr < 0) return;
+  const int gc = seg_of_chunk(p, b, cb, cs, cn);
+  if (gc != gr) return;                                   // different levels never overlap
+  const int end = rs + rn;                                // one past the group's last row
+  __shared__ float4 cbx[64];
+  const float4* sb = reinterpret_cast<const float4*>(p.sorted_boxes) + (long long)b * p.cap;
+  const int t = threadIdx.x;
+  const int ncol = min(end - cb * 64, 64);
+  if (ncol <= 0) return;
+  if (t < ncol) cbx[t] = sb[cb * 64 + t];
+  __syncthreads();
+  const int row = rb * 64 + t;
+  if (row >= end) return;
+  const float4 a = sb[row];
+  const float sa = (a.z - a.x) * (a.w - a.y);
+  u64 bits = 0;
+  const int start = (rb == cb) ? t + 1 : 0;
+  for (int j = start; j < ncol; ++j) {
+    const float4 c = cbx[j];
+    float left = fmaxf(a.x, c.x), right = fminf(a.z, c.z);
+    float top = fmaxf(a.y, c.y), bottom = fminf(a.w, c.w);
+    float wdt = fmaxf(right - left, 0.f), hgt = fmaxf(bottom - top, 0.f);
+    float inter = wdt * hgt;
+    float sb2 = (c.z - c.x) * (c.w - c.y);
+    float ovr = inter / (sa + sb2 - inter);
+    if (ovr > p.iou_thr) bits |= 1ull << j;
+  }
+  p.mask[((long long)b * p.cap + row) * (p.cap / 64) + cb] = bits;
+}
+
+// greedy reduce of one group (block = (image, group)): survivors of each 64-row chunk -> keepbits; at most max_keep per group
+__global__ __launch_bounds__(256) void nms_reduce_levels_kernel(NmsParams p) {
+  __shared__ u64 removed[NMS_MAX_CAP / 64 + 4];
+  __shared__ unsigned char klist[64];
+  __shared__ int s_nk;
+  __shared__ int s_kept;
+  const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  const int start = p.seg_start[b * p.n_groups + g], n = p.seg_n[b * p.n_groups + g];
+  const int nw = p.cap / 64;
+  const int c0 = start / 64, nchunks = (n + 63) / 64;
+  for (int i = tid; i < nchunks; i += 256) removed[i] = 0;
+  if (tid == 0) s_kept = 0;
+  __syncthreads();
+  const u64* mask = p.mask + (long long)b * p.cap * nw;
+  u64* kb_out = p.keepbits + (long long)b * nw;
+  for (int c = 0; c < nchunks; ++c) {
+    const int kept_before = s_kept;
+    if (kept_before >= p.max_keep) {                      // the rest of the group cannot reach the output
+      for (int i = c + tid; i < nchunks; i += 256) kb_out[c0 + i] = 0;
+      break;
+    }
+    if (tid < 64) {
+      const int row = start + c * 64 + lane;
+      u64 d = c * 64 + lane < n ? mask[(long long)row * nw + c0 + c] : 0ull;
+      u64 cur = removed[c];
+      u64 keep = 0;
+      int room = p.max_keep - kept_before;
+      const int rows_here = min(64, n - c * 64);
+      for (int i = 0; i < rows_here; ++i) {
+        u64 di = __shfl(d, i);
+        if (!((cur >> i) & 1ull) && room > 0) { keep |= 1ull << i; cur |= di; --room; }
+      }
+      if ((keep >> lane) & 1ull) klist[__popcll(keep & ((1ull << lane) - 1ull))] = (unsigned char)lane;
+      if (lane == 0) { s_nk = __popcll(keep); kb_out[c0 + c] = keep; s_kept = kept_before + __popcll(keep); }
+    }
+    __syncthreads();
+    // OR the mask rows of the kept boxes into the removed set of the later chunks: one (kept row, word) pair per thread
+    // step, so all loads of a chunk are independent and in flight together
+    const int nk = s_nk, nwr = nchunks - (c + 1);
+    for (int idx = tid; idx < nk * nwr; idx += 256) {
+      const int i = klist[idx / nwr], wv = c + 1 + idx % nwr;
+      const u64 v = mask[(long long)(start + c * 64 + i) * nw + c0 + wv];
+      if (v) atomicOr(&removed[wv], v);
+    }
+    __syncthreads();
+  }
+}
+
+// survivors of all groups -> global (score desc, position asc) order -> first max_keep rows of the output
+__global__ __launch_bounds__(1024) void nms_select_kernel(NmsParams p) {
+  __shared__ u64 keys[8192];
+  __shared__ int s_n;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) s_n = 0;
+  __syncthreads();
+  const int nw = p.cap / 64;
+  const int nchunks = p.n_total[b] / 64;
+  const u64* kb = p.keepbits + (long long)b * nw;
+  for (int idx = tid; idx < nchunks * 64; idx += 1024) {
+    if ((kb[idx >> 6] >> (idx & 63)) & 1ull) {
+      const long long a = (long long)b * p.cap + idx;
+      const float sc = p.scores[p.sorted_src[a]];
+      const int k = atomicAdd(&s_n, 1);
+      if (k < 8192) keys[k] = ((u64)(~f2key(sc)) << 32) | ((u64)(unsigned)p.sorted_pos[a] << 16) | (unsigned)idx;
+    }
+  }
+  __syncthreads();
+  const int n = min(s_n, 8192);
+  const int npad = next_pow2(n < 2 ? 2 : n);
+  for (int i = n + tid; i < npad; i += 1024) keys[i] = ~0ull;
+  __syncthreads();
+  bitonic_sort_lds(keys, npad);
+  const int nout = min(n, p.max_keep);
+  for (int k = tid; k < nout; k += 1024) {
+    const int idx = (int)(keys[k] & 0xFFFFu);
+    const int src = p.sorted_src[(long long)b * p.cap + idx];
+    const float* bx = p.boxes + (long long)src * 4;
+    float* o = p.out_dets + ((long long)b * p.max_keep + k) * 5;
+    o[0] = bx[0]; o[1] = bx[1]; o[2] = bx[2]; o[3] = bx[3]; o[4] = p.scores[src];
+    p.out_src[(long long)b * p.max_keep + k] = src;
+  }
+  if (tid == 0) p.out_counts[b] = nout;
+}
+
+int launch_nms_levels(const NmsParams& p, int B, hipStream_t s) {
+  ProfScope ps("nms", 0, 0, s);
+  if (p.cap % 64 || p.cap > NMS_MAX_CAP + 64 * NMS_MAX_GROUPS || p.cap >= 65536 || p.n_groups > NMS_MAX_GROUPS || p.ids ||
+      p.n_groups * p.max_keep > 8192 || !p.seg_start || !p.seg_n || !p.sorted_pos || !p.keepbits)
+    return NUHTC_E_INVALID;
+  int slot_pow2 = 2;
+  while (slot_pow2 < p.slot) slot_pow2 <<= 1;
+  size_t lds = (size_t)slot_pow2 * sizeof(u64);
+  hipLaunchKernelGGL(nms_prepare_levels_kernel, dim3(B, p.n_groups), dim3(1024), lds, s, p);
+  hipLaunchKernelGGL(nms_mask_levels_kernel, dim3(p.cap / 64, p.cap / 64, B), dim3(64), 0, s, p);
+  hipLaunchKernelGGL(nms_reduce_levels_kernel, dim3(B, p.n_groups), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(nms_select_kernel, dim3(B), dim3(1024), 0, s, p);
+  return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
+}
+
 int nms_set_attributes() {
   // the sort image can exceed the default 64 KiB dynamic-LDS limit (gfx950 has 160 KiB per workgroup)
   hipError_t e = hipFuncSetAttribute((const void*)nms_prepare_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NMS_MAX_CAP * 8);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)nms_prepare_levels_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NMS_MAX_CAP * 8);
   return e == hipSuccess ? 0 : NUHTC_E_HIP;
 }
 

@@ -13,7 +13,8 @@ struct RoiWs {
   float *cand_boxes, *cand_scores;
   int* cand_count;
   float *nms_sboxes;
-  int *nms_src, *nms_ntotal;
+  int *nms_src, *nms_ntotal, *nms_seg_start, *nms_seg_n, *nms_pos;
+  unsigned long long* nms_keepbits;
   unsigned long long* nms_mask;
   float* rpn_dets;
   int *rpn_src, *rpn_counts;
@@ -157,16 +158,18 @@ int alloc_roi_workspace(nuhtc_engine* e) {
   w->rpn_slot = c.rpn_nms_pre;
   int maxc = 0;
   for (int l = 0; l < 4; ++l) maxc += std::min(c.rpn_nms_pre, e->st[l].H * e->st[l].W * 3);
-  w->rpn_cap = round_up(std::max(maxc, 64), 64);
+  w->rpn_cap = round_up(std::max(maxc, 64), 64) + 64 * 3;   // each level's segment of the sorted list is 64-aligned (launch_nms_levels)
   w->rpn_pow2 = pow2_ge(maxc);
   e->roi_cap = c.max_cc_proposals + c.rpn_max_per_img;
   w->det_cap = round_up(e->roi_cap * c.num_classes, 64);
   w->det_pow2 = pow2_ge(e->roi_cap * c.num_classes);
-  if (w->rpn_cap > NMS_MAX_CAP || w->det_cap > NMS_MAX_CAP) { e->err = "candidate capacity exceeds NMS_MAX_CAP (reduce rpn_nms_pre / max_cc_proposals)"; return NUHTC_E_INVALID; }
+  if (maxc > NMS_MAX_CAP || w->det_cap > NMS_MAX_CAP) { e->err = "candidate capacity exceeds NMS_MAX_CAP (reduce rpn_nms_pre / max_cc_proposals)"; return NUHTC_E_INVALID; }
   const int nmscap = std::max(w->rpn_cap, w->det_cap);
   if ((rc = wsa(e, &w->cand_boxes, "rpn_cand_boxes", {B, 4, w->rpn_slot, 4}, 0)) || (rc = wsa(e, &w->cand_scores, "rpn_cand_scores", {B, 4, w->rpn_slot}, 0)) ||
       (rc = wsa(e, &w->cand_count, "rpn_cand_count", {B, 4}, 1)) || (rc = wsa(e, &w->nms_sboxes, nullptr, {B, nmscap, 4}, 0)) ||
       (rc = wsa(e, &w->nms_src, nullptr, {B, nmscap}, 1)) || (rc = wsa(e, &w->nms_ntotal, nullptr, {B}, 1)) ||
+      (rc = wsa(e, &w->nms_seg_start, nullptr, {B, 4}, 1)) || (rc = wsa(e, &w->nms_seg_n, nullptr, {B, 4}, 1)) ||
+      (rc = wsa(e, &w->nms_pos, nullptr, {B, nmscap}, 1)) || (rc = wsa(e, &w->nms_keepbits, nullptr, {B, nmscap / 64}, 3)) ||
       (rc = wsa(e, &w->nms_mask, nullptr, {B, nmscap, nmscap / 64}, 3)) || (rc = wsa(e, &w->rpn_dets, "rpn_props", {B, c.rpn_max_per_img, 5}, 0)) ||
       (rc = wsa(e, &w->rpn_src, nullptr, {B, c.rpn_max_per_img}, 1)) || (rc = wsa(e, &w->rpn_counts, "rpn_counts", {B}, 1)))
     return rc;
@@ -249,7 +252,8 @@ int run_roi_path(nuhtc_engine* e, int B, const float* rois_fixed, int n_rois, in
     np.cap = w->rpn_cap; np.cap_pow2 = w->rpn_pow2; np.iou_thr = c.rpn_nms_iou; np.max_keep = c.rpn_max_per_img;
     np.sorted_boxes = w->nms_sboxes; np.sorted_src = w->nms_src; np.n_total = w->nms_ntotal; np.mask = w->nms_mask;
     np.out_dets = w->rpn_dets; np.out_src = w->rpn_src; np.out_counts = w->rpn_counts;
-    RUN(launch_nms(np, B, s2));
+    np.seg_start = w->nms_seg_start; np.seg_n = w->nms_seg_n; np.sorted_pos = w->nms_pos; np.keepbits = w->nms_keepbits;
+    RUN(launch_nms_levels(np, B, s2));
     if (hipEventRecord(e->ev_side, s2) != hipSuccess) FAIL(e, NUHTC_E_HIP, "hipEventRecord failed");
     // ---- connected-component ("watershed") proposals (htc_roi_head_cus.py:283-342)
     if (c.watershed_proposal && c.max_cc_proposals > 0) {
