@@ -7,6 +7,7 @@
 // htc_mask_head.py:22-39), the bbox-head FCs (convfc_bbox_head.py:158-196) and the attention-pool similarity /
 // aggregation products (nuhtc/models/roi_extractors_cus.py:228-235).
 #include <cstdlib>
+#include <mutex>
 
 #include "common.h"
 
@@ -369,13 +370,12 @@ __global__ __launch_bounds__(256, (MT * NT <= 3 ? 4 : 3)) void gemm_kernel(GemmP
   }
 }
 
-// geometry ids: 0 = 128x(32·nt) tiles, one 32-row strip per wave (nt = 1,2,3,4); 1 = 128x128 tiles, 64x64 per wave (2x2);
-//               2 = 256x64 tiles, 64x64 per wave (4x1 waves)
+// block tile 128 x (32·NT): one 32-row strip per wave, NT accumulators (128x128 with 64x64 per wave, 256x64 and BK = 32 were
+// measured slower on every shape of the path and are not instantiated)
 template <int MT, int NT, int WM, int WN>
-static void launch_cfg(const GemmParams& q, int bk, int mtiles, hipStream_t s) {
+static void launch_cfg(const GemmParams& q, int mtiles, hipStream_t s) {
   constexpr int BN = 32 * NT * WN;
   dim3 grid(cdiv(mtiles, 8) * 8 * (q.N / BN), 1, q.batch > 0 ? q.batch : 1);
-  (void)bk;
   if (q.amode == A_CONV3) hipLaunchKernelGGL((gemm_kernel<MT, NT, WM, WN, 16, A_CONV3>), grid, dim3(256), 0, s, q);
   else hipLaunchKernelGGL((gemm_kernel<MT, NT, WM, WN, 16, A_PLAIN>), grid, dim3(256), 0, s, q);
 }
@@ -383,6 +383,8 @@ static void launch_cfg(const GemmParams& q, int bk, int mtiles, hipStream_t s) {
 // per-device page of zeros for the out-of-image taps of the implicit-GEMM convolutions (allocated on first use)
 static const float* zero_page() {
   static std::map<int, float*> pages;
+  static std::mutex mu;              // engines of different host threads may convolve for the first time together
+  std::lock_guard<std::mutex> lock(mu);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   auto it = pages.find(dev);
@@ -393,14 +395,8 @@ static const float* zero_page() {
   return z;
 }
 
-static int g_bk = 0, g_geo128 = 0, g_geo256 = 0;
 int launch_gemm(const GemmParams& p, hipStream_t s) {
   if (p.M <= 0) return 0;
-  if (g_bk == 0) {
-    const char* e = getenv("NUHTC_GEMM_BK"); g_bk = e ? atoi(e) : 16; if (g_bk != 32) g_bk = 16;
-    e = getenv("NUHTC_GEMM_G128"); g_geo128 = e ? atoi(e) : 0;
-    e = getenv("NUHTC_GEMM_G256"); g_geo256 = e ? atoi(e) : 0;
-  }
   if (p.K % 32 != 0 || p.N % 32 != 0) return NUHTC_E_INVALID;
   if (p.amode == A_CONV3 && (p.cC % 32 != 0 || p.K != 9 * p.cC)) return NUHTC_E_INVALID;
   int nt = (p.N % 96 == 0) ? 3 : (p.N % 128 == 0) ? 4 : (p.N % 64 == 0) ? 2 : 1;
@@ -416,9 +412,6 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
       if (nt > 2 && p.N % 64 == 0) nt = 2; else nt = 1;
     }
   }
-  int geo = 0;
-  if (g_geo128 && p.N % 128 == 0) geo = 1;
-  if (g_geo256 && p.N == 64) geo = 2;
   GemmParams q = p;
   if (q.alpha == 0.f) q.alpha = 1.f;
   if (q.amode == A_CONV3 && !q.zeros) {
@@ -437,11 +430,9 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
   }
   // algorithmic work of the launch (device-side row counts are not known here: the capacity M is an upper bound)
   ProfScope ps(tag, 2.0 * p.M * p.N * p.K * nb, 4.0 * nb * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N), s);
-  if (geo == 1) launch_cfg<2, 2, 2, 2>(q, g_bk, cdiv(p.M, 128), s);
-  else if (geo == 2) launch_cfg<2, 2, 4, 1>(q, g_bk, cdiv(p.M, 256), s);
-  else if (nt == 1) launch_cfg<1, 1, 4, 1>(q, g_bk, cdiv(p.M, 128), s);
-  else if (nt == 2) launch_cfg<1, 2, 4, 1>(q, g_bk, cdiv(p.M, 128), s);
-  else if (nt == 3) launch_cfg<1, 3, 4, 1>(q, g_bk, cdiv(p.M, 128), s);
-  else launch_cfg<1, 4, 4, 1>(q, g_bk, cdiv(p.M, 128), s);
+  if (nt == 1) launch_cfg<1, 1, 4, 1>(q, cdiv(p.M, 128), s);
+  else if (nt == 2) launch_cfg<1, 2, 4, 1>(q, cdiv(p.M, 128), s);
+  else if (nt == 3) launch_cfg<1, 3, 4, 1>(q, cdiv(p.M, 128), s);
+  else launch_cfg<1, 4, 4, 1>(q, cdiv(p.M, 128), s);
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
 }
