@@ -378,15 +378,46 @@ __global__ __launch_bounds__(256) void window_attn_mfma_kernel(const float* __re
 #pragma unroll
     for (int q = 0; q < 4; ++q) kf[tj][q] = kp[q];
   }
+  // V operand of the second product, shared by both query tiles: lane (d = l32, half), one dword per MFMA step
+  float vv[2][16];
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = min(tj * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, WS2 - 1);
+      vv[tj][r] = base[j * ld + 2 * C + l32];
+    }
 #pragma unroll 1
   for (int ti = 0; ti < 2; ++ti) {
     const int i = min(ti * 32 + l32, WS2 - 1);
+    // everything this query tile reads is requested before the first MFMA: the Q fragments, and the bias (+ shift mask)
+    // terms, which do not depend on the scores and arrive behind the 32 MFMAs of the first product
     v4f qf[4];
     {
       const v4f* qp = reinterpret_cast<const v4f*>(base + i * ld + half * 16);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) qf[q] = qp[q] * scale;
+      for (int q = 0; q < 4; ++q) qf[q] = qp[q];
     }
+    float bb[2][16];
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int jc = min(tj * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, WS2 - 1);
+        bb[tj][r] = bT[jc * WS2 + i];
+      }
+    if (mk) {
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int jc = min(tj * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, WS2 - 1);
+          bb[tj][r] += mk[jc * WS2 + i];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) qf[q] *= scale;
     f32x16 st[2];
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj) {
@@ -407,9 +438,7 @@ __global__ __launch_bounds__(256) void window_attn_mfma_kernel(const float* __re
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int j = tj * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int jc = min(j, WS2 - 1);
-        float v = st[tj][r] + bT[jc * WS2 + i];
-        if (mk) v += mk[jc * WS2 + i];
+        float v = st[tj][r] + bb[tj][r];
         v = j < WS2 ? v : -3.0e38f;
         st[tj][r] = v;
         mx = fmaxf(mx, v);
@@ -433,11 +462,7 @@ __global__ __launch_bounds__(256) void window_attn_mfma_kernel(const float* __re
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int j = min(tj * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, WS2 - 1);
-        const float vv = base[j * ld + 2 * C + l32];
-        ot = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, st[tj][r] * rsum, ot, 0, 0, 0);
-      }
+      for (int r = 0; r < 16; ++r) ot = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[tj][r], st[tj][r] * rsum, ot, 0, 0, 0);
     long long orow = (long long)win * WS2 + ti * 32 + l32;
     if (ti * 32 + l32 < WS2 && out_map) orow = out_map[orow];
     if (ti * 32 + l32 < WS2 && orow >= 0) {
