@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const float* __restric
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void window_attn_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ biasT,
+__global__ __launch_bounds__(256, 3) void window_attn_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ biasT,
                                                                const float* __restrict__ mask, const int* __restrict__ out_map, float* __restrict__ out, int nPairs,
                                                                int nWperImg, int C, int nH) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
