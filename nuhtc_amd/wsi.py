@@ -44,10 +44,15 @@ def _unpack(eng, B, i0, coords, P, rec):
         bits = np.unpackbits(words.view(np.uint8).reshape(len(order), P, P // 8), axis=-1, bitorder='little').astype(bool)
         ox, oy = int(coords[i0 + b][0]), int(coords[i0 + b][1])
         for k, j in enumerate(order):
-            ys, xs = np.nonzero(bits[k])
-            if len(ys) == 0:
+            # a pasted mask lives inside the integer hull of its box (fcn_mask_head.py:344-412): search only there
+            bx = boxes[b, j]
+            hy0, hy1 = max(int(np.floor(bx[1])) - 1, 0), min(int(np.ceil(bx[3])) + 1, P)
+            hx0, hx1 = max(int(np.floor(bx[0])) - 1, 0), min(int(np.ceil(bx[2])) + 1, P)
+            crop = bits[k, hy0:hy1, hx0:hx1]
+            rows, cols = np.flatnonzero(crop.any(1)), np.flatnonzero(crop.any(0))
+            if len(rows) == 0:
                 continue
-            y0, y1, x0, x1 = ys.min(), ys.max() + 1, xs.min(), xs.max() + 1
+            y0, y1, x0, x1 = hy0 + rows[0], hy0 + rows[-1] + 1, hx0 + cols[0], hx0 + cols[-1] + 1
             rec['tile'].append(i0 + b)
             rec['box'].append(boxes[b, j, :4].astype(np.float64) + np.array([ox, oy, ox, oy]))
             rec['score'].append(float(boxes[b, j, 4]))
