@@ -395,14 +395,64 @@ __global__ __launch_bounds__(256) void roi_feat7_lds_kernel(RoiFeatParams p) {
 
 // 14x14 mask features: 4 waves per RoI, bins interleaved across the waves
 __global__ __launch_bounds__(256) void roi_feat14_kernel(RoiFeatParams p) {
+  __shared__ float tile0[TP0 * TP0 * 64];
+  __shared__ float tile1[TP1 * TP1 * 64];
+  __shared__ AxisEnt tab[2][2][16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = blockIdx.x;
   if (r >= *p.r_dev) return;
   const float* roi = p.rois + (long long)r * 5;
   const int b = (int)roi[0];
   const RoiGeom g0 = roi_geom(roi, 0.25f, 14, 0), g1 = roi_geom(roi, 0.125f, 14, 0);
-  // the semantic term is sampled on the same grid as FPN level 0 (same scale, bins and adaptive sample count): the
-  // pre-added map x0 + sem gives both in one interpolation
+  float* out = p.out + (long long)r * 196 * 64;
+  // Nuclei-sized detections take one sample per bin (adaptive grid ceil(size / 14) = 1) and touch at most 8x8 / 5x5
+  // pixels of the stride-4 / stride-8 maps: same LDS-staged, packed-fp32 evaluation as the 7x7 kernel.  The semantic term
+  // is sampled on the same grid as FPN level 0 (same scale, bins and sample count): x0 + sem gives both in one pass.
+  const bool one = g0.gw == 1 && g0.gh == 1 && g1.gw == 1 && g1.gh == 1;
+  const LevelPlan l0 = plan_level(g0, 14, 1, p.H0, p.W0, TP0, lane);
+  const LevelPlan l1 = plan_level(g1, 14, 1, p.H1, p.W1, TP1, lane);
+  const int part = blockIdx.y;     // big detections are split over gridDim.y blocks (a few of them set the launch's duration)
+  if (one && l0.ok && l1.ok) {   // block-uniform
+    if (part != 0) return;
+    const int cp2 = 2 * (lane & 31), hw = lane >> 5;
+    v2f gsum[2];
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      const int Hl = l ? p.H3 : p.H2, Wl = l ? p.W3 : p.W2;
+      const float st = l ? 32.f : 16.f;
+      float cx = floorf((roi[1] + roi[3]) / (2.0f * st)), cy = floorf((roi[2] + roi[4]) / (2.0f * st));
+      cx = fminf(fmaxf(cx, 0.f), (float)(Wl - 1));
+      cy = fminf(fmaxf(cy, 0.f), (float)(Hl - 1));
+      const float* G = l ? p.G3 : p.G2;
+      gsum[l] = *reinterpret_cast<const v2f*>(G + (((long long)b * Hl + (int)cy) * Wl + (int)cx) * 64 + cp2);
+    }
+    if (wave == 0) {
+      const int ax = lane >> 5, idx = lane & 31;
+      if (idx < 14) {
+        AxisEnt e0 = l0.ent, e1 = l1.ent;
+        const int m0 = ax ? l0.fw * 64 : 64, m1 = ax ? l1.fw * 64 : 64;
+        e0.lo *= m0; e0.hi *= m0; e1.lo *= m1; e1.hi *= m1;
+        tab[0][ax][idx] = e0; tab[1][ax][idx] = e1;
+      }
+    }
+    stage_tile(p.x0sem, p.H0, p.W0, b, l0, tile0, lane, wave);
+    stage_tile(p.x1, p.H1, p.W1, b, l1, tile1, lane, wave);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    const v2f zero2 = {0.f, 0.f};
+    for (int pair = wave; pair < 98; pair += 4) {
+      const int bin = 2 * pair + hw;
+      const int ph = bin / 14, pw = bin - ph * 14;
+      v2f v = zero2;
+      v += l0.empty ? zero2 : bin_lds2<1>(tile0 + cp2, tab[0][0], tab[0][1], pw, ph);
+      v += l1.empty ? zero2 : bin_lds2<1>(tile1 + cp2, tab[1][0], tab[1][1], pw, ph);
+      v += gsum[0];
+      v += gsum[1];
+      *reinterpret_cast<v2f*>(out + bin * 64 + cp2) = v;
+    }
+    return;
+  }
+  // larger detections: gathers straight from the maps
   const float* f0 = p.x0sem + (long long)b * p.H0 * p.W0 * 64;
   const float* f1 = p.x1 + (long long)b * p.H1 * p.W1 * 64;
   float gsum[2];
@@ -416,8 +466,7 @@ __global__ __launch_bounds__(256) void roi_feat14_kernel(RoiFeatParams p) {
     const float* G = l ? p.G3 : p.G2;
     gsum[l] = G[(((long long)b * Hl + (int)cy) * Wl + (int)cx) * 64 + lane];
   }
-  float* out = p.out + (long long)r * 196 * 64;
-  for (int bin = wave; bin < 196; bin += 4) {
+  for (int bin = part * 4 + wave; bin < 196; bin += 4 * gridDim.y) {
     const int ph = bin / 14, pw = bin - ph * 14;
     float v = 0.f;
     v += roi_bin(f0, p.H0, p.W0, g0.x1, g0.y1, g0.bw, g0.bh, g0.gw, g0.gh, pw, ph, lane);
@@ -435,7 +484,7 @@ int launch_roi_feat(const RoiFeatParams& p, int P, int r_cap, hipStream_t s) {
     if (hipMemsetAsync(p.fb_count, 0, sizeof(int), s) != hipSuccess) return NUHTC_E_HIP;
     hipLaunchKernelGGL(roi_classify_kernel, dim3(cdiv(r_cap, 4)), dim3(256), 0, s, p);
     hipLaunchKernelGGL(roi_feat7_lds_kernel, dim3(FB_SLOTS * FB_QUADS + r_cap), dim3(256), 0, s, p);
-  } else if (P == 14) hipLaunchKernelGGL(roi_feat14_kernel, dim3(r_cap), dim3(256), 0, s, p);
+  } else if (P == 14) hipLaunchKernelGGL(roi_feat14_kernel, dim3(r_cap, 7), dim3(256), 0, s, p);
   else return NUHTC_E_INVALID;
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
 }
