@@ -268,47 +268,52 @@ __device__ __forceinline__ v2f bin_lds2(const float* tile, const AxisEnt* tx, co
 }
 
 // RoIs whose footprint does not fit the LDS tiles (large proposals): taken from the fallback list written by
-// roi_classify_kernel; one wave per output bin so that a 300-px RoI with its 6x6 adaptive semantic sampling grid does not
-// serialise ~30k dependent loads in a single wave.  These blocks are the FIRST FB_SLOTS * FB_QUADS blocks of the one
-// roi_feat7 launch: the few long chains of big RoIs start at once and run beside the stream of LDS-path blocks.
-#define FB_SLOTS 1024   // fallback RoIs processed concurrently (more are looped over)
-#define FB_QUADS 13     // 49 bins / 4 waves
-__device__ __forceinline__ void roi_feat7_generic_block(const RoiFeatParams& p, int slot, int quad) {
-  const int lane = threadIdx.x & 63;
-  const int bin = quad * 4 + (threadIdx.x >> 6);
-  if (bin >= 49) return;
+// roi_classify_kernel.  A 300-px RoI samples its semantic term on a 6x6 grid per 14x14 bin, ~600 dependent gathers per
+// output bin, so one block works on ONE output bin: wave 0 takes the two FPN terms and the first semantic sub-bin, waves
+// 1-3 the other three sub-bins, and the four partial results are combined in the reference's order through LDS.  These
+// blocks are the FIRST FB_SLOTS * 49 blocks of the one roi_feat7 launch: the few long chains of big RoIs start at once and
+// run beside the stream of LDS-path blocks.
+#define FB_SLOTS 256    // fallback RoIs processed concurrently (more are looped over)
+__device__ __forceinline__ void roi_feat7_generic_block(const RoiFeatParams& p, int slot, int bin, float (*part)[64]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ph = bin / 7, pw = bin - ph * 7;
   const int nfb = *p.fb_count;
   for (int i = slot; i < nfb; i += FB_SLOTS) {
     const int r = p.fb_list[i];
     const float* roi = p.rois + (long long)r * 5;
     const int b = (int)roi[0];
-    float gs2[2];
-#pragma unroll
-    for (int l = 0; l < 2; ++l) {
-      const int Hl = l ? p.H3 : p.H2, Wl = l ? p.W3 : p.W2;
-      const float st = l ? 32.f : 16.f;
-      float cx = floorf((roi[1] + roi[3]) / (2.0f * st)), cy = floorf((roi[2] + roi[4]) / (2.0f * st));
-      cx = fminf(fmaxf(cx, 0.f), (float)(Wl - 1));
-      cy = fminf(fmaxf(cy, 0.f), (float)(Hl - 1));
-      const float* G = l ? p.G3 : p.G2;
-      gs2[l] = G[(((long long)b * Hl + (int)cy) * Wl + (int)cx) * 64 + lane];
-    }
-    float* out = p.out + (long long)r * 49 * 64;
-    const RoiGeom g0 = roi_geom(roi, 0.25f, 7, 2), g1 = roi_geom(roi, 0.125f, 7, 2), gs = roi_geom(roi, 0.25f, 14, 0);
-    const float* f0 = p.x0 + (long long)b * p.H0 * p.W0 * 64;
-    const float* f1 = p.x1 + (long long)b * p.H1 * p.W1 * 64;
+    const RoiGeom gs = roi_geom(roi, 0.25f, 14, 0);
     const float* fs = p.sem + (long long)b * p.H0 * p.W0 * 64;
+    // semantic sub-bin of this wave: (2pw + (wave & 1), 2ph + (wave >> 1))
+    const float sub = roi_bin(fs, p.H0, p.W0, gs.x1, gs.y1, gs.bw, gs.bh, gs.gw, gs.gh, 2 * pw + (wave & 1), 2 * ph + (wave >> 1), lane);
+    if (wave) part[wave - 1][lane] = sub;
     float v = 0.f;
-    v += roi_bin(f0, p.H0, p.W0, g0.x1, g0.y1, g0.bw, g0.bh, g0.gw, g0.gh, pw, ph, lane);
-    v += roi_bin(f1, p.H1, p.W1, g1.x1, g1.y1, g1.bw, g1.bh, g1.gw, g1.gh, pw, ph, lane);
-    v += gs2[0];
-    v += gs2[1];
-    const float a = roi_bin(fs, p.H0, p.W0, gs.x1, gs.y1, gs.bw, gs.bh, gs.gw, gs.gh, 2 * pw, 2 * ph, lane);
-    const float bq = roi_bin(fs, p.H0, p.W0, gs.x1, gs.y1, gs.bw, gs.bh, gs.gw, gs.gh, 2 * pw + 1, 2 * ph, lane);
-    const float c = roi_bin(fs, p.H0, p.W0, gs.x1, gs.y1, gs.bw, gs.bh, gs.gw, gs.gh, 2 * pw, 2 * ph + 1, lane);
-    const float d = roi_bin(fs, p.H0, p.W0, gs.x1, gs.y1, gs.bw, gs.bh, gs.gw, gs.gh, 2 * pw + 1, 2 * ph + 1, lane);
-    out[(ph * 7 + pw) * 64 + lane] = v + (((a + bq) + c) + d) * 0.25f;
+    if (wave == 0) {
+      float gs2[2];
+#pragma unroll
+      for (int l = 0; l < 2; ++l) {
+        const int Hl = l ? p.H3 : p.H2, Wl = l ? p.W3 : p.W2;
+        const float st = l ? 32.f : 16.f;
+        float cx = floorf((roi[1] + roi[3]) / (2.0f * st)), cy = floorf((roi[2] + roi[4]) / (2.0f * st));
+        cx = fminf(fmaxf(cx, 0.f), (float)(Wl - 1));
+        cy = fminf(fmaxf(cy, 0.f), (float)(Hl - 1));
+        const float* G = l ? p.G3 : p.G2;
+        gs2[l] = G[(((long long)b * Hl + (int)cy) * Wl + (int)cx) * 64 + lane];
+      }
+      const RoiGeom g0 = roi_geom(roi, 0.25f, 7, 2), g1 = roi_geom(roi, 0.125f, 7, 2);
+      const float* f0 = p.x0 + (long long)b * p.H0 * p.W0 * 64;
+      const float* f1 = p.x1 + (long long)b * p.H1 * p.W1 * 64;
+      v += roi_bin(f0, p.H0, p.W0, g0.x1, g0.y1, g0.bw, g0.bh, g0.gw, g0.gh, pw, ph, lane);
+      v += roi_bin(f1, p.H1, p.W1, g1.x1, g1.y1, g1.bw, g1.bh, g1.gw, g1.gh, pw, ph, lane);
+      v += gs2[0];
+      v += gs2[1];
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const float a = sub, bq = part[0][lane], c = part[1][lane], d = part[2][lane];
+      p.out[(long long)r * 49 * 64 + (ph * 7 + pw) * 64 + lane] = v + (((a + bq) + c) + d) * 0.25f;
+    }
+    __syncthreads();
   }
 }
 
@@ -336,11 +341,11 @@ __global__ __launch_bounds__(256) void roi_feat7_lds_kernel(RoiFeatParams p) {
   // one RoI per block: the 4 waves share the staged footprints and split the 49 bins, so each SIMD holds 4 waves of
   // 4 different RoIs (LDS allows 4 blocks per CU) and the LDS / global latencies of one hide behind the others
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (blockIdx.x < FB_SLOTS * FB_QUADS) {               // fallback blocks first (see roi_feat7_generic_block)
-    roi_feat7_generic_block(p, blockIdx.x / FB_QUADS, blockIdx.x % FB_QUADS);
+  if (blockIdx.x < FB_SLOTS * 49) {                     // fallback blocks first (see roi_feat7_generic_block)
+    roi_feat7_generic_block(p, blockIdx.x / 49, blockIdx.x % 49, reinterpret_cast<float(*)[64]>(tile1));
     return;
   }
-  const int r = blockIdx.x - FB_SLOTS * FB_QUADS;
+  const int r = blockIdx.x - FB_SLOTS * 49;
   if (r >= *p.r_dev || p.fb_flag[r]) return;
   const float* roi = p.rois + (long long)r * 5;
   const int b = (int)roi[0];
@@ -483,7 +488,7 @@ int launch_roi_feat(const RoiFeatParams& p, int P, int r_cap, hipStream_t s) {
   if (P == 7) {
     if (hipMemsetAsync(p.fb_count, 0, sizeof(int), s) != hipSuccess) return NUHTC_E_HIP;
     hipLaunchKernelGGL(roi_classify_kernel, dim3(cdiv(r_cap, 4)), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(roi_feat7_lds_kernel, dim3(FB_SLOTS * FB_QUADS + r_cap), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(roi_feat7_lds_kernel, dim3(FB_SLOTS * 49 + r_cap), dim3(256), 0, s, p);
   } else if (P == 14) hipLaunchKernelGGL(roi_feat14_kernel, dim3(r_cap, 7), dim3(256), 0, s, p);
   else return NUHTC_E_INVALID;
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
