@@ -45,13 +45,13 @@ struct nuhtc_engine {
   // workspace
   float *img, *tokA, *tokB, *xw, *qkv, *att, *hid;
   float *c[4], *lat[4], *x[4], *rpn[4], *semg[4];
-  float *tmpA, *tmpB, *sem_feat, *sem_pred, *x0sem;
+  float *tmpA, *tmpB, *tmpR, *sem_feat, *sem_pred, *x0sem;   // tmpR: RPN conv output (side stream)
   // proposals / roi path
   int roi_cap = 0;          // rois per tile: max_cc_proposals + rpn_max_per_img
   int cand_cap = 0;         // rpn candidates per tile (<= 4 * nms_pre), det candidates per tile
   int* overflow = nullptr;  // dev int[4]
   hipStream_t side = nullptr;       // proposal selection / NMS run here, concurrently with the semantic head on the caller's stream
-  hipEvent_t ev_rpn = nullptr, ev_side = nullptr;
+  hipEvent_t ev_rpn = nullptr, ev_side = nullptr, ev_fpn = nullptr;
   struct RoiWs* rw = nullptr;
 };
 

@@ -64,6 +64,7 @@ void nuhtc_destroy(nuhtc_engine* e) {
   if (e->side) hipStreamDestroy(e->side);
   if (e->ev_rpn) hipEventDestroy(e->ev_rpn);
   if (e->ev_side) hipEventDestroy(e->ev_side);
+  if (e->ev_fpn) hipEventDestroy(e->ev_fpn);
   for (void* p : e->allocs) hipFree(p);
   delete e;
 }
@@ -338,12 +339,14 @@ int nuhtc_finalize(nuhtc_engine* e) {
       return rc;
   }
   if ((rc = ws(e, &e->tmpA, nullptr, {B, g0.H, g0.W, 64}, 0)) || (rc = ws(e, &e->tmpB, nullptr, {B, g0.H, g0.W, 64}, 0)) ||
+      (rc = ws(e, &e->tmpR, nullptr, {B, g0.H, g0.W, 64}, 0)) ||
       (rc = ws(e, &e->sem_feat, "sem_feat", {B, g0.H, g0.W, 64}, 0)) || (rc = ws(e, &e->x0sem, "x0sem", {B, g0.H, g0.W, 64}, 0)) || (rc = ws(e, &e->sem_pred, "sem_pred", {B, g0.H, g0.W}, 0)))
     return rc;
   if ((rc = alloc_roi_workspace(e))) return rc;
   HIP_CHECK(e, hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
   HIP_CHECK(e, hipEventCreateWithFlags(&e->ev_rpn, hipEventDisableTiming));
   HIP_CHECK(e, hipEventCreateWithFlags(&e->ev_side, hipEventDisableTiming));
+  HIP_CHECK(e, hipEventCreateWithFlags(&e->ev_fpn, hipEventDisableTiming));
   HIP_CHECK(e, hipDeviceSynchronize());
   e->raw.clear();
   e->finalized = true;
@@ -438,13 +441,18 @@ int run_neck_heads(nuhtc_engine* e, int B, hipStream_t s) {
     const StageGeom& g = e->st[i];
     RUN(conv3x3(e, e->lat[i], e->fpn_w[i], e->fpn_b[i], e->x[i], B, g.H, g.W, ACT_NONE, nullptr, 1, s));
   }
-  // RPN head (mmdet/models/dense_heads/rpn_head.py:62-68)
+  // RPN head (mmdet/models/dense_heads/rpn_head.py:62-68).  The RPN branch (conv + 1x1 heads here, proposal selection and
+  // NMS in run_roi_path) and the semantic branch below both depend only on the FPN maps: the RPN branch runs on the side
+  // stream from here on, so the tails of either branch's launches are filled by the other's blocks; joined before build_rois.
+  hipStream_t s2 = e->side;
+  if (hipEventRecord(e->ev_fpn, s) != hipSuccess || hipStreamWaitEvent(s2, e->ev_fpn, 0) != hipSuccess)
+    FAIL(e, NUHTC_E_HIP, "side-stream fork failed");
   for (int i = 0; i < 4; ++i) {
     const StageGeom& g = e->st[i];
-    RUN(conv3x3(e, e->x[i], e->rpn_w, e->rpn_b, e->tmpA, B, g.H, g.W, ACT_RELU, nullptr, 1, s));
-    RUN(launch_gemm(gp(e->tmpA, e->rpn_hw, e->rpn_hb, e->rpn[i], B * g.H * g.W, 32, 64), s));
+    RUN(conv3x3(e, e->x[i], e->rpn_w, e->rpn_b, e->tmpR, B, g.H, g.W, ACT_RELU, nullptr, 1, s2));
+    RUN(launch_gemm(gp(e->tmpR, e->rpn_hw, e->rpn_hb, e->rpn[i], B * g.H * g.W, 32, 64), s2));
   }
-  if (hipEventRecord(e->ev_rpn, s) != hipSuccess) FAIL(e, NUHTC_E_HIP, "hipEventRecord failed");   // RPN maps ready: side stream may start
+  if (hipEventRecord(e->ev_rpn, s2) != hipSuccess) FAIL(e, NUHTC_E_HIP, "hipEventRecord failed");   // RPN maps ready (side stream)
   // FusedSemanticHead (fused_semantic_head.py:97-111)
   for (int i = 0; i < 4; ++i) {
     const StageGeom& g = e->st[i];

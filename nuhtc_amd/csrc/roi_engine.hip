@@ -285,7 +285,8 @@ int run_roi_path(nuhtc_engine* e, int B, const float* rois_fixed, int n_rois, in
       RUN(launch_attn_pool(e->x[l], G, B, HW, c.att_thres, s));
     }
   }
-  if (!fixed && hipStreamWaitEvent(s, e->ev_side, 0) != hipSuccess) FAIL(e, NUHTC_E_HIP, "hipStreamWaitEvent failed");   // join
+  // join: the side stream carries the RPN branch (convs + heads from run_neck_heads, selection + NMS above)
+  if (hipStreamWaitEvent(s, fixed ? e->ev_rpn : e->ev_side, 0) != hipSuccess) FAIL(e, NUHTC_E_HIP, "hipStreamWaitEvent failed");
   RUN(launch_build_rois(use_cc ? w->cc_boxes : nullptr, w->cc_counts, std::max(c.max_cc_proposals, 1), w->rpn_dets, w->rpn_counts, c.rpn_max_per_img,
                         rois_fixed, n_rois, w->rois, w->roi_off, w->roi_cnt, w->roi_total, B, s));
   const int Rcap = fixed ? B * n_rois : B * e->roi_cap;
