@@ -128,6 +128,19 @@ int nuhtc_infer_fixed_load(nuhtc_engine* e, const uint8_t* tiles_dev, int B, int
  * Enqueues on `stream`; does not synchronise. */
 int nuhtc_mask_contours(nuhtc_engine* e, const nuhtc_dets* dets, int B, int cap, int16_t* xy_dev, int32_t* n_dev, void* stream);
 
+/* Cross-tile duplicate removal over all detections of a slide: tools/nuclei_merge.py:62-174 `merge_overlap`, strategy
+ * 'probability' (visit in descending score, ties by lower index; an alive detection removes every later one whose overlap
+ * with it exceeds `thr`).  Overlap = IoU of the instance masks (the reference intersects the polygons traced from them).
+ * All pointers are device memory of `device`:  boxes [n][4] int32 = x0,y0,x1,y1 (x1,y1 exclusive) of each mask crop in
+ * slide pixels; scores [n]; areas [n] = set pixels; bits = the crops, bit-packed row by row, (x1-x0+31)/32 uint32 words
+ * per row, pixel x of a row in bit (x&31) of word x>>5; bit_off [n] = word offset of each crop in `bits`.
+ * x_min..y_max bound all boxes (the slide extent).  keep_dev [n] receives 1 for kept detections.  Allocates its own scratch
+ * (about 110 bytes per detection), runs on `stream` and synchronises it before returning.
+ * NUHTC_E_CAPACITY: a detection has more than 24 higher-scored neighbours above the threshold. */
+int nuhtc_merge_overlap(int device, const int32_t* boxes, const float* scores, const int32_t* areas, const uint32_t* bits,
+                        const int64_t* bit_off, int64_t n, double thr, int x_min, int y_min, int x_max, int y_max,
+                        uint8_t* keep_dev, void* stream);
+
 /* Synchronises `stream` and reports whether the last nuhtc_infer overflowed a capacity
  * (returns NUHTC_E_CAPACITY) — call before trusting the results. */
 int nuhtc_check(nuhtc_engine* e, void* stream);

@@ -36,7 +36,7 @@ class Dets(ctypes.Structure):
 EXPORTS = ['nuhtc_default_config', 'nuhtc_create', 'nuhtc_destroy', 'nuhtc_last_error', 'nuhtc_load_weight',
            'nuhtc_finalize', 'nuhtc_infer', 'nuhtc_infer_fixed_load', 'nuhtc_check', 'nuhtc_get_buffer',
            'nuhtc_op_gemm', 'nuhtc_op_roi_align', 'nuhtc_op_nms', 'nuhtc_profile_enable', 'nuhtc_profile_read',
-           'nuhtc_mask_contours']
+           'nuhtc_mask_contours', 'nuhtc_merge_overlap']
 
 _lib = None
 
@@ -68,6 +68,7 @@ def load():
     lib.nuhtc_op_roi_align.argtypes = [vp, vp, ci, ci, ci, vp, ci, ci, cf, ci, vp, vp]
     lib.nuhtc_op_nms.argtypes = [vp, vp, vp, ci, cf, vp, vp, vp]
     lib.nuhtc_mask_contours.argtypes = [vp, ctypes.POINTER(Dets), ci, ci, vp, vp, vp]
+    lib.nuhtc_merge_overlap.argtypes = [ci, vp, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_double, ci, ci, ci, ci, vp, vp]
     lib.nuhtc_profile_enable.argtypes = [ci]
     lib.nuhtc_profile_read.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
     for name in EXPORTS:

@@ -94,46 +94,61 @@ def infer_tiles(model, tiles, coords, batch_size=16, depth=3):
     return rec
 
 
-def merge_overlap(rec, overlap_threshold=0.05):
+def pack_masks(masks):
+    """[(bool crop, x0, y0)] -> (boxes int32 [n,4] (x1,y1 exclusive), areas int32 [n], bits uint32 [...], bit_off int64 [n]):
+    the crop layout nuhtc_merge_overlap takes (rows of (w+31)//32 words, pixel x in bit x&31 of word x>>5)."""
+    n = len(masks)
+    boxes = np.zeros((n, 4), np.int32)
+    areas = np.zeros(n, np.int32)
+    off = np.zeros(n, np.int64)
+    parts, cur = [], 0
+    for i, (m, x0, y0) in enumerate(masks):
+        h, w = m.shape
+        boxes[i] = (x0, y0, x0 + w, y0 + h)
+        areas[i] = int(m.sum())
+        off[i] = cur
+        if h and w:
+            wpr = (w + 31) // 32
+            row = np.zeros((h, wpr * 32), np.uint8)
+            row[:, :w] = m
+            words = np.packbits(row.reshape(h, wpr, 4, 8), axis=-1, bitorder='little').reshape(h, wpr, 4).view(np.uint32).reshape(-1)
+            parts.append(words)
+            cur += words.size
+    bits = np.concatenate(parts) if parts else np.zeros(1, np.uint32)
+    return boxes, areas, bits, off
+
+
+def merge_overlap_packed(boxes, scores, areas, bits, off, overlap_threshold=0.05, device=0):
+    """nuhtc_merge_overlap on packed crops (see pack_masks); numpy in, kept indices (ascending) out."""
+    import ctypes
+    import torch
+    n = len(scores)
+    if n == 0:
+        return np.zeros(0, np.int64)
+    lib = hip.load()
+    dev = torch.device('cuda', device)
+    arrs = (np.ascontiguousarray(boxes, np.int32), np.ascontiguousarray(scores, np.float32), np.ascontiguousarray(areas, np.int32),
+            np.ascontiguousarray(bits, np.uint32).view(np.int32), np.ascontiguousarray(off, np.int64))
+    t = [torch.from_numpy(a).to(dev) for a in arrs]
+    keep = torch.zeros(n, dtype=torch.uint8, device=dev)
+    vp = lambda x: ctypes.c_void_p(x.data_ptr())
+    b = arrs[0]
+    with torch.cuda.device(dev):
+        rc = lib.nuhtc_merge_overlap(device, vp(t[0]), vp(t[1]), vp(t[2]), vp(t[3]), vp(t[4]), n, float(overlap_threshold),
+                                     int(b[:, 0].min()), int(b[:, 1].min()), int(b[:, 2].max()), int(b[:, 3].max()),
+                                     vp(keep), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc:
+        raise RuntimeError(f'nuhtc_merge_overlap failed ({rc})')
+    return np.nonzero(keep.cpu().numpy())[0].astype(np.int64)
+
+
+def merge_overlap(rec, overlap_threshold=0.05, device=0):
     """Cross-tile duplicate removal, strategy 'probability' of tools/nuclei_merge.py:62-174: detections sorted by
     score (descending), each still-alive one suppresses every later one it overlaps with IoU > threshold.
     The reference intersects shapely polygons of the cv2 contours; here IoU is taken on the pixel masks the
-    polygons are traced from (same objects, pixel-area instead of polygon-area IoU).  Returns kept indices."""
-    n = len(rec['score'])
-    if n == 0:
+    polygons are traced from (same objects, pixel-area instead of polygon-area IoU).  Runs on the GPU
+    (nuhtc_merge_overlap, csrc/merge.hip).  Returns kept indices (ascending)."""
+    if len(rec['score']) == 0:
         return np.zeros(0, np.int64)
-    order = np.argsort(-np.asarray(rec['score']), kind='stable')
-    boxes = np.array([[m[1], m[2], m[1] + m[0].shape[1], m[2] + m[0].shape[0]] for m in rec['mask']], np.int64)
-    cell = 64
-    grid = {}
-    for i in range(n):
-        for cy in range(boxes[i, 1] // cell, (boxes[i, 3] - 1) // cell + 1):
-            for cx in range(boxes[i, 0] // cell, (boxes[i, 2] - 1) // cell + 1):
-                grid.setdefault((cx, cy), []).append(i)
-    alive = np.ones(n, bool)
-    visited = np.zeros(n, bool)
-    keep = []
-    for q in order:
-        if visited[q]:
-            continue
-        visited[q] = True
-        keep.append(q)
-        mq, qx, qy = rec['mask'][q]
-        cands = set()
-        for cy in range(boxes[q, 1] // cell, (boxes[q, 3] - 1) // cell + 1):
-            for cx in range(boxes[q, 0] // cell, (boxes[q, 2] - 1) // cell + 1):
-                cands.update(grid.get((cx, cy), ()))
-        for c in cands:
-            if visited[c]:
-                continue
-            x0, y0 = max(boxes[q, 0], boxes[c, 0]), max(boxes[q, 1], boxes[c, 1])
-            x1, y1 = min(boxes[q, 2], boxes[c, 2]), min(boxes[q, 3], boxes[c, 3])
-            if x1 <= x0 or y1 <= y0:
-                continue
-            mc, cx0, cy0 = rec['mask'][c]
-            inter = int(np.logical_and(mq[y0 - qy:y1 - qy, x0 - qx:x1 - qx], mc[y0 - cy0:y1 - cy0, x0 - cx0:x1 - cx0]).sum())
-            union = int(mq.sum()) + int(mc.sum()) - inter
-            if union > 0 and inter / union > overlap_threshold:
-                visited[c] = True
-                alive[c] = False
-    return np.array(sorted(keep), np.int64)
+    boxes, areas, bits, off = pack_masks(rec['mask'])
+    return merge_overlap_packed(boxes, rec['score'], areas, bits, off, overlap_threshold, device)

@@ -120,7 +120,7 @@ def test_gather_records_gloo_world2():
 
 
 def test_merge_overlap_suppresses_cross_tile_duplicates():
-    from nuhtc_amd.wsi import merge_overlap
+    from oracle.merge import merge_overlap      # the product's merge runs on the GPU (tests/test_merge.py)
     disk = np.zeros((20, 20), bool)
     yy, xx = np.mgrid[0:20, 0:20]
     disk[(yy - 10) ** 2 + (xx - 10) ** 2 <= 64] = True

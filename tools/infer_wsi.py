@@ -99,6 +99,11 @@ def main():
     heads = parallel.gather_records(head.to(dev))
     vparts = parallel.gather_records(verts.to(dev))
     bparts = parallel.gather_records(blob.to(dev)) if want('coco') else [None] * len(heads)
+    mparts = None
+    if args.merge:       # the cross-tile merge runs on rank 0's GPU over the bit-packed mask crops of every rank
+        mb, ma, mbits, moff = wsi.pack_masks([rec['mask'][i] for i in keep])
+        packed = torch.from_numpy(np.concatenate([mb.astype(np.int64), ma[:, None].astype(np.int64), moff[:, None]], 1)) if n else torch.zeros((0, 6), dtype=torch.int64)
+        mparts = (parallel.gather_records(packed.to(dev)), parallel.gather_records(torch.from_numpy(mbits.view(np.int32).copy()).to(dev)))
     if rank == 0:
         from nuhtc_amd import outputs
         name = os.path.splitext(os.path.basename(args.source))[0]
@@ -135,7 +140,15 @@ def main():
             outputs.write_json(os.path.join(out_dir, name + '.geojson'), feats)
             outputs.write_json(os.path.join(out_dir, name + '_point.geojson'), points)
             if args.merge:
-                merged = contours.merge_features(feats, args.overlap_threshold, 'probability')
+                pk = [p.cpu().numpy() for p in mparts[0]]
+                wb = [p.cpu().numpy().view(np.uint32) for p in mparts[1]]
+                base = np.cumsum([0] + [len(w) for w in wb[:-1]])
+                allp = np.concatenate(pk, 0)
+                off_all = np.concatenate([p[:, 5] + b0 for p, b0 in zip(pk, base)]) if len(allp) else np.zeros(0, np.int64)
+                scores_all = np.concatenate([h.cpu().numpy()[:, 4] for h in heads]).astype(np.float32)
+                kept = wsi.merge_overlap_packed(allp[:, :4], scores_all, allp[:, 4], np.concatenate(wb), off_all,
+                                                args.overlap_threshold, device=local_rank if world > 1 else (torch.device(args.device).index or 0))
+                merged = [feats[i] for i in kept]
                 outputs.write_json(os.path.join(out_dir, name + '_merged.geojson'), merged)
                 msg += f', {len(merged)} after the cross-tile merge'
         if want('dsa'):
