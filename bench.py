@@ -52,6 +52,9 @@ def main():
     ap.add_argument('--in-flight', type=int, default=0,
                     help='also report the streaming rate with this many batches in flight (e.g. 3; off by default so that the '
                          'rocprofv3 summary of the default command sees every kernel without co-running kernels)')
+    ap.add_argument('--fixed-load', action='store_true',
+                    help='SURVEY 8d fixed-load mode: 1064 given RoIs and exactly 64 detections per tile (nuhtc_infer_fixed_load) instead of '
+                         'the free-running proposal / detection counts of the synthetic weights')
     ap.add_argument('--gemm-shapes', action='store_true', help='add the per-shape GEMM timings to the JSON line')
     args = ap.parse_args()
 
@@ -77,6 +80,11 @@ def main():
     tiles_np = synth.nuclei_tiles(B, 256, start=rank * B)
     tiles = eng.to_device(tiles_np)
     mode = hip.CH_SWAP   # tools/infer_wsi.py channel handling
+    if args.fixed_load:
+        rois = torch.from_numpy(synth.fixed_load_rois(B)).to(tiles.device)
+        step_fn = lambda e=eng: e.infer_fixed_load_async(tiles, rois, 64, mode)
+    else:
+        step_fn = lambda e=eng: e.infer_async(tiles, mode)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -85,12 +93,12 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        eng.infer_async(tiles, mode)
+        step_fn()
     eng.check()
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        eng.infer_async(tiles, mode)
+        step_fn()
     if dist is not None:
         # one gather of the per-tile detection records (boxes, labels, counts, keep flags) for the host-side merge
         rec = torch.cat([eng.boxes.reshape(B, -1), eng.labels.float(), eng.keep.float(), eng.counts.float()[:, None]], 1)
@@ -141,7 +149,7 @@ def main():
     hip.profile_enable(True)
     prof_steps = max(2, min(5, args.steps))
     for _ in range(prof_steps):
-        eng.infer_async(tiles, mode)
+        step_fn()
     prof_raw = hip.profile_read()
     hip.profile_enable(False)
     prof, shapes = {}, {}
@@ -168,7 +176,7 @@ def main():
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'htc_lite_swin PanNuke config, batch_size=16 256x256 tiles per GPU (BASELINE configs[1]), full path '
-                                   'incl. proposals, cascade, masks, per-tile mask-NMS', 'batch_per_gpu': B,
+                                   'incl. proposals, cascade, masks, per-tile mask-NMS' + (' [fixed load: 1064 RoIs, 64 detections per tile]' if args.fixed_load else ''), 'batch_per_gpu': B,
                        'weights': 'seeded synthetic (weights.bench_state_dict); pannuke.pth not distributed',
                        'tiles': 'synthetic nuclei tiles (nuhtc_amd.synth), resident in HBM',
                        'mean_rois_per_tile': float(roi_counts.mean()), 'mean_dets_per_tile': float(counts.mean())},
