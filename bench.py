@@ -55,6 +55,7 @@ def main():
     ap.add_argument('--fixed-load', action='store_true',
                     help='SURVEY 8d fixed-load mode: 1064 given RoIs and exactly 64 detections per tile (nuhtc_infer_fixed_load) instead of '
                          'the free-running proposal / detection counts of the synthetic weights')
+    ap.add_argument('--roi-size', default='12,40', help='--fixed-load: RoI side range in network pixels (SURVEY: 12,40; 40x nuclei: ~40,100)')
     ap.add_argument('--gemm-shapes', action='store_true', help='add the per-shape GEMM timings to the JSON line')
     args = ap.parse_args()
 
@@ -81,7 +82,7 @@ def main():
     tiles = eng.to_device(tiles_np)
     mode = hip.CH_SWAP   # tools/infer_wsi.py channel handling
     if args.fixed_load:
-        rois = torch.from_numpy(synth.fixed_load_rois(B)).to(tiles.device)
+        rois = torch.from_numpy(synth.fixed_load_rois(B, size=tuple(float(v) for v in args.roi_size.split(',')))).to(tiles.device)
         step_fn = lambda e=eng: e.infer_fixed_load_async(tiles, rois, 64, mode)
     else:
         step_fn = lambda e=eng: e.infer_async(tiles, mode)

@@ -11,9 +11,10 @@ struct RoiFeatParams {
   const float* x0sem;   // x0 + sem (P = 7 LDS path: both are sampled at the same points, so one interpolation serves both)
   int H0, W0, H1, W1, H2, W2, H3, W3;
   float* out;           // [R][P*P][64]
-  int* fb_count;        // P=7: RoIs that do not fit the LDS tiles (processed by the generic kernel)
-  int* fb_list;         // [R]
-  unsigned char* fb_flag; // [R] 1 = handled by the generic path
+  int* fb_count;        // P=7: [0] big RoIs (one block per bin), [1] mid-size RoIs (gather kernel); the rest fit the LDS tiles
+  int* fb_list;         // [R] big RoIs
+  int* mid_list;        // [R] mid-size RoIs
+  unsigned char* fb_flag; // [R] 0 = LDS path, 1 = gather kernel, 2 = one block per bin
 };
 
 struct BboxTailParams {
@@ -83,7 +84,10 @@ struct TilePostParams {
 int launch_attn_pool(const float* F, float* G, int B, int HW, float tau, hipStream_t s);
 int launch_build_rois(const float* cc_boxes, const int* cc_counts, int cc_cap, const float* rpn_dets, const int* rpn_counts, int rpn_cap,
                       const float* fixed, int n_fixed, float* rois, int* roi_off, int* roi_cnt, int* total, int B, hipStream_t s);
-int launch_roi_feat(const RoiFeatParams& p, int P, int r_cap, hipStream_t s);
+// `side` / `ev_fork` / `ev_join` (optional): the mid-size-RoI gather kernel of the P = 7 path runs on `side` beside the LDS-path
+// kernel and is joined back into `s` before returning
+int launch_roi_feat(const RoiFeatParams& p, int P, int r_cap, hipStream_t s, hipStream_t side = nullptr, hipEvent_t ev_fork = nullptr,
+                    hipEvent_t ev_join = nullptr);
 int launch_bbox_tail(const BboxTailParams& p, int r_cap, hipStream_t s);
 int launch_det_candidates(const DetCandParams& p, int B, hipStream_t s);
 int launch_det_finish(const DetFinishParams& p, hipStream_t s);

@@ -155,8 +155,8 @@ __device__ __forceinline__ RoiGeom roi_geom(const float* roi, float scale, int P
 // of the regular sampling grid once (14 sample columns + 14 sample rows per map, computed by 28 lanes in parallel), and
 // then evaluates the 49 bins from LDS with exactly the arithmetic of roi_bin() (same products, same summation order), so
 // both paths are bit-identical.  RoIs with a larger footprint fall back to the global-memory path.
-#define TP0 8
-#define TP1 5
+#define TP0 12
+#define TP1 7
 struct AxisEnt { int lo, hi; float l, h; };
 
 // per-axis part of mmcv's bilinear_interpolate for sample coordinate c on an axis of `size` pixels
@@ -317,6 +317,88 @@ __device__ __forceinline__ void roi_feat7_generic_block(const RoiFeatParams& p, 
   }
 }
 
+// One bin with a compile-time G x G sample grid: all 4·G² taps are loaded before the first one is consumed (roi_bin() walks
+// the samples one by one, each a round trip to L2), then accumulated in roi_bin()'s order -- identical result.
+template <int G>
+__device__ __forceinline__ float bin_gather(const float* __restrict__ fb, int H, int W, const RoiGeom& g, int pw, int ph, int lane) {
+  Tap t[G * G];
+#pragma unroll
+  for (int iy = 0; iy < G; ++iy) {
+    const float y = g.y1 + (float)ph * g.bh + ((float)iy + 0.5f) * g.bh / (float)G;
+#pragma unroll
+    for (int ix = 0; ix < G; ++ix) {
+      const float x = g.x1 + (float)pw * g.bw + ((float)ix + 0.5f) * g.bw / (float)G;
+      t[iy * G + ix] = make_tap(y, x, H, W);
+    }
+  }
+  float v[G * G][4];
+#pragma unroll
+  for (int k = 0; k < G * G; ++k) {
+    v[k][0] = fb[(long long)t[k].o00 * 64 + lane]; v[k][1] = fb[(long long)t[k].o01 * 64 + lane];
+    v[k][2] = fb[(long long)t[k].o10 * 64 + lane]; v[k][3] = fb[(long long)t[k].o11 * 64 + lane];
+  }
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < G * G; ++k) acc += t[k].w1 * v[k][0] + t[k].w2 * v[k][1] + t[k].w3 * v[k][2] + t[k].w4 * v[k][3];
+  return acc / (float)(G * G);
+}
+
+// RoIs too large for the LDS tiles but with at most 2x2 semantic samples per 14x14 bin (up to ~110 px at network scale,
+// i.e. every nucleus-sized box of a 40x slide): gathered straight from the L2-resident maps, one RoI per block, bins over
+// the 4 waves, every bin's loads in flight together; no LDS, so 8 blocks share a CU.
+__global__ __launch_bounds__(256) void roi_feat7_gather_kernel(RoiFeatParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nmid = p.fb_count[1];
+  for (int i = blockIdx.x; i < nmid; i += gridDim.x) {
+    const int r = p.mid_list[i];
+    const float* roi = p.rois + (long long)r * 5;
+    const int b = (int)roi[0];
+    float gs2[2];
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      const int Hl = l ? p.H3 : p.H2, Wl = l ? p.W3 : p.W2;
+      const float st = l ? 32.f : 16.f;
+      float cx = floorf((roi[1] + roi[3]) / (2.0f * st)), cy = floorf((roi[2] + roi[4]) / (2.0f * st));
+      cx = fminf(fmaxf(cx, 0.f), (float)(Wl - 1));
+      cy = fminf(fmaxf(cy, 0.f), (float)(Hl - 1));
+      const float* G = l ? p.G3 : p.G2;
+      gs2[l] = G[(((long long)b * Hl + (int)cy) * Wl + (int)cx) * 64 + lane];
+    }
+    const RoiGeom g0 = roi_geom(roi, 0.25f, 7, 2), g1 = roi_geom(roi, 0.125f, 7, 2), gs = roi_geom(roi, 0.25f, 14, 0);
+    const long long hw0 = (long long)b * p.H0 * p.W0 * 64;
+    const float* f1 = p.x1 + (long long)b * p.H1 * p.W1 * 64;
+    float* out = p.out + (long long)r * 49 * 64;
+    if (gs.gw == 1) {          // (classify guarantees gw == gh here) same sample points as level 0: x0 + sem in one pass
+      const float* f0s = p.x0sem + hw0;
+      for (int bin = wave; bin < 49; bin += 4) {
+        const int ph = bin / 7, pw = bin - ph * 7;
+        float v = 0.f;
+        v += bin_gather<2>(f0s, p.H0, p.W0, g0, pw, ph, lane);
+        v += bin_gather<2>(f1, p.H1, p.W1, g1, pw, ph, lane);
+        v += gs2[0];
+        v += gs2[1];
+        out[bin * 64 + lane] = v;
+      }
+    } else {                   // 2x2 semantic samples per 14x14 bin
+      const float* f0 = p.x0 + hw0;
+      const float* fs = p.sem + hw0;
+      for (int bin = wave; bin < 49; bin += 4) {
+        const int ph = bin / 7, pw = bin - ph * 7;
+        float v = 0.f;
+        v += bin_gather<2>(f0, p.H0, p.W0, g0, pw, ph, lane);
+        v += bin_gather<2>(f1, p.H1, p.W1, g1, pw, ph, lane);
+        v += gs2[0];
+        v += gs2[1];
+        const float a = bin_gather<2>(fs, p.H0, p.W0, gs, 2 * pw, 2 * ph, lane);
+        const float bq = bin_gather<2>(fs, p.H0, p.W0, gs, 2 * pw + 1, 2 * ph, lane);
+        const float c = bin_gather<2>(fs, p.H0, p.W0, gs, 2 * pw, 2 * ph + 1, lane);
+        const float d = bin_gather<2>(fs, p.H0, p.W0, gs, 2 * pw + 1, 2 * ph + 1, lane);
+        out[bin * 64 + lane] = v + (((a + bq) + c) + d) * 0.25f;
+      }
+    }
+  }
+}
+
 // pre-pass: which RoIs fit the LDS tiles (one wave per RoI, the same plan code as the main kernel)
 __global__ __launch_bounds__(256) void roi_classify_kernel(RoiFeatParams p) {
   const int lane = threadIdx.x & 63;
@@ -327,10 +409,12 @@ __global__ __launch_bounds__(256) void roi_classify_kernel(RoiFeatParams p) {
   const bool sem_g1 = gs.gw == 1 && gs.gh == 1;
   const LevelPlan l0 = plan_level(g0, 7, 2, p.H0, p.W0, TP0, lane);
   const LevelPlan l1 = plan_level(g1, 7, 2, p.H1, p.W1, TP1, lane);
-  const bool fb = !(sem_g1 && l0.ok && l1.ok);
+  // 0: LDS path; 1: gather path (at most 2x2 semantic samples per bin); 2: one block per bin (big proposals)
+  const int cls = (sem_g1 && l0.ok && l1.ok) ? 0 : (gs.gw == gs.gh && gs.gw <= 2) ? 1 : 2;
   if (lane == 0) {
-    p.fb_flag[r] = fb ? 1 : 0;
-    if (fb) p.fb_list[atomicAdd(p.fb_count, 1)] = r;
+    p.fb_flag[r] = (unsigned char)cls;
+    if (cls == 2) p.fb_list[atomicAdd(&p.fb_count[0], 1)] = r;
+    else if (cls == 1) p.mid_list[atomicAdd(&p.fb_count[1], 1)] = r;
   }
 }
 
@@ -482,13 +566,18 @@ __global__ __launch_bounds__(256) void roi_feat14_kernel(RoiFeatParams p) {
   }
 }
 
-int launch_roi_feat(const RoiFeatParams& p, int P, int r_cap, hipStream_t s) {
+int launch_roi_feat(const RoiFeatParams& p, int P, int r_cap, hipStream_t s, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join) {
   ProfScope ps(P == 7 ? "roi_feat7" : "roi_feat14", 0, 0, s);
   if (r_cap <= 0) return 0;
   if (P == 7) {
-    if (hipMemsetAsync(p.fb_count, 0, sizeof(int), s) != hipSuccess) return NUHTC_E_HIP;
+    if (hipMemsetAsync(p.fb_count, 0, 2 * sizeof(int), s) != hipSuccess) return NUHTC_E_HIP;
     hipLaunchKernelGGL(roi_classify_kernel, dim3(cdiv(r_cap, 4)), dim3(256), 0, s, p);
+    const bool fork = side && ev_fork && ev_join;
+    if (fork && (hipEventRecord(ev_fork, s) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess)) return NUHTC_E_HIP;
+    hipLaunchKernelGGL(roi_feat7_gather_kernel, dim3(r_cap < 4096 ? r_cap : 4096), dim3(256), 0, fork ? side : s, p);
+    if (fork && hipEventRecord(ev_join, side) != hipSuccess) return NUHTC_E_HIP;
     hipLaunchKernelGGL(roi_feat7_lds_kernel, dim3(FB_SLOTS * 49 + r_cap), dim3(256), 0, s, p);
+    if (fork && hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) return NUHTC_E_HIP;
   } else if (P == 14) hipLaunchKernelGGL(roi_feat14_kernel, dim3(r_cap, 7), dim3(256), 0, s, p);
   else return NUHTC_E_INVALID;
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;

@@ -43,10 +43,10 @@ def nuclei_tiles(n, size=256, start=0):
     return np.stack([nuclei_tile(start + i, size) for i in range(n)])
 
 
-def fixed_load_rois(n_tiles, n_rois=1064, net_size=512, seed=7):
+def fixed_load_rois(n_tiles, n_rois=1064, net_size=512, seed=7, size=(12, 40)):
     """Fixed-load mode: per tile `n_rois` boxes, sizes U(12,40) px in network space. (n_tiles,n_rois,4) f32."""
     rng = np.random.default_rng(seed)
-    wh = rng.uniform(12, 40, (n_tiles, n_rois, 2)).astype(np.float32)
+    wh = rng.uniform(size[0], size[1], (n_tiles, n_rois, 2)).astype(np.float32)
     c = rng.uniform(0, net_size, (n_tiles, n_rois, 2)).astype(np.float32)
     b = np.concatenate([c - wh / 2, c + wh / 2], -1)
     return np.clip(b, 0, net_size).astype(np.float32)
