@@ -187,12 +187,16 @@ __device__ __forceinline__ int half_max(int v) {
 struct LevelPlan { AxisEnt ent; int fx0, fy0, fw, fh; bool ok, empty; };
 
 // lanes 0..n-1 build the x entries, lanes 32..32+n-1 the y entries of a P x P bin grid with g samples per bin and axis
-__device__ __forceinline__ LevelPlan plan_level(const RoiGeom& g, int P, int gsamp, int H, int W, int tp, int lane) {
+// (band variant: only the y entries [yfirst, yfirst + ycount) take part, e.g. the sample rows of one output bin row; the
+// footprint limits are then tpw x tph)
+__device__ __forceinline__ LevelPlan plan_band(const RoiGeom& g, int P, int gsx, int gsy, int H, int W, int tpw, int tph, int yfirst, int ycount,
+                                               int lane) {
   LevelPlan lp;
   const bool is_y = lane >= 32;
   const int idx = lane & 31;
+  const int gsamp = is_y ? gsy : gsx;
   const int n = P * gsamp;
-  const bool active = idx < n;
+  const bool active = is_y ? (idx >= yfirst && idx < yfirst + ycount && idx < n) : idx < n;
   const int pb = active ? idx / gsamp : 0, is = active ? idx - pb * gsamp : 0;
   const float start = is_y ? g.y1 : g.x1, bs = is_y ? g.bh : g.bw;
   const float c = start + (float)pb * bs + ((float)is + 0.5f) * bs / (float)gsamp;   // same expression as roi_bin()
@@ -205,10 +209,14 @@ __device__ __forceinline__ LevelPlan plan_level(const RoiGeom& g, int P, int gsa
   lp.empty = x_hi < 0 || y_hi < 0;
   lp.fx0 = lp.empty ? 0 : x_lo; lp.fy0 = lp.empty ? 0 : y_lo;
   lp.fw = lp.empty ? 0 : x_hi - x_lo + 1; lp.fh = lp.empty ? 0 : y_hi - y_lo + 1;
-  lp.ok = lp.fw <= tp && lp.fh <= tp;
+  lp.ok = lp.fw <= tpw && lp.fh <= tph;
   const int f0 = is_y ? lp.fy0 : lp.fx0;
   if (valid) { lp.ent.lo -= f0; lp.ent.hi -= f0; }   // invalid entries keep offset 0 with zero weights
+  else { lp.ent.lo = lp.ent.hi = 0; lp.ent.l = lp.ent.h = 0.f; }
   return lp;
+}
+__device__ __forceinline__ LevelPlan plan_level(const RoiGeom& g, int P, int gsamp, int H, int W, int tp, int lane) {
+  return plan_band(g, P, gsamp, gsamp, H, W, tp, tp, 0, 32, lane);
 }
 
 // the block's 4 waves copy the footprint pixel by pixel (one 256-byte pixel per global->LDS instruction)
@@ -246,15 +254,15 @@ __device__ __forceinline__ float bin_lds(const float* tile, int fw, const AxisEn
 // arithmetic per tap), not by LDS or memory.  `cp2` = 2 * (lane & 31) is the lane's first channel; the two half-waves
 // work on different bins, so the axis tables are read per lane.
 typedef float v2f __attribute__((ext_vector_type(2)));
-template <int G>
+template <int GX, int GY = GX>
 __device__ __forceinline__ v2f bin_lds2(const float* tile, const AxisEnt* tx, const AxisEnt* ty, int pw, int ph) {
   v2f acc = {0.f, 0.f};
 #pragma unroll
-  for (int iy = 0; iy < G; ++iy) {
-    const AxisEnt ey = ty[ph * G + iy];
+  for (int iy = 0; iy < GY; ++iy) {
+    const AxisEnt ey = ty[ph * GY + iy];
 #pragma unroll
-    for (int ix = 0; ix < G; ++ix) {
-      const AxisEnt ex = tx[pw * G + ix];
+    for (int ix = 0; ix < GX; ++ix) {
+      const AxisEnt ex = tx[pw * GX + ix];
       const float w1 = ey.h * ex.h, w2 = ey.h * ex.l, w3 = ey.l * ex.h, w4 = ey.l * ex.l;
       // (the tables of this path hold element offsets: x entries * 64, y entries * fw * 64; `tile` already includes cp2)
       const v2f v1 = *reinterpret_cast<const v2f*>(tile + (ey.lo + ex.lo));
@@ -264,7 +272,7 @@ __device__ __forceinline__ v2f bin_lds2(const float* tile, const AxisEnt* tx, co
       acc += w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
     }
   }
-  return acc / (float)(G * G);
+  return acc / (float)(GX * GY);
 }
 
 // RoIs whose footprint does not fit the LDS tiles (large proposals): taken from the fallback list written by
@@ -343,17 +351,44 @@ __device__ __forceinline__ float bin_gather(const float* __restrict__ fb, int H,
   return acc / (float)(G * G);
 }
 
-// RoIs too large for the LDS tiles but with at most 2x2 semantic samples per 14x14 bin (up to ~110 px at network scale,
-// i.e. every nucleus-sized box of a 40x slide): gathered straight from the L2-resident maps, one RoI per block, bins over
-// the 4 waves, every bin's loads in flight together; no LDS, so 8 blocks share a CU.
-__global__ __launch_bounds__(256) void roi_feat7_gather_kernel(RoiFeatParams p) {
+// RoIs too large for the square LDS tiles but with at most 2x2 semantic samples per 14x14 bin (up to ~110 px at network scale:
+// every nucleus-sized box of a 40x slide).  Gathering their taps straight from L2 moves ~0.8 MB per RoI through the texture
+// path; instead one block takes ONE ROW of output bins: the input rows that row samples (<= BH rows of <= BW pixels) are
+// staged in LDS once and the 7 bins of the row are evaluated from there exactly like in roi_feat7_lds_kernel.  When the
+// semantic grid is finer than the FPN grid (2 samples per 14x14 bin) it cannot share a pass with level 0: its band is staged
+// into the same tile afterwards.
+#define BW0 30
+#define BH0 6
+#define BW1 16
+#define BH1 4
+struct BandPlans { LevelPlan l0, l1, ls; bool ok; };
+__device__ __forceinline__ BandPlans plan_bands(const RoiFeatParams& p, const RoiGeom& g0, const RoiGeom& g1, const RoiGeom& gs, int ph, int lane) {
+  BandPlans bp;
+  bp.l0 = plan_band(g0, 7, 2, 2, p.H0, p.W0, BW0, BH0, 2 * ph, 2, lane);
+  bp.l1 = plan_band(g1, 7, 2, 2, p.H1, p.W1, BW1, BH1, 2 * ph, 2, lane);
+  bp.ok = bp.l0.ok && bp.l1.ok;
+  if (gs.gw == 2 || gs.gh == 2) {
+    bp.ls = plan_band(gs, 14, gs.gw, gs.gh, p.H0, p.W0, BW0, BH0, 2 * ph * gs.gh, 2 * gs.gh, lane);
+    bp.ok = bp.ok && bp.ls.ok;
+  } else {
+    bp.ls = bp.l0;
+  }
+  return bp;
+}
+
+__global__ __launch_bounds__(256) void roi_feat7_band_kernel(RoiFeatParams p) {
+  __shared__ float tile0[BW0 * BH0 * 64];
+  __shared__ float tile1[BW1 * BH1 * 64];
+  __shared__ AxisEnt tabx[3][32];
+  __shared__ AxisEnt taby[3][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nmid = p.fb_count[1];
-  for (int i = blockIdx.x; i < nmid; i += gridDim.x) {
-    const int r = p.mid_list[i];
+  const int cp2 = 2 * (lane & 31), hw = lane >> 5;
+  const int njobs = p.fb_count[1] * 7;
+  for (int job = blockIdx.x; job < njobs; job += gridDim.x) {
+    const int r = p.mid_list[job / 7], ph = job % 7;
     const float* roi = p.rois + (long long)r * 5;
     const int b = (int)roi[0];
-    float gs2[2];
+    v2f gsum[2];
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
       const int Hl = l ? p.H3 : p.H2, Wl = l ? p.W3 : p.W2;
@@ -362,40 +397,53 @@ __global__ __launch_bounds__(256) void roi_feat7_gather_kernel(RoiFeatParams p) 
       cx = fminf(fmaxf(cx, 0.f), (float)(Wl - 1));
       cy = fminf(fmaxf(cy, 0.f), (float)(Hl - 1));
       const float* G = l ? p.G3 : p.G2;
-      gs2[l] = G[(((long long)b * Hl + (int)cy) * Wl + (int)cx) * 64 + lane];
+      gsum[l] = *reinterpret_cast<const v2f*>(G + (((long long)b * Hl + (int)cy) * Wl + (int)cx) * 64 + cp2);
     }
     const RoiGeom g0 = roi_geom(roi, 0.25f, 7, 2), g1 = roi_geom(roi, 0.125f, 7, 2), gs = roi_geom(roi, 0.25f, 14, 0);
-    const long long hw0 = (long long)b * p.H0 * p.W0 * 64;
-    const float* f1 = p.x1 + (long long)b * p.H1 * p.W1 * 64;
-    float* out = p.out + (long long)r * 49 * 64;
-    if (gs.gw == 1) {          // (classify guarantees gw == gh here) same sample points as level 0: x0 + sem in one pass
-      const float* f0s = p.x0sem + hw0;
-      for (int bin = wave; bin < 49; bin += 4) {
-        const int ph = bin / 7, pw = bin - ph * 7;
-        float v = 0.f;
-        v += bin_gather<2>(f0s, p.H0, p.W0, g0, pw, ph, lane);
-        v += bin_gather<2>(f1, p.H1, p.W1, g1, pw, ph, lane);
-        v += gs2[0];
-        v += gs2[1];
-        out[bin * 64 + lane] = v;
-      }
-    } else {                   // 2x2 semantic samples per 14x14 bin
-      const float* f0 = p.x0 + hw0;
-      const float* fs = p.sem + hw0;
-      for (int bin = wave; bin < 49; bin += 4) {
-        const int ph = bin / 7, pw = bin - ph * 7;
-        float v = 0.f;
-        v += bin_gather<2>(f0, p.H0, p.W0, g0, pw, ph, lane);
-        v += bin_gather<2>(f1, p.H1, p.W1, g1, pw, ph, lane);
-        v += gs2[0];
-        v += gs2[1];
-        const float a = bin_gather<2>(fs, p.H0, p.W0, gs, 2 * pw, 2 * ph, lane);
-        const float bq = bin_gather<2>(fs, p.H0, p.W0, gs, 2 * pw + 1, 2 * ph, lane);
-        const float c = bin_gather<2>(fs, p.H0, p.W0, gs, 2 * pw, 2 * ph + 1, lane);
-        const float d = bin_gather<2>(fs, p.H0, p.W0, gs, 2 * pw + 1, 2 * ph + 1, lane);
-        out[bin * 64 + lane] = v + (((a + bq) + c) + d) * 0.25f;
+    const bool sem2 = gs.gw == 2 || gs.gh == 2;           // (classify guarantees gw, gh in {1, 2} and that the bands fit)
+    const BandPlans bp = plan_bands(p, g0, g1, gs, ph, lane);
+    if (wave == 0) {
+      const int ax = lane >> 5, idx = lane & 31;
+      AxisEnt e0 = bp.l0.ent, e1 = bp.l1.ent, es = bp.ls.ent;
+      const int m0 = ax ? bp.l0.fw * 64 : 64, m1 = ax ? bp.l1.fw * 64 : 64, ms = ax ? bp.ls.fw * 64 : 64;
+      e0.lo *= m0; e0.hi *= m0; e1.lo *= m1; e1.hi *= m1; es.lo *= ms; es.hi *= ms;
+      if (ax == 0) { tabx[0][idx] = e0; tabx[1][idx] = e1; tabx[2][idx] = es; }
+      else {
+        if (idx >= 2 * ph && idx < 2 * ph + 2) { taby[0][idx - 2 * ph] = e0; taby[1][idx - 2 * ph] = e1; }
+        if (idx >= 2 * ph * gs.gh && idx < (2 * ph + 2) * gs.gh) taby[2][idx - 2 * ph * gs.gh] = es;
       }
     }
+    stage_tile(sem2 ? p.x0 : p.x0sem, p.H0, p.W0, b, bp.l0, tile0, lane, wave);
+    stage_tile(p.x1, p.H1, p.W1, b, bp.l1, tile1, lane, wave);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    const v2f zero2 = {0.f, 0.f};
+    const int pw = min(2 * wave + hw, 6);                 // 7 bins of the row: one per half-wave (the 8th slot idles)
+    const bool live = 2 * wave + hw < 7;
+    v2f v = zero2;
+    v += bp.l0.empty ? zero2 : bin_lds2<2>(tile0 + cp2, tabx[0], taby[0], pw, 0);
+    v += bp.l1.empty ? zero2 : bin_lds2<2>(tile1 + cp2, tabx[1], taby[1], pw, 0);
+    v += gsum[0];
+    v += gsum[1];
+    if (sem2) {
+      __syncthreads();                                    // every wave is done with the level-0 band
+      stage_tile(p.sem, p.H0, p.W0, b, bp.ls, tile0, lane, wave);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (!bp.ls.empty) {
+        v2f a, bq, c, d;
+#define SEM4(GX_, GY_)                                                                   \
+        a = bin_lds2<GX_, GY_>(tile0 + cp2, tabx[2], taby[2], 2 * pw, 0);                \
+        bq = bin_lds2<GX_, GY_>(tile0 + cp2, tabx[2], taby[2], 2 * pw + 1, 0);           \
+        c = bin_lds2<GX_, GY_>(tile0 + cp2, tabx[2], taby[2], 2 * pw, 1);                \
+        d = bin_lds2<GX_, GY_>(tile0 + cp2, tabx[2], taby[2], 2 * pw + 1, 1);
+        if (gs.gw == 2 && gs.gh == 2) { SEM4(2, 2) } else if (gs.gw == 2) { SEM4(2, 1) } else { SEM4(1, 2) }
+#undef SEM4
+        v += (((a + bq) + c) + d) * 0.25f;
+      }
+    }
+    if (live) *reinterpret_cast<v2f*>(p.out + (long long)r * 49 * 64 + (ph * 7 + pw) * 64 + cp2) = v;
+    __syncthreads();                                      // tables / tiles are rewritten by the next job
   }
 }
 
@@ -410,7 +458,11 @@ __global__ __launch_bounds__(256) void roi_classify_kernel(RoiFeatParams p) {
   const LevelPlan l0 = plan_level(g0, 7, 2, p.H0, p.W0, TP0, lane);
   const LevelPlan l1 = plan_level(g1, 7, 2, p.H1, p.W1, TP1, lane);
   // 0: LDS path; 1: gather path (at most 2x2 semantic samples per bin); 2: one block per bin (big proposals)
-  const int cls = (sem_g1 && l0.ok && l1.ok) ? 0 : (gs.gw == gs.gh && gs.gw <= 2) ? 1 : 2;
+  int cls = (sem_g1 && l0.ok && l1.ok) ? 0 : (gs.gw <= 2 && gs.gh <= 2) ? 1 : 2;
+  if (cls == 1) {
+    for (int ph = 0; ph < 7; ++ph)
+      if (!plan_bands(p, g0, g1, gs, ph, lane).ok) cls = 2;
+  }
   if (lane == 0) {
     p.fb_flag[r] = (unsigned char)cls;
     if (cls == 2) p.fb_list[atomicAdd(&p.fb_count[0], 1)] = r;
@@ -574,7 +626,7 @@ int launch_roi_feat(const RoiFeatParams& p, int P, int r_cap, hipStream_t s, hip
     hipLaunchKernelGGL(roi_classify_kernel, dim3(cdiv(r_cap, 4)), dim3(256), 0, s, p);
     const bool fork = side && ev_fork && ev_join;
     if (fork && (hipEventRecord(ev_fork, s) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess)) return NUHTC_E_HIP;
-    hipLaunchKernelGGL(roi_feat7_gather_kernel, dim3(r_cap < 4096 ? r_cap : 4096), dim3(256), 0, fork ? side : s, p);
+    hipLaunchKernelGGL(roi_feat7_band_kernel, dim3(7 * (r_cap < 2048 ? r_cap : 2048)), dim3(256), 0, fork ? side : s, p);
     if (fork && hipEventRecord(ev_join, side) != hipSuccess) return NUHTC_E_HIP;
     hipLaunchKernelGGL(roi_feat7_lds_kernel, dim3(FB_SLOTS * 49 + r_cap), dim3(256), 0, s, p);
     if (fork && hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) return NUHTC_E_HIP;
