@@ -219,14 +219,20 @@ __device__ __forceinline__ LevelPlan plan_level(const RoiGeom& g, int P, int gsa
   return plan_band(g, P, gsamp, gsamp, H, W, tp, tp, 0, 32, lane);
 }
 
-// the block's 4 waves copy the footprint pixel by pixel (one 256-byte pixel per global->LDS instruction)
+// the block's 4 waves copy the footprint with 16-byte global->LDS loads: one instruction moves 4 pixels (4 x 256 bytes; the
+// LDS image is pixel-major, so the 64 lanes' 16-byte pieces are contiguous there, while every lane forms its own source
+// address -- pixels of different footprint rows are not adjacent in the map)
 __device__ __forceinline__ void stage_tile(const float* __restrict__ map, int H, int W, int b, const LevelPlan& lp, float* tile, int lane, int wave) {
   const int npx = lp.fh * lp.fw;
-  for (int pp = wave; pp < npx; pp += 4) {
-    const int yy = pp / lp.fw, xx = pp - yy * lp.fw;
-    const float* src = map + (((long long)b * H + lp.fy0 + yy) * W + lp.fx0 + xx) * 64 + lane;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(tile + pp * 64), 4, 0, 0);
+  const int sub = lane >> 4, c4 = (lane & 15) * 4;
+  for (int p4 = wave * 4; p4 < npx; p4 += 16) {
+    const int pp = p4 + sub;
+    if (pp < npx) {
+      const int yy = pp / lp.fw, xx = pp - yy * lp.fw;
+      const float* src = map + (((long long)b * H + lp.fy0 + yy) * W + lp.fx0 + xx) * 64 + c4;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(tile + p4 * 64), 16, 0, 0);
+    }
   }
 }
 
