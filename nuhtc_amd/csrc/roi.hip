@@ -331,32 +331,6 @@ __device__ __forceinline__ void roi_feat7_generic_block(const RoiFeatParams& p, 
   }
 }
 
-// One bin with a compile-time G x G sample grid: all 4·G² taps are loaded before the first one is consumed (roi_bin() walks
-// the samples one by one, each a round trip to L2), then accumulated in roi_bin()'s order -- identical result.
-template <int G>
-__device__ __forceinline__ float bin_gather(const float* __restrict__ fb, int H, int W, const RoiGeom& g, int pw, int ph, int lane) {
-  Tap t[G * G];
-#pragma unroll
-  for (int iy = 0; iy < G; ++iy) {
-    const float y = g.y1 + (float)ph * g.bh + ((float)iy + 0.5f) * g.bh / (float)G;
-#pragma unroll
-    for (int ix = 0; ix < G; ++ix) {
-      const float x = g.x1 + (float)pw * g.bw + ((float)ix + 0.5f) * g.bw / (float)G;
-      t[iy * G + ix] = make_tap(y, x, H, W);
-    }
-  }
-  float v[G * G][4];
-#pragma unroll
-  for (int k = 0; k < G * G; ++k) {
-    v[k][0] = fb[(long long)t[k].o00 * 64 + lane]; v[k][1] = fb[(long long)t[k].o01 * 64 + lane];
-    v[k][2] = fb[(long long)t[k].o10 * 64 + lane]; v[k][3] = fb[(long long)t[k].o11 * 64 + lane];
-  }
-  float acc = 0.f;
-#pragma unroll
-  for (int k = 0; k < G * G; ++k) acc += t[k].w1 * v[k][0] + t[k].w2 * v[k][1] + t[k].w3 * v[k][2] + t[k].w4 * v[k][3];
-  return acc / (float)(G * G);
-}
-
 // RoIs too large for the square LDS tiles but with at most 2x2 semantic samples per 14x14 bin (up to ~110 px at network scale:
 // every nucleus-sized box of a 40x slide).  Gathering their taps straight from L2 moves ~0.8 MB per RoI through the texture
 // path; instead one block takes ONE ROW of output bins: the input rows that row samples (<= BH rows of <= BW pixels) are
