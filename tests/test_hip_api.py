@@ -219,3 +219,28 @@ def test_device_contours_match_host_mirror(hip_device, model):
     assert (eng.contour_n[0, :len(shapes)].cpu().numpy() > 0).all()
     for i, m in enumerate(shapes):
         assert np.array_equal(got[i], host.trace_outer_contour(m)), i
+
+
+def test_infer_cli_writes_overlays(hip_device, tmp_path):
+    """tools/infer.py (BASELINE configs[0] plumbing): a folder of PNG tiles -> one overlay per image."""
+    import subprocess
+    import sys
+    import torch
+    from PIL import Image
+    from nuhtc_amd import synth, weights
+    tiles = synth.nuclei_tiles(4, 64, start=80)
+    (tmp_path / 'imgs').mkdir()
+    for i, t in enumerate(tiles):
+        Image.fromarray(t).save(tmp_path / 'imgs' / f't{i}.png')
+    ck = tmp_path / 'w.pth'
+    torch.save(dict(state_dict=weights.bench_state_dict(0, obj_bias=0.0)), ck)
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, 'tools/infer.py'), str(tmp_path / 'imgs'), CFG, str(ck), '--output',
+                                   str(tmp_path / 'o')], text=True)
+    assert out.count('instances') == 4
+    for i in range(4):
+        im = np.array(Image.open(tmp_path / 'o' / f't{i}.png'))
+        assert im.shape == (64, 64, 3)
+    # a CPU device is an error, not a fallback
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools/infer.py'), str(tmp_path / 'imgs'), CFG, str(ck), '--device', 'cpu'],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and 'cpu' in (r.stderr + r.stdout).lower()
