@@ -268,3 +268,52 @@ def test_consep_classes_and_batch_independence(hip_device):
 def match_instances_nc(ref, got, nc):
     pad = lambda r: ([*r[0]] + [np.zeros((0, 5), np.float32)] * (5 - nc), [*r[1]] + [[]] * (5 - nc))
     return match_instances(pad(ref), pad(got))
+
+
+def test_roi_features_all_size_classes(hip_device):
+    """7x7 RoI features across the three code paths (square LDS tiles, row bands, per-bin gathers) and the 14x14 mask features:
+    RoIs from 8 to 300 px with independent sides (so the semantic sample grid differs per axis), some hanging over the image
+    border, given to the engine through the fixed-load entry point; the oracle is fed the engine's own maps and stage RoIs.
+    Tolerance: fp32 sums in a different order (x0 + sem interpolated together, packed accumulation): 2e-4 absolute."""
+    import torch
+    from nuhtc_amd import hip, synth, weights
+    from nuhtc_amd.engine import Engine
+    from oracle import model as O
+    sd = weights.bench_state_dict(3)
+    B, n = 2, 480
+    eng = Engine(sd, device=0, max_batch=B, tile=(256, 256))
+    eng.enable_token_dump()            # (also keeps the per-stage RoI lists)
+    rng = np.random.default_rng(17)
+    wh = np.concatenate([rng.uniform(8, 44, (n // 3, 2)), rng.uniform(40, 115, (n // 3, 2)), rng.uniform(100, 300, (n // 3, 2))])
+    wh = np.stack([rng.permutation(wh) for _ in range(B)]).astype(np.float32)
+    ctr = rng.uniform(-10, 522, (B, n, 2)).astype(np.float32)
+    rois = np.clip(np.concatenate([ctr - wh / 2, ctr + wh / 2], -1), 0, 512).astype(np.float32)
+    rois[:, :, 2:] = np.maximum(rois[:, :, 2:], rois[:, :, :2] + 4)           # keep them non-degenerate
+    tiles = eng.to_device(synth.nuclei_tiles(B, 256, start=3))
+    eng.infer_fixed_load_async(tiles, torch.from_numpy(rois).to(tiles.device), 40, hip.CH_SWAP)
+    eng.check()
+    R = B * n
+    counts = eng.buffer('roi_fallback_count').cpu().numpy()
+    assert counts[0] > 20 and counts[1] > 20, counts        # big and mid-size classes are both populated
+    x = [_nchw(eng.buffer(f'x{i}')[:B]) for i in range(4)]
+    sem_feat = _nchw(eng.buffer('sem_feat')[:B])
+    r2 = eng.buffer('rois_stage2')[:R].cpu()
+    with torch.no_grad():
+        ref = O.bbox_feats(x, sem_feat, r2)
+    got = eng.buffer('bbox_feats')[:R].cpu().reshape(R, 7, 7, 64).permute(0, 3, 1, 2)
+    err = (got - ref).abs().reshape(R, -1).max(1).values
+    w = (r2[:, 3] - r2[:, 1]).numpy(); h = (r2[:, 4] - r2[:, 2]).numpy()
+    for lo, hi in ((0, 44), (44, 112), (112, 1000)):
+        sel = (np.maximum(w, h) >= lo) & (np.maximum(w, h) < hi)
+        print(f'RoIs with max side in [{lo},{hi}): {int(sel.sum())}, max |err| {float(err[torch.from_numpy(sel)].max()) if sel.any() else 0:.2e}')
+    assert float(err.max()) <= 2e-4, float(err.max())
+    # 14x14 mask features of the 40 detections per tile (boxes of all sizes as well)
+    D = int(eng.buffer('det_total').item())
+    assert D == B * 40
+    mrois = eng.buffer('mask_rois')[:D].cpu()
+    with torch.no_grad():
+        mref = O.roi_extract(x, mrois, 14, 0) + O.semantic_roi(sem_feat, mrois)
+    mgot = eng.buffer('mask_feats')[:D].cpu().reshape(D, 14, 14, 64).permute(0, 3, 1, 2)
+    ms = (mrois[:, 3:] - mrois[:, 1:3]).max(1).values
+    print(f'mask RoIs: {D}, max side {float(ms.min()):.0f}..{float(ms.max()):.0f} px, max |err| {float((mgot - mref).abs().max()):.2e}')
+    assert float((mgot - mref).abs().max()) <= 2e-4
