@@ -91,6 +91,7 @@ struct GemmParams {
   // batching (blockIdx.z)
   int batch;
   long long sA, sW, sC, sRi, sRj;
+  unsigned long long* stamps;   // dev instrumentation (-DNUHTC_GEMM_STAMPS), null otherwise
 };
 int launch_gemm(const GemmParams& p, hipStream_t s);
 

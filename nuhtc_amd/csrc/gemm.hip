@@ -8,6 +8,8 @@
 // aggregation products (nuhtc/models/roi_extractors_cus.py:228-235).
 #include <cstdlib>
 #include <mutex>
+#include <vector>
+#include <cstdio>
 
 #include "common.h"
 
@@ -72,6 +74,12 @@ __global__ __launch_bounds__(256, (MT * NT <= 3 ? 4 : 3)) void gemm_kernel(GemmP
   }
   if (m0 >= Meff) return;
 
+#ifdef NUHTC_GEMM_STAMPS   // dev instrumentation (tools/dev/stamps.py): per-wave phase times and in-loop waits
+  unsigned long long st0 = __builtin_amdgcn_s_memtime(), st1 = 0, st2 = 0, st3 = 0, st5 = 0, st6 = 0;
+#define STAMP(x_) x_
+#else
+#define STAMP(x_)
+#endif
   const float* __restrict__ A = p.A + (long long)z * p.sA;
   const float* __restrict__ Wt = p.W + (long long)z * p.sW;
   float* __restrict__ C = p.C + (long long)z * p.sC;
@@ -114,8 +122,10 @@ __global__ __launch_bounds__(256, (MT * NT <= 3 ? 4 : 3)) void gemm_kernel(GemmP
     r = r < BN ? r : BN - 1;
     w_ptr[j] = Wt + (long long)(n0 + r) * p.K + kc * 4;
   }
-  // a partial last staging pass (e.g. BN = 96 rows with 64 rows per pass) is clamped to the tile's last row on both the
-  // load and the LDS store side: the surplus threads rewrite that row with identical data, so nothing is conditional
+  // a partial last staging pass (e.g. BN = 96 rows with 64 rows per pass) belongs to whole waves (a wave stages RPP/4 = 16
+  // consecutive rows per pass): the surplus waves skip it behind a scalar branch, so no lane is ever masked and the
+  // per-CU vector-memory path, which bounds the K = 96..192 launches, carries no duplicate rows
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   int a_srow[NA], w_srow[NB];
 #pragma unroll
   for (int j = 0; j < NA; ++j) { int r = rbase + RPP * j; a_srow[j] = r < BM ? r : BM - 1; }
@@ -150,7 +160,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 3 ? 4 : 3)) void gemm_kernel(GemmP
       }                                                                                                         \
     } else if ((f_) < NA + NB) {                                                                                \
       const int j = (f_) >= NA && (f_) < NA + NB ? (f_) - NA : 0;                                               \
-      rb[j] = *reinterpret_cast<const v4f*>(w_ptr[j] + (kt_) * BK);                                             \
+      if (wave_u * (RPP / 4) + RPP * j < BN) rb[j] = *reinterpret_cast<const v4f*>(w_ptr[j] + (kt_) * BK);      \
     }                                                                                                           \
   }
 #define STORE_ONE(f_, buf_)                                                                                     \
@@ -160,7 +170,8 @@ __global__ __launch_bounds__(256, (MT * NT <= 3 ? 4 : 3)) void gemm_kernel(GemmP
       *reinterpret_cast<v4f*>(As + (buf_) * LDK * BM + a_srow[j] * LDK + kc * 4) = ra[j];                        \
     } else if ((f_) < NA + NB) {                                                                                \
       const int j = (f_) >= NA && (f_) < NA + NB ? (f_) - NA : 0;                                               \
-      *reinterpret_cast<v4f*>(Bs + (buf_) * LDK * BN + w_srow[j] * LDK + kc * 4) = rb[j];                        \
+      if (wave_u * (RPP / 4) + RPP * j < BN)                                                                    \
+        *reinterpret_cast<v4f*>(Bs + (buf_) * LDK * BN + w_srow[j] * LDK + kc * 4) = rb[j];                      \
     }                                                                                                           \
   }
 #define LOAD_TILE(kt_)                                                                                          \
@@ -219,40 +230,44 @@ __global__ __launch_bounds__(256, (MT * NT <= 3 ? 4 : 3)) void gemm_kernel(GemmP
   __syncthreads();
   LOAD_TILE(nk > 1 ? 1 : 0)
   READ_FRAGS(0, 0, fa_a, fa_b)
+  STAMP(__builtin_amdgcn_s_waitcnt(0xC07F); st1 = __builtin_amdgcn_s_memtime();)
   int kt = 0;
-  for (; kt + 1 < nk; ++kt) {       // every iteration here has a successor tile: no conditional inside the body
-    const int buf = kt & 1;
-#pragma unroll
-    for (int i = 0; i < NMF; ++i) {
-      MFMA_AT(i, fa_a, fa_b)
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int u = 0; u < FPG; ++u) {
-        const int f = i * FPG + u;
-        if (f < NRD) READ_ONE(f, buf, 1, fb_a, fb_b)
-        else STORE_ONE(f - NRD, buf ^ 1)        // waits (vmcnt) for that staging load, issued a whole k-tile ago
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): this wave's LDS writes have landed
-    __builtin_amdgcn_s_barrier();                // raw barrier: no vmcnt(0) (nothing is in flight here anyway)
-    __builtin_amdgcn_sched_barrier(0);
-    const int ktn = kt + 2 < nk ? kt + 2 : nk - 1;   // the clamped reload at the end is never used
-    CONV_BEGIN()
-#pragma unroll
-    for (int i = 0; i < NMF; ++i) {
-      MFMA_AT(i, fb_a, fb_b)
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int u = 0; u < FPG; ++u) {
-        const int f = i * FPG + u;
-        if (f < NST) LOAD_ONE(f, ktn)
-        else READ_ONE(f - NST, buf ^ 1, 0, fa_a, fa_b)
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    CONV_END()
+#define KT_BODY(LD_)                                                                                           \
+  {                                                                                                            \
+    const int buf = kt & 1;                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < NMF; ++i) {                                                          \
+      MFMA_AT(i, fa_a, fa_b)                                                                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+      _Pragma("unroll") for (int u = 0; u < FPG; ++u) {                                                        \
+        const int f = i * FPG + u;                                                                             \
+        STAMP(if (f == NRD) { unsigned long long w0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0x0070); st6 += __builtin_amdgcn_s_memtime() - w0; }) \
+        if (f < NRD) READ_ONE(f, buf, 1, fb_a, fb_b)                                                           \
+        else STORE_ONE(f - NRD, buf ^ 1) /* waits (vmcnt) for that staging load, issued a whole k-tile ago */  \
+      }                                                                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+    }                                                                                                          \
+    __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0): this wave's LDS writes have landed */                   \
+    STAMP(st5 -= __builtin_amdgcn_s_memtime();)                                                                \
+    __builtin_amdgcn_s_barrier();       /* raw barrier: no vmcnt(0) (nothing is in flight here anyway) */      \
+    STAMP(st5 += __builtin_amdgcn_s_memtime();)                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    if (LD_) CONV_BEGIN()                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < NMF; ++i) {                                                          \
+      MFMA_AT(i, fb_a, fb_b)                                                                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+      _Pragma("unroll") for (int u = 0; u < FPG; ++u) {                                                        \
+        const int f = i * FPG + u;                                                                             \
+        if (f < NST) { if (LD_) LOAD_ONE(f, kt + 2) }                                                          \
+        else READ_ONE(f - NST, buf ^ 1, 0, fa_a, fa_b)                                                         \
+      }                                                                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+    }                                                                                                          \
+    if (LD_) CONV_END()                                                                                        \
   }
+  for (; kt + 2 < nk; ++kt) KT_BODY(1)   // tiles with a successor two ahead: no conditional inside the body
+  KT_BODY(0)                             // tile nk-2 (K >= 32): nothing left to load
+  ++kt;
+#undef KT_BODY
   READ_FRAGS(kt & 1, 1, fb_a, fb_b)
   MFMA_GROUP(fa_a, fa_b)
   MFMA_GROUP(fb_a, fb_b)
@@ -275,6 +290,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 3 ? 4 : 3)) void gemm_kernel(GemmP
   // instruction covering 8 full 128-byte row segments per wave.
   const float* ri = p.cos_ri ? p.cos_ri + (long long)z * p.sRi : nullptr;
   const float* rj = p.cos_rj ? p.cos_rj + (long long)z * p.sRj : nullptr;
+  STAMP(st2 = __builtin_amdgcn_s_memtime();)
   __syncthreads();                              // every wave is done reading the k-loop's LDS tiles
   float* tb = lds + wave * (32 * 32);           // this wave's transpose tile [row][col]
   const int rr = lane >> 3, c4 = (lane & 7) * 4;
@@ -322,52 +338,84 @@ __global__ __launch_bounds__(256, (MT * NT <= 3 ? 4 : 3)) void gemm_kernel(GemmP
 #pragma unroll
       for (int j = 0; j < 4; ++j) riv[j] = ri[mrow[j]];
     }
+    // Vector-memory operations retire in issue order, so a load issued after a column tile's stores would wait for those
+    // stores to be acknowledged (thousands of cycles under load) before its data counts as landed.  Bias / column norms of
+    // every column tile are therefore loaded before the first store, and the row-dependent terms (residual, FPN parent)
+    // of tile t+1 are requested (into the registers tile t's terms just left) before tile t is stored: the wait for them
+    // never has a store ahead of it.
+    // (launch_gemm rejects bias together with the cosine epilogue and residual together with the FPN term, so one column
+    // vector per tile and one row-term array serve all epilogues)
+    const float* colp = p.act == ACT_COS ? rj : p.bias;
+    const float* rowp = p.res ? p.res : p.up;
+    const int rowld = p.res ? p.ldr : p.N;
+    unsigned rowoff[4];   // element offsets (launch_gemm checks they fit 32 bits)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rowoff[j] = (unsigned)(p.res ? drow[j] : aux[j]) * (unsigned)rowld + (unsigned)(n0 + wn * NT * 32 + c4);
+    v4f colv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      colv[t] = v4f{0.f, 0.f, 0.f, 0.f};
+      if (colp) colv[t] = *reinterpret_cast<const v4f*>(colp + n0 + (wn * NT + t) * 32 + c4);
+    }
+    v4f rowv[4];
+#define EPI_LOADS(t_)                                                                                                   \
+  if (rowp) {                                                                                                           \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                       \
+        rowv[j] = *reinterpret_cast<const v4f*>(rowp + rowoff[j] + (t_) * 32);                                          \
+  }
+    EPI_LOADS(0)
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) tb[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + i32] = acc[mi][t][r];
       const int n = n0 + (wn * NT + t) * 32 + c4;            // this lane's 4 columns
-      v4f addv[4], upv[4];
-      if (p.res) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) addv[j] = *reinterpret_cast<const v4f*>(p.res + (long long)drow[j] * p.ldr + n);
-      }
-      if (p.up) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) upv[j] = *reinterpret_cast<const v4f*>(p.up + (long long)aux[j] * p.N + n);
-      }
-      v4f bias4 = {0.f, 0.f, 0.f, 0.f}, rj4 = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias) bias4 = *reinterpret_cast<const v4f*>(p.bias + n);
-      if (rj) rj4 = *reinterpret_cast<const v4f*>(rj + n);
       // (DS operations of one wave execute in order: the reads below see the writes above, and the next sub-tile's writes
       // cannot overtake these reads)
+      v4f v[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        v4f v = *reinterpret_cast<const v4f*>(tb + (8 * j + rr) * 32 + c4) * p.alpha;
-        if (p.bias) v += bias4;
+        v[j] = *reinterpret_cast<const v4f*>(tb + (8 * j + rr) * 32 + c4) * p.alpha;
+        if (p.bias) v[j] += colv[t];
         if (p.act == ACT_RELU) {
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+          v[j].x = fmaxf(v[j].x, 0.f); v[j].y = fmaxf(v[j].y, 0.f); v[j].z = fmaxf(v[j].z, 0.f); v[j].w = fmaxf(v[j].w, 0.f);
         } else if (p.act == ACT_GELU) {
-          v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+          v[j].x = gelu_erf(v[j].x); v[j].y = gelu_erf(v[j].y); v[j].z = gelu_erf(v[j].z); v[j].w = gelu_erf(v[j].w);
         } else if (p.act == ACT_COS) {
-          v.x = fmaxf(v.x * riv[j] * rj4.x - p.cos_tau, 0.f) + p.cos_tau;
-          v.y = fmaxf(v.y * riv[j] * rj4.y - p.cos_tau, 0.f) + p.cos_tau;
-          v.z = fmaxf(v.z * riv[j] * rj4.z - p.cos_tau, 0.f) + p.cos_tau;
-          v.w = fmaxf(v.w * riv[j] * rj4.w - p.cos_tau, 0.f) + p.cos_tau;
+          v[j].x = fmaxf(v[j].x * riv[j] * colv[t].x - p.cos_tau, 0.f) + p.cos_tau;
+          v[j].y = fmaxf(v[j].y * riv[j] * colv[t].y - p.cos_tau, 0.f) + p.cos_tau;
+          v[j].z = fmaxf(v[j].z * riv[j] * colv[t].z - p.cos_tau, 0.f) + p.cos_tau;
+          v[j].w = fmaxf(v[j].w * riv[j] * colv[t].w - p.cos_tau, 0.f) + p.cos_tau;
         }
-        if (p.up) v += upv[j];
-        if (p.res) v += addv[j];
+        if (rowp) v[j] += rowv[j];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < NT) EPI_LOADS(t + 1)          // requested before this tile's stores are issued
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
         if (!((okmask >> j) & 1u)) continue;
         if (p.store == ST_DECONV2) {
           const int tap = n / p.ldc, oc = n - tap * p.ldc;     // ldc % 4 == 0: the 4 columns share one tap
-          *reinterpret_cast<v4f*>(C + ((long long)aux[j] + (tap >> 1) * (2 * p.cW) + (tap & 1)) * p.ldc + oc) = v;
+          *reinterpret_cast<v4f*>(C + ((long long)aux[j] + (tap >> 1) * (2 * p.cW) + (tap & 1)) * p.ldc + oc) = v[j];
         } else {
-          *reinterpret_cast<v4f*>(C + (long long)drow[j] * p.ldc + n) = v;
+          *reinterpret_cast<v4f*>(C + (long long)drow[j] * p.ldc + n) = v[j];
         }
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the live ranges of one column tile from overlapping the next
     }
+#undef EPI_LOADS
   }
+#ifdef NUHTC_GEMM_STAMPS
+  st3 = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0)
+  if (lane == 0 && p.stamps) {
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    unsigned long long* o = p.stamps + ((long long)blockIdx.x * 4 + wave) * 8;
+    o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = __builtin_amdgcn_s_memtime(); o[5] = hw; o[6] = st5; o[7] = st6;
+  }
+#endif
+#undef STAMP
 }
 
 // block tile 128 x (32·NT): one 32-row strip per wave, NT accumulators (128x128 with 64x64 per wave, 256x64 and BK = 32 were
@@ -399,6 +447,8 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
   if (p.M <= 0) return 0;
   if (p.K % 32 != 0 || p.N % 32 != 0) return NUHTC_E_INVALID;
   if (p.amode == A_CONV3 && (p.cC % 32 != 0 || p.K != 9 * p.cC)) return NUHTC_E_INVALID;
+  if ((p.res && p.up) || (p.act == ACT_COS && p.bias)) return NUHTC_E_INVALID;
+  if ((p.res && (long long)p.M * p.ldr >= (1ll << 31)) || (p.up && (long long)p.M * p.N >= (1ll << 31))) return NUHTC_E_INVALID;
   int nt = (p.N % 96 == 0) ? 3 : (p.N % 128 == 0) ? 4 : (p.N % 64 == 0) ? 2 : 1;
   {
     // small problems: narrower column tiles until the launch has enough workgroups for the 256 CUs (a 128x96 tile
@@ -430,9 +480,29 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
   }
   // algorithmic work of the launch (device-side row counts are not known here: the capacity M is an upper bound)
   ProfScope ps(tag, 2.0 * p.M * p.N * p.K * nb, 4.0 * nb * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N), s);
+#ifdef NUHTC_GEMM_STAMPS
+  static unsigned long long* stamp_buf = nullptr;
+  if (!stamp_buf && hipMalloc(&stamp_buf, 8ull * 8 * 4 * 65536) != hipSuccess) return NUHTC_E_HIP;
+  q.stamps = stamp_buf;
+#endif
   if (nt == 1) launch_cfg<1, 1, 4, 1>(q, cdiv(p.M, 128), s);
   else if (nt == 2) launch_cfg<1, 2, 4, 1>(q, cdiv(p.M, 128), s);
   else if (nt == 3) launch_cfg<1, 3, 4, 1>(q, cdiv(p.M, 128), s);
   else launch_cfg<1, 4, 4, 1>(q, cdiv(p.M, 128), s);
+#ifdef NUHTC_GEMM_STAMPS
+  {
+    static int cnt = 0;   // the 5th launch of the process is dumped to /tmp/stamps.txt
+    if (++cnt == 5) {
+      hipDeviceSynchronize();
+      int nb_ = cdiv(cdiv(p.M, 128), 8) * 8 * (p.N / (32 * nt));
+      if (nb_ > 65536) nb_ = 65536;
+      std::vector<unsigned long long> h((size_t)nb_ * 32);
+      hipMemcpy(h.data(), stamp_buf, h.size() * 8, hipMemcpyDeviceToHost);
+      FILE* f = fopen("/tmp/stamps.txt", "w");
+      for (int b = 0; b < nb_; ++b) for (int w = 0; w < 4; ++w) { auto* o = &h[((size_t)b * 4 + w) * 8]; fprintf(f, "%d %d %llu %llu %llu %llu %llu %llu %llu %llu\n", b, w, o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]); }
+      fclose(f);
+    }
+  }
+#endif
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
 }
