@@ -1,0 +1,96 @@
+"""BASELINE configs[2] (synthetic WSI): the canvas generator (CPU) and the slide-level path on the GPU -- tile stream,
+detection records, cross-tile merge -- including the tile-sharded layout of the multi-GPU run."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = os.path.join(ROOT, 'configs/nuhtc/htc_lite_swin_pannuke_infer.py')
+
+
+def test_canvas_is_rank_independent():
+    """Any block of tile rows renders the same pixels as the whole canvas (each rank renders only its rows)."""
+    from nuhtc_amd import synth
+    full, y0 = synth.nuclei_canvas(5)
+    assert y0 == 0 and full.shape == (synth.canvas_side(5),) * 2 + (3,) and full.dtype == np.uint8
+    for rows in ((0, 1), (1, 4), (2, 3), (4, 5)):
+        band, y = synth.nuclei_canvas(5, rows=rows)
+        assert y == rows[0] * 192 and np.array_equal(band, full[y:y + band.shape[0]])
+    par, _ = synth.nuclei_canvas_parallel(5, workers=3)
+    assert np.array_equal(par, full)
+    # H&E-like statistics: mostly background, a visible fraction of dark nuclei
+    dark = (full.astype(np.int32).sum(-1) < 400).mean()
+    assert 0.05 < dark < 0.5
+
+
+def test_canvas_tiles_view():
+    from nuhtc_amd import synth
+    from nuhtc_amd.parallel import shard_range
+    full, _ = synth.nuclei_canvas(3)
+    lo, hi = shard_range(9, 1, 2)                      # second of two ranks: tiles 5..8, tile rows 1..2
+    band, y0 = synth.nuclei_canvas(3, rows=(lo // 3, (hi - 1) // 3 + 1))
+    t = synth.CanvasTiles(band, y0, 3, lo, hi)
+    assert len(t) == hi - lo and t.shape == (hi - lo, 256, 256, 3)
+    for k in range(len(t)):
+        x, y = t.coords[k]
+        assert (x, y) == ((lo + k) % 3 * 192, (lo + k) // 3 * 192)
+        assert np.array_equal(t[k], full[y:y + 256, x:x + 256])
+    assert t[1:3].shape == (2, 256, 256, 3) and np.array_equal(t[1:3][1], t[2])
+    assert t[4:4].shape == (0, 256, 256, 3)
+
+
+@pytest.fixture(scope='module')
+def model(hip_device, tmp_path_factory):
+    import torch
+    from nuhtc_amd import weights
+    from nuhtc_amd.apis import init_detector
+    p = str(tmp_path_factory.mktemp('w') / 'w.pth')
+    torch.save(dict(state_dict=weights.bench_state_dict(0)), p)
+    m = init_detector(CFG, p, device='cuda:0', max_batch=8)
+    m.opts.update(margin=2, min_area=10, mask_nms_thr=0.05)
+    return m
+
+
+@pytest.mark.gpu
+def test_slide_merge_and_sharding(model):
+    """4x4 tiles over one canvas: the device merge equals the sequential oracle on the slide's records, removes
+    duplicates from the 64-pixel overlaps, and two 'ranks' (contiguous tile blocks, each rendering its own rows) produce
+    the same merged slide as one."""
+    from nuhtc_amd import synth, wsi
+    from nuhtc_amd.parallel import shard_range
+    from oracle.merge import merge_overlap as oracle_merge
+    G = 4
+    full, _ = synth.nuclei_canvas(G)
+    tiles = synth.CanvasTiles(full, 0, G, 0, G * G)
+    rec = wsi.infer_tiles(model, tiles, tiles.coords, 8)
+    n = len(rec['score'])
+    assert n > 50
+    kept = wsi.merge_overlap(rec, 0.05)
+    assert np.array_equal(kept, oracle_merge(rec, 0.05))
+    assert 0 < len(kept) < n                                         # overlap zones held duplicates
+    parts = []
+    for r in range(2):
+        lo, hi = shard_range(G * G, r, 2)
+        band, y0 = synth.nuclei_canvas(G, rows=(lo // G, (hi - 1) // G + 1))
+        t = synth.CanvasTiles(band, y0, G, lo, hi)
+        parts.append(wsi.infer_tiles(model, t, t.coords, 8))
+    both = {k: parts[0][k] + parts[1][k] for k in ('score', 'mask', 'box', 'label')}
+    assert len(both['score']) == n
+    kept2 = wsi.merge_overlap(both, 0.05)
+    key = lambda rc, i: (tuple(np.round(rc['box'][i], 3)), round(rc['score'][i], 6), rc['label'][i])
+    assert sorted(key(rec, i) for i in kept) == sorted(key(both, i) for i in kept2)
+
+
+@pytest.mark.gpu
+def test_bench_wsi_cli(hip_device):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools/bench_wsi.py'), '--grid', '6', '--workers', '2'],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d['tiles'] == 36 and d['n_gpus'] == 1
+    assert 0 < d['detections_after_merge'] < d['detections_after_tile_nms']
+    assert d['tiles_per_s_inference'] > 0

@@ -1,0 +1,92 @@
+"""BASELINE configs[2] end to end: a synthetic slide (G x G tiles of 256x256 at stride 192 over one S-nuclei canvas),
+the tile stream sharded in contiguous blocks across one process per GPU, one variable-length gather of the detection
+records and the cross-tile mask merge on rank 0 (tools/infer_wsi.py:460-531 + tools/nuclei_merge.py:62-174).
+
+    python tools/bench_wsi.py --grid 100                      # 10 000 tiles, one GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/bench_wsi.py --grid 100
+
+Prints one JSON line on rank 0.  Inputs start in host memory (pageable tiles, as the slide reader delivers them), so
+the inference rate here includes H2D copies, device contour tracing, D2H of the kept masks and the host-side record
+building -- it is the slide-level rate, not bench.py's HBM-resident `value`."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--grid', type=int, default=100, help='tiles per side (default 100 -> 10 000 tiles)')
+    ap.add_argument('--batch_size', type=int, default=16)
+    ap.add_argument('--depth', type=int, default=3, help='batches in flight per GPU')
+    ap.add_argument('--overlap_threshold', type=float, default=0.05)
+    ap.add_argument('--workers', type=int, default=16, help='host processes rendering the synthetic canvas')
+    ap.add_argument('--config', default=os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'configs/nuhtc/htc_lite_swin_pannuke_infer.py'))
+    ap.add_argument('--checkpoint', default=None, help='pannuke.pth when available; seeded synthetic weights otherwise')
+    args = ap.parse_args()
+    from nuhtc_amd import parallel, synth
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    rank = int(os.environ.get('RANK', 0))
+    G = args.grid
+    lo, hi = parallel.shard_range(G * G, rank, world)
+    t0 = time.perf_counter()
+    band, y0 = synth.nuclei_canvas_parallel(G, rows=(lo // G, (hi - 1) // G + 1), workers=args.workers)   # before any GPU call: the pool forks
+    t_canvas = time.perf_counter() - t0
+    tiles = synth.CanvasTiles(band, y0, G, lo, hi)
+
+    import torch
+    from nuhtc_amd import weights, wsi
+    from nuhtc_amd.apis import init_detector
+    rank, local_rank, world = parallel.init_from_env()
+    ck = args.checkpoint
+    if ck is None:
+        ck = f'/tmp/nuhtc_bench_wsi_{os.getpid()}.pth'
+        torch.save(dict(state_dict=weights.bench_state_dict(0)), ck)
+    model = init_detector(args.config, ck, device=f'cuda:{local_rank}', max_batch=args.batch_size)
+    model.opts.update(margin=2, min_area=10, mask_nms_thr=0.05)
+    dev = torch.device('cuda', local_rank)
+    wsi.infer_tiles(model, tiles[0:3 * args.batch_size], tiles.coords[:3 * args.batch_size], args.batch_size, args.depth)   # warm-up
+    sync = lambda: (torch.distributed.barrier() if world > 1 else None, torch.cuda.synchronize(dev))
+    sync()
+    t0 = time.perf_counter()
+    rec = wsi.infer_tiles(model, tiles, tiles.coords, args.batch_size, args.depth)
+    sync()
+    t_infer = time.perf_counter() - t0
+
+    # one gather of the bit-packed mask crops + scores, merge on rank 0's GPU
+    t0 = time.perf_counter()
+    mb, ma, mbits, moff = wsi.pack_masks(rec['mask'])
+    n = len(rec['score'])
+    packed = torch.from_numpy(np.concatenate([mb.astype(np.int64), ma[:, None].astype(np.int64), moff[:, None]], 1)) if n else torch.zeros((0, 6), dtype=torch.int64)
+    pk = [p.cpu().numpy() for p in parallel.gather_records(packed.to(dev))]
+    wb = [p.cpu().numpy().view(np.uint32) for p in parallel.gather_records(torch.from_numpy(mbits.view(np.int32).copy()).to(dev))]
+    sc = [p.cpu().numpy() for p in parallel.gather_records(torch.tensor(rec['score'], dtype=torch.float32).to(dev))]
+    sync()
+    t_gather = time.perf_counter() - t0
+    if rank == 0:
+        t0 = time.perf_counter()
+        base = np.cumsum([0] + [len(w) for w in wb[:-1]])
+        allp = np.concatenate(pk, 0)
+        off_all = np.concatenate([p[:, 5] + b0 for p, b0 in zip(pk, base)]) if len(allp) else np.zeros(0, np.int64)
+        kept = wsi.merge_overlap_packed(allp[:, :4], np.concatenate(sc), allp[:, 4], np.concatenate(wb), off_all, args.overlap_threshold, device=local_rank)
+        t_merge = time.perf_counter() - t0
+        total = G * G
+        print(json.dumps({
+            'workload': f'synthetic WSI, {G}x{G} tiles of 256x256 at stride 192 (BASELINE configs[2]), batch {args.batch_size}, {args.depth} batches in flight per GPU',
+            'tiles': total, 'n_gpus': world, 'infer_s': round(t_infer, 3), 'tiles_per_s_inference': round(total / t_infer, 1),
+            'gather_pack_s': round(t_gather, 3), 'merge_s': round(t_merge, 4), 'tiles_per_s_end_to_end': round(total / (t_infer + t_gather + t_merge), 1),
+            'detections_after_tile_nms': int(len(allp)), 'detections_after_merge': int(len(kept)),
+            'canvas_render_s_host': round(t_canvas, 1), 'weights': 'pannuke.pth' if args.checkpoint else 'seeded synthetic'}))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    if args.checkpoint is None and os.path.exists(ck):
+        os.remove(ck)
+
+
+if __name__ == '__main__':
+    main()
