@@ -155,6 +155,48 @@ class Engine:
             out.append(d)
         return out
 
+    def export_async(self, B, cap=None, contour_cap=256):
+        """After infer_async: enqueue, on the current stream, everything the slide loop needs from the batch -- the outer
+        contours (nuhtc_mask_contours) and a gather of the kept detections, in (tile, slot) order, into fixed-capacity
+        pinned host buffers.  No host synchronisation: every device -> host copy of a result would otherwise block
+        the submitting thread behind the other batches in flight.  Read with export_read() once the stream (or an
+        event recorded after this call) has completed."""
+        K, P, W = self.cfg.max_per_img, self.cfg.tile_h, self.cfg.tile_h * (self.cfg.tile_w // 32)
+        cap = int(cap or min(self.cfg.max_batch * K, 96 * self.cfg.max_batch))
+        ex = getattr(self, '_ex', None)
+        if ex is None or ex['cap'] != cap or ex['ccap'] != contour_cap:
+            pin = lambda *shape, dtype: torch.zeros(*shape, dtype=dtype).pin_memory()
+            ex = self._ex = dict(cap=cap, ccap=contour_cap, nk=pin(1, dtype=torch.int32), idx=pin(cap, dtype=torch.int64),
+                                 boxes=pin(cap, 5, dtype=torch.float32), labels=pin(cap, dtype=torch.int32), cn=pin(cap, dtype=torch.int32),
+                                 xy=pin(cap, contour_cap, 2, dtype=torch.int16), words=pin(cap, W, dtype=torch.int32),
+                                 ar=torch.arange(K, device=self.device, dtype=torch.int32))
+        self.contours_async(B, contour_cap)
+        kept = (self.keep[:B] != 0) & (ex['ar'][None, :] < self.counts[:B, None])
+        flat = kept.reshape(-1)
+        idx = torch.argsort((~flat).to(torch.uint8), stable=True)[:cap]       # kept detections first, (tile, slot) ascending
+        ex['nk'].copy_(flat.sum(dtype=torch.int32).reshape(1), non_blocking=True)
+        ex['idx'].copy_(idx, non_blocking=True)
+        ex['boxes'].copy_(self.boxes[:B].reshape(B * K, 5)[idx], non_blocking=True)
+        ex['labels'].copy_(self.labels[:B].reshape(B * K)[idx], non_blocking=True)
+        ex['cn'].copy_(self.contour_n[:B].reshape(B * K)[idx], non_blocking=True)
+        ex['xy'].copy_(self.contour_xy[:B].reshape(B * K, contour_cap, 2)[idx], non_blocking=True)
+        ex['words'].copy_(self.masks[:B].reshape(B * K, W)[idx], non_blocking=True)
+        ex['B'] = B
+
+    def export_read(self):
+        """-> dict of numpy views (n kept detections: tile index in the batch, slot, box+score, label, contour length
+        (<= 0: traced by the host mirror), contour vertices, bit-packed mask words) of the pinned buffers export_async
+        filled, or None when the batch held more kept detections than the buffers (use the synchronous path then).
+        The views are valid until the next export_async of this engine."""
+        ex = self._ex
+        n = int(ex['nk'][0])
+        if n > ex['cap']:
+            return None
+        K = self.cfg.max_per_img
+        idx = ex['idx'][:n].numpy()
+        return dict(n=n, tile=idx // K, slot=idx % K, boxes=ex['boxes'][:n].numpy(), labels=ex['labels'][:n].numpy(), cn=ex['cn'][:n].numpy(),
+                    xy=ex['xy'][:n].numpy(), words=ex['words'][:n].numpy().view(np.uint32))
+
     def results(self, B, with_masks=True):
         """Device outputs of the last infer -> list of (bbox_results, segm_results) exactly like the reference
         (`bbox2result` mmdet/core/bbox/transforms.py:100-117; `get_seg_masks` list-of-bool-arrays per class)."""

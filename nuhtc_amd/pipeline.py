@@ -8,6 +8,7 @@ i+1.  Measured on MI355X at B=16 (bench.py `pipelined`): 16.4 ms per batch alone
 The reference has no counterpart (its DataLoader overlaps only the CPU tile reads with the GPU, tools/infer_wsi.py:466-476)."""
 import collections
 
+import numpy as np
 import torch
 
 from .engine import Engine
@@ -26,21 +27,26 @@ class EnginePipeline:
     def depth(self):
         return len(self.engines)
 
-    def submit(self, tiles, channel_mode, tag=None):
+    def submit(self, tiles, channel_mode, tag=None, export=False):
         """Enqueue one batch (host ndarray / tensor, or device tensor) on the next slot; returns the slot's engine.
-        Blocks only when that slot still holds an uncollected batch."""
+        Blocks only when that slot still holds an uncollected batch.  export=True also enqueues Engine.export_async."""
         slot = self.next
         if any(p[0] == slot for p in self.pending):
             raise RuntimeError('pipeline slot still holds an uncollected batch: call collect() first')
         self.next = (slot + 1) % self.depth
         eng, st = self.engines[slot], self.streams[slot]
         st.wait_stream(torch.cuda.current_stream(self.device))
+        # the host source of an asynchronous H2D copy must outlive the copy: keep it (and the device batch) referenced
+        # until the batch is collected, callers may hand in temporaries
+        src = torch.from_numpy(np.ascontiguousarray(tiles)) if isinstance(tiles, np.ndarray) else tiles
         with torch.cuda.stream(st):
-            dev = eng.to_device(tiles)
+            dev = eng.to_device(src)
             B = eng.infer_async(dev, channel_mode)
+            if export:                      # contours + gather of the kept detections into pinned host buffers, still asynchronous
+                eng.export_async(B)
             ev = torch.cuda.Event()
             ev.record(st)
-        self.pending.append((slot, B, ev, tag, dev))
+        self.pending.append((slot, B, ev, tag, (dev, src)))
         return eng
 
     def full(self):

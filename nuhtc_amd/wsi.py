@@ -25,46 +25,63 @@ def tile_grid(image, patch_size=256, step_size=192):
     return np.stack(tiles), np.array(coords, np.int64)
 
 
-def _unpack(eng, B, i0, coords, P, rec):
-    """Device outputs of one finished batch -> detection records (kept detections only), in slide coordinates."""
-    rings = eng.contours(B)             # slot -> open contour in tile pixels, traced on the GPU
-    counts = eng.counts[:B].cpu().numpy()
-    boxes = eng.boxes[:B].cpu().numpy()
-    labels = eng.labels[:B].cpu().numpy()
-    keep = eng.keep[:B].cpu().numpy()
-    for b in range(B):
-        n = int(counts[b])
-        idx = np.nonzero(keep[b, :n])[0]
-        if len(idx) == 0:
-            continue
-        # class-major order like np.concatenate(result[0]) in the reference, then score order from mask_nms
-        order = idx[np.lexsort((idx, labels[b, idx]))]
-        order = order[np.argsort(boxes[b, order, 4], kind='stable')[::-1]]
-        words = eng.masks[b, torch_index(order, eng)].cpu().numpy().view(np.uint32)
-        bits = np.unpackbits(words.view(np.uint8).reshape(len(order), P, P // 8), axis=-1, bitorder='little').astype(bool)
-        ox, oy = int(coords[i0 + b][0]), int(coords[i0 + b][1])
-        for k, j in enumerate(order):
-            # a pasted mask lives inside the integer hull of its box (fcn_mask_head.py:344-412): search only there
-            bx = boxes[b, j]
-            hy0, hy1 = max(int(np.floor(bx[1])) - 1, 0), min(int(np.ceil(bx[3])) + 1, P)
-            hx0, hx1 = max(int(np.floor(bx[0])) - 1, 0), min(int(np.ceil(bx[2])) + 1, P)
-            crop = bits[k, hy0:hy1, hx0:hx1]
-            rows, cols = np.flatnonzero(crop.any(1)), np.flatnonzero(crop.any(0))
-            if len(rows) == 0:
-                continue
-            y0, y1, x0, x1 = hy0 + rows[0], hy0 + rows[-1] + 1, hx0 + cols[0], hx0 + cols[-1] + 1
-            rec['tile'].append(i0 + b)
-            rec['box'].append(boxes[b, j, :4].astype(np.float64) + np.array([ox, oy, ox, oy]))
-            rec['score'].append(float(boxes[b, j, 4]))
-            rec['label'].append(int(labels[b, j]))
-            rec['mask'].append((bits[k, y0:y1, x0:x1].copy(), ox + int(x0), oy + int(y0)))
-            c = rings[b][int(j)]
-            rec['ring'].append(np.concatenate([c, c[:1]], 0) + np.array([ox, oy], np.int64))   # mask2inst + contour_map
-
-
-def torch_index(order, eng):
+def _gather_sync(eng, B):
+    """Synchronous twin of Engine.export_async / export_read (any number of kept detections)."""
     import torch
-    return torch.from_numpy(np.ascontiguousarray(order)).to(eng.device)
+    K = eng.cfg.max_per_img
+    eng.contours_async(B)
+    counts = eng.counts[:B].cpu().numpy()
+    keep = eng.keep[:B].cpu().numpy()
+    kept = (keep != 0) & (np.arange(K)[None, :] < counts[:, None])
+    tile, slot = np.nonzero(kept)
+    sel = torch.from_numpy(np.stack([tile, slot])).to(eng.device)
+    return dict(n=len(tile), tile=tile, slot=slot, boxes=eng.boxes[sel[0], sel[1]].cpu().numpy(), labels=eng.labels[sel[0], sel[1]].cpu().numpy(),
+                cn=eng.contour_n[sel[0], sel[1]].cpu().numpy(), xy=eng.contour_xy[sel[0], sel[1]].cpu().numpy(),
+                words=eng.masks[sel[0], sel[1]].reshape(len(tile), -1).cpu().numpy().view(np.uint32))
+
+
+def _unpack(eng, B, i0, coords, P, rec, exported=False):
+    """Kept detections of one finished batch -> records in slide coordinates.  `exported`: the batch was submitted with
+    export=True (its results already sit in the engine's pinned buffers); otherwise they are fetched here."""
+    from . import contours as host
+    g = eng.export_read() if exported else None
+    if g is None:
+        g = _gather_sync(eng, B)
+    n = g['n']
+    if n == 0:
+        return
+    tile, slot, boxes, labels = g['tile'], g['slot'], g['boxes'], g['labels']
+    # per tile: class-major order like np.concatenate(result[0]) in the reference, then score order from mask_nms
+    # (stable descending sort by score of the class-major list); tiles ascending
+    cls_major = np.lexsort((slot, labels, tile))
+    order = cls_major[np.lexsort((np.arange(n), boxes[cls_major, 4], -tile[cls_major]))[::-1]]
+    W = P // 32
+    for k in order:
+        b, bx = int(tile[k]), boxes[k]
+        # a pasted mask lives inside the integer hull of its box (fcn_mask_head.py:344-412): unpack only those rows
+        hy0, hy1 = max(int(np.floor(bx[1])) - 1, 0), min(int(np.ceil(bx[3])) + 1, P)
+        hx0, hx1 = max(int(np.floor(bx[0])) - 1, 0), min(int(np.ceil(bx[2])) + 1, P)
+        if hy1 <= hy0 or hx1 <= hx0:
+            continue
+        rows_w = g['words'][k].reshape(P, W)[hy0:hy1]
+        crop = np.unpackbits(rows_w.view(np.uint8), axis=-1, bitorder='little')[:, hx0:hx1].astype(bool)
+        rows, cols = np.flatnonzero(crop.any(1)), np.flatnonzero(crop.any(0))
+        if len(rows) == 0:
+            continue
+        ox, oy = int(coords[i0 + b][0]), int(coords[i0 + b][1])
+        y0, y1, x0, x1 = hy0 + rows[0], hy0 + rows[-1] + 1, hx0 + cols[0], hx0 + cols[-1] + 1
+        rec['tile'].append(i0 + b)
+        rec['box'].append(bx[:4].astype(np.float64) + np.array([ox, oy, ox, oy]))
+        rec['score'].append(float(bx[4]))
+        rec['label'].append(int(labels[k]))
+        rec['mask'].append((crop[rows[0]:rows[-1] + 1, cols[0]:cols[-1] + 1].copy(), ox + int(x0), oy + int(y0)))
+        nv = int(g['cn'][k])
+        if nv > 0:
+            c = g['xy'][k, :nv].astype(np.int64)
+        else:   # the contour overflowed the device capacities: host mirror on the full mask
+            full = np.unpackbits(g['words'][k].reshape(P, W).view(np.uint8), axis=-1, bitorder='little').astype(bool)
+            c = host.trace_outer_contour(full)
+        rec['ring'].append(np.concatenate([c, c[:1]], 0) + np.array([ox, oy], np.int64))   # mask2inst + contour_map
 
 
 def infer_tiles(model, tiles, coords, batch_size=16, depth=3):
@@ -82,13 +99,12 @@ def infer_tiles(model, tiles, coords, batch_size=16, depth=3):
     def finish():
         eng, B, stream, i0 = pipe.collect()
         with torch.cuda.stream(stream):
-            _unpack(eng, B, i0, coords, P, rec)
-            stream.synchronize()
+            _unpack(eng, B, i0, coords, P, rec, exported=True)
 
     for i in range(0, len(tiles), batch_size):
         if pipe.full():
             finish()
-        pipe.submit(tiles[i:i + batch_size], hip.CH_SWAP, tag=i)
+        pipe.submit(tiles[i:i + batch_size], hip.CH_SWAP, tag=i, export=True)
     while pipe.pending:
         finish()
     return rec
