@@ -2,8 +2,8 @@
 GPU at once, each on its own engine (weights + workspace, 123 MB + ~0.3 GB per tile of max_batch) and its own HIP stream.
 While one batch is in the under-filled tail of a launch (stage-3/4 GEMMs, the single-block proposal / detection kernels)
 the other batch's kernels fill the idle CUs, and the host's result unpacking of batch i overlaps the GPU work of batch
-i+1.  Measured on MI355X at B=16 (bench.py `pipelined`): 16.4 ms per batch alone, ≈ 14.2 ms per batch with three in flight
-(970 -> ≈ 1130 tiles/s); with two in flight the gain depends on which hardware queues the streams land on (0-13 %).
+i+1.  Measured on MI355X at B=16 (bench.py `pipelined`): 13.4 ms per batch alone, ≈ 12.3 ms per batch with three in flight
+(1190 -> ≈ 1300 tiles/s); with two in flight the gain depends on which hardware queues the streams land on (0-13 %).
 
 The reference has no counterpart (its DataLoader overlaps only the CPU tile reads with the GPU, tools/infer_wsi.py:466-476)."""
 import collections
