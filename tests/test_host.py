@@ -137,3 +137,55 @@ def test_tile_grid_matches_reference_contract():
     tiles, coords = tile_grid(img, 256, 192)
     assert tiles.shape == (36, 256, 256, 3) and coords[:, 0].max() == 960 and (tiles[-1][40:, :, :] == 0).all()
     assert (tiles[0] == img[:256, :256]).all()
+
+
+def test_unpack_record_order_and_crops():
+    """wsi._unpack on an exported batch (no GPU: a stand-in engine): per tile the records follow the reference's order --
+    class-major concatenation, then `np.argsort(score)[::-1]` (ties in reverse class-major position, tools/infer_wsi.py:60-84)
+    -- tiles ascending, crops tight, rings closed and shifted to slide coordinates."""
+    from nuhtc_amd import wsi
+    rng = np.random.default_rng(5)
+    P, K, B = 64, 12, 4
+    tile, slot, boxes, labels, words, cn, xy = [], [], [], [], [], [], []
+    for b in range(B):
+        for j in sorted(rng.choice(K, 7, replace=False)):
+            x0, y0 = rng.integers(2, 30, 2)
+            w, h = rng.integers(3, 20, 2)
+            m = np.zeros((P, P), np.uint8)
+            m[y0:y0 + h, x0:x0 + w] = 1
+            m[y0, x0] = 0                                              # the tight crop still starts at (x0, y0): row / col stay occupied
+            tile.append(b); slot.append(j)
+            boxes.append([x0 - 0.4, y0 - 0.3, x0 + w + 0.2, y0 + h + 0.1, rng.choice([0.9, 0.8, 0.8, 0.55])])   # many score ties
+            labels.append(int(rng.integers(0, 3)))
+            words.append(np.packbits(m, axis=-1, bitorder='little').view(np.uint32).reshape(-1))
+            ring = np.array([[x0 + 1, y0], [x0 + w - 1, y0], [x0 + w - 1, y0 + h - 1], [x0, y0 + h - 1]], np.int16)
+            pad = np.zeros((8, 2), np.int16); pad[:4] = ring
+            cn.append(4); xy.append(pad)
+    g = dict(n=len(tile), tile=np.array(tile), slot=np.array(slot), boxes=np.array(boxes, np.float32), labels=np.array(labels, np.int32),
+             cn=np.array(cn, np.int32), xy=np.stack(xy), words=np.stack(words))
+
+    class Eng:
+        def export_read(self):
+            return g
+    coords = np.array([[1000 * i, 500 + i] for i in range(10)])
+    rec = dict(tile=[], box=[], score=[], label=[], mask=[], ring=[])
+    wsi._unpack(Eng(), B, 3, coords, P, rec, exported=True)
+    # reference order, tile by tile
+    want = []
+    for b in range(B):
+        idx = np.nonzero(g['tile'] == b)[0]
+        order = idx[np.lexsort((g['slot'][idx], g['labels'][idx]))]
+        order = order[np.argsort(g['boxes'][order, 4], kind='stable')[::-1]]
+        want.extend(order.tolist())
+    assert len(rec['score']) == len(want) == g['n']
+    for r, k in enumerate(want):
+        b = int(g['tile'][k])
+        ox, oy = coords[3 + b]
+        assert rec['tile'][r] == 3 + b and rec['label'][r] == g['labels'][k] and rec['score'][r] == float(g['boxes'][k, 4])
+        assert np.allclose(rec['box'][r], g['boxes'][k, :4].astype(np.float64) + [ox, oy, ox, oy])
+        full = np.unpackbits(g['words'][k].view(np.uint8).reshape(P, P // 8), axis=-1, bitorder='little').astype(bool)
+        ys, xs = np.nonzero(full)
+        crop, x0, y0 = rec['mask'][r]
+        assert (x0, y0) == (ox + xs.min(), oy + ys.min()) and np.array_equal(crop, full[ys.min():ys.max() + 1, xs.min():xs.max() + 1])
+        ring = rec['ring'][r]
+        assert ring.shape == (5, 2) and np.array_equal(ring[0], ring[-1]) and np.array_equal(ring[:4], g['xy'][k, :4].astype(np.int64) + [ox, oy])
