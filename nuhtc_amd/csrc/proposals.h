@@ -19,6 +19,8 @@ struct RpnSelParams {
   int* cand_count;      // [B][4]
   int img_h, img_w;
   float min_size;
+  unsigned* keys;       // [B][4][key_stride] scratch: the sortable score keys of one (image, level), written once and re-read by the select passes
+  int key_stride;       // >= anchors of the largest level
 };
 
 // Generic batched NMS over `n_groups` slots per image.

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(1024) void rpn_level_kernel(RpnLevels lv, RpnSelPar
   __shared__ int hist[256];
   __shared__ int sc16[17];
   __shared__ unsigned s_prefix;
-  __shared__ int s_need, s_cnt;
+  __shared__ int s_need, s_cnt, s_eq;
   const int b = blockIdx.x, L = blockIdx.y;
   const int tid = threadIdx.x;
   const int h = lv.h[L], w = lv.w[L], stride = lv.stride[L];
@@ -77,6 +77,11 @@ __global__ __launch_bounds__(1024) void rpn_level_kernel(RpnLevels lv, RpnSelPar
   };
   int nsel;
   if (n > k) {
+    // the scores sit 128 bytes apart in the head's NHWC output (3 logits of 32 channels): they are turned into sortable
+    // keys once, into a contiguous scratch row that the five passes below stream through
+    unsigned* kk = p.keys + (long long)(b * 4 + L) * p.key_stride;
+    for (int idx = tid; idx < n; idx += 1024) kk[idx] = f2key(score_of(idx));
+    __syncthreads();
     // radix select: find key T of rank k (descending) over 32-bit score keys
     unsigned prefix = 0, maskbits = 0;
     int need = k;   // still to take from the candidates matching `prefix` under `maskbits`
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(1024) void rpn_level_kernel(RpnLevels lv, RpnSelPar
       for (int i = tid; i < 256; i += 1024) hist[i] = 0;
       __syncthreads();
       for (int idx = tid; idx < n; idx += 1024) {
-        unsigned key = f2key(score_of(idx));
+        unsigned key = kk[idx];
         if ((key & maskbits) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
       }
       __syncthreads();
@@ -98,6 +103,7 @@ __global__ __launch_bounds__(1024) void rpn_level_kernel(RpnLevels lv, RpnSelPar
         if (bin < 0) bin = 0;
         s_prefix = prefix | ((unsigned)bin << shift);
         s_need = need - acc;
+        s_eq = hist[bin];               // after the last pass: how many keys equal the rank-k key
       }
       __syncthreads();
       prefix = s_prefix;
@@ -109,22 +115,32 @@ __global__ __launch_bounds__(1024) void rpn_level_kernel(RpnLevels lv, RpnSelPar
     if (tid == 0) s_cnt = 0;
     for (int i = tid; i < 4096; i += 1024) keys[i] = ~0ull;
     __syncthreads();
-    int eq_before = 0;
-    for (int base = 0; base < n; base += 1024) {
-      int idx = base + tid;
-      unsigned key = idx < n ? f2key(score_of(idx)) : 0u;
-      int is_eq = (idx < n && key == T) ? 1 : 0;
-      int tot;
-      int rank = block_exscan_1024(is_eq, sc16, &tot) + eq_before;
-      bool take = idx < n && (key > T || (is_eq && rank < need));
-      if (take) {
-        int pos = atomicAdd(&s_cnt, 1);
-        keys[pos] = ((u64)(~key) << 32) | (unsigned)idx;
+    if ((k - need) + s_eq <= 4096) {
+      // usual case: every key >= T fits the sort image; (key desc, index asc) order puts the `need` lowest-index ties
+      // first, so the list is simply cut at k after the sort
+      for (int idx = tid; idx < n; idx += 1024) {
+        const unsigned key = kk[idx];
+        if (key >= T) keys[atomicAdd(&s_cnt, 1)] = ((u64)(~key) << 32) | (unsigned)idx;
       }
-      eq_before += tot;
+    } else {
+      // a plateau of equal scores wider than the image: take exactly `need` of them by index rank (ordered block scans)
+      int eq_before = 0;
+      for (int base = 0; base < n; base += 1024) {
+        int idx = base + tid;
+        unsigned key = idx < n ? kk[idx] : 0u;
+        int is_eq = (idx < n && key == T) ? 1 : 0;
+        int tot;
+        int rank = block_exscan_1024(is_eq, sc16, &tot) + eq_before;
+        bool take = idx < n && (key > T || (is_eq && rank < need));
+        if (take) {
+          int pos = atomicAdd(&s_cnt, 1);
+          keys[pos] = ((u64)(~key) << 32) | (unsigned)idx;
+        }
+        eq_before += tot;
+      }
     }
     __syncthreads();
-    nsel = s_cnt;   // == k
+    nsel = k;       // s_cnt >= k entries were written; the sort leaves the k selected ones in front
     bitonic_sort_lds(keys, 4096);
   } else {
     // n <= nms_pre: the reference does not sort (rpn_head.py:167) -> index order
@@ -180,7 +196,9 @@ __global__ __launch_bounds__(1024) void rpn_level_kernel(RpnLevels lv, RpnSelPar
 
 int launch_rpn_select(const RpnLevels& lv, const RpnSelParams& p, int B, hipStream_t s) {
   ProfScope ps("rpn_select", 0, 0, s);
-  if (p.nms_pre > 4096 || p.slot < p.nms_pre) return NUHTC_E_INVALID;
+  if (p.nms_pre > 4096 || p.slot < p.nms_pre || !p.keys) return NUHTC_E_INVALID;
+  for (int l = 0; l < 4; ++l)
+    if (lv.h[l] * lv.w[l] * 3 > p.key_stride) return NUHTC_E_INVALID;
   hipLaunchKernelGGL(rpn_level_kernel, dim3(B, 4), dim3(1024), 0, s, lv, p);
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
 }

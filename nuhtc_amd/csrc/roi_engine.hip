@@ -11,6 +11,8 @@
 struct RoiWs {
   // RPN proposals
   float *cand_boxes, *cand_scores;
+  unsigned* rpn_keys;   // [B][4][key_stride]
+  int rpn_key_stride;
   int* cand_count;
   float *nms_sboxes;
   int *nms_src, *nms_ntotal, *nms_seg_start, *nms_seg_n, *nms_pos;
@@ -165,7 +167,9 @@ int alloc_roi_workspace(nuhtc_engine* e) {
   w->det_pow2 = pow2_ge(e->roi_cap * c.num_classes);
   if (maxc > NMS_MAX_CAP || w->det_cap > NMS_MAX_CAP) { e->err = "candidate capacity exceeds NMS_MAX_CAP (reduce rpn_nms_pre / max_cc_proposals)"; return NUHTC_E_INVALID; }
   const int nmscap = std::max(w->rpn_cap, w->det_cap);
-  if ((rc = wsa(e, &w->cand_boxes, "rpn_cand_boxes", {B, 4, w->rpn_slot, 4}, 0)) || (rc = wsa(e, &w->cand_scores, "rpn_cand_scores", {B, 4, w->rpn_slot}, 0)) ||
+  w->rpn_key_stride = round_up(e->st[0].H * e->st[0].W * 3, 64);
+  if ((rc = wsa(e, &w->rpn_keys, nullptr, {B, 4, w->rpn_key_stride}, 1)) ||
+      (rc = wsa(e, &w->cand_boxes, "rpn_cand_boxes", {B, 4, w->rpn_slot, 4}, 0)) || (rc = wsa(e, &w->cand_scores, "rpn_cand_scores", {B, 4, w->rpn_slot}, 0)) ||
       (rc = wsa(e, &w->cand_count, "rpn_cand_count", {B, 4}, 1)) || (rc = wsa(e, &w->nms_sboxes, nullptr, {B, nmscap, 4}, 0)) ||
       (rc = wsa(e, &w->nms_src, nullptr, {B, nmscap}, 1)) || (rc = wsa(e, &w->nms_ntotal, nullptr, {B}, 1)) ||
       (rc = wsa(e, &w->nms_seg_start, nullptr, {B, 4}, 1)) || (rc = wsa(e, &w->nms_seg_n, nullptr, {B, 4}, 1)) ||
@@ -239,7 +243,7 @@ int run_roi_path(nuhtc_engine* e, int B, const float* rois_fixed, int n_rois, in
     RpnLevels lv;
     for (int l = 0; l < 4; ++l) { lv.out[l] = e->rpn[l]; lv.h[l] = e->st[l].H; lv.w[l] = e->st[l].W; lv.stride[l] = 4 << l; }
     RpnSelParams sp;
-    sp.nms_pre = c.rpn_nms_pre; sp.slot = w->rpn_slot; sp.cand_boxes = w->cand_boxes; sp.cand_scores = w->cand_scores; sp.cand_count = w->cand_count;
+    sp.nms_pre = c.rpn_nms_pre; sp.slot = w->rpn_slot; sp.cand_boxes = w->cand_boxes; sp.cand_scores = w->cand_scores; sp.cand_count = w->cand_count; sp.keys = w->rpn_keys; sp.key_stride = w->rpn_key_stride;
     sp.img_h = Hn; sp.img_w = Wn; sp.min_size = c.rpn_min_bbox_size;
     // RPN selection + NMS depend only on the RPN maps: they run on the side stream, overlapping the semantic head /
     // connected-component kernels the caller's stream is still working through (fork at ev_rpn, join before build_rois)
