@@ -124,40 +124,55 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-template <int NV>   // NV = ceil(C/64) elements per lane
+template <int NV>   // NV = ceil(C/256) 16-byte chunks per lane (C % 4 == 0): one row per wave
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const int* __restrict__ src_map,
                                                         const int* __restrict__ dst_map, const float* __restrict__ g,
                                                         const float* __restrict__ b, float* __restrict__ y,
                                                         float* __restrict__ pad_dst, const float* __restrict__ pad_val,
                                                         int rows, int C) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
+  const int C4 = C >> 2;
   long long src = src_map ? src_map[row] : row;
   if (src < 0) {
     if (pad_dst) {   // padding row of a window: its QKV row is the bias
-      float* pr = pad_dst + row * 3 * C;
-      for (int c = lane; c < 3 * C; c += 64) pr[c] = pad_val[c];
+      v4f* pr = reinterpret_cast<v4f*>(pad_dst + row * 3 * C);
+      const v4f* pv = reinterpret_cast<const v4f*>(pad_val);
+      for (int c = lane; c < 3 * C4; c += 64) pr[c] = pv[c];
     } else {
-      float* yr = y + row * C;
+      v4f* yr = reinterpret_cast<v4f*>(y + row * C);
 #pragma unroll
-      for (int j = 0; j < NV; ++j) { int c = lane + 64 * j; if (c < C) yr[c] = 0.f; }
+      for (int j = 0; j < NV; ++j) { int c = lane + 64 * j; if (c < C4) yr[c] = (v4f){0.f, 0.f, 0.f, 0.f}; }
     }
     return;
   }
-  float* yr = y + (dst_map ? (long long)dst_map[row] : row) * C;
-  const float* xr = x + src * C;
-  float v[NV];
+  v4f* yr = reinterpret_cast<v4f*>(y + (dst_map ? (long long)dst_map[row] : row) * C);
+  const v4f* xr = reinterpret_cast<const v4f*>(x + src * C);
+  v4f v[NV];
   float sum = 0.f;
 #pragma unroll
-  for (int j = 0; j < NV; ++j) { int c = lane + 64 * j; v[j] = c < C ? xr[c] : 0.f; sum += v[j]; }
+  for (int j = 0; j < NV; ++j) {
+    int c = lane + 64 * j;
+    v[j] = c < C4 ? xr[c] : (v4f){0.f, 0.f, 0.f, 0.f};
+    sum += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+  }
   const float mean = wave_sum(sum) / (float)C;
   float var = 0.f;
 #pragma unroll
-  for (int j = 0; j < NV; ++j) { int c = lane + 64 * j; float d = c < C ? v[j] - mean : 0.f; var = fmaf(d, d, var); }
+  for (int j = 0; j < NV; ++j) {
+    int c = lane + 64 * j;
+    if (c < C4) {
+      v[j] -= mean;
+      var = fmaf(v[j].x, v[j].x, fmaf(v[j].y, v[j].y, fmaf(v[j].z, v[j].z, fmaf(v[j].w, v[j].w, var))));
+    }
+  }
   const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)C + 1e-5f);
+  const v4f* g4 = reinterpret_cast<const v4f*>(g);
+  const v4f* b4 = reinterpret_cast<const v4f*>(b);
 #pragma unroll
-  for (int j = 0; j < NV; ++j) { int c = lane + 64 * j; if (c < C) yr[c] = (v[j] - mean) * rstd * g[c] + b[c]; }
+  for (int j = 0; j < NV; ++j) { int c = lane + 64 * j; if (c < C4) yr[c] = v[j] * rstd * g4[c] + b4[c]; }
 }
 
 // C = 96 (stage 0, the most rows): one row per 32-lane half-wave, 24 lanes x one 16-byte load each
@@ -207,11 +222,11 @@ static int layernorm_any(const float* x, const int* src_map, const int* dst_map,
     return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
   }
   dim3 grid(cdiv(rows, 4)), blk(256);
-  int nv = cdiv(C, 64);
-  if (nv <= 2) hipLaunchKernelGGL(layernorm_kernel<2>, grid, blk, 0, s, x, src_map, dst_map, g, b, y, pad_dst, pad_val, rows, C);
+  if (C % 4 != 0) return NUHTC_E_INVALID;
+  int nv = cdiv(C, 256);
+  if (nv <= 1) hipLaunchKernelGGL(layernorm_kernel<1>, grid, blk, 0, s, x, src_map, dst_map, g, b, y, pad_dst, pad_val, rows, C);
+  else if (nv <= 2) hipLaunchKernelGGL(layernorm_kernel<2>, grid, blk, 0, s, x, src_map, dst_map, g, b, y, pad_dst, pad_val, rows, C);
   else if (nv <= 3) hipLaunchKernelGGL(layernorm_kernel<3>, grid, blk, 0, s, x, src_map, dst_map, g, b, y, pad_dst, pad_val, rows, C);
-  else if (nv <= 6) hipLaunchKernelGGL(layernorm_kernel<6>, grid, blk, 0, s, x, src_map, dst_map, g, b, y, pad_dst, pad_val, rows, C);
-  else if (nv <= 12) hipLaunchKernelGGL(layernorm_kernel<12>, grid, blk, 0, s, x, src_map, dst_map, g, b, y, pad_dst, pad_val, rows, C);
   else return NUHTC_E_INVALID;
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
 }
