@@ -394,11 +394,13 @@ __global__ __launch_bounds__(256, 3) void window_attn_mfma_kernel(const float* _
     for (int q = 0; q < 4; ++q) kf[tj][q] = kp[q];
   }
   // V operand of the second product, shared by both query tiles: lane (d = l32, half), one dword per MFMA step
+  // (registers r >= NR1 of the second key tile hold keys 49..63 in both half-waves: masked out, never loaded or multiplied)
+  constexpr int NR1 = 9;
   float vv[2][16];
 #pragma unroll
   for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < (tj ? NR1 : 16); ++r) {
       const int j = min(tj * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, WS2 - 1);
       vv[tj][r] = base[j * ld + 2 * C + l32];
     }
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(256, 3) void window_attn_mfma_kernel(const float* _
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int r = 0; r < (tj ? NR1 : 16); ++r) {
         const int jc = min(tj * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, WS2 - 1);
         bb[tj][r] = bT[jc * WS2 + i];
       }
@@ -425,7 +427,7 @@ __global__ __launch_bounds__(256, 3) void window_attn_mfma_kernel(const float* _
 #pragma unroll
       for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; r < (tj ? NR1 : 16); ++r) {
           const int jc = min(tj * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, WS2 - 1);
           bb[tj][r] += mk[jc * WS2 + i];
         }
@@ -451,7 +453,7 @@ __global__ __launch_bounds__(256, 3) void window_attn_mfma_kernel(const float* _
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int r = 0; r < (tj ? NR1 : 16); ++r) {
         const int j = tj * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         float v = st[tj][r] + bb[tj][r];
         v = j < WS2 ? v : -3.0e38f;
@@ -463,7 +465,7 @@ __global__ __launch_bounds__(256, 3) void window_attn_mfma_kernel(const float* _
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int r = 0; r < (tj ? NR1 : 16); ++r) {
         const float e = __expf(st[tj][r] - mx);
         st[tj][r] = e;
         sum += e;
@@ -477,7 +479,7 @@ __global__ __launch_bounds__(256, 3) void window_attn_mfma_kernel(const float* _
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) ot = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[tj][r], st[tj][r] * rsum, ot, 0, 0, 0);
+      for (int r = 0; r < (tj ? NR1 : 16); ++r) ot = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[tj][r], st[tj][r] * rsum, ot, 0, 0, 0);
     long long orow = (long long)win * WS2 + ti * 32 + l32;
     if (ti * 32 + l32 < WS2 && out_map) orow = out_map[orow];
     if (ti * 32 + l32 < WS2 && orow >= 0) {
