@@ -169,18 +169,20 @@ class Engine:
             ex = self._ex = dict(cap=cap, ccap=contour_cap, nk=pin(1, dtype=torch.int32), idx=pin(cap, dtype=torch.int64),
                                  boxes=pin(cap, 5, dtype=torch.float32), labels=pin(cap, dtype=torch.int32), cn=pin(cap, dtype=torch.int32),
                                  xy=pin(cap, contour_cap, 2, dtype=torch.int16), words=pin(cap, W, dtype=torch.int32),
-                                 ar=torch.arange(K, device=self.device, dtype=torch.int32))
+                                 ar=torch.arange(K, device=self.device, dtype=torch.int32),
+                                 rows=torch.arange(self.cfg.max_batch, device=self.device, dtype=torch.int32))
         self.contours_async(B, contour_cap)
-        kept = (self.keep[:B] != 0) & (ex['ar'][None, :] < self.counts[:B, None])
+        MB = self.cfg.max_batch          # the gather runs over all max_batch rows (fixed shapes); rows >= B hold stale results
+        kept = (self.keep != 0) & (ex['ar'][None, :] < self.counts[:, None]) & (ex['rows'][:, None] < B)
         flat = kept.reshape(-1)
         idx = torch.argsort((~flat).to(torch.uint8), stable=True)[:cap]       # kept detections first, (tile, slot) ascending
         ex['nk'].copy_(flat.sum(dtype=torch.int32).reshape(1), non_blocking=True)
         ex['idx'].copy_(idx, non_blocking=True)
-        ex['boxes'].copy_(self.boxes[:B].reshape(B * K, 5)[idx], non_blocking=True)
-        ex['labels'].copy_(self.labels[:B].reshape(B * K)[idx], non_blocking=True)
-        ex['cn'].copy_(self.contour_n[:B].reshape(B * K)[idx], non_blocking=True)
-        ex['xy'].copy_(self.contour_xy[:B].reshape(B * K, contour_cap, 2)[idx], non_blocking=True)
-        ex['words'].copy_(self.masks[:B].reshape(B * K, W)[idx], non_blocking=True)
+        ex['boxes'].copy_(self.boxes.reshape(MB * K, 5)[idx], non_blocking=True)
+        ex['labels'].copy_(self.labels.reshape(MB * K)[idx], non_blocking=True)
+        ex['cn'].copy_(self.contour_n.reshape(MB * K)[idx], non_blocking=True)
+        ex['xy'].copy_(self.contour_xy.reshape(MB * K, contour_cap, 2)[idx], non_blocking=True)
+        ex['words'].copy_(self.masks.reshape(MB * K, W)[idx], non_blocking=True)
         ex['B'] = B
 
     def export_read(self):

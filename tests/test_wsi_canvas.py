@@ -81,6 +81,10 @@ def test_slide_merge_and_sharding(model):
     both = {k: parts[0][k] + parts[1][k] for k in ('score', 'mask', 'box', 'label')}
     assert len(both['score']) == n
     kept2 = wsi.merge_overlap(both, 0.05)
+    # ragged batching (last batches of 1 and 2 tiles, fewer rows than the export capacity) must not change the records
+    for bs in (5, 7):
+        r2 = wsi.infer_tiles(model, tiles, tiles.coords, bs)
+        assert r2['tile'] == rec['tile'] and r2['score'] == rec['score'] and all(np.array_equal(a, b) for a, b in zip(r2['ring'], rec['ring']))
     key = lambda rc, i: (tuple(np.round(rc['box'][i], 3)), round(rc['score'][i], 6), rc['label'][i])
     assert sorted(key(rec, i) for i in kept) == sorted(key(both, i) for i in kept2)
 
