@@ -27,18 +27,60 @@ PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 
 DOMINANT = 'gemm_kernel<3>'      # all Swin-T linears (N % 96 == 0): 96 % of the path's FLOPs
 
 
-def cpu_baseline(sd, tiles, n):
+def _instance_parity(ref, got):
+    """(bbox_results, segm_results) of the oracle and of the HIP path for one tile -> instances matched one to one with
+    the same class, box IoU >= 0.999 and score within 1e-3; mask IoU of the matched pairs (BASELINE metric: per-instance IoU)."""
+    cat = lambda r: (np.concatenate(r[0], 0), np.concatenate([np.full(len(b), c) for c, b in enumerate(r[0])]), [m for cl in r[1] for m in cl])
+    (rb, rl, rm), (gb, gl, gm) = cat(ref), cat(got)
+    out = dict(ref=len(rb), hip=len(gb), matched=0, mask_iou_min=1.0, mask_iou_below=0)
+    if len(rb) == 0 or len(gb) == 0:
+        return out
+    x1 = np.maximum(rb[:, None, 0], gb[None, :, 0]); y1 = np.maximum(rb[:, None, 1], gb[None, :, 1])
+    x2 = np.minimum(rb[:, None, 2], gb[None, :, 2]); y2 = np.minimum(rb[:, None, 3], gb[None, :, 3])
+    inter = np.clip(x2 - x1, 0, None) * np.clip(y2 - y1, 0, None)
+    ar = (rb[:, 2] - rb[:, 0]) * (rb[:, 3] - rb[:, 1]); ag = (gb[:, 2] - gb[:, 0]) * (gb[:, 3] - gb[:, 1])
+    iou = inter / np.maximum(ar[:, None] + ag[None, :] - inter, 1e-12)
+    iou[rl[:, None] != gl[None, :]] = -1
+    used = set()
+    for i in np.argsort(-rb[:, 4]):
+        j = int(np.argmax(iou[i]))
+        if iou[i, j] >= 0.999 and j not in used and abs(rb[i, 4] - gb[j, 4]) < 1e-3:
+            used.add(j)
+            out['matched'] += 1
+            u = np.logical_or(rm[i], gm[j]).sum()
+            v = np.logical_and(rm[i], gm[j]).sum() / u if u else 1.0
+            out['mask_iou_min'] = min(out['mask_iou_min'], float(v))
+            out['mask_iou_below'] += int(v < 0.999)
+    return out
+
+
+def cpu_baseline(sd, tiles, n, eng=None, mode=1):
     """Oracle (CPU restatement of the reference path, oracle/model.py) timed on the host cores: reported next to
-    the GPU number, never the thing shipped."""
+    the GPU number, never the thing shipped.  With `eng`, the same sample also serves as the parity check of the run:
+    the HIP path's instances against the oracle's (north star: IoU >= 0.999 per instance, identical class ids)."""
     from oracle import model as O
     orc = O.Oracle(sd)
     threads = torch.get_num_threads()
     orc(tiles[:1], 1)  # warm-up (builds oracle/libnuhtc_oracle.so on first use)
     t0 = time.perf_counter()
-    orc(tiles[:n], 1)
+    ref = orc(tiles[:n], mode)
     dt = time.perf_counter() - t0
-    return dict(value=n / dt, unit='tiles/s', cores=threads, kind='port',
-                sample=f'{n} synthetic nuclei tiles, one batch, oracle/model.py fp32 torch-cpu + C RoIAlign/NMS, {dt:.1f} s')
+    out = dict(value=n / dt, unit='tiles/s', cores=threads, kind='port',
+               sample=f'{n} synthetic nuclei tiles, one batch, oracle/model.py fp32 torch-cpu + C RoIAlign/NMS, {dt:.1f} s')
+    if eng is not None:
+        eng.infer_async(eng.to_device(tiles[:n]), mode)
+        got = eng.results(n)
+        tot = dict(ref=0, hip=0, matched=0, mask_iou_min=1.0, mask_iou_below=0)
+        for r, g in zip(ref, got):
+            q = _instance_parity(r, g)
+            for k in ('ref', 'hip', 'matched', 'mask_iou_below'):
+                tot[k] += q[k]
+            tot['mask_iou_min'] = min(tot['mask_iou_min'], q['mask_iou_min'])
+        out['parity'] = dict(tiles=n, instances_oracle=tot['ref'], instances_hip=tot['hip'],
+                             matched_same_class_box_iou_ge_0999=tot['matched'], matched_mask_iou_min=round(tot['mask_iou_min'], 6),
+                             matched_mask_iou_below_0999=tot['mask_iou_below'],
+                             note='detections before the per-tile margin / mask-NMS filter; a matched mask below 0.999 is a pixel whose probability sits on the 0.5 threshold (fp32 summation order), an unmatched instance one at the score threshold or a rank swap in a greedy NMS where two scores agree to an ulp')
+    return out
 
 
 def main():
@@ -193,7 +235,7 @@ def main():
         if args.gemm_shapes:
             out['gemm_shapes'] = shapes
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(sd, tiles_np, min(args.cpu_tiles, B))
+            out['cpu_baseline'] = cpu_baseline(sd, tiles_np, min(args.cpu_tiles, B), eng, mode)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
