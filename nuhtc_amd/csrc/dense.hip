@@ -50,22 +50,25 @@ int launch_sem_fuse(const float* g0, const float* g1, const float* g2, const flo
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
 }
 
-// y[row] = act(dot(x[row, 0:64], w) + b);  one 16-lane group per row (float4 per lane), 4 rows per wave
+// y[row] = act(dot(x[row, 0:64], w) + b);  one 16-lane group per row (float4 per lane), 4 rows per wave.  Grid-stride over the
+// rows: with a device-side row count the launch is sized by capacity, and a workgroup per 16 rows of an (often 90 % empty)
+// capacity spent more time on early exits than on the rows.
 __global__ void conv1x1_n1_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
                                   float* __restrict__ y, long long rows, const int* __restrict__ rows_dev, int rows_mul, int sigmoid) {
-  long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
   if (rows_dev) { long long rd = (long long)(*rows_dev) * rows_mul; rows = rd < rows ? rd : rows; }
   const int l = threadIdx.x & 15;
-  float acc = 0.f;
-  if (row < rows) {
-    float4 v = reinterpret_cast<const float4*>(x)[row * 16 + l];
-    float4 ww = reinterpret_cast<const float4*>(w)[l];
-    acc = v.x * ww.x + v.y * ww.y + v.z * ww.z + v.w * ww.w;
-  }
-  acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4); acc += __shfl_xor(acc, 8);
-  if (row < rows && l == 0) {
-    float v = acc + b[0];
-    y[row] = sigmoid ? 1.0f / (1.0f + expf(-v)) : v;
+  const float4 ww = reinterpret_cast<const float4*>(w)[l];
+  const float bias = b[0];
+  const long long stride = ((long long)gridDim.x * blockDim.x) >> 4;
+  // (all 16 lanes of a row group run the same trip count, so the shuffles below always see their partners)
+  for (long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4; row < rows; row += stride) {
+    const float4 v = reinterpret_cast<const float4*>(x)[row * 16 + l];
+    float acc = v.x * ww.x + v.y * ww.y + v.z * ww.z + v.w * ww.w;
+    acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4); acc += __shfl_xor(acc, 8);
+    if (l == 0) {
+      const float u = acc + bias;
+      y[row] = sigmoid ? 1.0f / (1.0f + expf(-u)) : u;
+    }
   }
 }
 
@@ -82,7 +85,8 @@ int launch_conv1x1_n1_dev(const float* x, const float* w, const float* b, float*
                           int sigmoid, hipStream_t s) {
   long long threads = (long long)rows_cap * 16;
   if (rows_cap <= 0) return 0;
-  hipLaunchKernelGGL(conv1x1_n1_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, x, w, b, y, (long long)rows_cap,
+  const long long nb = (threads + 255) / 256;
+  hipLaunchKernelGGL(conv1x1_n1_kernel, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, s, x, w, b, y, (long long)rows_cap,
                      rows_dev, rows_mul, sigmoid);
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
 }
