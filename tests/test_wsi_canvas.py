@@ -85,6 +85,18 @@ def test_slide_merge_and_sharding(model):
     for bs in (5, 7):
         r2 = wsi.infer_tiles(model, tiles, tiles.coords, bs)
         assert r2['tile'] == rec['tile'] and r2['score'] == rec['score'] and all(np.array_equal(a, b) for a, b in zip(r2['ring'], rec['ring']))
+    # more kept detections than the export buffers hold: the synchronous gather takes over, same records
+    import nuhtc_amd.engine as E
+    orig = E.Engine.export_async
+    pipe = model.pipeline((256, 256), 3)
+    try:
+        E.Engine.export_async = lambda self, B, cap=None, contour_cap=256: orig(self, B, 8, contour_cap)
+        r3 = wsi.infer_tiles(model, tiles, tiles.coords, 8)
+    finally:
+        E.Engine.export_async = orig
+        for e in pipe.engines:
+            e._ex = None
+    assert r3['tile'] == rec['tile'] and r3['score'] == rec['score'] and all(np.array_equal(a[0], b[0]) for a, b in zip(r3['mask'], rec['mask']))
     key = lambda rc, i: (tuple(np.round(rc['box'][i], 3)), round(rc['score'][i], 6), rc['label'][i])
     assert sorted(key(rec, i) for i in kept) == sorted(key(both, i) for i in kept2)
 
