@@ -59,6 +59,22 @@ def patch_config(cfg):
     return cfg
 
 
+def set_test_scale_factor(cfg, mag):
+    """tools/infer_wsi.py:416-419 (same in infer_patch.py): every MultiScaleFlipAug step of the test pipeline gets
+    `scale_factor = float(80 / mag)` (40x -> 2.0, 20x -> 4.0)."""
+    sf = float(80 / mag)
+    pipes = []
+    if 'data' in cfg and 'test' in cfg.data and 'pipeline' in cfg.data.test:
+        pipes.append(cfg.data.test.pipeline)
+    if 'test_pipeline' in cfg:
+        pipes.append(cfg.test_pipeline)
+    for pipe in pipes:
+        for step in pipe:
+            if step.type == 'MultiScaleFlipAug':
+                step['scale_factor'] = sf
+    return sf
+
+
 def _expect(cond, what):
     if not cond:
         raise ValueError(f'unsupported config for the MI355X htc_lite_swin engine: {what}')

@@ -101,7 +101,10 @@ int launch_contours(const uint32_t* masks, const uint8_t* keep, const int32_t* c
                     int cap, int16_t* xy, int32_t* n, hipStream_t s);
 
 // ----------------------------------------------------------------------------- Swin kernels (swin.hip)
-int launch_preproc(const uint8_t* tiles, float* img, int B, int th, int tw, int swap, const float* mean_istd, hipStream_t s);
+// xtab / ytab: dev int4 per output column / row {src index 0, src index 1, weight 0, weight 1} from cv_linear_tables()
+void cv_linear_tables(int ssize, int dsize, bool horizontal, std::vector<int>& tab);
+int launch_preproc(const uint8_t* tiles, float* img, int B, int th, int tw, int Hn, int Wn, const int* xtab, const int* ytab, int swap,
+                   const float* mean_istd, hipStream_t s);
 int launch_patch_embed(const float* img, const float* w, const float* b, const float* g, const float* beta, float* tok,
                        int B, int Hn, int Wn, hipStream_t s);
 // LayerNorm of `rows` rows of C channels: dst row m reads src row src_map[m] (or m when src_map==null); src_map[m]<0 -> zeros

@@ -28,6 +28,7 @@ struct nuhtc_engine {
   bool debug_tokens = false;
   int lastB = 0;
   int Hn = 0, Wn = 0;
+  int *rs_xtab = nullptr, *rs_ytab = nullptr;   // cv2 linear-resize tables (swin.hip preproc)
 
   StageGeom st[4];
   // backbone weights

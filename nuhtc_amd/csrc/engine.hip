@@ -37,7 +37,15 @@ const char* nuhtc_last_error(const nuhtc_engine* e) { return e ? e->err.c_str() 
 int nuhtc_create(const nuhtc_config* cfg, int device, nuhtc_engine** out) {
   if (!cfg || !out) { g_create_error = "null argument"; return NUHTC_E_INVALID; }
   if (cfg->abi_version != NUHTC_ABI_VERSION) { g_create_error = "abi_version mismatch"; return NUHTC_E_INVALID; }
-  if (cfg->scale_factor != 2.0f) { g_create_error = "only scale_factor == 2.0 is supported (40x slides / PanNuke config)"; return NUHTC_E_INVALID; }
+  {
+    // network input = mmcv.rescale_size: int(size*scale + 0.5); Pad(size_divisor=32) must be a no-op and the per-axis
+    // factors new/old (mmdet Resize: w_scale, h_scale) must both equal scale_factor, i.e. scale*tile is an integer
+    const double sh = (double)cfg->tile_h * cfg->scale_factor, sw = (double)cfg->tile_w * cfg->scale_factor;
+    if (!(cfg->scale_factor >= 1.0f && cfg->scale_factor <= 8.0f) || sh != floor(sh) || sw != floor(sw) || ((long long)sh % 32) || ((long long)sw % 32)) {
+      g_create_error = "scale_factor (80/mag) must be in [1,8] and give a network input (tile*scale) that is a multiple of 32";
+      return NUHTC_E_INVALID;
+    }
+  }
   if (cfg->tile_h % 16 || cfg->tile_w % 16 || cfg->tile_h <= 0 || cfg->tile_w <= 0) { g_create_error = "tile size must be a positive multiple of 16"; return NUHTC_E_INVALID; }
   if (cfg->tile_w % 32) { g_create_error = "tile_w must be a multiple of 32 (bit-packed mask rows)"; return NUHTC_E_INVALID; }
   if (cfg->num_classes < 1 || cfg->num_classes > 16) { g_create_error = "num_classes out of range"; return NUHTC_E_INVALID; }
@@ -195,9 +203,15 @@ int nuhtc_finalize(nuhtc_engine* e) {
   HIP_CHECK(e, hipSetDevice(e->device));
   const nuhtc_config& c = e->cfg;
   const int B = c.max_batch;
-  const int Hn = 2 * c.tile_h, Wn = 2 * c.tile_w;
+  const int Hn = (int)(c.tile_h * (double)c.scale_factor + 0.5), Wn = (int)(c.tile_w * (double)c.scale_factor + 0.5);
   e->Hn = Hn; e->Wn = Wn;
   int rc;
+  {
+    std::vector<int> tx, ty;
+    cv_linear_tables(c.tile_w, Wn, true, tx);
+    cv_linear_tables(c.tile_h, Hn, false, ty);
+    if ((rc = upload_i(e, &e->rs_xtab, tx)) || (rc = upload_i(e, &e->rs_ytab, ty))) return rc;
+  }
   // ---- geometry
   for (int s = 0; s < 4; ++s) {
     StageGeom& g = e->st[s];
@@ -494,7 +508,7 @@ int nuhtc_infer(nuhtc_engine* e, const uint8_t* tiles, int B, int channel_mode, 
   e->lastB = B;
   float mi[6];
   for (int i = 0; i < 3; ++i) { mi[i] = e->cfg.mean[i]; mi[3 + i] = (float)(1.0 / (double)e->cfg.std[i]); }
-  RUN(launch_preproc(tiles, e->img, B, e->cfg.tile_h, e->cfg.tile_w, channel_mode == NUHTC_CH_SWAP, mi, s));
+  RUN(launch_preproc(tiles, e->img, B, e->cfg.tile_h, e->cfg.tile_w, e->Hn, e->Wn, e->rs_xtab, e->rs_ytab, channel_mode == NUHTC_CH_SWAP, mi, s));
   RUN(run_backbone(e, B, s));
   RUN(run_neck_heads(e, B, s));
   RUN(run_roi_path(e, B, nullptr, 0, 0, s, out));
@@ -511,7 +525,7 @@ int nuhtc_infer_fixed_load(nuhtc_engine* e, const uint8_t* tiles, int B, int cha
   e->lastB = B;
   float mi[6];
   for (int i = 0; i < 3; ++i) { mi[i] = e->cfg.mean[i]; mi[3 + i] = (float)(1.0 / (double)e->cfg.std[i]); }
-  RUN(launch_preproc(tiles, e->img, B, e->cfg.tile_h, e->cfg.tile_w, channel_mode == NUHTC_CH_SWAP, mi, s));
+  RUN(launch_preproc(tiles, e->img, B, e->cfg.tile_h, e->cfg.tile_w, e->Hn, e->Wn, e->rs_xtab, e->rs_ytab, channel_mode == NUHTC_CH_SWAP, mi, s));
   RUN(run_backbone(e, B, s));
   RUN(run_neck_heads(e, B, s));
   RUN(run_roi_path(e, B, rois, n_rois, n_dets, s, out));

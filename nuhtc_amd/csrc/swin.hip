@@ -8,51 +8,72 @@
 //   window_attn   : softmax(q·s·kᵀ + relpos_bias + shift_mask)·v per (window, head), N=49, d=32
 //                   (swin.py:79-117); one wave per (window, head), K/V staged in LDS, one query row per lane,
 //                   scores/softmax entirely in registers.
+#include <cmath>
 #include <cstdlib>
 
 #include "common.h"
 
 // ----------------------------------------------------------------------------- preproc
+// cv2.resize(INTER_LINEAR) on uint8 exactly as OpenCV's 8-bit fixed-point path computes it (the per-axis tables are
+// built on the host by cv_linear_tables() the way cv::resize builds xofs/ialpha/yofs/ibeta):
+//   horizontal  S = p[sx]*a0 + p[sx1]*a1                  (11 fractional bits, border columns: one tap at 2048)
+//   vertical    ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16)   two separately truncated products, rows clamped, weights kept
+//   dst         (v + 2) >> 2
+// then mmcv.imnormalize (channel swap, (x-mean)*(1/std)).   mmdet/datasets/pipelines/transforms.py:207-236,686-700
 struct NormConst { float mean[3]; float istd[3]; };
 
-__global__ void preproc_kernel(const uint8_t* __restrict__ tiles, float* __restrict__ img, int B, int th, int tw, int swap,
-                               NormConst nc) {
-  const int Hn = 2 * th, Wn = 2 * tw;
+void cv_linear_tables(int ssize, int dsize, bool horizontal, std::vector<int>& tab) {
+  tab.resize((size_t)dsize * 4);
+  const double scale = 1.0 / ((double)dsize / (double)ssize);
+  for (int d = 0; d < dsize; ++d) {
+    float f = (float)((d + 0.5) * scale - 0.5);
+    int s0 = (int)floorf(f);
+    f -= (float)s0;
+    if (horizontal) {   // cv::resize resets the weight at the left / right border ...
+      if (s0 < 0) { f = 0.f; s0 = 0; }
+      if (s0 >= ssize - 1) { f = 0.f; s0 = ssize - 1; }
+    }
+    const int w0 = (int)lrintf((1.f - f) * 2048.f), w1 = (int)lrintf(f * 2048.f);   // saturate_cast<short>: round half to even
+    int i0 = s0, i1 = s0 + 1;
+    i0 = i0 < 0 ? 0 : (i0 > ssize - 1 ? ssize - 1 : i0);   // ... the vertical pass only clamps the row indices
+    i1 = i1 < 0 ? 0 : (i1 > ssize - 1 ? ssize - 1 : i1);
+    tab[(size_t)d * 4 + 0] = i0; tab[(size_t)d * 4 + 1] = i1; tab[(size_t)d * 4 + 2] = w0; tab[(size_t)d * 4 + 3] = w1;
+  }
+}
+
+__global__ void preproc_kernel(const uint8_t* __restrict__ tiles, float* __restrict__ img, int B, int th, int tw, int Hn, int Wn,
+                               const int4* __restrict__ xtab, const int4* __restrict__ ytab, int swap, NormConst nc) {
   long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   long long total = (long long)B * Hn * Wn;
   if (idx >= total) return;
   int x = idx % Wn;
   int y = (idx / Wn) % Hn;
   int b = idx / ((long long)Wn * Hn);
-  // even d: taps (d/2-1, d/2) weights (1,3)/4 ; odd d: (d/2, d/2+1) weights (3,1)/4 ; edge clamped
-  int y0 = (y & 1) ? (y >> 1) : (y >> 1) - 1, wy0 = (y & 1) ? 3 : 1;
-  int x0 = (x & 1) ? (x >> 1) : (x >> 1) - 1, wx0 = (x & 1) ? 3 : 1;
-  int y1 = min(y0 + 1, th - 1), x1 = min(x0 + 1, tw - 1);
-  y0 = max(y0, 0);
-  x0 = max(x0, 0);
+  const int4 tx = xtab[x], ty = ytab[y];
   const uint8_t* t = tiles + (long long)b * th * tw * 3;
-  const uint8_t* p00 = t + ((long long)y0 * tw + x0) * 3;
-  const uint8_t* p01 = t + ((long long)y0 * tw + x1) * 3;
-  const uint8_t* p10 = t + ((long long)y1 * tw + x0) * 3;
-  const uint8_t* p11 = t + ((long long)y1 * tw + x1) * 3;
+  const uint8_t* p00 = t + ((long long)ty.x * tw + tx.x) * 3;
+  const uint8_t* p01 = t + ((long long)ty.x * tw + tx.y) * 3;
+  const uint8_t* p10 = t + ((long long)ty.y * tw + tx.x) * 3;
+  const uint8_t* p11 = t + ((long long)ty.y * tw + tx.y) * 3;
   float* o = img + idx * 3;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     int sc = swap ? 2 - c : c;
-    int h0 = p00[sc] * wx0 + p01[sc] * (4 - wx0);
-    int h1 = p10[sc] * wx0 + p11[sc] * (4 - wx0);
-    int v = h0 * wy0 + h1 * (4 - wy0);   // 16 x value
-    int u = (((v >> 2) + 2) >> 2);
+    int s0 = p00[sc] * tx.z + p01[sc] * tx.w;
+    int s1 = p10[sc] * tx.z + p11[sc] * tx.w;
+    int u = (((ty.z * (s0 >> 4)) >> 16) + ((ty.w * (s1 >> 4)) >> 16) + 2) >> 2;
     o[c] = ((float)u - nc.mean[c]) * nc.istd[c];
   }
 }
 
-int launch_preproc(const uint8_t* tiles, float* img, int B, int th, int tw, int swap, const float* mean_istd, hipStream_t s) {
-  ProfScope ps("preproc", 0, (double)B * th * tw * (3.0 + 48.0), s);
+int launch_preproc(const uint8_t* tiles, float* img, int B, int th, int tw, int Hn, int Wn, const int* xtab, const int* ytab, int swap,
+                   const float* mean_istd, hipStream_t s) {
+  ProfScope ps("preproc", 0, (double)B * (3.0 * th * tw + 12.0 * Hn * Wn), s);
   NormConst nc;
   for (int i = 0; i < 3; ++i) { nc.mean[i] = mean_istd[i]; nc.istd[i] = mean_istd[3 + i]; }
-  long long total = (long long)B * 4 * th * tw;
-  hipLaunchKernelGGL(preproc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, tiles, img, B, th, tw, swap, nc);
+  long long total = (long long)B * Hn * Wn;
+  hipLaunchKernelGGL(preproc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, tiles, img, B, th, tw, Hn, Wn,
+                     (const int4*)xtab, (const int4*)ytab, swap, nc);
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
 }
 

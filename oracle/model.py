@@ -35,30 +35,66 @@ MAX_RATIO = abs(math.log(16 / 1000))  # mmdet/core/bbox/coder/delta_xywh_bbox_co
 
 
 # ----------------------------------------------------------------------------- a1 pre-processing
-def resize2x_u8(img):
-    """cv2.resize(img, (2W,2H), INTER_LINEAR) on uint8 for an exact x2 factor.
+def _cv_linear_tables(ssize, dsize):
+    """Per-axis source offsets and 11-bit fixed-point weights exactly as cv::resize builds them for INTER_LINEAR
+    (opencv-python 4.x `imgproc/src/resize.cpp`, `cv::hal::resize` -> the `xofs/ialpha` loop): `scale = 1/(dsize/ssize)` in
+    double, `f = (float)((d+0.5)*scale-0.5)`, `s = floor(f)`, `f -= s` in float, weights
+    `saturate_cast<short>((1-f)*2048)`, `saturate_cast<short>(f*2048)` (round half to even).  Returned unclamped:
+    the two passes treat the borders differently (see `cv2_resize_linear_u8`)."""
+    scale = 1.0 / (float(dsize) / float(ssize))
+    d = np.arange(dsize, dtype=np.float64)
+    f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = (f - s.astype(np.float32)).astype(np.float32)
+    return s, f
 
-    mmdet/datasets/pipelines/transforms.py:207-236 -> mmcv.imrescale -> cv2.resize.  OpenCV's
-    fixed-point path: source coord (d+0.5)/2-0.5 edge-clamped, 11-bit weights (0.25/0.75 exact),
-    out = (((h0*w_a + h1*w_b) >> 2) ... ) == ((a + 3b + 3c + 9d) >> 2 + 2) >> 2 with weights in
-    units of 1/4.  cv2 is absent from every box we can reach: formula derived, unverified (<=1 LSB)."""
+
+def cv2_resize_linear_u8(img, dsize_w, dsize_h):
+    """cv2.resize(img, (dsize_w, dsize_h), interpolation=cv2.INTER_LINEAR) for uint8 images, bit for bit.
+
+    Reference call chain: mmdet/datasets/pipelines/transforms.py:207-236 (`Resize._resize_img`) -> mmcv.imrescale ->
+    cv2.resize(INTER_LINEAR).  OpenCV's 8-bit linear path (`resizeGeneric_<HResizeLinear<uchar,int,short,2048,...>,
+    VResizeLinear<uchar,int,short,FixedPtCast<int,uchar,22>,...>>`; the IPP branch is not taken for 8u linear unless
+    `useIPP_NotExact`) is third-party code absent from /root/reference and from this image: PARITY UNPINNED, restated
+    from the published source, pinned by the hand-worked cases in tests/test_oracle_ops.py.
+
+      horizontal: sx<0 -> (sx,fx)=(0,0); sx>=W-1 -> (W-1,0);  H[dx] = S[sx]*a0 + S[sx+1]*a1   (int32, 11 fractional bits)
+      vertical:   rows clip(sy), clip(sy+1) to [0,H-1], weights NOT reset at the border;
+                  dst = ((( b0*(H0>>4) )>>16) + (( b1*(H1>>4) )>>16) + 2) >> 2      -- two separately truncated products
+    """
     img = np.asarray(img, np.uint8)
-    H, W = img.shape[:2]
-
-    def taps(n):
-        d = np.arange(2 * n)
-        # even d -> src (d/2 - .25): neighbours (d/2-1, d/2) with weights (1,3)/4 ; odd -> (d//2, d//2+1) (3,1)/4
-        i0 = np.where(d % 2 == 0, d // 2 - 1, d // 2)
-        w0 = np.where(d % 2 == 0, 1, 3)
-        i1 = i0 + 1
-        return np.clip(i0, 0, n - 1), np.clip(i1, 0, n - 1), w0, 4 - w0
-    y0, y1, wy0, wy1 = taps(H)
-    x0, x1, wx0, wx1 = taps(W)
+    sq = img.ndim == 2
+    if sq:
+        img = img[:, :, None]
+    Hs, Ws = img.shape[:2]
+    if (dsize_w, dsize_h) == (Ws, Hs):     # cv::resize: "dsize == ssize -> src.copyTo(dst)"
+        return img[:, :, 0].copy() if sq else img.copy()
+    sx, fx = _cv_linear_tables(Ws, dsize_w)
+    lo, hi = sx < 0, sx >= Ws - 1
+    fx = np.where(lo | hi, np.float32(0), fx)
+    sx = np.where(lo, 0, np.where(hi, Ws - 1, sx))
+    a0 = np.rint((np.float32(1) - fx) * np.float32(2048)).astype(np.int32)
+    a1 = np.rint(fx * np.float32(2048)).astype(np.int32)
+    sx1 = np.minimum(sx + 1, Ws - 1)       # weight 0 wherever the clamp acts
+    sy, fy = _cv_linear_tables(Hs, dsize_h)
+    b0 = np.rint((np.float32(1) - fy) * np.float32(2048)).astype(np.int32)
+    b1 = np.rint(fy * np.float32(2048)).astype(np.int32)
+    y0 = np.clip(sy, 0, Hs - 1)
+    y1 = np.clip(sy + 1, 0, Hs - 1)
     s = img.astype(np.int32)
-    # horizontal pass (weights in quarters), then vertical, then the two rounding shifts
-    h = s[:, x0] * wx0[None, :, None] + s[:, x1] * wx1[None, :, None]
-    v = h[y0] * wy0[:, None, None] + h[y1] * wy1[:, None, None]   # = 16 * value
-    return ((((v >> 2) + 2) >> 2)).astype(np.uint8)
+    h = s[:, sx] * a0[None, :, None] + s[:, sx1] * a1[None, :, None]
+    h4 = h >> 4
+    v = ((b0[:, None, None] * h4[y0]) >> 16) + ((b1[:, None, None] * h4[y1]) >> 16)
+    out = np.clip((v + 2) >> 2, 0, 255).astype(np.uint8)
+    return out[:, :, 0] if sq else out
+
+
+def resize2x_u8(img):
+    """The x2 case of `cv2_resize_linear_u8` (tools/infer_wsi.py:416-419: scale_factor = 80/mag = 2 at 40x).  For an exact
+    x2 factor the weights are 512/1536 (2048 at the left/right border) and the formula collapses to
+    `(((a+3b)>>2) + ((3c+9d)>>2) + 2) >> 2` with (a,b) the far row's (far,near) columns and (c,d) the near row's."""
+    img = np.asarray(img)
+    return cv2_resize_linear_u8(img, 2 * img.shape[1], 2 * img.shape[0])
 
 
 def preprocess(tiles_u8, channel_mode=0, scale=2):
@@ -68,12 +104,11 @@ def preprocess(tiles_u8, channel_mode=0, scale=2):
                      caller passes **RGB** tiles, no swap.
     channel_mode 1 = `tools/infer_wsi.py` (RGB ndarray treated as BGR and swapped):
                      caller passes RGB tiles, channels are reversed before normalisation."""
-    assert scale == 2
     out = []
     mean = np.array(MEAN, np.float32)
     istd = (1.0 / np.array(STD, np.float64)).astype(np.float32) if False else None
     for t in np.asarray(tiles_u8):
-        r = resize2x_u8(t).astype(np.float32)
+        r = cv2_resize_linear_u8(t, int(t.shape[1] * scale), int(t.shape[0] * scale)).astype(np.float32)
         if channel_mode == 1:
             r = r[:, :, ::-1]
         # mmcv.imnormalize: cv2.subtract(img, mean) ; cv2.multiply(img, 1/std) with float64 scalars on f32 data
@@ -528,7 +563,7 @@ class Oracle:
 
     def __call__(self, tiles_u8, channel_mode=0, **kw):
         tiles_u8 = np.asarray(tiles_u8)
-        return self.forward_tensor(preprocess(tiles_u8, channel_mode), tiles_u8.shape[1:3], **kw)
+        return self.forward_tensor(preprocess(tiles_u8, channel_mode, self.scale), tiles_u8.shape[1:3], **kw)
 
 
 # ----------------------------------------------------------------------------- a27-a28 per-tile filter + mask-NMS

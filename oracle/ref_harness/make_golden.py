@@ -40,6 +40,121 @@ def calibrate(seed, tiles, channel_mode):
     return cls_add, np.float32(sem_bias)
 
 
+def five_class_head(seed, tiles, channel_mode, sem_bias, target_dets=60):
+    """Head weights for the five-class case.  The seeded N(0, sigma) classifier rows are nearly parallel to nothing in
+    particular, so class logits hardly vary from RoI to RoI and at most two classes ever pass the 0.35 threshold.  Here the
+    five class rows of every stage's NormedLinear are set to principal directions of that stage's (normalised) fc features
+    over the RoIs of these tiles -- stage 1/2 directions matched (with sign) to the stage-0 ones by correlation, so the three
+    stages vote alike -- the class biases centre each class logit, and one objectness offset is bisected (on the oracle's
+    detection post-processing) to ~target_dets detections per tile.  Returns {name: tensor} overrides, stored in the fixture."""
+    import torch.nn.functional as F
+    sd = weights.seeded_state_dict(seed)
+    sd['roi_head.semantic_head.conv_logits.bias'] = torch.tensor([float(sem_bias)])
+    _, it = O.Oracle(sd)(tiles, channel_mode, keep=True)
+    feats = []
+    for k in range(3):
+        p = f'roi_head.bbox_head.{k}.'
+        f = O.bbox_feats(it['x'], it['sem_feat'], it['stage_rois'][k]).flatten(1)
+        h = F.relu(F.linear(f, sd[p + 'shared_fcs.0.weight'], sd[p + 'shared_fcs.0.bias']))
+        h = F.relu(F.linear(h, sd[p + 'shared_fcs.1.weight'], sd[p + 'shared_fcs.1.bias']))
+        feats.append(h)
+
+    def pcs(h, n):
+        xh = h / (h.norm(dim=1, keepdim=True) + 1e-6)
+        _, _, vt = torch.linalg.svd(xh - xh.mean(0, keepdim=True), full_matrices=False)
+        return xh, vt[:n]
+    xh0, v0 = pcs(feats[0], 5)
+    s0 = (xh0 @ v0.T).numpy()
+    over = {}
+    rows = [v0]
+    for k in (1, 2):
+        # stage-k directions: ridge regression of the stage-0 class scores on the stage-k features (the best linear
+        # agreement between the stages' votes)
+        xh, _ = pcs(feats[k], 1)
+        xc = (xh - xh.mean(0, keepdim=True)).double()
+        gram = xc.T @ xc
+        lam = 1e-3 * float(torch.trace(gram)) / gram.shape[0]
+        u = torch.linalg.solve(gram + lam * torch.eye(gram.shape[0], dtype=torch.float64), xc.T @ torch.from_numpy(s0).double())
+        u = (u / u.norm(dim=0, keepdim=True)).T.float()
+        for c in range(5):
+            print('stage', k, 'class', c, 'corr with stage 0', round(float(np.corrcoef(s0[:, c], (xh @ u[c]).numpy())[0, 1]), 3))
+        rows.append(u)
+    # equal spread for the five classes (else the first principal direction wins almost every RoI): mix each row with the
+    # mean feature direction, which lowers the spread of cos(x, row) without changing which RoIs rank high
+    for k in range(3):
+        xh = feats[k] / (feats[k].norm(dim=1, keepdim=True) + 1e-6)
+        m = xh.mean(0)
+        m = m / m.norm()
+
+        def spread(row, a):
+            w = a * m + row
+            return float((xh @ (w / w.norm())).std())
+        target = min(spread(r, 0.0) for r in rows[k])
+        mixed = []
+        for r in rows[k]:
+            lo, hi = 0.0, 50.0
+            for _ in range(40):
+                mid = 0.5 * (lo + hi)
+                if spread(r, mid) > target:
+                    lo = mid
+                else:
+                    hi = mid
+            mixed.append(0.5 * (lo + hi) * m + r)
+        rows[k] = torch.stack(mixed)
+    for k in range(3):
+        p = f'roi_head.bbox_head.{k}.'
+        w = sd[p + 'fc_cls.weight'].clone()
+        w[:5] = rows[k]
+        b = sd[p + 'fc_cls.bias'].clone()
+        sd[p + 'fc_cls.weight'] = w
+        cls, _ = O.bbox_head(sd, k, O.bbox_feats(it['x'], it['sem_feat'], it['stage_rois'][k]))
+        b[:5] = b[:5] - cls[:, :5].mean(0)
+        over[p + 'fc_cls.weight'] = w
+        over[p + 'fc_cls.bias'] = b
+        sd[p + 'fc_cls.bias'] = b
+    stage = [O.bbox_head(sd, k, O.bbox_feats(it['x'], it['sem_feat'], it['stage_rois'][k])) for k in range(3)]
+    cls_mean = sum(c for c, _ in stage) / 3.0
+    rois, reg = it['stage_rois'][2], stage[2][1]
+    img_hw = tuple(O.preprocess(tiles[:1], channel_mode).shape[-2:])
+    nb = len(tiles)
+
+    def per_class(db, off):
+        c = cls_mean.clone()
+        c[:, :5] += db
+        c[:, 5] += off
+        lab = torch.cat([O.detect_post(rois[rois[:, 0] == i, 1:], c[rois[:, 0] == i], reg[rois[:, 0] == i], img_hw, 2.0)[1]
+                         for i in range(nb)])
+        return np.bincount(lab.numpy(), minlength=5).astype(np.float64)
+
+    def bisect(db):
+        lo, hi = -12.0, 12.0
+        for _ in range(20):
+            mid = 0.5 * (lo + hi)
+            if per_class(db, mid).sum() > target_dets * nb:
+                hi = mid
+            else:
+                lo = mid
+        return 0.5 * (lo + hi)
+    # balance the classes: one objectness offset sets the total (~target_dets per tile), per-class bias shifts even out
+    # the detections per class; alternate a few times
+    db = torch.zeros(5)
+    for it_ in range(40):
+        off = bisect(db)
+        n = per_class(db, off)
+        print('balance', it_, 'offset', round(off, 3), 'dets per class', n)
+        db = db + torch.from_numpy((0.3 * 0.93 ** it_) * np.clip(np.log((n.mean() + 1) / (n + 1)), -1, 1)).float()
+    db = torch.from_numpy(np.round(db.numpy(), 3))
+    off = np.float32(round(bisect(db), 3))
+    for k in range(3):
+        p = f'roi_head.bbox_head.{k}.fc_cls.bias'
+        over[p] = over[p].clone()
+        over[p][:5] += db
+        over[p][5] += float(off)
+    count = lambda o: per_class(db, o).sum() / nb
+    print('five-class head: objectness offset', off, 'dets/tile', count(float(off)))
+    return over
+
+
 def sub(t):
     """subsample + checksums of a tensor (shared with tests/golden_util.py)."""
     a = t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
@@ -54,12 +169,17 @@ def put(store, name, t):
         store[f'{name}.{k}'] = v
 
 
-def run_case(name, tile_size, n_tiles, seed, channel_mode):
+def run_case(name, tile_size, n_tiles, seed, channel_mode, five=False):
     model, cfg = mmcv_stub.build_reference_detector(CFG)
     tiles = synth.nuclei_tiles(n_tiles, tile_size, start=100 * seed)
     CLS_BIAS_ADD, sem_bias = calibrate(seed, tiles, channel_mode)
     sd = weights.seeded_state_dict(seed)
     sd['roi_head.semantic_head.conv_logits.bias'] = torch.tensor([float(sem_bias)])
+    overrides = {}
+    if five:
+        CLS_BIAS_ADD = np.zeros(7, np.float32)
+        overrides = five_class_head(seed, tiles, channel_mode, sem_bias)
+        sd.update(overrides)
     for k in range(3):
         sd[f'roi_head.bbox_head.{k}.fc_cls.bias'] = sd[f'roi_head.bbox_head.{k}.fc_cls.bias'] + torch.from_numpy(CLS_BIAS_ADD)
     missing, unexpected = model.load_state_dict(sd, strict=False)
@@ -113,6 +233,8 @@ def run_case(name, tile_size, n_tiles, seed, channel_mode):
 
     g = dict(tiles=tiles, seed=np.array(seed), channel_mode=np.array(channel_mode), sem_bias=np.array(sem_bias, np.float32),
              cls_bias_add=np.array(CLS_BIAS_ADD, np.float32))
+    for k, v in overrides.items():
+        g['override.' + k] = v.numpy()
     put(g, 'embed', cap['embed'][0][1][0])
     for s in range(4):
         for b in range(O.DEPTHS[s]):
@@ -156,6 +278,8 @@ CASES = [
     ('small_b2', 64, 2, 0, 0),
     ('small_wsi_b3', 96, 3, 1, 1),
     ('full_b1', 256, 1, 2, 0),
+    # all five classes live, ~60 detections per 256x256 tile (a realistic PanNuke load), WSI channel mode, batch of 2
+    ('five_b2', 256, 2, 3, 1, True),
 ]
 
 if __name__ == '__main__':

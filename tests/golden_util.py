@@ -32,6 +32,9 @@ def seeded_sd(g):
     from nuhtc_amd import weights
     sd = weights.seeded_state_dict(int(g['seed']))
     sd['roi_head.semantic_head.conv_logits.bias'] = torch.tensor([float(g['sem_bias'])])
+    for key in g.files:                                   # tensors the generator replaced (five-class head)
+        if key.startswith('override.'):
+            sd[key[len('override.'):]] = torch.from_numpy(g[key])
     for k in range(3):
         sd[f'roi_head.bbox_head.{k}.fc_cls.bias'] = sd[f'roi_head.bbox_head.{k}.fc_cls.bias'] + torch.from_numpy(g['cls_bias_add'])
     return sd

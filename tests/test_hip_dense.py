@@ -58,7 +58,7 @@ def test_gemm_op_shapes(hip_device):
     assert not errs, '\n'.join(errs)
 
 
-@pytest.mark.parametrize('case', ['small_b2', 'small_wsi_b3', 'full_b1'])
+@pytest.mark.parametrize('case', ['small_b2', 'small_wsi_b3', 'full_b1', 'five_b2'])
 def test_dense_stages_vs_oracle_and_golden(hip_device, case):
     from oracle import model as O
     g = G.load(case)

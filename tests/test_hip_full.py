@@ -84,7 +84,7 @@ def _nchw(t):
     return t.permute(0, 3, 1, 2).contiguous().cpu()
 
 
-@pytest.mark.parametrize('case', ['small_b2', 'small_wsi_b3', 'full_b1'])
+@pytest.mark.parametrize('case', ['small_b2', 'small_wsi_b3', 'full_b1', 'five_b2'])
 def test_full_path_vs_oracle_and_golden(hip_device, case):
     """Stage-by-stage parity with the oracle fed the engine's own inputs of that stage (so rounding differences do
     not compound through the thresholded / greedy steps), then end-to-end agreement with oracle and reference golden."""

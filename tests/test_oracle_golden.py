@@ -7,7 +7,7 @@ import torch
 import golden_util as G
 from oracle import model as O
 
-CASES = ['small_b2', 'small_wsi_b3', 'full_b1']
+CASES = ['small_b2', 'small_wsi_b3', 'full_b1', 'five_b2']
 
 
 @pytest.fixture(scope='module', params=CASES)

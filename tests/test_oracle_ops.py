@@ -102,6 +102,70 @@ def test_resize2x_properties():
     assert np.abs(out.astype(np.float32) - f).max() <= 1.0
 
 
+def _cv_resize_scalar(img, dw, dh):
+    """Literal scalar transcription of OpenCV's 8-bit INTER_LINEAR loops (one channel), independent of the vectorised
+    oracle: table loop of cv::resize, HResizeLinear, VResizeLinear<uchar,int,short,FixedPtCast<int,uchar,22>>."""
+    H, W = img.shape
+    sx_, a_ = [], []
+    scale_x, scale_y = 1.0 / (dw / W), 1.0 / (dh / H)
+    for dx in range(dw):
+        fx = np.float32((dx + 0.5) * scale_x - 0.5)
+        sx = int(np.floor(fx))
+        fx = np.float32(fx - np.float32(sx))
+        if sx < 0:
+            fx, sx = np.float32(0), 0
+        if sx >= W - 1:
+            fx, sx = np.float32(0), W - 1
+        sx_.append(sx)
+        a_.append((int(np.rint((np.float32(1) - fx) * np.float32(2048))), int(np.rint(fx * np.float32(2048)))))
+    out = np.zeros((dh, dw), np.uint8)
+    for dy in range(dh):
+        fy = np.float32((dy + 0.5) * scale_y - 0.5)
+        sy = int(np.floor(fy))
+        fy = np.float32(fy - np.float32(sy))
+        b0, b1 = int(np.rint((np.float32(1) - fy) * np.float32(2048))), int(np.rint(fy * np.float32(2048)))
+        r0, r1 = min(max(sy, 0), H - 1), min(max(sy + 1, 0), H - 1)
+        for dx in range(dw):
+            sx = sx_[dx]
+            sx1 = min(sx + 1, W - 1)
+            S0 = int(img[r0, sx]) * a_[dx][0] + int(img[r0, sx1]) * a_[dx][1]
+            S1 = int(img[r1, sx]) * a_[dx][0] + int(img[r1, sx1]) * a_[dx][1]
+            out[dy, dx] = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2
+    return out
+
+
+def test_resize_cv2_fixed_point_known_answers():
+    # 1) the two vertical products are truncated separately: rows (1,2) over (1,0), output pixel (2,2) takes
+    #    far row (1,2) weights (1,3)/4 -> (1+6)>>2 = 1, near row (1,0) weights (3,9)/4 -> 3>>2 = 0, (1+0+2)>>2 = 0
+    #    (summing the four taps first would give ((10>>2)+2)>>2 = 1)
+    img = np.array([[1, 2, 0], [1, 0, 0], [0, 0, 0]], np.uint8)
+    out = O.resize2x_u8(img)
+    assert out[2, 2] == 0
+    # 2) hand-worked interior pixel: a,b = 10,200 (far row), c,d = 90,35 (near row), even/even output
+    img = np.array([[10, 200], [90, 35]], np.uint8)
+    out = O.resize2x_u8(img)
+    #    out[2,2]: far row = row 0, far col = col 0:  ((10+600)>>2) + ((270+315)>>2) + 2 >> 2 = (152+146+2)>>2 = 75
+    assert out[2, 2] == 75
+    #    out[1,1] (odd/odd): far row = row 1 (weights swap): rows (0: near, 1: far), cols (0 near, 1 far)
+    #    near row 0: 3*(3*10+200)=690>>2=172 ; far row 1: (3*90+35)=305>>2=76 ; (172+76+2)>>2 = 62
+    assert out[1, 1] == 62
+    # 3) left/right border columns take one source column at weight 2048 (fx reset to 0) ...
+    #    (H>>4 = 128*v there, so the far row contributes exactly v and the near row exactly 3v)
+    assert out[2, 0] == (10 + 3 * 90 + 2) >> 2 == 70
+    assert out[2, 3] == (200 + 3 * 35 + 2) >> 2 == 76
+    #    ... while the top/bottom border rows keep weights (1,3)/4 on the same clamped row: (v>>2) + (3v>>2)
+    assert out[0, 0] == 10 and out[3, 3] == 35
+    assert out[0, 2] == ((((10 + 600) >> 2) + ((3 * (10 + 600)) >> 2) + 2) >> 2)   # 152 + 457 + 2 >> 2 = 152
+    # 4) vectorised oracle == literal scalar loops, x2 / x4 / non-integer factors, odd sizes
+    rng = np.random.default_rng(5)
+    for (h, w, dh, dw) in [(7, 9, 14, 18), (5, 6, 20, 24), (9, 7, 13, 10), (8, 8, 3, 5), (6, 6, 6, 6)]:
+        a = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        np.testing.assert_array_equal(O.cv2_resize_linear_u8(a, dw, dh), _cv_resize_scalar(a, dw, dh))
+    a3 = rng.integers(0, 256, (6, 5, 3), dtype=np.uint8)
+    for c in range(3):
+        np.testing.assert_array_equal(O.cv2_resize_linear_u8(a3, 20, 24)[:, :, c], _cv_resize_scalar(a3[:, :, c], 20, 24))
+
+
 def test_cc_proposals_matches_scipy_pipeline():
     # the "watershed" step reduces to hole-filled 4-connected components (SURVEY A.7): check against the literal
     # scipy sequence of the reference (fill -> EDT -> label(dist>0.25)) on a random blob mask

@@ -43,8 +43,6 @@ def main():
     from PIL import Image, ImageDraw
     from nuhtc_amd import evaluation, outputs
     from nuhtc_amd.apis import concat_results, inference_detector, init_detector
-    if a.mag != 40:
-        raise SystemExit('only --mag 40 (scale_factor 80/mag = 2.0) is supported by the engine')
     with open(a.csv, newline='') as f:
         rows = list(csv.DictReader(f))
     if rows and a.image_col not in rows[0]:
@@ -54,7 +52,10 @@ def main():
         rng = np.random.default_rng()
         paths = [paths[i] for i in rng.permutation(len(paths))[:min(a.vis_samples, len(paths))]]
         os.makedirs(a.vis_dir, exist_ok=True)
-    model = init_detector(a.config, a.checkpoint, device=a.device, max_batch=a.batch_size)
+    from nuhtc_amd.config import Config, set_test_scale_factor
+    cfg = Config.fromfile(a.config)
+    set_test_scale_factor(cfg, a.mag)                  # reference infer_patch.py: scale_factor = 80 / mag
+    model = init_detector(cfg, a.checkpoint, device=a.device, max_batch=a.batch_size)
     model.CLASSES = ('T', 'I', 'C', 'D', 'E')[:model.opts['num_classes']]
     doc = {'images': [], 'annotations': [], 'categories': [{'id': 0, 'name': 'nucleus', 'supercategory': 'nucleus'}]}
     nuclei_id = vis_count = 0

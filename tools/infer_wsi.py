@@ -53,8 +53,6 @@ def main():
     from nuhtc_amd import contours, parallel, wsi
     from nuhtc_amd.apis import init_detector
     rank, local_rank, world = parallel.init_from_env()
-    if args.mag != 40:
-        raise SystemExit('only --mag 40 (scale_factor 80/mag = 2.0) is supported by the engine')
     if args.source.endswith('.npz'):
         z = np.load(args.source)
         tiles, coords = z['tiles'], z['coords']
@@ -68,7 +66,12 @@ def main():
     else:
         tiles, coords = wsi.tile_grid(np.load(args.source), args.patch_size, args.step_size)
     lo, hi = parallel.shard_range(len(tiles), rank, world)
-    model = init_detector(args.config, args.checkpoint, device=f'cuda:{local_rank}' if world > 1 else args.device, max_batch=args.batch_size)
+    from nuhtc_amd.config import Config, set_test_scale_factor
+    cfg = Config.fromfile(args.config)
+    sf = set_test_scale_factor(cfg, args.mag)          # reference :416-419: scale_factor = 80 / mag
+    if rank == 0:
+        print('scale_factor: ', sf)
+    model = init_detector(cfg, args.checkpoint, device=f'cuda:{local_rank}' if world > 1 else args.device, max_batch=args.batch_size)
     model.CLASSES = ('T', 'I', 'C', 'D', 'E')[:model.opts['num_classes']]
     model.opts.update(margin=args.margin, min_area=args.min_area, mask_nms_thr=0.05)
     rec = wsi.infer_tiles(model, tiles[lo:hi], coords[lo:hi], args.batch_size)
