@@ -52,10 +52,10 @@ typedef struct nuhtc_engine nuhtc_engine;
  * configs/nuhtc/htc_lite_swin_pytorch_fpn_{PanNuke,CoNSeP,...}_seasaw_CAS.py that the path reads. */
 typedef struct nuhtc_config {
   int32_t abi_version;       /* = NUHTC_ABI_VERSION */
-  int32_t num_classes;       /* 5 (PanNuke) / 4 (CoNSeP) ...                      config:5   */
+  int32_t num_classes;       /* 5 (PanNuke) / 4 (CoNSeP) ... ; 1..14              config:5   */
   int32_t tile_h, tile_w;    /* input tile size in pixels (256)                              */
   int32_t max_batch;         /* workspace is sized for this many tiles per nuhtc_infer call  */
-  float   scale_factor;      /* 2.0 : MultiScaleFlipAug(scale_factor) / 80/mag    config:6   */
+  float   scale_factor;      /* 2.0 : MultiScaleFlipAug(scale_factor) = 80/mag (tools/infer_wsi.py:416-419); 1..8, tile*scale a multiple of 32 */
   float   mean[3], std[3];   /* img_norm_cfg                                     config:8   */
   /* test_cfg.rpn                                                                config:256-261 */
   int32_t rpn_nms_pre;       /* 3000 */
@@ -88,7 +88,9 @@ void nuhtc_destroy(nuhtc_engine* e);
 const char* nuhtc_last_error(const nuhtc_engine* e);
 
 /* Uploads one tensor of the mmdet state_dict (SURVEY Appendix B naming, fp32, host memory, C order).
- * Replaces `load_checkpoint(model, ckpt)` (nuhtc/apis/inference.py:44); unknown names are rejected. */
+ * Replaces `load_checkpoint(model, ckpt)` (nuhtc/apis/inference.py:44).  Names outside the path's schema are rejected with
+ * NUHTC_E_NOTFOUND (buffers such as relative_position_index, loss_cls.cum_samples, roi_head.kernel, EMA / optimizer entries
+ * are the caller's to drop), a wrong shape or ndim > 4 with NUHTC_E_INVALID; nuhtc_last_error() names the tensor. */
 int nuhtc_load_weight(nuhtc_engine* e, const char* name, const float* host_data, const int64_t* shape, int ndim);
 
 /* Checks that every tensor of the path was loaded and pre-packs weights (NHWC / k-major layouts,
@@ -141,8 +143,10 @@ int nuhtc_merge_overlap(int device, const int32_t* boxes, const float* scores, c
                         const int64_t* bit_off, int64_t n, double thr, int x_min, int y_min, int x_max, int y_max,
                         uint8_t* keep_dev, void* stream);
 
-/* Synchronises `stream` and reports whether the last nuhtc_infer overflowed a capacity
- * (returns NUHTC_E_CAPACITY) — call before trusting the results. */
+/* Synchronises `stream` and reports whether the last nuhtc_infer overflowed max_cc_proposals on some tile (returns
+ * NUHTC_E_CAPACITY) — call before trusting the results.  That is the only capacity of the path that is not the reference's
+ * own cap: RPN candidates, RoIs and detection candidates are sized for their worst case (nms_pre per level,
+ * max_cc_proposals + rpn_max_per_img, RoIs x classes), detections are cut at max_per_img as the reference cuts them. */
 int nuhtc_check(nuhtc_engine* e, void* stream);
 
 /* Parity-test access to intermediate tensors of the last nuhtc_infer call (device pointers into the

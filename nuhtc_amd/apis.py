@@ -27,28 +27,41 @@ class Detector:
         self.max_cc_proposals = max_cc_proposals
         self.opts = engine_options(cfg)
         self.CLASSES = tuple(str(i) for i in range(self.opts['num_classes']))
-        self._engines = {}
+        self._engines = {}          # (tile size[, depth]) -> engine, least recently used first
+        self.max_engines = 4        # each holds the weights + a workspace of ~0.3 GB per tile of max_batch
+
+    def _cached(self, key, make):
+        if key in self._engines:
+            self._engines[key] = self._engines.pop(key)         # move to the most-recent end
+            return self._engines[key]
+        while len(self._engines) >= self.max_engines:           # evict the least recently used size
+            old = self._engines.pop(next(iter(self._engines)))
+            old.close()
+        self._engines[key] = make()
+        return self._engines[key]
 
     def engine(self, tile_hw):
         from .engine import Engine
         key = (int(tile_hw[0]), int(tile_hw[1]))
-        if key not in self._engines:
+
+        def make():
             opts = dict(self.opts)
             nc = opts.pop('num_classes')
-            self._engines[key] = Engine(self.state_dict, device=self.device, max_batch=self.max_batch, tile=key, num_classes=nc,
-                                        max_cc_proposals=self.max_cc_proposals, **opts)
-        return self._engines[key]
+            return Engine(self.state_dict, device=self.device, max_batch=self.max_batch, tile=key, num_classes=nc,
+                          max_cc_proposals=self.max_cc_proposals, **opts)
+        return self._cached(key, make)
 
     def pipeline(self, tile_hw, depth=3):
         """`depth` engines on their own streams for the streaming (WSI) path: nuhtc_amd.pipeline.EnginePipeline."""
         from .pipeline import EnginePipeline
         key = (int(tile_hw[0]), int(tile_hw[1]), int(depth))
-        if key not in self._engines:
+
+        def make():
             opts = dict(self.opts)
             nc = opts.pop('num_classes')
-            self._engines[key] = EnginePipeline(self.state_dict, device=self.device, depth=depth, max_batch=self.max_batch, tile=key[:2],
-                                                num_classes=nc, max_cc_proposals=self.max_cc_proposals, **opts)
-        return self._engines[key]
+            return EnginePipeline(self.state_dict, device=self.device, depth=depth, max_batch=self.max_batch, tile=key[:2],
+                                  num_classes=nc, max_cc_proposals=self.max_cc_proposals, **opts)
+        return self._cached(key, make)
 
     def eval(self):
         return self

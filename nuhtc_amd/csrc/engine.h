@@ -21,6 +21,7 @@ struct nuhtc_engine {
   int device = 0;
   std::string err;
   std::map<std::string, HostTensor> raw;
+  std::map<std::string, std::vector<int64_t>> schema;   // names / shapes nuhtc_load_weight accepts
   std::map<std::string, BufInfo> bufs;
   std::vector<void*> allocs;
   size_t bytes_allocated = 0;

@@ -48,7 +48,8 @@ int nuhtc_create(const nuhtc_config* cfg, int device, nuhtc_engine** out) {
   }
   if (cfg->tile_h % 16 || cfg->tile_w % 16 || cfg->tile_h <= 0 || cfg->tile_w <= 0) { g_create_error = "tile size must be a positive multiple of 16"; return NUHTC_E_INVALID; }
   if (cfg->tile_w % 32) { g_create_error = "tile_w must be a multiple of 32 (bit-packed mask rows)"; return NUHTC_E_INVALID; }
-  if (cfg->num_classes < 1 || cfg->num_classes > 16) { g_create_error = "num_classes out of range"; return NUHTC_E_INVALID; }
+  // class logits live in rows of 16 floats: num_classes + 2 (objectness pair) values per RoI, see bbox_tail_kernel
+  if (cfg->num_classes < 1 || cfg->num_classes > 14) { g_create_error = "num_classes out of range (1..14)"; return NUHTC_E_INVALID; }
   if (cfg->max_batch < 1 || cfg->max_batch > 256) { g_create_error = "max_batch out of range"; return NUHTC_E_INVALID; }
   if (cfg->rpn_nms_pre < 1 || cfg->rpn_nms_pre > 4096 || cfg->rpn_max_per_img < 1 || cfg->rpn_max_per_img > 4096) { g_create_error = "rpn_nms_pre / rpn_max_per_img out of range (<=4096)"; return NUHTC_E_INVALID; }
   if (cfg->max_per_img < 1 || cfg->max_per_img > 2048) { g_create_error = "max_per_img out of range"; return NUHTC_E_INVALID; }
@@ -77,12 +78,55 @@ void nuhtc_destroy(nuhtc_engine* e) {
   delete e;
 }
 
+// Names and shapes of the state_dict entries the path reads (the same table as nuhtc_amd/weights.py:schema).
+static std::map<std::string, std::vector<int64_t>> weight_schema(int nc) {
+  std::map<std::string, std::vector<int64_t>> s;
+  auto wb = [&](const std::string& p, std::vector<int64_t> w) { s[p + ".weight"] = w; s[p + ".bias"] = {w[0]}; };
+  wb("backbone.patch_embed.projection", {96, 3, 4, 4});
+  s["backbone.patch_embed.norm.weight"] = {96}; s["backbone.patch_embed.norm.bias"] = {96};
+  for (int st = 0; st < 4; ++st) {
+    const int64_t C = 96 << st;
+    for (int b = 0; b < DEPTHS[st]; ++b) {
+      const std::string p = "backbone.stages." + std::to_string(st) + ".blocks." + std::to_string(b) + ".";
+      s[p + "norm1.weight"] = {C}; s[p + "norm1.bias"] = {C}; s[p + "norm2.weight"] = {C}; s[p + "norm2.bias"] = {C};
+      s[p + "attn.w_msa.relative_position_bias_table"] = {169, NHEADS[st]};
+      wb(p + "attn.w_msa.qkv", {3 * C, C}); wb(p + "attn.w_msa.proj", {C, C});
+      wb(p + "ffn.layers.0.0", {4 * C, C}); wb(p + "ffn.layers.1", {C, 4 * C});
+    }
+    if (st < 3) {
+      const std::string p = "backbone.stages." + std::to_string(st) + ".downsample.";
+      s[p + "norm.weight"] = {4 * C}; s[p + "norm.bias"] = {4 * C}; s[p + "reduction.weight"] = {2 * C, 4 * C};
+    }
+    s["backbone.norm" + std::to_string(st) + ".weight"] = {C}; s["backbone.norm" + std::to_string(st) + ".bias"] = {C};
+    wb("neck.lateral_convs." + std::to_string(st) + ".conv", {64, C, 1, 1});
+    wb("neck.fpn_convs." + std::to_string(st) + ".conv", {64, 64, 3, 3});
+    wb("roi_head.semantic_head.lateral_convs." + std::to_string(st) + ".conv", {64, 64, 1, 1});
+    wb("roi_head.semantic_head.convs." + std::to_string(st) + ".conv", {64, 64, 3, 3});
+    wb("roi_head.mask_head.0.convs." + std::to_string(st) + ".conv", {64, 64, 3, 3});
+  }
+  wb("rpn_head.rpn_conv", {64, 64, 3, 3}); wb("rpn_head.rpn_cls", {3, 64, 1, 1}); wb("rpn_head.rpn_reg", {12, 64, 1, 1});
+  for (int k = 0; k < 3; ++k) {
+    const std::string p = "roi_head.bbox_head." + std::to_string(k) + ".";
+    wb(p + "shared_fcs.0", {256, 3136}); wb(p + "shared_fcs.1", {256, 256}); wb(p + "fc_cls", {nc + 2, 256}); wb(p + "fc_reg", {4, 256});
+  }
+  wb("roi_head.mask_head.0.upsample", {64, 64, 2, 2}); wb("roi_head.mask_head.0.conv_logits", {1, 64, 1, 1});
+  wb("roi_head.mask_head.0.conv_res.conv", {64, 64, 1, 1});   // unused at test time (res_feat is None), accepted
+  wb("roi_head.semantic_head.conv_embedding.conv", {64, 64, 1, 1}); wb("roi_head.semantic_head.conv_logits", {1, 64, 1, 1});
+  return s;
+}
+
 int nuhtc_load_weight(nuhtc_engine* e, const char* name, const float* host, const int64_t* shape, int ndim) {
-  if (!e || !name || !host || !shape || ndim < 1 || ndim > 4) return NUHTC_E_INVALID;
+  if (!e) return NUHTC_E_INVALID;
+  if (!name || !host || !shape) FAIL(e, NUHTC_E_INVALID, "nuhtc_load_weight: null argument");
+  if (ndim < 1 || ndim > 4) FAIL(e, NUHTC_E_INVALID, std::string("nuhtc_load_weight: ") + name + ": ndim must be 1..4");
   if (e->finalized) FAIL(e, NUHTC_E_STATE, "load_weight after finalize");
+  if (e->schema.empty()) e->schema = weight_schema(e->cfg.num_classes);
+  auto it = e->schema.find(name);
+  if (it == e->schema.end()) FAIL(e, NUHTC_E_NOTFOUND, std::string("nuhtc_load_weight: unknown weight name: ") + name);
   HostTensor t;
   size_t n = 1;
   for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+  if (t.shape != it->second) FAIL(e, NUHTC_E_INVALID, std::string("nuhtc_load_weight: bad shape for ") + name);
   t.data.assign(host, host + n);
   e->raw[name] = std::move(t);
   return 0;

@@ -56,7 +56,11 @@ class Engine:
         rc = self.lib.nuhtc_create(ctypes.byref(cfg), self.device.index, ctypes.byref(self.h))
         if rc:
             raise HipError(f'nuhtc_create failed ({rc}): {self.lib.nuhtc_last_error(None).decode()}')
+        from .weights import schema
+        names = schema(num_classes)
         for name, t in state_dict.items():
+            if name not in names:      # buffers / EMA / optimizer entries: not part of the path (the library rejects them)
+                continue
             a = np.ascontiguousarray(t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else t, dtype=np.float32)
             if a.ndim == 0:
                 a = a.reshape(1)

@@ -52,6 +52,10 @@ class EnginePipeline:
     def full(self):
         return len(self.pending) >= self.depth
 
+    def close(self):
+        for e in self.engines:
+            e.close()
+
     def collect(self):
         """Oldest submitted batch: waits for it and returns (engine, B, stream, tag); read the engine's output tensors on
         `stream` (torch.cuda.stream(stream)) before submitting to that slot again."""

@@ -462,16 +462,18 @@ def mask_head(sd, feats):
     return F.conv2d(x, sd[p + 'conv_logits.weight'], sd[p + 'conv_logits.bias']).sigmoid()
 
 
-def paste_masks(prob, boxes, H, W, thr=0.5):
+def paste_masks(prob, boxes, H, W, thr=0.5, return_values=False):
     """FCNMaskHead.get_seg_masks/_do_paste_mask (mmdet/models/roi_heads/mask_heads/fcn_mask_head.py:229-307,344-412).
     prob (D,1,28,28), boxes (D,4) in output-pixel space -> bool (D,H,W).
 
     CPU semantics of the reference: one instance per chunk with skip_empty=True, i.e. only pixels inside the
     integer hull [floor(x0)-1, ceil(x1)+1) x [floor(y0)-1, ceil(y1)+1) (clamped to the canvas) are sampled,
-    everything else stays False (this matters for boxes wider than ~112 px, whose bilinear tail leaves the hull)."""
+    everything else stays False (this matters for boxes wider than ~112 px, whose bilinear tail leaves the hull).
+    return_values=True (tests only) also returns the sampled probabilities (D,H,W), so that a pixel that differs between
+    two implementations can be shown to sit on the threshold."""
     D = prob.shape[0]
     if D == 0:
-        return np.zeros((0, H, W), bool)
+        return (np.zeros((0, H, W), bool), np.zeros((0, H, W), np.float32)) if return_values else np.zeros((0, H, W), bool)
     x0, y0, x1, y1 = torch.split(boxes, 1, dim=1)
     iy = torch.arange(0, H).float() + 0.5
     ix = torch.arange(0, W).float() + 0.5
@@ -488,6 +490,8 @@ def paste_masks(prob, boxes, H, W, thr=0.5):
     iy[torch.isinf(iy)] = 0
     grid = torch.stack([ix[:, None, :].expand(D, H, W), iy[:, :, None].expand(D, H, W)], 3)
     m = F.grid_sample(prob.float(), grid, align_corners=False)[:, 0]
+    if return_values:
+        return ((m >= thr) & in_hull).numpy(), m.numpy()
     return ((m >= thr) & in_hull).numpy()
 
 

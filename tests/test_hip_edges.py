@@ -7,7 +7,7 @@ idempotence of the per-tile mask-NMS keep set, structural invariants of the outp
 import numpy as np
 import pytest
 
-from test_hip_full import match_instances
+import parity_util as P
 
 pytestmark = pytest.mark.gpu
 
@@ -32,10 +32,12 @@ def test_blank_noise_and_single_tile_batches(hip_device):
                       rng.integers(0, 256, (64, 64, 3), dtype=np.uint8), np.full((64, 64, 3), 127, np.uint8)])
     eng = Engine(sd, device=0, max_batch=8, tile=(64, 64))
     got = eng(tiles, 1)
-    ref = O.Oracle(sd)(tiles, 1)
+    ref, it = O.Oracle(sd)(tiles, 1, keep=True)
+    vals = P.oracle_paste_values(O, it, (64, 64))
     for i, (g, r) in enumerate(zip(got, ref)):
-        nr, ng, nm, miou, low = match_instances(r, g)
-        assert nm >= 0.98 * max(nr, ng) and low <= 1, (i, nr, ng, nm, low)
+        rep, fails = P.compare_strict(r, g, values=vals[i])   # exact counts; a miss must sit on a threshold
+        print(f'tile {i}: {P.fmt(rep)}', *rep['explained'], sep='\n    ')
+        assert not fails, (i, fails)
     # a batch of one gives the same answer as the same tile inside a batch
     for i in (0, 2, 3):
         one = eng(tiles[i:i + 1], 1)[0]
@@ -72,10 +74,12 @@ def test_non_square_tile_and_detection_cap(hip_device):
     tiles = np.ascontiguousarray(base[:, :64, :96])               # 64 x 96 tiles
     eng = Engine(sd, device=0, max_batch=2, tile=(64, 96))
     got = eng(tiles, 0)
-    ref = O.Oracle(sd)(tiles, 0)
-    for g, r in zip(got, ref):
-        nr, ng, nm, miou, low = match_instances(r, g)
-        assert ng > 0 and nm >= 0.98 * max(nr, ng) and low <= 1, (nr, ng, nm, low)
+    ref, it = O.Oracle(sd)(tiles, 0, keep=True)
+    vals = P.oracle_paste_values(O, it, (64, 96))
+    for i, (g, r) in enumerate(zip(got, ref)):
+        rep, fails = P.compare_strict(r, g, values=vals[i])
+        print(f'tile {i}: {P.fmt(rep)}', *rep['explained'], sep='\n    ')
+        assert rep['n_got'] > 0 and not fails, fails
         assert all(m.shape == (64, 96) for cl in g[1] for m in cl)
     # max_per_img truncates to the best-scoring detections of the uncapped run
     cap = 7

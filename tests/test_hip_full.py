@@ -5,6 +5,7 @@ import pytest
 import torch
 
 import golden_util as G
+import parity_util as P
 
 pytestmark = pytest.mark.gpu
 
@@ -14,36 +15,6 @@ def _engine(g, **kw):
     sd = G.seeded_sd(g)
     tiles = g['tiles']
     return Engine(sd, device=0, max_batch=kw.pop('max_batch', len(tiles)), tile=tiles.shape[1:3], **kw), sd
-
-
-def box_iou(a, b):
-    x1 = np.maximum(a[:, None, 0], b[None, :, 0]); y1 = np.maximum(a[:, None, 1], b[None, :, 1])
-    x2 = np.minimum(a[:, None, 2], b[None, :, 2]); y2 = np.minimum(a[:, None, 3], b[None, :, 3])
-    inter = np.clip(x2 - x1, 0, None) * np.clip(y2 - y1, 0, None)
-    aa = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]); ab = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
-    return inter / np.maximum(aa[:, None] + ab[None, :] - inter, 1e-12)
-
-
-def match_instances(ref, got):
-    """ref/got: (bbox_results, segm_results). Returns (n_ref, n_got, n_matched, min_mask_iou, n_mask_iou_below_0.999)."""
-    rb = np.concatenate(ref[0], 0); gb = np.concatenate(got[0], 0)
-    rl = np.concatenate([np.full(len(b), c) for c, b in enumerate(ref[0])]); gl = np.concatenate([np.full(len(b), c) for c, b in enumerate(got[0])])
-    rm = [m for cl in ref[1] for m in cl]; gm = [m for cl in got[1] for m in cl]
-    if len(rb) == 0 or len(gb) == 0:
-        return len(rb), len(gb), 0, 1.0, 0
-    iou = box_iou(rb[:, :4], gb[:, :4])
-    iou[rl[:, None] != gl[None, :]] = -1
-    used, matched, min_iou, low = set(), 0, 1.0, 0
-    for i in np.argsort(-rb[:, 4]):
-        j = int(np.argmax(iou[i]))
-        if iou[i, j] >= 0.999 and j not in used and abs(rb[i, 4] - gb[j, 4]) < 1e-3:
-            used.add(j); matched += 1
-            if rm and gm:
-                inter = np.logical_and(rm[i], gm[j]).sum(); uni = np.logical_or(rm[i], gm[j]).sum()
-                v = inter / uni if uni else 1.0
-                min_iou = min(min_iou, v)
-                low += v < 0.999
-    return len(rb), len(gb), matched, min_iou, low
 
 
 def test_roi_align_op(hip_device):
@@ -122,11 +93,15 @@ def test_full_path_vs_oracle_and_golden(hip_device, case):
         else:
             # same multiset of proposals; the order may swap where two scores agree to ~1 ulp (expf vs torch sigmoid)
             d = np.abs(a[:, None, :] - b[None, :, :]).max(-1)
-            unmatched = int((d.min(1) > 1e-3).sum())
             displaced = int((np.abs(a - b).max(1) > 1e-3).sum())
-            print(f'  tile {i} rpn proposals: {unmatched} rows without a partner, {displaced} rows at a different rank')
-            if unmatched > 0.005 * len(a):
-                msgs.append(f'tile {i}: {unmatched} rpn proposals differ')
+            lone_a, lone_b = np.nonzero(d.min(1) > 1e-3)[0], np.nonzero(d.min(0) > 1e-3)[0]
+            print(f'  tile {i} rpn proposals: {len(lone_a)} oracle rows / {len(lone_b)} hip rows without a partner, {displaced} rows at a different rank')
+            for rows, other, lone, tag in ((a, b, lone_a, 'oracle'), (b, a, lone_b, 'hip')):
+                for k in lone:
+                    why = P.explain_proposal(rows[k], other)
+                    print(f'    {tag}-only proposal {rows[k].tolist()}: {why}')
+                    if why is None:
+                        msgs.append(f'tile {i}: {tag}-only rpn proposal {rows[k].tolist()} is not explained by a threshold')
     # --- a14: connected-component proposals from the engine's own semantic logits: exact
     cc_ref = O.cc_proposals(sem_pred, (Hn, Wn))
     cc_counts = eng.buffer('cc_counts')[:B].cpu().numpy()
@@ -194,10 +169,16 @@ def test_full_path_vs_oracle_and_golden(hip_device, case):
                 # got[i] is class-grouped; regroup the oracle paste the same way
                 lab = hip_labels[i, :n]
                 order = np.concatenate([np.nonzero(lab == c)[0] for c in range(nc)]) if n else np.zeros(0, int)
-                diff = int((pm[order] != hm).sum())
-                print(case, 'tile', i, 'pasted mask pixel mismatches', diff, 'of', int(hm.sum()), 'set pixels')
-                if diff > max(2, 1e-5 * hm.size):
-                    msgs.append(f'tile {i}: {diff} pasted mask pixels differ')
+                diff = pm[order] != hm
+                nd = int(diff.sum())
+                print(case, 'tile', i, 'pasted mask pixel mismatches', nd, 'of', int(hm.sum()), 'set pixels')
+                if nd:
+                    # a pixel may differ only where the pasted probability sits on the 0.5 threshold
+                    _, vals = O.paste_masks(prob_hip[off - n:off], (mrois[off - n:off, 1:] / 2.0), tiles.shape[1], tiles.shape[2], return_values=True)
+                    dist = float(np.abs(vals[order][diff] - 0.5).max())
+                    print(f'    farthest differing pixel: pasted probability {dist:.2e} from 0.5')
+                    if dist > 1e-5:
+                        msgs.append(f'tile {i}: {nd} pasted mask pixels differ, up to {dist:.2e} from the threshold')
                 areas = eng.areas[i, :n].cpu().numpy()
                 if n and (areas[order] != hm.reshape(n, -1).sum(1)).any():
                     msgs.append(f'tile {i}: mask areas differ from popcounts')
@@ -214,19 +195,22 @@ def test_full_path_vs_oracle_and_golden(hip_device, case):
             msgs.append(f'tile {i}: mask-NMS keep set differs ({len(kb)} vs {len(hip_kept)})')
     # --- end to end: free-running oracle and the reference golden (rounding differences may flip near-threshold
     # decisions; report the agreement, require it to be near-total)
-    ref = O.Oracle(sd)(tiles, mode)
+    ref, it = O.Oracle(sd)(tiles, mode, keep=True)
+    vals = P.oracle_paste_values(O, it, tiles.shape[1:3])
     for i in range(B):
-        for tag, r in (('oracle', ref[i]), ('golden', None)):
-            if r is None:
-                gd, gl = g[f'det{i}'], g[f'lab{i}']
-                gm = np.unpackbits(g[f'masks{i}'], axis=-1).astype(bool)
-                r = ([gd[gl == c] for c in range(5)], [[gm[j] for j in range(len(gd)) if gl[j] == c] for c in range(5)])
-            nr, ng, nm, miou, low = match_instances(r, got[i])
-            print(f'{case} tile {i} end-to-end vs {tag}: ref {nr} hip {ng} matched(box IoU>=0.999, same class, |dscore|<1e-3) {nm}, '
-                  f'masks below IoU 0.999: {low} (min {miou:.5f})')
-            # the golden was produced on another CPU: a single-pixel flip on a ~35 px mask already reads IoU 0.97
-            if nm < 0.98 * max(nr, ng) or low > 0.01 * max(nm, 1) + 1:
-                msgs.append(f'tile {i} vs {tag}: {nr}/{ng} dets, {nm} matched, {low} masks below IoU 0.999 (min {miou})')
+        gd, gl = g[f'det{i}'], g[f'lab{i}']
+        gm = np.unpackbits(g[f'masks{i}'], axis=-1).astype(bool)
+        gold = ([gd[gl == c] for c in range(5)], [[gm[j] for j in range(len(gd)) if gl[j] == c] for c in range(5)])
+        # the golden was produced by the reference's own code on the build container's CPU, the oracle runs on this box's CPU:
+        # they list the same instances in the same order unless a decision flipped between the two CPUs
+        ob = P.flatten(ref[i])[0]
+        same_order = len(gd) == len(ob) and (len(gd) == 0 or np.abs(gd - ob).max() < 1e-3)
+        for tag, r, v in (('oracle', ref[i], vals[i]), ('golden', gold, vals[i] if same_order else None)):
+            rep, fails = P.compare_strict(r, got[i], values=v, values_side='ref')
+            print(f'{case} tile {i} end-to-end vs {tag}: {P.fmt(rep)}')
+            for e in rep['explained']:
+                print('    tolerated:', e)
+            msgs += [f'tile {i} vs {tag}: {f}' for f in fails]
     assert not msgs, '\n'.join(msgs)
 
 
@@ -250,24 +234,19 @@ def test_consep_classes_and_batch_independence(hip_device):
     base = synth.nuclei_tiles(3, 256, start=40)
     tiles = np.stack([base[0], base[1], base[2], base[0], base[2], base[1]])
     got = eng(tiles, 1)
-    ref = O.Oracle(sd, num_classes=4, max_per_img=300)(base, 1)
+    ref, it = O.Oracle(sd, num_classes=4, max_per_img=300)(base, 1, keep=True)
+    vals = P.oracle_paste_values(O, it, (256, 256))
     msgs = []
     for i, r in zip((0, 1, 2), ref):
-        nr, ng, nm, miou, low = match_instances_nc(r, got[i], 4)
-        print(f'consep tile {i}: ref {nr} hip {ng} matched {nm} masks below 0.999: {low} (min {miou:.5f})')
-        assert ng <= 300
-        if nm < 0.98 * max(nr, ng) or low > 0.01 * max(nm, 1) + 1:
-            msgs.append(f'tile {i}: {nr}/{ng}/{nm}, {low} low-IoU masks')
+        rep, fails = P.compare_strict(r, got[i], max_per_img=300, values=vals[i])
+        print(f'consep tile {i}: {P.fmt(rep)}', *rep['explained'], sep='\n    ')
+        assert rep['n_got'] <= 300
+        msgs += [f'tile {i}: {f}' for f in fails]
     for a, b in ((0, 3), (2, 4), (1, 5)):   # same tile at different batch positions -> bit-identical outputs
         for c in range(4):
             if not np.array_equal(got[a][0][c], got[b][0][c]) or any(not np.array_equal(x, y) for x, y in zip(got[a][1][c], got[b][1][c])):
                 msgs.append(f'tiles {a} and {b} differ in class {c}')
     assert not msgs, '\n'.join(msgs)
-
-
-def match_instances_nc(ref, got, nc):
-    pad = lambda r: ([*r[0]] + [np.zeros((0, 5), np.float32)] * (5 - nc), [*r[1]] + [[]] * (5 - nc))
-    return match_instances(pad(ref), pad(got))
 
 
 def test_roi_features_all_size_classes(hip_device):
