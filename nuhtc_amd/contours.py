@@ -2,65 +2,88 @@
 
 Reference: tools/infer_wsi.py:51-58 `mask2inst` = `cv2.findContours(mask, RETR_TREE, CHAIN_APPROX_SIMPLE)[0][0]`, ring
 closed by repeating the first point, shifted by the tile origin (:533-539); QuPath features (:548-585);
-tools/nuclei_merge.py:62-174 polygon-IoU merge.  cv2 and shapely are not available: the border follower below traces
-the 8-connected outer border of the first component in raster order (what OpenCV returns first for a single blob) with
-CHAIN_APPROX_SIMPLE-style compression, and polygon overlap is evaluated by even-odd rasterisation at pixel centres.
-Parity with the reference is defined on polygon rasters (IoU), not on vertex lists."""
+tools/nuclei_merge.py:62-174 polygon-IoU merge.  cv2 and shapely are not available: the border follower below follows
+OpenCV's conventions (which component comes first in the list, start pixel, orientation, CHAIN_APPROX_SIMPLE vertex rule)
+and is checked vertex for vertex against oracle/contour.py, the restatement of the published Suzuki-Abe algorithm."""
 import json
 
 import numpy as np
 
-# 8-neighbourhood in clockwise order starting east (x right, y down)
+# Freeman chain codes as OpenCV numbers them: 0 = east, counter-clockwise on the screen (x right, y down)
 _DX = (1, 1, 0, -1, -1, -1, 0, 1)
-_DY = (0, 1, 1, 1, 0, -1, -1, -1)
+_DY = (0, -1, -1, -1, 0, 1, 1, 1)
+
+
+def contour_start(mask):
+    """Start pixel (y, x) of the contour `cv2.findContours(mask, RETR_TREE, CHAIN_APPROX_SIMPLE)` lists first, or None for an
+    empty mask.  OpenCV links every border it finds at the head of its parent's child list, so the first listed contour is
+    the outer border of the top-level component found last in the raster scan: among the 8-connected components that are not
+    enclosed in a hole of another one, the one whose first pixel in raster order comes last.  A component is top-level iff
+    the background pixel west of its first pixel belongs to the background region connected to the image frame (4-connected,
+    the image taken with a frame of zeros as cv::findContours pads it)."""
+    from scipy import ndimage as ndi
+    m = np.asarray(mask, bool)
+    if not m.any():
+        return None
+    lab, n = ndi.label(m, structure=np.ones((3, 3), int))
+    flat = lab.reshape(-1)
+    first = np.full(n + 1, flat.size, np.int64)
+    idx = np.nonzero(flat)[0]
+    np.minimum.at(first, flat[idx], idx)
+    if n == 1:
+        return divmod(int(first[1]), m.shape[1])
+    pad = np.zeros((m.shape[0] + 2, m.shape[1] + 2), bool)
+    pad[1:-1, 1:-1] = m
+    bg, _ = ndi.label(~pad)                       # 4-connected background regions; the frame's region is bg[0, 0]
+    outer = bg == bg[0, 0]
+    best = None
+    for k in range(1, n + 1):
+        y, x = divmod(int(first[k]), m.shape[1])
+        if outer[y + 1, x] and (best is None or first[k] > best[0]):      # padded coords: west neighbour = (y+1, x+1-1)
+            best = (first[k], y, x)
+    return best[1], best[2]
 
 
 def trace_outer_contour(mask):
-    """Outer border (Moore tracing, 8-connectivity) of the component that contains the first foreground pixel in raster
-    order.  Returns an (n,2) int array of (x,y) vertices with collinear runs compressed; empty if the mask is empty."""
+    """`cv2.findContours(mask, RETR_TREE, CHAIN_APPROX_SIMPLE)[0][0]` (tools/infer_wsi.py:51-54) as an (n,2) int array of
+    (x, y): the outer border (Suzuki-Abe border following, 8-connectivity, counter-clockwise on the screen: down the left side
+    first) of the component `contour_start` selects, starting at its first pixel in raster order, a vertex wherever the chain
+    code changes.  Empty array for an empty mask.  The device kernel (csrc/contour.hip) runs the same steps; both are checked
+    against the full border-following restatement in oracle/contour.py."""
     m = np.asarray(mask, bool)
-    H, W = m.shape
-    ys, xs = np.nonzero(m)
-    if len(ys) == 0:
+    st = contour_start(m)
+    if st is None:
         return np.zeros((0, 2), np.int64)
-    y0, x0 = int(ys[0]), int(xs[0])     # first pixel in raster order: its west and north neighbours are background
+    H, W = m.shape
+    y0, x0 = st
 
     def fg(y, x):
         return 0 <= y < H and 0 <= x < W and m[y, x]
-    pts = [(x0, y0)]
-    cy, cx = y0, x0
-    d = 4                                # we "arrived" from the west: start the scan just after it
-    if not any(fg(y0 + _DY[k], x0 + _DX[k]) for k in range(8)):
-        return np.array(pts, np.int64)   # isolated pixel
-    start_d = None
-    for _ in range(4 * H * W + 8):
-        found = False
-        for t in range(1, 9):
-            k = (d + t) % 8
-            ny, nx = cy + _DY[k], cx + _DX[k]
-            if fg(ny, nx):
-                found = True
-                break
-        if not found:
+    s = 4                                     # the west neighbour of the start is background: search clockwise from it
+    while True:
+        s = (s - 1) & 7
+        if fg(y0 + _DY[s], x0 + _DX[s]) or s == 4:
             break
-        if (cy, cx) == (y0, x0):
-            if start_d is None:
-                start_d = k
-            elif k == start_d:
-                break                    # Jacob's stopping criterion: back at the start leaving in the same direction
+    if s == 4:
+        return np.array([[x0, y0]], np.int64)  # isolated pixel
+    y1, x1 = y0 + _DY[s], x0 + _DX[s]
+    pts = []
+    cy, cx, prev_s = y0, x0, s ^ 4
+    while True:
+        while True:                           # counter-clockwise from the code after the one pointing back
+            s += 1
+            ny, nx = cy + _DY[s & 7], cx + _DX[s & 7]
+            if fg(ny, nx):
+                break
+        s &= 7
+        if s != prev_s:
+            pts.append((cx, cy))
+            prev_s = s
+        if (ny, nx) == (y0, x0) and (cy, cx) == (y1, x1):
+            break
         cy, cx = ny, nx
-        pts.append((cx, cy))
-        d = (k + 4) % 8                  # direction pointing back to where we came from
-    if len(pts) > 1 and pts[-1] == pts[0]:
-        pts.pop()
-    # CHAIN_APPROX_SIMPLE: keep only vertices where the step direction changes
-    p = np.array(pts, np.int64)
-    if len(p) <= 2:
-        return p
-    step = np.roll(p, -1, 0) - p
-    prev = p - np.roll(p, 1, 0)
-    keep = np.any(step != prev, axis=1)
-    return p[keep] if keep.any() else p[:1]
+        s = (s + 4) & 7
+    return np.array(pts, np.int64)
 
 
 def mask_to_ring(mask, origin=(0, 0)):

@@ -1,16 +1,24 @@
 // Outer-contour extraction of the kept instance masks on the GPU, so that only vertex lists cross PCIe on the WSI path.
-// Replaces `mask2inst` of tools/infer_wsi.py:51-54 (cv2.findContours(mask, RETR_TREE, CHAIN_APPROX_SIMPLE)[0][0]) for the
-// masks nuhtc_infer leaves in device memory.  Same algorithm as the host mirror nuhtc_amd/contours.py
-// `trace_outer_contour` (Moore border following of the component holding the first foreground pixel in raster order,
-// 8-connectivity, Jacob's stopping criterion, then removal of the vertices where the step direction does not change), which
-// is what the parity test compares against vertex by vertex.
+// Replaces `mask2inst` of tools/infer_wsi.py:51-54, `cv2.findContours(mask, RETR_TREE, CHAIN_APPROX_SIMPLE)[0][0]`, for the
+// masks nuhtc_infer leaves in device memory, vertex for vertex:
+//   * which border: OpenCV lists the top-level outer border it found LAST first (every border is linked at the head of its
+//     parent's child list), i.e. the outer border of the component -- not enclosed in a hole of another one -- whose first
+//     pixel in raster order comes last;
+//   * the walk: Suzuki-Abe border following with Freeman codes 0 = east counted counter-clockwise on the screen: from the
+//     start pixel search clockwise from west for the first set neighbour (i1), then repeatedly counter-clockwise from the
+//     code after the one pointing back; stop when stepping from i1 back into the start;
+//   * CHAIN_APPROX_SIMPLE: a pixel is a vertex when the code leaving it differs from the code that entered it (for the
+//     start: code(i1) ^ 4).
+// Checked against oracle/contour.py (the published algorithm with the full border labelling and hierarchy) on engine masks
+// and on fragmented / nested / border-touching shapes (tests/test_hip_api.py).
 //
-// One wave per detection slot.  The wave copies the instance's bit-packed tile mask to LDS (coalesced), finds the first
-// set bit with a wave reduction, lane 0 walks the border (a serial chain of LDS bit tests: ~100-300 steps for a nucleus)
-// into an LDS point list, and the whole wave compresses that list (direction-change test + ballot prefix) into the output.
+// One wave per detection slot: the wave copies the bit-packed tile mask to LDS, lane 0 walks the border of the component
+// holding the first set pixel, marking the pixels it visits and writing vertices straight to the output; the wave then looks
+// for a run start (set pixel, clear west neighbour) the walk did not visit.  None (one blob, no hole: the usual nucleus) ->
+// done.  Otherwise the wave floods the background that is 4-connected to the image frame (bit-parallel, run filling by carry
+// propagation), and every further run start whose west neighbour lies in that region and was not visited starts another
+// top-level border, walked the same way; the last one walked is the answer.
 #include "common.h"
-
-#define RAW_CAP 2048   // border pixels kept in LDS per instance before compression
 
 struct ContourParams {
   const uint32_t* masks;   // [B*max_per_img][H][wpr] bit-packed rows
@@ -19,130 +27,156 @@ struct ContourParams {
   int max_per_img, H, W, wpr;
   int cap;                 // output vertices per instance
   int16_t* xy;             // [B*max_per_img][cap][2]
-  int32_t* n;              // [B*max_per_img] vertex count; 0 = not traced (not kept / empty); -1 = overflow (trace on the host)
+  int32_t* n;              // [B*max_per_img] vertex count; 0 = not traced (not kept / empty); -1 = more than cap vertices (trace on the host)
 };
 
-template <bool LDS_MASK>
-__global__ __launch_bounds__(256) void contour_kernel(ContourParams p, int total) {
+#define CT_WAVES 2
+
+// Freeman codes, 0 = east, counter-clockwise on the screen: dx = {1,1,0,-1,-1,-1,0,1}, dy = {0,-1,-1,-1,0,1,1,1}; 2 bits hold d + 1
+#define CDX(k) ((int)((0x901Au >> (2 * (k))) & 3u) - 1)
+#define CDY(k) ((int)((0xA901u >> (2 * (k))) & 3u) - 1)
+
+// bits of `m` reachable from the seed bits `x` (x subset of m) along runs of consecutive ones of m, inside one word
+__device__ __forceinline__ uint32_t run_fill(uint32_t x, uint32_t m) {
+  const uint32_t up = (((m + x) ^ m) & m) | x;
+  const uint32_t xr = __brev(x), mr = __brev(m);
+  const uint32_t dn = __brev((((mr + xr) ^ mr) & mr) | xr);
+  return up | dn;
+}
+
+__global__ __launch_bounds__(64 * CT_WAVES) void contour_kernel(ContourParams p, int total) {
   extern __shared__ uint32_t smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int det = blockIdx.x * 4 + wave;
+  const int det = blockIdx.x * CT_WAVES + wave;
   if (det >= total) return;
   const int b = det / p.max_per_img, r = det - b * p.max_per_img;
   if (r >= p.counts[b] || (p.keep && !p.keep[det])) {
     if (lane == 0) p.n[det] = 0;
     return;
   }
-  const int words = p.H * p.wpr;
-  const int per_wave = (LDS_MASK ? words : 0) + RAW_CAP;
-  uint32_t* lm = smem + wave * per_wave;                 // LDS image of the mask (when it fits)
-  uint32_t* raw = lm + (LDS_MASK ? words : 0);           // border points, x | y << 16
+  const int H = p.H, W = p.W, wpr = p.wpr, words = H * wpr;
+  uint32_t* M = smem + wave * 3 * words;     // the mask
+  uint32_t* V = M + words;                   // pixels visited by a border walk
+  uint32_t* O = V + words;                   // background connected to the image frame (slow path only)
   const uint32_t* gm = p.masks + (long long)det * words;
-  // ---- stage the mask and find the first foreground pixel in raster order
-  int first = 0x7fffffff;
+  // ---- stage the mask; first set pixel in raster order and the bounding rows / word columns
+  int first = 0x7fffffff, wy0 = 0x7fffffff, wy1 = -1, wx0 = 0x7fffffff, wx1 = -1;
   for (int i = lane; i < words; i += 64) {
     const uint32_t w = gm[i];
-    if (LDS_MASK) lm[i] = w;
-    if (w && i < first) first = i;
+    M[i] = w;
+    V[i] = 0;
+    if (w) {
+      const int y = i / wpr, x = i - y * wpr;
+      first = min(first, i); wy0 = min(wy0, y); wy1 = max(wy1, y); wx0 = min(wx0, x); wx1 = max(wx1, x);
+    }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o));
+  for (int o = 32; o > 0; o >>= 1) {
+    first = min(first, __shfl_xor(first, o));
+    wy0 = min(wy0, __shfl_xor(wy0, o)); wy1 = max(wy1, __shfl_xor(wy1, o));
+    wx0 = min(wx0, __shfl_xor(wx0, o)); wx1 = max(wx1, __shfl_xor(wx1, o));
+  }
   if (first == 0x7fffffff) {          // empty mask
     if (lane == 0) p.n[det] = 0;
     return;
   }
-  const uint32_t* m = LDS_MASK ? lm : gm;
-  // (all 64 lanes of the wave run the same control flow up to here; LDS writes of this wave are visible to it after the
-  // implicit wave-level ordering of ds operations -- no block barrier: waves of a block are independent)
-  __builtin_amdgcn_s_waitcnt(0xC07F);
-  int nraw = 0;
-  bool overflow = false;
-  if (lane == 0) {
-    const int H = p.H, W = p.W, wpr = p.wpr;
-    const int y0 = first / wpr, x0 = (first - y0 * wpr) * 32 + __ffs(m[first]) - 1;
-    auto fg = [&](int y, int x) -> bool {
-      return y >= 0 && y < H && x >= 0 && x < W && ((m[y * wpr + (x >> 5)] >> (x & 31)) & 1u);
-    };
-    // 8-neighbourhood clockwise from east (x right, y down), 2 bits per direction holding d + 1:
-    // dx = {1,1,0,-1,-1,-1,0,1}, dy = {0,1,1,1,0,-1,-1,-1}
-#define DXK(k) ((int)((0x901Au >> (2 * (k))) & 3u) - 1)
-#define DYK(k) ((int)((0x01A9u >> (2 * (k))) & 3u) - 1)
-    raw[0] = (uint32_t)x0 | ((uint32_t)y0 << 16);
-    nraw = 1;
-    bool any = false;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) any |= fg(y0 + DYK(k), x0 + DXK(k));
-    if (any) {
-      int cy = y0, cx = x0, d = 4, start_d = -1;
-      const int limit = 4 * H * W + 8;
-      for (int it = 0; it < limit; ++it) {
-        int k = 0, ny = 0, nx = 0;
-        bool found = false;
-        for (int t = 1; t <= 8; ++t) {
-          k = (d + t) & 7;
-          ny = cy + DYK(k);
-          nx = cx + DXK(k);
-          if (fg(ny, nx)) { found = true; break; }
-        }
-        if (!found) break;
-        if (cy == y0 && cx == x0) {
-          if (start_d < 0) start_d = k;
-          else if (k == start_d) break;          // back at the start, leaving in the same direction
-        }
-        cy = ny;
-        cx = nx;
-        if (nraw >= RAW_CAP) { overflow = true; break; }
-        raw[nraw++] = (uint32_t)cx | ((uint32_t)cy << 16);
-        d = (k + 4) & 7;
-      }
-      if (!overflow && nraw > 1 && raw[nraw - 1] == raw[0]) --nraw;
-    }
-#undef DXK
-#undef DYK
-  }
-  nraw = __shfl(nraw, 0);
-  overflow = __shfl((int)overflow, 0) != 0;
-  if (overflow) {
-    if (lane == 0) p.n[det] = -1;
-    return;
-  }
-  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
   int16_t* out = p.xy + (long long)det * p.cap * 2;
-  if (nraw <= 2) {                      // nothing to compress (contours.py returns the points as they are)
-    if (lane < nraw && lane < p.cap) {
-      out[2 * lane] = (int16_t)(raw[lane] & 0xffff);
-      out[2 * lane + 1] = (int16_t)(raw[lane] >> 16);
+  const int cap = p.cap;
+
+  auto fg = [&](int y, int x) -> bool {
+    return y >= 0 && y < H && x >= 0 && x < W && ((M[y * wpr + (x >> 5)] >> (x & 31)) & 1u);
+  };
+  // lane 0: walk the outer border that starts at pixel `start` (raster index), mark it in V, emit vertices; returns the count
+  auto walk = [&](int start) -> int {
+    const int y0 = start / W, x0 = start - y0 * W;
+    int nout = 0;
+    auto emit = [&](int x, int y) {
+      if (nout < cap) { out[2 * nout] = (int16_t)x; out[2 * nout + 1] = (int16_t)y; }
+      ++nout;
+    };
+    V[y0 * wpr + (x0 >> 5)] |= 1u << (x0 & 31);
+    int s = 4;
+    do { s = (s - 1) & 7; } while (!fg(y0 + CDY(s), x0 + CDX(s)) && s != 4);
+    if (s == 4) { emit(x0, y0); return nout; }      // isolated pixel
+    const int y1 = y0 + CDY(s), x1 = x0 + CDX(s);
+    int cy = y0, cx = x0, prev_s = s ^ 4;
+    for (int it = 0; it < 4 * H * W + 8; ++it) {
+      int ny, nx;
+      do { ++s; ny = cy + CDY(s & 7); nx = cx + CDX(s & 7); } while (!fg(ny, nx));
+      s &= 7;
+      if (s != prev_s) { emit(cx, cy); prev_s = s; }
+      if (ny == y0 && nx == x0 && cy == y1 && cx == x1) break;
+      cy = ny; cx = nx;
+      V[cy * wpr + (cx >> 5)] |= 1u << (cx & 31);
+      s = (s + 4) & 7;
     }
-    if (lane == 0) p.n[det] = nraw <= p.cap ? nraw : -1;
-    return;
-  }
-  // ---- CHAIN_APPROX_SIMPLE: keep the points where the step to the next point differs from the step from the previous one
+    return nout;
+  };
+  // wave: first run start (set pixel whose west neighbour is clear) not visited yet, optionally only those whose west
+  // neighbour lies in O (pixels left of the image count as outside); raster index or 0x7fffffff
+  auto next_start = [&](bool need_outer) -> int {
+    int best = 0x7fffffff;
+    for (int i = lane; i < words; i += 64) {
+      const uint32_t w = M[i];
+      if (!w) continue;
+      const int xw = i % wpr;
+      const uint32_t west = (w << 1) | (xw ? M[i - 1] >> 31 : 0u);
+      uint32_t c = w & ~west & ~V[i];
+      if (need_outer) c &= (O[i] << 1) | (xw ? O[i - 1] >> 31 : 1u);
+      if (c) best = min(best, (i / wpr) * W + xw * 32 + __ffs(c) - 1);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o));
+    return best;
+  };
+
   int nout = 0;
-  for (int base = 0; base < nraw; base += 64) {
-    const int i = base + lane;
-    bool kp = false;
-    uint32_t cur = 0;
-    if (i < nraw) {
-      cur = raw[i];
-      const uint32_t nx = raw[i + 1 < nraw ? i + 1 : 0], pv = raw[i > 0 ? i - 1 : nraw - 1];
-      const int cx = cur & 0xffff, cy = cur >> 16;
-      const int sx = (int)(nx & 0xffff) - cx, sy = (int)(nx >> 16) - cy;
-      const int qx = cx - (int)(pv & 0xffff), qy = cy - (int)(pv >> 16);
-      kp = sx != qx || sy != qy;
+  if (lane == 0) nout = walk((first / wpr) * W + (first % wpr) * 32 + __ffs(M[first]) - 1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  int cand = next_start(false);
+  if (cand != 0x7fffffff) {
+    // ---- more than one component, or a hole: flood the frame-connected background inside the bounding rows / columns
+    for (int i = lane; i < words; i += 64) {
+      const int y = i / wpr, xw = i - y * wpr;
+      uint32_t seed = 0;
+      if (y < wy0 || y > wy1 || xw < wx0 || xw > wx1 || y == 0 || y == H - 1) seed = ~0u;
+      if (xw == 0) seed |= 1u;
+      if (xw == wpr - 1) seed |= 1u << ((W - 1) & 31);
+      O[i] = seed & ~M[i];
     }
-    const unsigned long long bal = __ballot(kp);
-    const int pos = nout + __popcll(bal & ((1ull << lane) - 1ull));
-    if (kp && pos < p.cap) {
-      out[2 * pos] = (int16_t)(cur & 0xffff);
-      out[2 * pos + 1] = (int16_t)(cur >> 16);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const int bw = wx1 - wx0 + 1, items = (wy1 - wy0 + 1) * bw;
+    for (int iter = 0; iter < H * W; ++iter) {
+      bool changed = false;
+      for (int t = lane; t < items; t += 64) {
+        const int y = wy0 + t / bw, xw = wx0 + t % bw, i = y * wpr + xw;
+        const uint32_t bg = ~M[i], cur = O[i];
+        uint32_t nb = (cur << 1) | (cur >> 1);
+        if (xw > 0) nb |= O[i - 1] >> 31;
+        if (xw < wpr - 1) nb |= O[i + 1] << 31;
+        if (y > 0) nb |= O[i - wpr];
+        if (y < H - 1) nb |= O[i + wpr];
+        const uint32_t nw = run_fill((cur | nb) & bg, bg);
+        if (nw != cur) { O[i] = nw; changed = true; }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      if (!__any(changed)) break;
     }
-    nout += __popcll(bal);
+    // ---- every unvisited run start on the frame-connected background starts another top-level outer border
+    for (int guard = 0; guard < H * W; ++guard) {
+      cand = next_start(true);
+      if (cand == 0x7fffffff) break;
+      if (lane == 0) nout = walk(cand);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+    }
   }
-  if (nout == 0) {                      // (cannot happen for a closed border of > 2 points; mirrors `p[:1]`)
-    if (lane == 0) { out[0] = (int16_t)(raw[0] & 0xffff); out[1] = (int16_t)(raw[0] >> 16); }
-    nout = 1;
-  }
-  if (lane == 0) p.n[det] = nout <= p.cap ? nout : -1;
+  if (lane == 0) p.n[det] = nout <= cap ? nout : -1;
 }
 
 int launch_contours(const uint32_t* masks, const uint8_t* keep, const int32_t* counts, int B, int max_per_img, int H, int W,
@@ -151,11 +185,14 @@ int launch_contours(const uint32_t* masks, const uint8_t* keep, const int32_t* c
   if (W % 32 != 0 || cap < 1 || H > 32767 || W > 32767) return NUHTC_E_INVALID;
   ContourParams p{masks, keep, counts, max_per_img, H, W, W / 32, cap, xy, n};
   const int total = B * max_per_img;
-  const int words = H * (W / 32);
+  const size_t lds = (size_t)CT_WAVES * 3 * H * (W / 32) * sizeof(uint32_t);
+  if (lds > 160 * 1024) return NUHTC_E_INVALID;     // tiles beyond ~660x660: trace on the host (nuhtc_amd/contours.py)
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)contour_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return NUHTC_E_HIP;
+    attr_set = true;
+  }
   ProfScope ps("contours", 0, 0, s);
-  dim3 grid(cdiv(total, 4)), blk(256);
-  const size_t lds_full = 4 * (size_t)(words + RAW_CAP) * sizeof(uint32_t);
-  if (lds_full <= 64 * 1024) hipLaunchKernelGGL(contour_kernel<true>, grid, blk, lds_full, s, p, total);
-  else hipLaunchKernelGGL(contour_kernel<false>, grid, blk, 4 * RAW_CAP * sizeof(uint32_t), s, p, total);
+  hipLaunchKernelGGL(contour_kernel, dim3(cdiv(total, CT_WAVES)), dim3(64 * CT_WAVES), lds, s, p, total);
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
 }

@@ -172,13 +172,25 @@ def test_pannuke_dataset_cli_exports_and_scores(hip_device, tmp_path):
     assert os.path.exists(tmp_path / 'b' / 'class_stats.csv') and os.path.exists(tmp_path / 'b' / 'tissue_stats.csv')
 
 
-def test_device_contours_match_host_mirror(hip_device, model):
-    """nuhtc_mask_contours against nuhtc_amd.contours.trace_outer_contour, vertex by vertex (integer work: exact), on the
-    engine's own masks and on hand-made shapes written into the mask buffer (thin lines, holes, single pixels, blobs that
-    touch the tile border, a contour longer than the device capacity)."""
+class _OracleContour:
+    """The checker of the contour kernel: oracle/contour.py, the restatement of the published Suzuki-Abe border following with
+    OpenCV's list order / start pixel / orientation / CHAIN_APPROX_SIMPLE rule (not the product's own host tracer)."""
+
+    @staticmethod
+    def trace_outer_contour(mask):
+        from oracle import contour as OC
+        c, _ = OC.find_contours_tree(mask)
+        return c[0] if c else np.zeros((0, 2), np.int64)
+
+
+def test_device_contours_match_oracle(hip_device, model):
+    """nuhtc_mask_contours against oracle/contour.py (`cv2.findContours(RETR_TREE, CHAIN_APPROX_SIMPLE)[0][0]`), vertex by
+    vertex (integer work: exact), on the engine's own masks and on hand-made shapes written into the mask buffer (thin lines,
+    holes, single pixels, spurs, several blobs, an island inside a hole, blobs that touch the tile border, random fragmented
+    masks, a contour longer than the device capacity)."""
     import torch
-    from nuhtc_amd import contours as host
     from nuhtc_amd import synth
+    host = _OracleContour
     eng = model.engine((64, 64))
     tiles = synth.nuclei_tiles(4, 64, start=70)
     B = eng.infer_async(eng.to_device(tiles), 1)
@@ -209,6 +221,19 @@ def test_device_contours_match_host_mirror(hip_device, model):
     m = (xx + yy) % 2 == 0; m[:, 40:] = False; shapes.append(m)                              # checkerboard: long 8-connected border
     rng = np.random.default_rng(3)
     m = rng.uniform(size=(64, 64)) < 0.55; shapes.append(m)                                  # noise
+    m = np.zeros((64, 64), bool); m[3:9, 3:9] = True; m[30:40, 10:20] = True; m[30:35, 40:50] = True; shapes.append(m)   # three blobs: [0][0] is the last found
+    m = np.zeros((64, 64), bool); m[5:40, 5:40] = True; m[10:35, 10:35] = False; m[20:25, 20:25] = True; shapes.append(m)  # island inside a hole: not top-level
+    m = m.copy(); m[50:55, 2:8] = True; shapes.append(m)                                     # ... plus a later top-level blob
+    m = np.zeros((64, 64), bool); m[10:13, 10:13] = True; m[11, 13:20] = True; shapes.append(m)     # block with a one-pixel spur
+    m = np.zeros((64, 64), bool); m[5:30, 5] = True; m[29, 5:30] = True; shapes.append(m)    # one-pixel L
+    m = np.zeros((64, 64), bool); m[20:30, 0:6] = True; m[20:24, 58:64] = True; shapes.append(m)    # blobs on the left / right edges, same first row
+    from scipy import ndimage as ndi
+    for k in range(24):                                                                      # smooth random blobs, fragmented
+        a = ndi.gaussian_filter(rng.standard_normal((64, 64)), rng.uniform(1.5, 4.0))
+        m = a > np.quantile(a, rng.uniform(0.6, 0.9))
+        if k % 3 == 0:
+            m &= ~(ndi.gaussian_filter(rng.standard_normal((64, 64)), 1.5) > 0.12)
+        shapes.append(m)
     masks = eng.masks.clone()
     for i, m in enumerate(shapes):
         packed = np.packbits(m.reshape(64, 8, 8), axis=-1, bitorder='little').reshape(64, 8).view(np.uint32).reshape(64, 2)
@@ -217,7 +242,7 @@ def test_device_contours_match_host_mirror(hip_device, model):
     eng.counts[0] = len(shapes)
     got = eng.contours(1, cap=32, kept_only=False)[0]          # small cap: the checkerboard / noise overflow to the host path
     raw_n = eng.contour_n[0, :len(shapes)].cpu().numpy()
-    assert (raw_n == -1).sum() >= 1 and (raw_n > 0).sum() >= 7
+    assert (raw_n == -1).sum() >= 1 and (raw_n > 0).sum() >= 12
     for i, m in enumerate(shapes):
         assert np.array_equal(got[i], host.trace_outer_contour(m)), i
     got = eng.contours(1, cap=1024, kept_only=False)[0]
