@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NUHTC_ABI_VERSION 1
+#define NUHTC_ABI_VERSION 2
 
 enum {
   NUHTC_OK = 0,
@@ -130,18 +130,29 @@ int nuhtc_infer_fixed_load(nuhtc_engine* e, const uint8_t* tiles_dev, int B, int
  * Enqueues on `stream`; does not synchronise. */
 int nuhtc_mask_contours(nuhtc_engine* e, const nuhtc_dets* dets, int B, int cap, int16_t* xy_dev, int32_t* n_dev, void* stream);
 
+/* Overlap measure of nuhtc_merge_overlap. */
+enum {
+  NUHTC_OVERLAP_MASK = 0,     /* IoU of the instance masks (pixel sets) */
+  NUHTC_OVERLAP_POLYGON = 1   /* the reference's: IoU of the shapely polygons of the rings tools/infer_wsi.py writes (first contour of
+                                 cv2.findContours through the border-pixel centres; buffer(0) + largest part when the ring touches
+                                 itself, tools/nuclei_merge.py:37-59), computed exactly from the mask crops (csrc/merge.hip) */
+};
+
 /* Cross-tile duplicate removal over all detections of a slide: tools/nuclei_merge.py:62-174 `merge_overlap`, strategy
  * 'probability' (visit in descending score, ties by lower index; an alive detection removes every later one whose overlap
- * with it exceeds `thr`).  Overlap = IoU of the instance masks (the reference intersects the polygons traced from them).
+ * with it exceeds `thr`, compared as a double division like the reference's `inter.area / (a.area + b.area - inter.area)`).
  * All pointers are device memory of `device`:  boxes [n][4] int32 = x0,y0,x1,y1 (x1,y1 exclusive) of each mask crop in
- * slide pixels; scores [n]; areas [n] = set pixels; bits = the crops, bit-packed row by row, (x1-x0+31)/32 uint32 words
- * per row, pixel x of a row in bit (x&31) of word x>>5; bit_off [n] = word offset of each crop in `bits`.
+ * slide pixels (the bounding box of the mask's set pixels); scores [n]; areas [n] = set pixels (NUHTC_OVERLAP_MASK only, may
+ * be NULL otherwise); bits = the crops, bit-packed row by row, (x1-x0+31)/32 uint32 words per row, pixel x of a row in bit
+ * (x&31) of word x>>5; bit_off [n] = word offset of each crop in `bits`; n_words = total words of `bits`.
  * x_min..y_max bound all boxes (the slide extent).  keep_dev [n] receives 1 for kept detections.  Allocates its own scratch
- * (about 110 bytes per detection), runs on `stream` and synchronises it before returning.
- * NUHTC_E_CAPACITY: a detection has more than 24 higher-scored neighbours above the threshold. */
+ * (about 120 bytes per detection, plus a copy of `bits` in polygon mode), runs on `stream` and synchronises it before
+ * returning.  A detection may have any number of higher-scored overlapping neighbours (24 are kept inline, the rest in a
+ * spill pool that is grown and the pass repeated when it runs out); NUHTC_E_CAPACITY only if 2^30 spill entries do not
+ * suffice.  NUHTC_E_INVALID in polygon mode if a crop exceeds about 430x430 pixels. */
 int nuhtc_merge_overlap(int device, const int32_t* boxes, const float* scores, const int32_t* areas, const uint32_t* bits,
-                        const int64_t* bit_off, int64_t n, double thr, int x_min, int y_min, int x_max, int y_max,
-                        uint8_t* keep_dev, void* stream);
+                        const int64_t* bit_off, int64_t n, int64_t n_words, int overlap, double thr, int x_min, int y_min,
+                        int x_max, int y_max, uint8_t* keep_dev, void* stream);
 
 /* Synchronises `stream` and reports whether the last nuhtc_infer overflowed max_cc_proposals on some tile (returns
  * NUHTC_E_CAPACITY) — call before trusting the results.  That is the only capacity of the path that is not the reference's

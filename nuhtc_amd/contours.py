@@ -119,9 +119,100 @@ def rasterize_polygon(ring, x0, y0, w, h):
     return out
 
 
+class RingRegion:
+    """Exact region of a closed integer ring whose edges run along the 8 chain-code directions (every ring infer_wsi.py
+    writes), as shapely sees it in tools/nuclei_merge.py:37-59: the points of non-zero winding number (`buffer(0)` of a ring
+    that touches itself), of several parts the largest.  Such a region is a union of the quarter triangles that the two
+    diagonals cut out of the unit cells between integer points, so it is held as four boolean planes N, E, S, W over the
+    cells of the ring's bounding box; areas are multiples of 1/4 and exact."""
+
+    def __init__(self, ring):
+        r = np.asarray(ring, np.int64)
+        if len(r) and np.array_equal(r[0], r[-1]):
+            r = r[:-1]
+        self.x0 = self.y0 = 0
+        self.q = np.zeros((4, 0, 0), bool)
+        if len(r) < 3:
+            return
+        d = np.roll(r, -1, 0) - r
+        if not ((d[:, 0] == 0) | (d[:, 1] == 0) | (np.abs(d[:, 0]) == np.abs(d[:, 1]))).all():
+            raise ValueError('ring has an edge that is not horizontal, vertical or diagonal')
+        self.x0, self.y0 = int(r[:, 0].min()), int(r[:, 1].min())
+        w, h = int(r[:, 0].max()) - self.x0, int(r[:, 1].max()) - self.y0
+        if w == 0 or h == 0:
+            return
+        xa, ya = (r[:, 0] - self.x0).astype(np.float64), (r[:, 1] - self.y0).astype(np.float64)
+        xb, yb = np.roll(xa, -1), np.roll(ya, -1)
+        cy = np.arange(h, dtype=np.float64)[:, None]
+        cx = np.arange(w, dtype=np.float64)[None, :]
+        q = np.zeros((4, h, w), bool)
+        # winding number at the centroid-side sample point of each quarter (never on an edge or a vertex):
+        # N (x+.5, y+.25), E (x+.75, y+.5), S (x+.5, y+.75), W (x+.25, y+.5)
+        for k, (ox, oy) in enumerate(((0.5, 0.25), (0.75, 0.5), (0.5, 0.75), (0.25, 0.5))):
+            wn = np.zeros((h, w), np.int64)
+            py = cy + oy
+            for e in range(len(r)):
+                if ya[e] == yb[e]:
+                    continue
+                lo, hi = min(ya[e], yb[e]), max(ya[e], yb[e])
+                rows = (py[:, 0] > lo) & (py[:, 0] < hi)
+                if not rows.any():
+                    continue
+                xc = xa[e] + (py[rows] - ya[e]) * (xb[e] - xa[e]) / (yb[e] - ya[e])
+                wn[rows] += np.where(cx + ox > xc, 1 if yb[e] > ya[e] else -1, 0)
+            q[k] = wn != 0
+        self.q = self._largest_part(q)
+
+    @staticmethod
+    def _largest_part(q):
+        """Parts = sets of quarters connected through shared edges (not through points): label on a 3x3 sub-grid per cell."""
+        from scipy import ndimage as ndi
+        N, E, S, W = q
+        h, w = N.shape
+        g = np.zeros((3 * h, 3 * w), bool)
+        g[0::3, 1::3], g[1::3, 2::3], g[2::3, 1::3], g[1::3, 0::3] = N, E, S, W
+        g[0::3, 2::3], g[2::3, 2::3], g[2::3, 0::3], g[0::3, 0::3] = N & E, E & S, S & W, W & N    # neighbours inside a cell
+        lab, k = ndi.label(g)
+        if k <= 1:
+            return q
+        planes = (lab[0::3, 1::3], lab[1::3, 2::3], lab[2::3, 1::3], lab[1::3, 0::3])
+        area = np.zeros(k + 1, np.int64)
+        for pl, l in zip(q, planes):
+            np.add.at(area, l[pl], 1)
+        best = int(np.argmax(area[1:])) + 1
+        return np.stack([pl & (l == best) for pl, l in zip(q, planes)])
+
+    @property
+    def area4(self):
+        return int(self.q.sum())
+
+    def inter4(self, other):
+        x0, y0 = max(self.x0, other.x0), max(self.y0, other.y0)
+        x1 = min(self.x0 + self.q.shape[2], other.x0 + other.q.shape[2])
+        y1 = min(self.y0 + self.q.shape[1], other.y0 + other.q.shape[1])
+        if x1 <= x0 or y1 <= y0:
+            return 0
+        a = self.q[:, y0 - self.y0:y1 - self.y0, x0 - self.x0:x1 - self.x0]
+        b = other.q[:, y0 - other.y0:y1 - other.y0, x0 - other.x0:x1 - other.x0]
+        return int((a & b).sum())
+
+
 def polygon_iou(ring_a, ring_b, supersample=1):
+    """IoU of two ring polygons as tools/nuclei_merge.py:128-129 computes it.  Exact (RingRegion) for traced rings; rings with
+    other edge directions or non-integer vertices (GeoJSON from elsewhere) fall back to an even-odd raster at
+    `supersample` samples per pixel."""
     a = np.asarray(ring_a, np.float64)
     b = np.asarray(ring_b, np.float64)
+    try:
+        if not (np.array_equal(a, np.round(a)) and np.array_equal(b, np.round(b))):
+            raise ValueError('non-integer vertices')
+        ra = ring_a if isinstance(ring_a, RingRegion) else RingRegion(a.astype(np.int64))
+        rb = ring_b if isinstance(ring_b, RingRegion) else RingRegion(b.astype(np.int64))
+        inter = ra.inter4(rb)
+        union = ra.area4 + rb.area4 - inter
+        return inter / union if union else 0.0
+    except ValueError:
+        pass
     x0 = int(np.floor(min(a[:, 0].min(), b[:, 0].min()))) - 1
     y0 = int(np.floor(min(a[:, 1].min(), b[:, 1].min()))) - 1
     x1 = int(np.ceil(max(a[:, 0].max(), b[:, 0].max()))) + 1
@@ -160,7 +251,18 @@ def merge_features(features, overlap_threshold=0.01, merge_strategy='probability
     order = sorted(range(n), key=lambda i: -features[i]['properties'].get('score', 0))
     rings = [np.asarray(features[i]['geometry']['coordinates'][0], np.float64) for i in order]
     boxes = np.array([[r[:, 0].min(), r[:, 1].min(), r[:, 0].max(), r[:, 1].max()] for r in rings]) if n else np.zeros((0, 4))
-    areas = [None] * n
+    regs = [None] * n
+
+    def region(i):
+        """exact region of a traced ring, or the ring itself when it is not one (polygon_iou then rasterises)"""
+        if regs[i] is None:
+            try:
+                if not np.array_equal(rings[i], np.round(rings[i])):
+                    raise ValueError
+                regs[i] = RingRegion(rings[i].astype(np.int64))
+            except ValueError:
+                regs[i] = rings[i]
+        return regs[i]
     cell = 64.0
     grid = {}
     for i in range(n):
@@ -182,16 +284,25 @@ def merge_features(features, overlap_threshold=0.01, merge_strategy='probability
                 continue
             if boxes[q, 0] > boxes[c, 2] or boxes[c, 0] > boxes[q, 2] or boxes[q, 1] > boxes[c, 3] or boxes[c, 1] > boxes[q, 3]:
                 continue
-            if polygon_iou(rings[q], rings[c]) > overlap_threshold:
+            rq, rc_ = region(q), region(c)
+            if isinstance(rq, RingRegion) and isinstance(rc_, RingRegion):
+                inter = rq.inter4(rc_)
+                union = rq.area4 + rc_.area4 - inter
+                iou = inter / union if union else 0.0
+            else:
+                iou = polygon_iou(rings[q], rings[c], supersample=4)
+            if iou > overlap_threshold:
                 sub.append(c)
                 visited[c] = True
         if sub and merge_strategy == 'area':
-            for c in sub:
-                if areas[c] is None:
-                    r = rings[c]
-                    areas[c] = rasterize_polygon(r - [np.floor(boxes[c, 0]), np.floor(boxes[c, 1])], 0, 0,
-                                                 int(boxes[c, 2] - boxes[c, 0]) + 2, int(boxes[c, 3] - boxes[c, 1]) + 2).sum()
-            kept.append(max(sub, key=lambda c: areas[c]))
+            def area_of(c):
+                rg = region(c)
+                if isinstance(rg, RingRegion):
+                    return rg.area4 / 4.0
+                r = rings[c]
+                return float(rasterize_polygon(r - [np.floor(boxes[c, 0]), np.floor(boxes[c, 1])], 0, 0,
+                                               int(boxes[c, 2] - boxes[c, 0]) + 2, int(boxes[c, 3] - boxes[c, 1]) + 2).sum())
+            kept.append(max(sub, key=area_of))
         else:
             kept.append(q)
         visited[q] = True

@@ -59,13 +59,10 @@ __global__ __launch_bounds__(64 * CT_WAVES) void contour_kernel(ContourParams p,
   uint32_t* V = M + words;                   // pixels visited by a border walk
   uint32_t* O = V + words;                   // background connected to the image frame (slow path only)
   const uint32_t* gm = p.masks + (long long)det * words;
-  // ---- stage the mask; first set pixel in raster order and the bounding rows / word columns
+  // ---- first set pixel in raster order and the bounding rows / word columns; only that rectangle is staged in LDS
   int first = 0x7fffffff, wy0 = 0x7fffffff, wy1 = -1, wx0 = 0x7fffffff, wx1 = -1;
   for (int i = lane; i < words; i += 64) {
-    const uint32_t w = gm[i];
-    M[i] = w;
-    V[i] = 0;
-    if (w) {
+    if (gm[i]) {
       const int y = i / wpr, x = i - y * wpr;
       first = min(first, i); wy0 = min(wy0, y); wy1 = max(wy1, y); wx0 = min(wx0, x); wx1 = max(wx1, x);
     }
@@ -80,13 +77,19 @@ __global__ __launch_bounds__(64 * CT_WAVES) void contour_kernel(ContourParams p,
     if (lane == 0) p.n[det] = 0;
     return;
   }
+  const int bw = wx1 - wx0 + 1, items = (wy1 - wy0 + 1) * bw;
+  for (int t = lane; t < items; t += 64) {
+    const int i = (wy0 + t / bw) * wpr + wx0 + t % bw;
+    M[i] = gm[i];
+    V[i] = 0;
+  }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
   int16_t* out = p.xy + (long long)det * p.cap * 2;
   const int cap = p.cap;
 
-  auto fg = [&](int y, int x) -> bool {
-    return y >= 0 && y < H && x >= 0 && x < W && ((M[y * wpr + (x >> 5)] >> (x & 31)) & 1u);
+  auto fg = [&](int y, int x) -> bool {       // everything outside the staged rectangle is background
+    return y >= wy0 && y <= wy1 && x >= wx0 * 32 && x < (wx1 + 1) * 32 && ((M[y * wpr + (x >> 5)] >> (x & 31)) & 1u);
   };
   // lane 0: walk the outer border that starts at pixel `start` (raster index), mark it in V, emit vertices; returns the count
   auto walk = [&](int start) -> int {
@@ -118,14 +121,14 @@ __global__ __launch_bounds__(64 * CT_WAVES) void contour_kernel(ContourParams p,
   // neighbour lies in O (pixels left of the image count as outside); raster index or 0x7fffffff
   auto next_start = [&](bool need_outer) -> int {
     int best = 0x7fffffff;
-    for (int i = lane; i < words; i += 64) {
+    for (int t = lane; t < items; t += 64) {
+      const int y = wy0 + t / bw, xw = wx0 + t % bw, i = y * wpr + xw;
       const uint32_t w = M[i];
       if (!w) continue;
-      const int xw = i % wpr;
-      const uint32_t west = (w << 1) | (xw ? M[i - 1] >> 31 : 0u);
+      const uint32_t west = (w << 1) | (xw > wx0 ? M[i - 1] >> 31 : 0u);
       uint32_t c = w & ~west & ~V[i];
-      if (need_outer) c &= (O[i] << 1) | (xw ? O[i - 1] >> 31 : 1u);
-      if (c) best = min(best, (i / wpr) * W + xw * 32 + __ffs(c) - 1);
+      if (need_outer) c &= (O[i] << 1) | (xw > wx0 ? O[i - 1] >> 31 : 1u);
+      if (c) best = min(best, y * W + xw * 32 + __ffs(c) - 1);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o));
@@ -138,28 +141,21 @@ __global__ __launch_bounds__(64 * CT_WAVES) void contour_kernel(ContourParams p,
   __builtin_amdgcn_wave_barrier();
   int cand = next_start(false);
   if (cand != 0x7fffffff) {
-    // ---- more than one component, or a hole: flood the frame-connected background inside the bounding rows / columns
-    for (int i = lane; i < words; i += 64) {
-      const int y = i / wpr, xw = i - y * wpr;
-      uint32_t seed = 0;
-      if (y < wy0 || y > wy1 || xw < wx0 || xw > wx1 || y == 0 || y == H - 1) seed = ~0u;
-      if (xw == 0) seed |= 1u;
-      if (xw == wpr - 1) seed |= 1u << ((W - 1) & 31);
-      O[i] = seed & ~M[i];
-    }
+    // ---- more than one component, or a hole: flood the frame-connected background inside the staged rectangle; whatever
+    // lies outside the rectangle (or outside the image: cv::findContours pads with zeros) is background connected to the frame
+    for (int t = lane; t < items; t += 64) O[(wy0 + t / bw) * wpr + wx0 + t % bw] = 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    const int bw = wx1 - wx0 + 1, items = (wy1 - wy0 + 1) * bw;
     for (int iter = 0; iter < H * W; ++iter) {
       bool changed = false;
       for (int t = lane; t < items; t += 64) {
         const int y = wy0 + t / bw, xw = wx0 + t % bw, i = y * wpr + xw;
         const uint32_t bg = ~M[i], cur = O[i];
         uint32_t nb = (cur << 1) | (cur >> 1);
-        if (xw > 0) nb |= O[i - 1] >> 31;
-        if (xw < wpr - 1) nb |= O[i + 1] << 31;
-        if (y > 0) nb |= O[i - wpr];
-        if (y < H - 1) nb |= O[i + wpr];
+        nb |= xw > wx0 ? O[i - 1] >> 31 : 1u;
+        nb |= xw < wx1 ? O[i + 1] << 31 : 0x80000000u;
+        nb |= y > wy0 ? O[i - wpr] : ~0u;
+        nb |= y < wy1 ? O[i + wpr] : ~0u;
         const uint32_t nw = run_fill((cur | nb) & bg, bg);
         if (nw != cur) { O[i] = nw; changed = true; }
       }

@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(HERE, 'libnuhtc_hip.so')
 
 OK, E_INVALID, E_HIP, E_STATE, E_CAPACITY, E_NOTFOUND = 0, -1, -2, -3, -4, -5
 CH_AS_IS, CH_SWAP = 0, 1
+OVERLAP_MASK, OVERLAP_POLYGON = 0, 1
 
 
 class Config(ctypes.Structure):
@@ -68,7 +69,7 @@ def load():
     lib.nuhtc_op_roi_align.argtypes = [vp, vp, ci, ci, ci, vp, ci, ci, cf, ci, vp, vp]
     lib.nuhtc_op_nms.argtypes = [vp, vp, vp, ci, cf, vp, vp, vp]
     lib.nuhtc_mask_contours.argtypes = [vp, ctypes.POINTER(Dets), ci, ci, vp, vp, vp]
-    lib.nuhtc_merge_overlap.argtypes = [ci, vp, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_double, ci, ci, ci, ci, vp, vp]
+    lib.nuhtc_merge_overlap.argtypes = [ci, vp, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int64, ci, ctypes.c_double, ci, ci, ci, ci, vp, vp]
     lib.nuhtc_profile_enable.argtypes = [ci]
     lib.nuhtc_profile_read.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
     for name in EXPORTS:

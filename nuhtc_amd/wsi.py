@@ -134,13 +134,16 @@ def pack_masks(masks):
     return boxes, areas, bits, off
 
 
-def merge_overlap_packed(boxes, scores, areas, bits, off, overlap_threshold=0.05, device=0):
-    """nuhtc_merge_overlap on packed crops (see pack_masks); numpy in, kept indices (ascending) out."""
+def merge_overlap_packed(boxes, scores, areas, bits, off, overlap_threshold=0.05, device=0, overlap='polygon'):
+    """nuhtc_merge_overlap on packed crops (see pack_masks); numpy in, kept indices (ascending) out.
+    overlap: 'polygon' (the reference's measure: IoU of the ring polygons, exact) or 'mask' (IoU of the pixel sets)."""
     import ctypes
     import torch
     n = len(scores)
     if n == 0:
         return np.zeros(0, np.int64)
+    if overlap not in ('polygon', 'mask'):
+        raise ValueError(f"overlap must be 'polygon' or 'mask', got {overlap!r}")
     lib = hip.load()
     dev = torch.device('cuda', device)
     arrs = (np.ascontiguousarray(boxes, np.int32), np.ascontiguousarray(scores, np.float32), np.ascontiguousarray(areas, np.int32),
@@ -150,7 +153,8 @@ def merge_overlap_packed(boxes, scores, areas, bits, off, overlap_threshold=0.05
     vp = lambda x: ctypes.c_void_p(x.data_ptr())
     b = arrs[0]
     with torch.cuda.device(dev):
-        rc = lib.nuhtc_merge_overlap(device, vp(t[0]), vp(t[1]), vp(t[2]), vp(t[3]), vp(t[4]), n, float(overlap_threshold),
+        rc = lib.nuhtc_merge_overlap(device, vp(t[0]), vp(t[1]), vp(t[2]), vp(t[3]), vp(t[4]), n, int(arrs[3].size),
+                                     hip.OVERLAP_POLYGON if overlap == 'polygon' else hip.OVERLAP_MASK, float(overlap_threshold),
                                      int(b[:, 0].min()), int(b[:, 1].min()), int(b[:, 2].max()), int(b[:, 3].max()),
                                      vp(keep), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
     if rc:
@@ -158,13 +162,14 @@ def merge_overlap_packed(boxes, scores, areas, bits, off, overlap_threshold=0.05
     return np.nonzero(keep.cpu().numpy())[0].astype(np.int64)
 
 
-def merge_overlap(rec, overlap_threshold=0.05, device=0):
+def merge_overlap(rec, overlap_threshold=0.05, device=0, overlap='polygon'):
     """Cross-tile duplicate removal, strategy 'probability' of tools/nuclei_merge.py:62-174: detections sorted by
     score (descending), each still-alive one suppresses every later one it overlaps with IoU > threshold.
-    The reference intersects shapely polygons of the cv2 contours; here IoU is taken on the pixel masks the
-    polygons are traced from (same objects, pixel-area instead of polygon-area IoU).  Runs on the GPU
-    (nuhtc_merge_overlap, csrc/merge.hip).  Returns kept indices (ascending)."""
+    overlap='polygon' (default) is the reference's measure: the IoU of the shapely polygons of the rings infer_wsi.py
+    writes (first cv2 contour through the border-pixel centres, buffer(0) + largest part for self-touching rings), computed
+    exactly on the GPU from the mask crops (nuhtc_merge_overlap, csrc/merge.hip); 'mask' is the IoU of the pixel sets.
+    Returns kept indices (ascending)."""
     if len(rec['score']) == 0:
         return np.zeros(0, np.int64)
     boxes, areas, bits, off = pack_masks(rec['mask'])
-    return merge_overlap_packed(boxes, rec['score'], areas, bits, off, overlap_threshold, device)
+    return merge_overlap_packed(boxes, rec['score'], areas, bits, off, overlap_threshold, device, overlap)

@@ -62,25 +62,80 @@ def test_pack_masks_layout():
     assert bits.tolist() == [1, 2, 0, 4, 1]
 
 
+def _special_shapes():
+    """Masks whose ring polygon differs from the pixel set in kind: fragments (only the component cv2 lists first counts),
+    holes with islands, a pinched blob (buffer(0) splits it, the largest part counts), one-pixel bridges and spurs, lines."""
+    out = []
+    m = np.zeros((20, 30), bool); m[2:9, 2:9] = True; m[12:18, 15:28] = True; out.append(m)                    # two fragments
+    m = np.zeros((24, 24), bool); m[1:23, 1:23] = True; m[5:19, 5:19] = False; m[9:15, 9:15] = True; out.append(m)   # ring + island
+    m = np.zeros((16, 16), bool); m[0:6, 0:6] = True; m[6:15, 6:15] = True; out.append(m)                      # pinch on a diagonal step
+    m = np.zeros((12, 30), bool); m[1:11, 1:9] = True; m[5, 9:18] = True; m[1:11, 18:29] = True; out.append(m)  # bridge between lobes
+    m = np.zeros((9, 20), bool); m[1:8, 1:8] = True; m[4, 8:19] = True; out.append(m)                           # spur
+    m = np.zeros((3, 17), bool); m[1, 1:16] = True; out.append(m)                                               # a line: no area
+    m = np.ones((14, 37), bool); out.append(m)                                                                   # crop wider than a word
+    m = np.zeros((40, 70), bool); m[5:35, 3:67] = True; m[10:30, 10:60] = False; m[15:25, 30:40] = True; m[0:3, 60:70] = True; out.append(m)
+    return out
+
+
 @pytest.mark.gpu
 def test_device_merge_matches_oracle(hip_device):
+    """Both overlap measures against their sequential oracles, keep sets bit for bit: 'polygon' (the reference's: IoU of the
+    ring polygons, oracle/merge_poly.py on rings traced by oracle/contour.py) and 'mask' (pixel sets, oracle/merge.py)."""
     from nuhtc_amd import wsi
-    from oracle.merge import merge_overlap as oracle_merge
+    from oracle.merge import merge_overlap as oracle_mask
+    from oracle.merge_poly import merge_overlap_masks as oracle_poly
     rng = np.random.default_rng(7)
-    for n, size, quant in ((1, 64, None), (40, 200, None), (600, 1200, None), (2500, 2600, 20), (3000, 900, None)):
+    n_diff = 0
+    for n, size, quant in ((1, 64, None), (40, 200, None), (600, 1200, None), (1500, 2000, 20), (1500, 700, None)):
         rec = random_slide(rng, n, size, quant=quant)
-        ref = oracle_merge(rec, 0.05)
-        got = wsi.merge_overlap(rec, 0.05)
-        assert np.array_equal(ref, got), (n, len(ref), len(got))
-        assert 0 < len(got) <= len(rec['score'])
+        ref = oracle_mask(rec, 0.05)
+        got = wsi.merge_overlap(rec, 0.05, overlap='mask')
+        assert np.array_equal(ref, got), ('mask', n, len(ref), len(got))
+        refp = oracle_poly(rec['mask'], rec['score'], 0.05)
+        gotp = wsi.merge_overlap(rec, 0.05, overlap='polygon')
+        assert np.array_equal(refp, gotp), ('polygon', n, len(refp), len(gotp), np.setxor1d(refp, gotp)[:10])
+        assert 0 < len(gotp) <= len(rec['score'])
+        n_diff += len(np.setxor1d(ref, refp))
+    print('keep-set entries on which mask IoU and polygon IoU disagree over these slides:', n_diff)
+    # shapes where polygon and pixel set differ in kind, shifted copies of each other at every small offset
+    shapes = _special_shapes()
+    masks, scores = [], []
+    for k, m in enumerate(shapes):
+        for j, (dx, dy) in enumerate(((0, 0), (1, 0), (3, 2), (7, 5), (-2, 9), (12, -3))):
+            masks.append((m, 300 * k + 50 + dx, 100 + dy)); scores.append(0.9 - 0.01 * j - 0.001 * k)
+        masks.append((m.T.copy(), 300 * k + 52, 98)); scores.append(0.5)
+    for thr in (0.0, 0.01, 0.05, 0.3):
+        refp = oracle_poly(masks, scores, thr)
+        gotp = wsi.merge_overlap(dict(score=scores, mask=masks), thr, overlap='polygon')
+        assert np.array_equal(refp, gotp), (thr, refp.tolist(), gotp.tolist())
     # other thresholds, including "suppress on any overlap" and "never"
     rec = random_slide(rng, 800, 900)
     for thr in (0.0, 0.3, 0.999):
-        assert np.array_equal(oracle_merge(rec, thr), wsi.merge_overlap(rec, thr))
+        assert np.array_equal(oracle_mask(rec, thr), wsi.merge_overlap(rec, thr, overlap='mask'))
+        assert np.array_equal(oracle_poly(rec['mask'], rec['score'], thr), wsi.merge_overlap(rec, thr, overlap='polygon'))
     # empty crops are never kept; empty input
     rec = dict(score=[0.9, 0.8], mask=[(np.zeros((0, 0), bool), 5, 5), (np.ones((3, 3), bool), 5, 5)])
-    assert wsi.merge_overlap(rec, 0.05).tolist() == [1] == oracle_merge(rec, 0.05).tolist()
+    assert wsi.merge_overlap(rec, 0.05, overlap='mask').tolist() == [1] == oracle_mask(rec, 0.05).tolist()
     assert wsi.merge_overlap(dict(score=[], mask=[]), 0.05).tolist() == []
+
+
+@pytest.mark.gpu
+def test_device_merge_dense_clump_spills(hip_device):
+    """Hundreds of detections on one spot: every one has far more than 24 higher-scored overlapping neighbours (the inline
+    suppressor list), and the 1000-detection case also overruns the first spill pool so the pass is repeated with a larger
+    one.  The keep set still equals the sequential oracle's."""
+    from nuhtc_amd import wsi
+    from oracle.merge import merge_overlap as oracle_mask
+    from oracle.merge_poly import merge_overlap_masks as oracle_poly
+    rng = np.random.default_rng(5)
+    for n, mode in ((300, 'polygon'), (1000, 'mask')):
+        masks = [(disc(int(rng.integers(6, 12))), int(rng.integers(100, 125)), int(rng.integers(100, 125))) for _ in range(n)]
+        scores = rng.uniform(0.35, 1.0, n).round(3).tolist()
+        rec = dict(score=scores, mask=masks)
+        for thr in (0.05, 0.6):
+            ref = oracle_poly(masks, scores, thr) if mode == 'polygon' else oracle_mask(rec, thr)
+            got = wsi.merge_overlap(rec, thr, overlap=mode)
+            assert np.array_equal(ref, got), (n, mode, thr, len(ref), len(got))
 
 
 @pytest.mark.gpu
@@ -92,9 +147,14 @@ def test_device_merge_slide_scale_properties(hip_device):
     rng = np.random.default_rng(11)
     rec = random_slide(rng, 150000, 19264, dup=0.4)
     t = time.time()
-    keep = wsi.merge_overlap(rec, 0.05)
+    keep = wsi.merge_overlap(rec, 0.05, overlap='mask')
     dt = time.time() - t
-    assert np.array_equal(keep, wsi.merge_overlap(rec, 0.05))
+    assert np.array_equal(keep, wsi.merge_overlap(rec, 0.05, overlap='mask'))
+    t = time.time()
+    keep_p = wsi.merge_overlap(rec, 0.05, overlap='polygon')
+    print(f'polygon overlap: {len(keep_p)} kept in {time.time() - t:.2f} s (incl. host packing); differs from the mask-IoU keep set in '
+          f'{len(np.setxor1d(keep, keep_p))} of {len(rec["score"])} detections')
+    assert np.array_equal(keep_p, wsi.merge_overlap(rec, 0.05, overlap='polygon'))
     n = len(rec['score'])
     assert 0.5 * n < len(keep) < n
     print(f'{n} detections -> {len(keep)} kept in {dt:.2f} s (incl. host packing)')

@@ -62,15 +62,23 @@ def test_slide_merge_and_sharding(model):
     the same merged slide as one."""
     from nuhtc_amd import synth, wsi
     from nuhtc_amd.parallel import shard_range
-    from oracle.merge import merge_overlap as oracle_merge
+    from oracle.merge import merge_overlap as oracle_mask
+    from oracle.merge_poly import merge_overlap_masks as oracle_poly
     G = 4
     full, _ = synth.nuclei_canvas(G)
     tiles = synth.CanvasTiles(full, 0, G, 0, G * G)
     rec = wsi.infer_tiles(model, tiles, tiles.coords, 8)
     n = len(rec['score'])
     assert n > 50
-    kept = wsi.merge_overlap(rec, 0.05)
-    assert np.array_equal(kept, oracle_merge(rec, 0.05))
+    kept = wsi.merge_overlap(rec, 0.05)                              # the reference's polygon-IoU measure (default)
+    assert np.array_equal(kept, oracle_poly(rec['mask'], rec['score'], 0.05))
+    kept_m = wsi.merge_overlap(rec, 0.05, overlap='mask')
+    assert np.array_equal(kept_m, oracle_mask(rec, 0.05))
+    print(f'{n} records: polygon-IoU keeps {len(kept)}, mask-IoU keeps {len(kept_m)}, they disagree on {len(np.setxor1d(kept, kept_m))}')
+    # the rings the engine traced are the rings the oracle traces from the same masks
+    from oracle import contour as OC
+    for (m, x0, y0), ring in zip(rec['mask'], rec['ring']):
+        assert np.array_equal(ring, OC.mask2inst(m) + np.array([x0, y0]))
     assert 0 < len(kept) < n                                         # overlap zones held duplicates
     parts = []
     for r in range(2):
