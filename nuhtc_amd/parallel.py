@@ -47,3 +47,43 @@ def gather_records(rec, group=None):
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad, group=group)
     return [b[:c] for b, c in zip(bufs, counts)]
+
+
+def gather_blobs(parts, group=None):
+    """The one exchange of the WSI path (north star: a single all-gather of the per-tile detections): `parts` is this rank's
+    list of tensors -- any dtypes, any leading lengths (0 allowed), trailing shapes equal on all ranks -- and every rank gets
+    back, per rank, the list of that rank's tensors.  All parts travel as ONE byte buffer: an all_gather of the small header
+    (leading lengths; this is the "counts" exchange of mmdet/apis/test.py:161-191) followed by one all_gather of the buffers
+    padded to the longest."""
+    parts = [p.contiguous() for p in parts]
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return [parts]
+    world = dist.get_world_size(group)
+    dev = parts[0].device
+    head = torch.tensor([p.shape[0] for p in parts], dtype=torch.int64, device=dev)
+    heads = [torch.zeros_like(head) for _ in range(world)]
+    dist.all_gather(heads, head, group=group)
+    heads = [h.cpu().tolist() for h in heads]
+    row_bytes = [p.element_size() * int(torch.tensor(p.shape[1:]).prod()) if p.dim() > 1 else p.element_size() for p in parts]
+
+    def seg_bytes(lengths):            # every segment starts on an 8-byte boundary
+        return [-(-n * rb // 8) * 8 for n, rb in zip(lengths, row_bytes)]
+    total = max(max(sum(seg_bytes(h)) for h in heads), 8)
+    buf = torch.zeros(total, dtype=torch.uint8, device=dev)
+    off = 0
+    for p, sb in zip(parts, seg_bytes(head.cpu().tolist())):
+        nb = p.numel() * p.element_size()
+        if nb:
+            buf[off:off + nb] = p.reshape(-1).view(torch.uint8)
+        off += sb
+    bufs = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(bufs, buf, group=group)
+    out = []
+    for b, h in zip(bufs, heads):
+        off, got = 0, []
+        for p, n, rb, sb in zip(parts, h, row_bytes, seg_bytes(h)):
+            seg = b[off:off + n * rb].view(p.dtype) if n else torch.zeros(0, dtype=p.dtype, device=dev)
+            got.append(seg.reshape((n,) + tuple(p.shape[1:])))
+            off += sb
+        out.append(got)
+    return out

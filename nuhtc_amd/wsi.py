@@ -173,3 +173,44 @@ def merge_overlap(rec, overlap_threshold=0.05, device=0, overlap='polygon'):
         return np.zeros(0, np.int64)
     boxes, areas, bits, off = pack_masks(rec['mask'])
     return merge_overlap_packed(boxes, rec['score'], areas, bits, off, overlap_threshold, device, overlap)
+
+
+def pack_records(rec, keep=None, tile_base=0, rles=None):
+    """Per-detection records of one rank -> the tensors that cross the node in the single gather (SURVEY §8e record layout):
+    head  float64 (n, 9): box x0,y0,x1,y1 (slide px), score, label, ring length, tile index, RLE length
+    verts int32   (sum ring lengths, 2): the closed rings, concatenated
+    crops int64   (n, 6): mask-crop box x0,y0,x1,y1 (x1,y1 exclusive), set pixels, word offset into `bits`
+    bits  int32   (words,): the bit-packed mask crops (the merge's input)
+    blob  uint8   (bytes,): optional COCO RLE strings, concatenated"""
+    import torch
+    keep = list(range(len(rec['score']))) if keep is None else list(keep)
+    n = len(keep)
+    head = np.zeros((n, 9), np.float64)
+    for k, i in enumerate(keep):
+        head[k, :4] = rec['box'][i]
+        head[k, 4], head[k, 5], head[k, 6] = rec['score'][i], rec['label'][i], len(rec['ring'][i])
+        head[k, 7] = tile_base + rec['tile'][i]
+        head[k, 8] = len(rles[k]) if rles else 0
+    verts = np.concatenate([rec['ring'][i] for i in keep], 0).astype(np.int32) if n else np.zeros((0, 2), np.int32)
+    mb, ma, mbits, moff = pack_masks([rec['mask'][i] for i in keep])
+    crops = np.concatenate([mb.astype(np.int64), ma[:, None].astype(np.int64), moff[:, None]], 1) if n else np.zeros((0, 6), np.int64)
+    if n == 0:
+        mbits = np.zeros(0, np.uint32)
+    blob = np.frombuffer(b''.join(rles), np.uint8).copy() if rles else np.zeros(0, np.uint8)
+    return [torch.from_numpy(head), torch.from_numpy(verts), torch.from_numpy(crops), torch.from_numpy(mbits.view(np.int32).copy()),
+            torch.from_numpy(blob)]
+
+
+def merge_gathered(gathered, overlap_threshold=0.05, device=0, overlap='polygon'):
+    """Rank 0 after the gather: `gathered` = per rank [head, verts, crops, bits, blob] (parallel.gather_blobs of pack_records)
+    -> kept indices into the rank-major concatenation of the records (nuhtc_merge_overlap on this GPU)."""
+    pk = [g[2].cpu().numpy() for g in gathered]
+    wb = [g[3].cpu().numpy().view(np.uint32) for g in gathered]
+    base = np.cumsum([0] + [len(w) for w in wb[:-1]])
+    allp = np.concatenate(pk, 0)
+    if len(allp) == 0:
+        return np.zeros(0, np.int64)
+    off_all = np.concatenate([p[:, 5] + b0 for p, b0 in zip(pk, base)])
+    scores = np.concatenate([g[0].cpu().numpy()[:, 4] for g in gathered]).astype(np.float32)
+    bits = np.concatenate(wb) if sum(len(w) for w in wb) else np.zeros(1, np.uint32)
+    return merge_overlap_packed(allp[:, :4], scores, allp[:, 4], bits, off_all, overlap_threshold, device, overlap)

@@ -96,6 +96,18 @@ def _gather_worker(rank, world, port, q):
     q.put((rank, flat[:, 0].tolist(), [p.shape[0] for p in parts]))
     empty = gather_records(torch.zeros(0, 3) if rank == 0 else torch.ones(2, 3))      # a rank with no detections
     q.put((rank, [p.shape[0] for p in empty]))
+    # the single packed exchange of the WSI path: several tensors of different dtypes and lengths in one buffer
+    from nuhtc_amd.parallel import gather_blobs
+    n = 3 + 2 * rank
+    mine = [torch.arange(n * 9, dtype=torch.float64).reshape(n, 9) + 100 * rank, torch.arange(8 * rank, dtype=torch.int32).reshape(-1, 2)[:3 * rank] if rank else torch.zeros((0, 2), dtype=torch.int32),
+            torch.full((n, 6), rank, dtype=torch.int64), torch.arange(5 + rank, dtype=torch.int32), torch.zeros(0, dtype=torch.uint8)]
+    got = gather_blobs(mine)
+    ok = len(got) == world and all(len(g) == 5 for g in got)
+    ok = ok and all(torch.equal(a, b) and a.dtype == b.dtype for a, b in zip(got[rank], mine))
+    other = got[1 - rank]
+    ok = ok and other[0].shape == (3 + 2 * (1 - rank), 9) and float(other[0][0, 0]) == 100.0 * (1 - rank) and other[3].tolist() == list(range(5 + 1 - rank))
+    ok = ok and other[2].dtype == torch.int64 and int(other[2].sum()) == (1 - rank) * 6 * (3 + 2 * (1 - rank)) and other[4].numel() == 0
+    q.put((rank, 'blobs', ok, [int(t.shape[0]) for t in other]))
     dist.destroy_process_group()
 
 
@@ -107,12 +119,14 @@ def test_gather_records_gloo_world2():
     procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    out = [q.get(timeout=120) for _ in range(4)]
+    out = [q.get(timeout=120) for _ in range(6)]
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
     firsts = [o for o in out if len(o) == 3]
     seconds = [o for o in out if len(o) == 2]
+    blobs = [o for o in out if len(o) == 4]
+    assert len(blobs) == 2 and all(o[2] for o in blobs), blobs
     for _, vals, sizes in firsts:
         assert vals == [float(i) for i in range(11)] and sizes == [6, 5]
     for _, sizes in seconds:

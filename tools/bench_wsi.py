@@ -58,22 +58,15 @@ def main():
     sync()
     t_infer = time.perf_counter() - t0
 
-    # one gather of the bit-packed mask crops + scores, merge on rank 0's GPU
+    # one gather of the records (boxes, scores, rings, bit-packed mask crops), merge on rank 0's GPU (polygon IoU)
     t0 = time.perf_counter()
-    mb, ma, mbits, moff = wsi.pack_masks(rec['mask'])
-    n = len(rec['score'])
-    packed = torch.from_numpy(np.concatenate([mb.astype(np.int64), ma[:, None].astype(np.int64), moff[:, None]], 1)) if n else torch.zeros((0, 6), dtype=torch.int64)
-    pk = [p.cpu().numpy() for p in parallel.gather_records(packed.to(dev))]
-    wb = [p.cpu().numpy().view(np.uint32) for p in parallel.gather_records(torch.from_numpy(mbits.view(np.int32).copy()).to(dev))]
-    sc = [p.cpu().numpy() for p in parallel.gather_records(torch.tensor(rec['score'], dtype=torch.float32).to(dev))]
+    gathered = parallel.gather_blobs([t.to(dev) for t in wsi.pack_records(rec)])       # ONE all-gather of every rank's records
     sync()
     t_gather = time.perf_counter() - t0
     if rank == 0:
         t0 = time.perf_counter()
-        base = np.cumsum([0] + [len(w) for w in wb[:-1]])
-        allp = np.concatenate(pk, 0)
-        off_all = np.concatenate([p[:, 5] + b0 for p, b0 in zip(pk, base)]) if len(allp) else np.zeros(0, np.int64)
-        kept = wsi.merge_overlap_packed(allp[:, :4], np.concatenate(sc), allp[:, 4], np.concatenate(wb), off_all, args.overlap_threshold, device=local_rank)
+        kept = wsi.merge_gathered(gathered, args.overlap_threshold, device=local_rank)
+        allp = np.concatenate([g[2].cpu().numpy() for g in gathered], 0)
         t_merge = time.perf_counter() - t0
         total = G * G
         print(json.dumps({

@@ -12,13 +12,14 @@ lib = hip.load(); dev = torch.device('cuda', 0)
 t = [torch.from_numpy(a).to(dev) for a in (boxes, np.asarray(rec['score'], np.float32), areas, bits.view(np.int32), off)]
 keep = torch.zeros(len(areas), dtype=torch.uint8, device=dev)
 vp = lambda x: ctypes.c_void_p(x.data_ptr())
-def run():
-    rc = lib.nuhtc_merge_overlap(0, vp(t[0]), vp(t[1]), vp(t[2]), vp(t[3]), vp(t[4]), len(areas), 0.05, int(boxes[:, 0].min()), int(boxes[:, 1].min()),
-                                 int(boxes[:, 2].max()), int(boxes[:, 3].max()), vp(keep), None)
+def run(mode):
+    rc = lib.nuhtc_merge_overlap(0, vp(t[0]), vp(t[1]), vp(t[2]), vp(t[3]), vp(t[4]), len(areas), int(bits.size), mode, 0.05, int(boxes[:, 0].min()),
+                                 int(boxes[:, 1].min()), int(boxes[:, 2].max()), int(boxes[:, 3].max()), vp(keep), None)
     assert rc == 0
-run(); torch.cuda.synchronize()
-t0 = time.time()
-for _ in range(5): run()
-torch.cuda.synchronize()
-dt = (time.time() - t0) / 5
-print('%d detections (%.1f MB of mask bits): %d kept, %.2f ms per merge = %.1f M detections/s' % (len(areas), bits.nbytes / 1e6, int(keep.sum()), dt * 1e3, len(areas) / dt / 1e6))
+for mode, name in ((hip.OVERLAP_MASK, 'mask IoU'), (hip.OVERLAP_POLYGON, 'polygon IoU')):
+    run(mode); torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(5): run(mode)
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / 5
+    print('%s: %d detections (%.1f MB of mask bits): %d kept, %.2f ms per merge = %.1f M detections/s' % (name, len(areas), bits.nbytes / 1e6, int(keep.sum()), dt * 1e3, len(areas) / dt / 1e6))

@@ -90,23 +90,12 @@ def main():
             full = np.zeros((P, P), np.uint8)
             full[y0 - oy:y0 - oy + crop.shape[0], x0 - ox:x0 - ox + crop.shape[1]] = crop
             rles.append(cocomask.encode(full)['counts'].encode('ascii'))
-    head = torch.zeros((n, 9), dtype=torch.float64)
-    for k, i in enumerate(keep):
-        head[k, :4] = torch.from_numpy(rec['box'][i])
-        head[k, 4], head[k, 5], head[k, 6] = rec['score'][i], rec['label'][i], len(rings[i])
-        head[k, 7] = lo + rec['tile'][i]                              # annidx: the tile's position in the slide's tile list
-        head[k, 8] = len(rles[k]) if rles else 0
-    verts = torch.from_numpy(np.concatenate([rings[i] for i in keep], 0).astype(np.float64)) if n else torch.zeros((0, 2), dtype=torch.float64)
-    blob = torch.from_numpy(np.frombuffer(b''.join(rles), np.uint8).copy()) if rles else torch.zeros(0, dtype=torch.uint8)
+    # the one exchange of the path: every rank's records (head, ring vertices, mask crops, RLE strings) in a single all-gather
     dev = torch.device('cuda', local_rank) if world > 1 and torch.cuda.is_available() else torch.device('cpu')
-    heads = parallel.gather_records(head.to(dev))
-    vparts = parallel.gather_records(verts.to(dev))
-    bparts = parallel.gather_records(blob.to(dev)) if want('coco') else [None] * len(heads)
-    mparts = None
-    if args.merge:       # the cross-tile merge runs on rank 0's GPU over the bit-packed mask crops of every rank
-        mb, ma, mbits, moff = wsi.pack_masks([rec['mask'][i] for i in keep])
-        packed = torch.from_numpy(np.concatenate([mb.astype(np.int64), ma[:, None].astype(np.int64), moff[:, None]], 1)) if n else torch.zeros((0, 6), dtype=torch.int64)
-        mparts = (parallel.gather_records(packed.to(dev)), parallel.gather_records(torch.from_numpy(mbits.view(np.int32).copy()).to(dev)))
+    gathered = parallel.gather_blobs([t.to(dev) for t in wsi.pack_records(rec, keep, tile_base=lo, rles=rles)])
+    heads = [g[0] for g in gathered]
+    vparts = [g[1] for g in gathered]
+    bparts = [g[4] if want('coco') else None for g in gathered]
     if rank == 0:
         from nuhtc_amd import outputs
         name = os.path.splitext(os.path.basename(args.source))[0]
@@ -143,14 +132,7 @@ def main():
             outputs.write_json(os.path.join(out_dir, name + '.geojson'), feats)
             outputs.write_json(os.path.join(out_dir, name + '_point.geojson'), points)
             if args.merge:
-                pk = [p.cpu().numpy() for p in mparts[0]]
-                wb = [p.cpu().numpy().view(np.uint32) for p in mparts[1]]
-                base = np.cumsum([0] + [len(w) for w in wb[:-1]])
-                allp = np.concatenate(pk, 0)
-                off_all = np.concatenate([p[:, 5] + b0 for p, b0 in zip(pk, base)]) if len(allp) else np.zeros(0, np.int64)
-                scores_all = np.concatenate([h.cpu().numpy()[:, 4] for h in heads]).astype(np.float32)
-                kept = wsi.merge_overlap_packed(allp[:, :4], scores_all, allp[:, 4], np.concatenate(wb), off_all,
-                                                args.overlap_threshold, device=local_rank if world > 1 else (torch.device(args.device).index or 0))
+                kept = wsi.merge_gathered(gathered, args.overlap_threshold, device=local_rank if world > 1 else (torch.device(args.device).index or 0))
                 merged = [feats[i] for i in kept]
                 outputs.write_json(os.path.join(out_dir, name + '_merged.geojson'), merged)
                 msg += f', {len(merged)} after the cross-tile merge'
