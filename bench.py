@@ -8,9 +8,15 @@ One step = one nuhtc_infer call on one batch of `--batch` synthetic 256x256x3 ti
 per-tile mask-NMS).  Workload = BASELINE.json configs[1] ("PanNuke fold1 batch_size=16 256x256 tiles, 1xMI355X")
 with seeded synthetic weights (models/pannuke.pth is not distributed) and synthetic nuclei tiles.
 With N > 1 (launched by torch.distributed.run, one rank per GPU) tiles are sharded across ranks (weak scaling:
-every rank processes its own batches, no data-path collective); the per-tile detection records of the last step
-are all-gathered once over RCCL, as the WSI path does before the host-side merge.
+every rank processes its own batches, no data-path collective); the detection records of the last step -- the layout the
+WSI path ships: heads, ring vertices, bit-packed mask crops (nuhtc_amd.wsi.pack_records) -- are exchanged in ONE all-gather
+over RCCL (nuhtc_amd.parallel.gather_blobs), inside the timed region, as before the host-side merge of a slide.
 Prints ONE JSON line on rank 0.
+
+Besides `value`: `roofline` (dominant kernel, live HIP-event timing), `roofline.pipeline_frac` (SURVEY 8d headline: executed
+FLOP of the whole step / step time / fp32-MFMA peak), `kernel_groups` (per group: TFLOP/s / 157.3 for the dense groups,
+algorithmic GB/s / 8000 for the gather / scan groups), `real_slide_roi_load` (the same step with 40-100 px RoIs, the size of
+40x nuclei after the x2 resize), `cpu_baseline` (the oracle on the host cores, bounded sample) with the parity of the run.
 """
 import argparse
 import json
@@ -24,73 +30,75 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
 DOMINANT = 'gemm_kernel<3>'      # all Swin-T linears (N % 96 == 0): 96 % of the path's FLOPs
+# kernel tags (csrc ProfScope) -> groups of SURVEY 8d; dense groups are priced against the fp32-MFMA roof, the others
+# against HBM with their ALGORITHMIC bytes (what the op must read + write once)
+GROUPS = {
+    'dense_swin_linears': ('mfma', ['gemm_kernel<3>']),
+    'dense_convs_fcs': ('mfma', ['gemm_kernel<1>', 'gemm_kernel<2>', 'gemm_kernel<4>', 'patch_embed', 'attn_pool']),
+    'attention': ('mfma', ['window_attn']),
+    'layernorm_gathers': ('hbm', ['layernorm', 'merge_ln', 'preproc', 'sem_fuse']),
+    'roi_gather': ('hbm', ['roi_feat7', 'roi_feat14']),
+    'nms_scan': ('hbm', ['nms', 'rpn_select', 'cc_proposals', 'det_candidates', 'bbox_tail', 'paste', 'tile_post', 'build_rois']),
+}
 
 
-def _instance_parity(ref, got):
-    """(bbox_results, segm_results) of the oracle and of the HIP path for one tile -> instances matched one to one with
-    the same class, box IoU >= 0.999 and score within 1e-3; mask IoU of the matched pairs (BASELINE metric: per-instance IoU)."""
-    cat = lambda r: (np.concatenate(r[0], 0), np.concatenate([np.full(len(b), c) for c, b in enumerate(r[0])]), [m for cl in r[1] for m in cl])
-    (rb, rl, rm), (gb, gl, gm) = cat(ref), cat(got)
-    out = dict(ref=len(rb), hip=len(gb), matched=0, mask_iou_min=1.0, mask_iou_below=0)
-    if len(rb) == 0 or len(gb) == 0:
-        return out
-    x1 = np.maximum(rb[:, None, 0], gb[None, :, 0]); y1 = np.maximum(rb[:, None, 1], gb[None, :, 1])
-    x2 = np.minimum(rb[:, None, 2], gb[None, :, 2]); y2 = np.minimum(rb[:, None, 3], gb[None, :, 3])
-    inter = np.clip(x2 - x1, 0, None) * np.clip(y2 - y1, 0, None)
-    ar = (rb[:, 2] - rb[:, 0]) * (rb[:, 3] - rb[:, 1]); ag = (gb[:, 2] - gb[:, 0]) * (gb[:, 3] - gb[:, 1])
-    iou = inter / np.maximum(ar[:, None] + ag[None, :] - inter, 1e-12)
-    iou[rl[:, None] != gl[None, :]] = -1
-    used = set()
-    for i in np.argsort(-rb[:, 4]):
-        j = int(np.argmax(iou[i]))
-        if iou[i, j] >= 0.999 and j not in used and abs(rb[i, 4] - gb[j, 4]) < 1e-3:
-            used.add(j)
-            out['matched'] += 1
-            u = np.logical_or(rm[i], gm[j]).sum()
-            v = np.logical_and(rm[i], gm[j]).sum() / u if u else 1.0
-            out['mask_iou_min'] = min(out['mask_iou_min'], float(v))
-            out['mask_iou_below'] += int(v < 0.999)
-    return out
-
-
-def cpu_baseline(sd, tiles, n, eng=None, mode=1):
-    """Oracle (CPU restatement of the reference path, oracle/model.py) timed on the host cores: reported next to
-    the GPU number, never the thing shipped.  With `eng`, the same sample also serves as the parity check of the run:
-    the HIP path's instances against the oracle's (north star: IoU >= 0.999 per instance, identical class ids)."""
+def cpu_baseline(sd, tiles, eng=None, mode=1, batch=4, timed=3):
+    """Oracle (CPU restatement of the reference path, oracle/model.py) timed on the host cores: reported next to the GPU
+    number, never the thing shipped.  Bounded sample (about 30 s): one warm-up batch of 2 tiles, then `timed` batches of
+    `batch` tiles each, timed one by one.  With `eng`, the same tiles are the parity check of the run: the HIP path's
+    instances against the oracle's with the strict comparator of the tests (tests/parity_util.py: exact counts, every
+    tolerated disagreement proven to sit on a threshold)."""
     from oracle import model as O
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tests'))
+    import parity_util as P
     orc = O.Oracle(sd)
     threads = torch.get_num_threads()
-    orc(tiles[:1], 1)  # warm-up (builds oracle/libnuhtc_oracle.so on first use)
-    t0 = time.perf_counter()
-    ref = orc(tiles[:n], mode)
-    dt = time.perf_counter() - t0
+    orc(tiles[:2], mode)               # warm-up (also builds oracle/libnuhtc_oracle.so on first use)
+    times, refs, vals = [], [], []
+    n = min(batch * timed, len(tiles))
+    for i in range(0, n, batch):
+        t0 = time.perf_counter()
+        r, it = orc(tiles[i:i + batch], mode, keep=True)
+        times.append(time.perf_counter() - t0)
+        refs += r
+        vals += P.oracle_paste_values(O, it, tiles.shape[1:3])
+    dt = sum(times)
     out = dict(value=n / dt, unit='tiles/s', cores=threads, kind='port',
-               sample=f'{n} synthetic nuclei tiles, one batch, oracle/model.py fp32 torch-cpu + C RoIAlign/NMS, {dt:.1f} s')
+               sample=f'{timed} timed batches of {batch} synthetic nuclei tiles after 1 warm-up batch of 2 (oracle/model.py, fp32 torch-cpu + C RoIAlign/NMS), '
+                      f'{dt:.1f} s; per batch {[round(batch / t, 3) for t in times]} tiles/s')
     if eng is not None:
         eng.infer_async(eng.to_device(tiles[:n]), mode)
         got = eng.results(n)
-        tot = dict(ref=0, hip=0, matched=0, mask_iou_min=1.0, mask_iou_below=0)
-        for r, g in zip(ref, got):
-            q = _instance_parity(r, g)
-            for k in ('ref', 'hip', 'matched', 'mask_iou_below'):
-                tot[k] += q[k]
-            tot['mask_iou_min'] = min(tot['mask_iou_min'], q['mask_iou_min'])
-        out['parity'] = dict(tiles=n, instances_oracle=tot['ref'], instances_hip=tot['hip'],
-                             matched_same_class_box_iou_ge_0999=tot['matched'], matched_mask_iou_min=round(tot['mask_iou_min'], 6),
-                             matched_mask_iou_below_0999=tot['mask_iou_below'],
-                             note='detections before the per-tile margin / mask-NMS filter; a matched mask below 0.999 is a pixel whose probability sits on the 0.5 threshold (fp32 summation order), an unmatched instance one at the score threshold or a rank swap in a greedy NMS where two scores agree to an ulp')
+        tot = dict(n_ref=0, n_got=0, matched=0, mask_px_flipped=0, masks_below_0999=0)
+        min_iou, max_dist, explained, failures = 1.0, 0.0, [], []
+        for i, (r, g) in enumerate(zip(refs, got)):
+            rep, fails = P.compare_strict(r, g, values=vals[i])
+            for k in tot:
+                tot[k] += rep[k]
+            min_iou = min(min_iou, rep['min_mask_iou'])
+            max_dist = max(max_dist, rep['max_px_threshold_dist'])
+            explained += [f'tile {i}: {e}' for e in rep['explained']]
+            failures += [f'tile {i}: {f}' for f in fails]
+        out['parity'] = dict(tiles=n, instances_oracle=tot['n_ref'], instances_hip=tot['n_got'],
+                             matched_same_class_box_iou_ge_0999=tot['matched'], mask_pixels_differing=tot['mask_px_flipped'],
+                             matched_mask_iou_min=round(min_iou, 6), matched_mask_iou_below_0999=tot['masks_below_0999'],
+                             farthest_flipped_pixel_from_threshold=max_dist, tolerated=explained, unexplained=failures,
+                             passed=not failures,
+                             note='detections before the per-tile margin / mask-NMS filter; every tolerated entry names the threshold it sits on (tests/parity_util.py)')
     return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-tiles', type=int, default=8)
+    ap.add_argument('--cpu-batch', type=int, default=4, help='cpu_baseline: tiles per timed oracle batch (3 timed batches)')
+    ap.add_argument('--no-roi-load', action='store_true', help='skip the second workload (fixed load with 40-100 px RoIs)')
     ap.add_argument('--in-flight', type=int, default=0,
                     help='also report the streaming rate with this many batches in flight (e.g. 3; off by default so that the '
                          'rocprofv3 summary of the default command sees every kernel without co-running kernels)')
@@ -142,11 +150,18 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step_fn()
-    if dist is not None:
-        # one gather of the per-tile detection records (boxes, labels, counts, keep flags) for the host-side merge
-        rec = torch.cat([eng.boxes.reshape(B, -1), eng.labels.float(), eng.keep.float(), eng.counts.float()[:, None]], 1)
-        gathered = [torch.empty_like(rec) for _ in range(world)]
-        dist.all_gather(gathered, rec)
+    # the exchange of the WSI path, once: the last step's kept detections in the record layout a slide ships (heads, ring
+    # vertices, bit-packed mask crops), one all-gather (at N = 1 the packing runs too, the collective is a no-op)
+    from nuhtc_amd import parallel, wsi
+    eng.export_async(B)
+    torch.cuda.current_stream().synchronize()
+    rec = dict(tile=[], box=[], score=[], label=[], mask=[], ring=[])
+    wsi._unpack(eng, B, 0, np.zeros((B, 2), np.int64), 256, rec, exported=True)
+    parts = wsi.pack_records(rec, tile_base=rank * B) + [torch.tensor([rank], dtype=torch.int32)]
+    gathered = parallel.gather_blobs([t.to(tiles.device) for t in parts])
+    ranks_seen = sorted(int(g[-1][0]) for g in gathered)
+    gathered_records = int(sum(g[0].shape[0] for g in gathered))
+    gathered_bytes = int(sum(t.numel() * t.element_size() for g in gathered for t in g))
     sync_all()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -209,10 +224,94 @@ def main():
     tot_ms = sum(v['ms'] for v in prof.values())
     breakdown = {k: round(v['ms'] / prof_steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])}
 
-    traffic = None
-    tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_traffic.json')
-    if os.path.exists(tf):   # HBM bytes per launch from separate rocprofv3 --pmc passes of this same command (committed summary)
-        traffic = json.load(open(tf))['hbm_bytes_per_launch']
+    # HBM bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes of this command
+    # (tools/dev/round_traffic.sh); the committed summary is used only while it belongs to the GEMM source of this build
+    traffic, traffic_note = None, 'no PMC summary for this build (rocprofv3 --pmc passes are run separately: tools/dev/round_traffic.sh)'
+    here = os.path.dirname(os.path.abspath(__file__))
+    tf = os.path.join(here, 'profiles', 'r02_traffic.json')
+    if os.path.exists(tf):
+        import hashlib
+        tj = json.load(open(tf))
+        sha = hashlib.sha1(open(os.path.join(here, 'nuhtc_amd', 'csrc', 'gemm.hip'), 'rb').read()).hexdigest()
+        if tj.get('gemm_hip_sha1') == sha:
+            traffic, traffic_note = tj['hbm_bytes_per_launch'], f"profiles/r02_traffic.json (FETCH_SIZE x2 + WRITE_SIZE passes, gemm.hip {sha[:10]})"
+        else:
+            traffic_note = 'profiles/r02_traffic.json is from another gemm.hip: not reported'
+    # per-group fractions: dense groups against the fp32-MFMA roof, gather / scan groups against HBM with their
+    # algorithmic bytes; `ms` = sum of launch durations per step (the RPN branch runs beside the semantic branch, so the sum
+    # over groups exceeds the step)
+    # algorithmic bytes of the kernels whose work depends on device-side counts (RoIs, detections): from the last step's counts
+    R = int(roi_counts.sum())
+    D = int(counts.sum())
+    rois2 = eng.buffer('rois_stage2')[:R].cpu().numpy() if not args.fixed_load else None
+    px = lambda wh, s: (np.ceil(wh[:, 0] / s) + 2) * (np.ceil(wh[:, 1] / s) + 2)
+    if rois2 is not None and R:
+        wh = rois2[:, 3:5] - rois2[:, 1:3]
+        roi7 = 3.0 * float(((px(wh, 4) + px(wh, 8)) * 256 + 7 * 7 * 64 * 4).sum())   # footprint on x0+sem / x1 + the 7x7x64 output, 3 stages
+    else:
+        roi7 = 3.0 * R * (2 * 36 * 256 + 12544)
+    dyn_bytes = {
+        'roi_feat7': roi7,
+        'roi_feat14': D * (2 * 36 * 256 + 14 * 14 * 64 * 4.0),
+        'rpn_select': B * (21760 * 15 * 4 + 9768 * 20.0),            # objectness + deltas of every anchor position in, candidates out
+        'nms': B * (9768 * 20 + 1000 * 20.0) + R * 5 * 24.0 + D * 24.0,
+        'cc_proposals': B * (128 * 128 * 4 + 3 * 512 * 512 / 8.0),
+        'bbox_tail': 3.0 * R * (20 * 4 + 5 * 4),
+        'det_candidates': R * (16 * 4 + 5 * 4.0),
+        'paste': D * (28 * 28 * 4 + 256 * 256 / 8.0),
+        'tile_post': D * (256 * 256 / 8.0 + 32),
+    }
+    for t, by in dyn_bytes.items():
+        if t in prof and prof[t]['bytes'] == 0:
+            prof[t]['bytes'] = by * prof_steps
+    groups, seen = {}, set()
+    for gname, (bound, tags) in GROUPS.items():
+        v = [prof[t] for t in tags if t in prof]
+        seen.update(t for t in tags if t in prof)
+        if not v:
+            continue
+        ms = sum(x['ms'] for x in v)
+        fl, by = sum(x['flops'] for x in v), sum(x['bytes'] for x in v)
+        g = {'bound': bound, 'ms_per_step': round(ms / prof_steps, 3)}
+        if bound == 'mfma':
+            g['tflops'] = round(fl / (ms * 1e-3) / 1e12, 2)
+            g['frac_of_fp32_mfma'] = round(fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+        else:
+            g['algorithmic_gbps'] = round(by / (ms * 1e-3) / 1e9, 1)
+            g['frac_of_hbm'] = round(by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4)
+        groups[gname] = g
+    other = [t for t in prof if t not in seen]
+    if other:
+        groups['other'] = {'ms_per_step': round(sum(prof[t]['ms'] for t in other) / prof_steps, 3), 'tags': other}
+    step_flops = sum(v['flops'] for v in prof.values()) / prof_steps          # FLOP the engine really executes per step
+    pipeline_frac = step_flops / (dt / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS
+
+    # second workload, on the record every round: the same step at the RoI sizes of a real 40x slide (40-100 px after the x2
+    # resize) instead of the synthetic weights' ~20 px boxes -- the 7x7 RoI features are the data-dependent part of the path
+    roi_load = None
+    if not args.no_roi_load and not args.fixed_load:
+        rois_b = torch.from_numpy(synth.fixed_load_rois(B, size=(40.0, 100.0))).to(tiles.device)
+        k2 = max(5, min(20, args.steps))
+        for _ in range(2):
+            eng.infer_fixed_load_async(tiles, rois_b, 64, mode)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(k2):
+            eng.infer_fixed_load_async(tiles, rois_b, 64, mode)
+        sync_all()
+        d2 = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([d2], device='cuda')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            d2 = float(t.item())
+        hip.profile_enable(True)
+        for _ in range(2):
+            eng.infer_fixed_load_async(tiles, rois_b, 64, mode)
+        p2 = hip.profile_read()
+        hip.profile_enable(False)
+        roi_ms = sum(v['ms'] for k, v in p2.items() if k.split('|')[0] in ('roi_feat7', 'roi_classify')) / 2
+        roi_load = {'workload': 'fixed load: 1064 given RoIs per tile with sides 40-100 network px, 64 detections per tile (nuhtc_infer_fixed_load)',
+                    'value': k2 * B * world / d2, 'unit': 'tiles/s', 'ms_per_step': d2 / k2 * 1e3, 'steps': k2, 'roi_feat7_ms_per_step': round(roi_ms, 3)}
     if rank == 0:
         out = {
             'metric': 'tiles/sec (256x256) whole-node', 'value': total_tiles / dt, 'unit': 'tiles/s', 'n_gpus': world,
@@ -224,18 +323,25 @@ def main():
                        'tiles': 'synthetic nuclei tiles (nuhtc_amd.synth), resident in HBM',
                        'mean_rois_per_tile': float(roi_counts.mean()), 'mean_dets_per_tile': float(counts.mean())},
             'roofline': {'bound': 'mfma', 'kernel': DOMINANT + ' (Swin-T linears, fp32 v_mfma_f32_32x32x2_f32)', 'achieved': achieved,
-                         'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
+                         'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_note,
+                         'pipeline_frac': pipeline_frac, 'pipeline_gflop_per_tile': step_flops / B / 1e9,
                          'algorithmic_bytes_per_launch': dom['bytes'] / dom['launches'],
                          'avg_launch_ms': dur_ms, 'launches_per_step': dom['launches'] // prof_steps,
                          'share_of_step_kernel_time': dom['ms'] / tot_ms},
             'kernel_ms_per_step': breakdown,
+            'kernel_groups': groups,
+            'exchange': {'collective': 'all_gather (header) + all_gather (one packed byte buffer): nuhtc_amd.parallel.gather_blobs',
+                         'ranks_seen': ranks_seen, 'records': gathered_records, 'bytes': gathered_bytes,
+                         'layout': 'head f64[n,9] | ring vertices i32[*,2] | crop boxes i64[n,6] | bit-packed mask crops i32[*] | rank id'},
         }
+        if roi_load:
+            out['real_slide_roi_load'] = roi_load
         if pipelined:
             out['pipelined'] = pipelined
         if args.gemm_shapes:
             out['gemm_shapes'] = shapes
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(sd, tiles_np, min(args.cpu_tiles, B), eng, mode)
+            out['cpu_baseline'] = cpu_baseline(sd, tiles_np, eng, mode, batch=args.cpu_batch)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

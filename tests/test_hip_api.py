@@ -274,3 +274,20 @@ def test_infer_cli_writes_overlays(hip_device, tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools/infer.py'), str(tmp_path / 'imgs'), CFG, str(ck), '--device', 'cpu'],
                        capture_output=True, text=True)
     assert r.returncode != 0 and 'cpu' in (r.stderr + r.stdout).lower()
+
+
+def test_real_checkpoint_parity_script(hip_device, tmp_path):
+    """oracle/check_checkpoint.py (the one-command oracle-vs-HIP check for a supplied checkpoint) on a checkpoint file
+    in the reference's format; synthetic weights stand in for models/pannuke.pth, which is not distributed."""
+    import subprocess
+    import sys
+    import torch
+    from nuhtc_amd import weights
+    ck = tmp_path / 'ck.pth'
+    sd = weights.bench_state_dict(0, obj_bias=0.0)
+    torch.save(dict(meta=dict(CLASSES=('T', 'I', 'C', 'D', 'E')), state_dict={**sd, 'roi_head.kernel': torch.ones(1, 1, 5, 5),
+                                                                                   'ema_backbone_norm0_weight': torch.zeros(96)}), ck)
+    r = subprocess.run([sys.executable, '-m', 'oracle.check_checkpoint', '--checkpoint', str(ck), '--tiles', '3', '--size', '64'],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    print(r.stdout[-1500:])
+    assert r.returncode == 0 and 'PARITY OK' in r.stdout, r.stderr[-1500:]

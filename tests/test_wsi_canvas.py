@@ -118,3 +118,59 @@ def test_bench_wsi_cli(hip_device):
     assert d['tiles'] == 36 and d['n_gpus'] == 1
     assert 0 < d['detections_after_merge'] < d['detections_after_tile_nms']
     assert d['tiles_per_s_inference'] > 0
+
+
+@pytest.mark.gpu
+def test_consep_1000px_crop_36_padded_tiles(hip_device, tmp_path):
+    """BASELINE configs[3]: CoNSeP config (4 classes, max_per_img 300), a 1000x1000 crop -> tile origins np.arange(0,1000,192)
+    = 6 per axis = 36 tiles of 256x256, the last row / column zero-padded past the edge (use_padding=True,
+    tools/wsi_core/WholeSlideImage.py:419-421,460-466).  Oracle on a subset that includes edge-padded tiles and the padded
+    corner; two tile-block shards ('2 x MI355X') give the same records and the same merged slide as one."""
+    import torch
+    import parity_util as P
+    from nuhtc_amd import synth, weights, wsi
+    from nuhtc_amd.apis import inference_detector, init_detector
+    from nuhtc_amd.parallel import shard_range
+    from oracle import model as O
+    from oracle.merge_poly import merge_overlap_masks as oracle_poly
+    cfg = os.path.join(ROOT, 'configs/nuhtc/htc_lite_swin_consep_infer.py')
+    sd = weights.bench_state_dict(5, num_classes=4, obj_bias=0.3)
+    ck = str(tmp_path / 'consep.pth')
+    torch.save(dict(state_dict=sd), ck)
+    model = init_detector(cfg, ck, device='cuda:0', max_batch=12)
+    assert model.opts['num_classes'] == 4 and model.opts['max_per_img'] == 300
+    model.opts.update(margin=2, min_area=10, mask_nms_thr=0.05)
+    # a 1000x1000 crop: four 512-pixel synthetic fields, cut to size
+    img = np.concatenate([np.concatenate([synth.nuclei_tile(300 + 2 * r + c, 512, mean_count=60) for c in range(2)], 1) for r in range(2)], 0)[:1000, :1000]
+    tiles, coords = wsi.tile_grid(img, 256, 192)
+    assert tiles.shape == (36, 256, 256, 3) and coords[-1].tolist() == [960, 960]
+    assert tiles[5][:, 40:].max() == 0 and tiles[35][40:, :].max() == 0 and tiles[35][:40, :40].max() > 0      # 1000 - 960 = 40 px of image
+    # --- engine vs oracle on interior, edge-padded and corner tiles (the API path of tools/infer_wsi.py: ndarray input)
+    sub = [0, 5, 14, 30, 35]
+    got = inference_detector(model, [tiles[i] for i in sub])
+    ref, it = O.Oracle(sd, num_classes=4, max_per_img=300)(tiles[sub], 1, keep=True)
+    vals = P.oracle_paste_values(O, it, (256, 256))
+    for k, i in enumerate(sub):
+        rep, fails = P.compare_strict(ref[k], got[k], max_per_img=300, values=vals[k])
+        print(f'consep crop tile {i} (origin {coords[i].tolist()}): {P.fmt(rep)}', *rep['explained'], sep='\n    ')
+        assert not fails, (i, fails)
+        assert len(got[k][0]) == 4
+    # --- the whole crop, one rank vs two contiguous shards
+    rec = wsi.infer_tiles(model, tiles, coords, 12)
+    n = len(rec['score'])
+    assert n > 100 and max(rec['label']) <= 3
+    parts = []
+    for r in range(2):
+        lo, hi = shard_range(36, r, 2)
+        p = wsi.infer_tiles(model, tiles[lo:hi], coords[lo:hi], 12)
+        p['tile'] = [t + lo for t in p['tile']]
+        parts.append(p)
+    both = {k: parts[0][k] + parts[1][k] for k in rec}
+    assert both['tile'] == rec['tile'] and both['score'] == rec['score'] and all(np.array_equal(a, b) for a, b in zip(both['ring'], rec['ring']))
+    kept = wsi.merge_overlap(rec, 0.05)
+    assert np.array_equal(kept, oracle_poly(rec['mask'], rec['score'], 0.05))
+    assert np.array_equal(kept, wsi.merge_overlap(both, 0.05)) and 0 < len(kept) < n
+    # no detection reaches into the zero padding beyond the 2-pixel margin rule, and masks stay inside the crop + tile frame
+    for (m, x0, y0) in rec['mask']:
+        assert x0 >= 0 and y0 >= 0 and x0 + m.shape[1] <= 960 + 256 and y0 + m.shape[0] <= 960 + 256
+    print(f'consep crop: {n} nuclei after per-tile mask-NMS, {len(kept)} after the cross-tile merge')
