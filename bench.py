@@ -107,6 +107,7 @@ def main():
                          'the free-running proposal / detection counts of the synthetic weights')
     ap.add_argument('--roi-size', default='12,40', help='--fixed-load: RoI side range in network pixels (SURVEY: 12,40; 40x nuclei: ~40,100)')
     ap.add_argument('--gemm-shapes', action='store_true', help='add the per-shape GEMM timings to the JSON line')
+    ap.add_argument('--roi-sort', action='store_true', help='--fixed-load (dev): hand the RoIs over sorted by position (locality experiment)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -132,7 +133,11 @@ def main():
     tiles = eng.to_device(tiles_np)
     mode = hip.CH_SWAP   # tools/infer_wsi.py channel handling
     if args.fixed_load:
-        rois = torch.from_numpy(synth.fixed_load_rois(B, size=tuple(float(v) for v in args.roi_size.split(',')))).to(tiles.device)
+        rois_np = synth.fixed_load_rois(B, size=tuple(float(v) for v in args.roi_size.split(',')))
+        if args.roi_sort:
+            key = ((rois_np[..., 1] + rois_np[..., 3]) / 2 // 32) * 1000 + (rois_np[..., 0] + rois_np[..., 2]) / 2
+            rois_np = np.take_along_axis(rois_np, np.argsort(key, axis=1)[..., None], axis=1)
+        rois = torch.from_numpy(np.ascontiguousarray(rois_np)).to(tiles.device)
         step_fn = lambda e=eng: e.infer_fixed_load_async(tiles, rois, 64, mode)
     else:
         step_fn = lambda e=eng: e.infer_async(tiles, mode)

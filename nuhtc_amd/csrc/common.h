@@ -54,6 +54,7 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 struct ProfScope {
   ProfScope(const char* tag, double flops, double bytes, hipStream_t s);
   ~ProfScope();
+  void device_rows(const int* m_dev, int m_mul, int m_cap);   // flops / bytes were given for m_cap rows, the real count is *m_dev * m_mul
   hipStream_t s_;
   int idx_;
 };

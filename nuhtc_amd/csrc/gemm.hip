@@ -478,8 +478,9 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
       it = names.emplace(key, "gemm_kernel<" + std::to_string(nt) + ">|N" + std::to_string(p.N) + "|K" + std::to_string(p.K) + (p.amode == A_CONV3 ? "|conv3" : "")).first;
     tag = it->second.c_str();
   }
-  // algorithmic work of the launch (device-side row counts are not known here: the capacity M is an upper bound)
+  // algorithmic work of the launch (a device-side row count is applied when the records are read)
   ProfScope ps(tag, 2.0 * p.M * p.N * p.K * nb, 4.0 * nb * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N), s);
+  ps.device_rows(p.m_dev, p.m_mul, p.M);
 #ifdef NUHTC_GEMM_STAMPS
   static unsigned long long* stamp_buf = nullptr;
   if (!stamp_buf && hipMalloc(&stamp_buf, 8ull * 8 * 4 * 65536) != hipSuccess) return NUHTC_E_HIP;

@@ -7,7 +7,7 @@
 
 #include "common.h"
 
-struct ProfRec { const char* tag; double flops, bytes; hipEvent_t a, b; };
+struct ProfRec { const char* tag; double flops, bytes; hipEvent_t a, b; const int* m_dev; int m_mul, m_cap; };
 static bool g_on = false;
 static std::vector<ProfRec> g_recs;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_pool;
@@ -23,9 +23,15 @@ ProfScope::ProfScope(const char* tag, double flops, double bytes, hipStream_t s)
     g_pool.push_back({a, b});
   }
   auto& ev = g_pool[g_pool_next++];
-  g_recs.push_back(ProfRec{tag, flops, bytes, ev.first, ev.second});
+  g_recs.push_back(ProfRec{tag, flops, bytes, ev.first, ev.second, nullptr, 1, 0});
   idx_ = (int)g_recs.size() - 1;
   hipEventRecord(ev.first, s_);
+}
+
+// the launch's row count lives on the device (RoI / detection lists): flops and bytes were given for the capacity `m_cap`
+// and are scaled to min(m_cap, *m_dev * m_mul) rows when the records are read
+void ProfScope::device_rows(const int* m_dev, int m_mul, int m_cap) {
+  if (idx_ >= 0 && m_dev && m_cap > 0) { g_recs[idx_].m_dev = m_dev; g_recs[idx_].m_mul = m_mul; g_recs[idx_].m_cap = m_cap; }
 }
 
 ProfScope::~ProfScope() {
@@ -45,11 +51,23 @@ extern "C" int nuhtc_profile_read(char* buf, size_t cap) {
   if (hipDeviceSynchronize() != hipSuccess) return NUHTC_E_HIP;
   struct Acc { long n = 0; double ms = 0, flops = 0, bytes = 0; };
   std::map<std::string, Acc> acc;
+  std::map<const int*, int> rows;          // device-side row counts (values of the last launch sequence: steady state)
   for (auto& r : g_recs) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+    double scale = 1.0;
+    if (r.m_dev) {
+      auto it = rows.find(r.m_dev);
+      if (it == rows.end()) {
+        int v = 0;
+        if (hipMemcpy(&v, r.m_dev, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) v = r.m_cap;
+        it = rows.emplace(r.m_dev, v).first;
+      }
+      const long long m = (long long)it->second * r.m_mul;
+      scale = (double)(m < r.m_cap ? m : r.m_cap) / (double)r.m_cap;
+    }
     Acc& a = acc[r.tag];
-    a.n++; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes;
+    a.n++; a.ms += ms; a.flops += r.flops * scale; a.bytes += r.bytes * scale;
   }
   std::string out;
   char line[256];
