@@ -331,44 +331,165 @@ __device__ __forceinline__ void roi_feat7_generic_block(const RoiFeatParams& p, 
   }
 }
 
-// RoIs too large for the square LDS tiles but with at most 2x2 semantic samples per 14x14 bin (up to ~110 px at network scale:
-// every nucleus-sized box of a 40x slide).  Gathering their taps straight from L2 moves ~0.8 MB per RoI through the texture
-// path; instead one block takes ONE ROW of output bins: the input rows that row samples (<= BH rows of <= BW pixels) are
-// staged in LDS once and the 7 bins of the row are evaluated from there exactly like in roi_feat7_lds_kernel.  When the
-// semantic grid is finer than the FPN grid (2 samples per 14x14 bin) it cannot share a pass with level 0: its band is staged
-// into the same tile afterwards.
-#define BW0 30
-#define BH0 6
-#define BW1 16
-#define BH1 4
-struct BandPlans { LevelPlan l0, l1, ls; bool ok; };
-__device__ __forceinline__ BandPlans plan_bands(const RoiFeatParams& p, const RoiGeom& g0, const RoiGeom& g1, const RoiGeom& gs, int ph, int lane) {
-  BandPlans bp;
-  bp.l0 = plan_band(g0, 7, 2, 2, p.H0, p.W0, BW0, BH0, 2 * ph, 2, lane);
-  bp.l1 = plan_band(g1, 7, 2, 2, p.H1, p.W1, BW1, BH1, 2 * ph, 2, lane);
-  bp.ok = bp.l0.ok && bp.l1.ok;
-  if (gs.gw == 2 || gs.gh == 2) {
-    bp.ls = plan_band(gs, 14, gs.gw, gs.gh, p.H0, p.W0, BW0, BH0, 2 * ph * gs.gh, 2 * gs.gh, lane);
-    bp.ok = bp.ok && bp.ls.ok;
-  } else {
-    bp.ls = bp.l0;
-  }
-  return bp;
+// RoIs too large for the square LDS tiles but with at most 2x2 semantic samples per 14x14 bin and sides up to SM_MAXSIDE px
+// at network scale: every nucleus-sized box of a 40x slide (40-100 px after the x2 resize).  Their footprint (up to 30x30
+// pixels of 256 bytes per map) fits no LDS tile, and gathering the taps of every sample from L2 moves each pixel 4-16 times.
+// RoIAlign is separable, though: a bin is  sum_y sum_x wy[y] * wx[x] * F[y][x]  with per-axis weights that are the sums of
+// the bilinear tap weights of the bin's samples (divided by the samples per axis).  One wave therefore STREAMS a RoI's
+// footprint row by row: a row (<= 32 pixels x 64 channels) is copied into a two-slot LDS ring by direct global->LDS loads
+// one row ahead, contracted along x into the 7 bin columns (6 merged taps per bin, static LDS offsets from a per-bin base)
+// and scattered into the 49 accumulators with the row's 7 y-weights.  Every footprint pixel is read once, there is no
+// block barrier (one wave = one block), and the arithmetic per RoI drops from ~4700 tap evaluations to ~65 rows x 90 FMAs.
+// The sum runs in a different order than mmcv's sample loop (rounding differences of a few 1e-7 relative).
+#define SM_MAXSIDE 112      // RoI side (network px) up to which the stream kernel applies: footprint <= 30 px on stride 4
+#define SM_ROWPX 40         // LDS ring slot: 32 footprint pixels + room for the padded taps of the last bin
+#define SM_J 6              // merged taps per bin and axis (bin span in pixels: <= 4.3 * 3/4 + 2)
+#define SM_FH 32            // rows of the dense y-weight table
+
+struct StreamTabs {
+  float wx[7][SM_J];        // merged x weights of bin pw, tap j = pixel xlo[pw] + j
+  int xlo[7];               // first footprint pixel (relative to fx0) of bin pw
+  float wy[7][SM_FH];       // merged y weights of bin ph at footprint row yrel
+};
+
+// sample s (0 .. 7*S-1) of an axis: mmcv's coordinate and bilinear entry
+__device__ __forceinline__ AxisEnt sm_sample(float start, float bs, int S, int s, int size, bool& valid) {
+  const int pb = s / S, is = s - pb * S;
+  const float c = start + (float)pb * bs + ((float)is + 0.5f) * bs / (float)S;   // same expression as roi_bin()
+  return axis_entry(c, size, valid);
 }
 
-__global__ __launch_bounds__(256) void roi_feat7_band_kernel(RoiFeatParams p) {
-  __shared__ float tile0[BW0 * BH0 * 64];
-  __shared__ float tile1[BW1 * BH1 * 64];
-  __shared__ AxisEnt tabx[3][32];
-  __shared__ AxisEnt taby[3][4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int cp2 = 2 * (lane & 31), hw = lane >> 5;
-  const int njobs = p.fb_count[1] * 7;
-  for (int job = blockIdx.x; job < njobs; job += gridDim.x) {
-    const int r = p.mid_list[job / 7], ph = job % 7;
+// one map of one RoI: adds RoIAlign(7x7, Sx x Sy samples per bin) of `map` into acc[49] (lane = channel)
+__device__ __forceinline__ void sm_accumulate(const float* __restrict__ map, int H, int W, int b, float x1, float y1, float bw, float bh,
+                                              int Sx, int Sy, StreamTabs* tb, float* ring, float (&acc)[49], int lane) {
+  // ---- footprint bounds over the valid samples (lanes 0..27: x samples, 32..59: y samples)
+  const bool is_y = lane >= 32;
+  const int idx = lane & 31;
+  const int S = is_y ? Sy : Sx;
+  bool valid = false;
+  AxisEnt e{0, 0, 0.f, 0.f};
+  if (idx < 7 * S) e = sm_sample(is_y ? y1 : x1, is_y ? bh : bw, S, idx, is_y ? H : W, valid);
+  const int lo = half_min(valid ? e.lo : (1 << 30)), hi = half_max(valid ? e.hi : -1);
+  const int fx0 = __shfl(lo, 0), fx1 = __shfl(hi, 0), fy0 = __shfl(lo, 32), fy1 = __shfl(hi, 32);
+  if (fx1 < 0 || fy1 < 0) return;                       // every sample of an axis lies outside the map: the term is 0
+  const int fw = fx1 - fx0 + 1, fh = min(fy1 - fy0 + 1, SM_FH);     // (roi_classify_kernel admits only RoIs with fw <= 32, fh <= SM_FH)
+  // ---- merged per-axis weights.  x: lane = (bin, tap) of the 7 x SM_J table; y: 4 entries of the 7 x SM_FH table per lane
+  if (lane < 7) {
+    int m = 1 << 30;
+    for (int is = 0; is < Sx; ++is) {
+      bool v;
+      const AxisEnt q = sm_sample(x1, bw, Sx, lane * Sx + is, W, v);
+      if (v) m = min(m, q.lo - fx0);
+    }
+    tb->xlo[lane] = m == (1 << 30) ? 0 : m;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  if (lane < 7 * SM_J) {
+    const int pw = lane / SM_J, j = lane - pw * SM_J;
+    const int px = fx0 + tb->xlo[pw] + j;
+    float wsum = 0.f;
+    for (int is = 0; is < Sx; ++is) {
+      bool v;
+      const AxisEnt q = sm_sample(x1, bw, Sx, pw * Sx + is, W, v);
+      if (v) { if (q.lo == px) wsum += q.h; if (q.hi == px) wsum += q.l; }
+    }
+    tb->wx[pw][j] = wsum / (float)Sx;
+  }
+  for (int t = lane; t < 7 * SM_FH; t += 64) {
+    const int ph = t / SM_FH, yr = t - ph * SM_FH;
+    float wsum = 0.f;
+    for (int is = 0; is < Sy; ++is) {
+      bool v;
+      const AxisEnt q = sm_sample(y1, bh, Sy, ph * Sy + is, H, v);
+      if (v) { if (q.lo == fy0 + yr) wsum += q.h; if (q.hi == fy0 + yr) wsum += q.l; }
+    }
+    tb->wy[ph][yr] = wsum / (float)Sy;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  float wxr[7][SM_J];
+  int xbase[7];
+#pragma unroll
+  for (int pw = 0; pw < 7; ++pw) {
+    xbase[pw] = tb->xlo[pw] * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < SM_J; ++j) wxr[pw][j] = tb->wx[pw][j];
+  }
+  // ---- stream the rows: slot (yr & 1) of the ring holds row yr; row yr + 1 is requested before row yr is used
+  const float* base = map + (((long long)b * H + fy0) * W + fx0) * 64;
+  const int sub = lane >> 4, c4 = (lane & 15) * 4;     // one global->LDS instruction moves 4 pixels (16 lanes x 16 bytes each)
+  const int n4 = (fw + 3) >> 2;
+  auto stage_row = [&](int yr) {
+    float* dst = ring + (yr & 1) * (SM_ROWPX * 64);
+    const float* src = base + (long long)yr * W * 64;
+    for (int q = 0; q < n4; ++q) {
+      int px = 4 * q + sub;
+      px = px < fw ? px : fw - 1;                       // the last group repeats the row's last pixel (never past the map)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + px * 64 + c4),
+                                       (__attribute__((address_space(3))) void*)(dst + q * 256), 16, 0, 0);
+    }
+  };
+  stage_row(0);
+  for (int yr = 0; yr < fh; ++yr) {
+    if (yr + 1 < fh) {
+      stage_row(yr + 1);
+      // rows land in order: all but the n4 loads just issued are done
+      if (n4 == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (n4 == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      else if (n4 == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (n4 == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else if (n4 == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (n4 == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else if (n4 == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_wave_barrier();
+    const float* row = ring + (yr & 1) * (SM_ROWPX * 64);
+    float T[7];
+#pragma unroll
+    for (int pw = 0; pw < 7; ++pw) {
+      float t = 0.f;
+#pragma unroll
+      for (int j = 0; j < SM_J; ++j) t = fmaf(wxr[pw][j], row[xbase[pw] + j * 64], t);
+      T[pw] = t;
+    }
+#pragma unroll
+    for (int ph = 0; ph < 7; ++ph) {
+      const float wyv = tb->wy[ph][yr];
+#pragma unroll
+      for (int pw = 0; pw < 7; ++pw) acc[ph * 7 + pw] = fmaf(wyv, T[pw], acc[ph * 7 + pw]);
+    }
+    __builtin_amdgcn_wave_barrier();                   // the slot of row yr is refilled with row yr + 2 in the next iteration
+  }
+}
+
+__global__ __launch_bounds__(64) void roi_feat7_stream_kernel(RoiFeatParams p) {
+  __shared__ __attribute__((aligned(16))) float ring[2 * SM_ROWPX * 64];
+  __shared__ StreamTabs tabs;
+  const int lane = threadIdx.x;
+  const int nm = p.fb_count[1];
+  // ring pixels beyond a footprint's width are read with zero weights: clear the ring once so they never hold NaN bits
+  // (afterwards they hold stale map values, which are finite)
+  for (int t = lane; t < 2 * SM_ROWPX * 64; t += 64) ring[t] = 0.f;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  for (int job = blockIdx.x; job < nm; job += gridDim.x) {
+    const int r = p.mid_list[job];
     const float* roi = p.rois + (long long)r * 5;
     const int b = (int)roi[0];
-    v2f gsum[2];
+    float acc[49];
+#pragma unroll
+    for (int k = 0; k < 49; ++k) acc[k] = 0.f;
+    const RoiGeom g0 = roi_geom(roi, 0.25f, 7, 2), g1 = roi_geom(roi, 0.125f, 7, 2), gs = roi_geom(roi, 0.25f, 14, 0);
+    const bool sem2 = gs.gw == 2 || gs.gh == 2;          // (classify guarantees gw, gh in {1, 2})
+    // FPN level 0 (+ the semantic term when it is sampled at the same points: one sample per 14x14 bin), level 1
+    sm_accumulate(sem2 ? p.x0 : p.x0sem, p.H0, p.W0, b, g0.x1, g0.y1, g0.bw, g0.bh, 2, 2, &tabs, ring, acc, lane);
+    sm_accumulate(p.x1, p.H1, p.W1, b, g1.x1, g1.y1, g1.bw, g1.bh, 2, 2, &tabs, ring, acc, lane);
+    // attention-pooled levels 2, 3: one vector per RoI, added to every bin
+    float gsum = 0.f;
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
       const int Hl = l ? p.H3 : p.H2, Wl = l ? p.W3 : p.W2;
@@ -377,53 +498,16 @@ __global__ __launch_bounds__(256) void roi_feat7_band_kernel(RoiFeatParams p) {
       cx = fminf(fmaxf(cx, 0.f), (float)(Wl - 1));
       cy = fminf(fmaxf(cy, 0.f), (float)(Hl - 1));
       const float* G = l ? p.G3 : p.G2;
-      gsum[l] = *reinterpret_cast<const v2f*>(G + (((long long)b * Hl + (int)cy) * Wl + (int)cx) * 64 + cp2);
+      gsum += G[(((long long)b * Hl + (int)cy) * Wl + (int)cx) * 64 + lane];
     }
-    const RoiGeom g0 = roi_geom(roi, 0.25f, 7, 2), g1 = roi_geom(roi, 0.125f, 7, 2), gs = roi_geom(roi, 0.25f, 14, 0);
-    const bool sem2 = gs.gw == 2 || gs.gh == 2;           // (classify guarantees gw, gh in {1, 2} and that the bands fit)
-    const BandPlans bp = plan_bands(p, g0, g1, gs, ph, lane);
-    if (wave == 0) {
-      const int ax = lane >> 5, idx = lane & 31;
-      AxisEnt e0 = bp.l0.ent, e1 = bp.l1.ent, es = bp.ls.ent;
-      const int m0 = ax ? bp.l0.fw * 64 : 64, m1 = ax ? bp.l1.fw * 64 : 64, ms = ax ? bp.ls.fw * 64 : 64;
-      e0.lo *= m0; e0.hi *= m0; e1.lo *= m1; e1.hi *= m1; es.lo *= ms; es.hi *= ms;
-      if (ax == 0) { tabx[0][idx] = e0; tabx[1][idx] = e1; tabx[2][idx] = es; }
-      else {
-        if (idx >= 2 * ph && idx < 2 * ph + 2) { taby[0][idx - 2 * ph] = e0; taby[1][idx - 2 * ph] = e1; }
-        if (idx >= 2 * ph * gs.gh && idx < (2 * ph + 2) * gs.gh) taby[2][idx - 2 * ph * gs.gh] = es;
-      }
-    }
-    stage_tile(sem2 ? p.x0 : p.x0sem, p.H0, p.W0, b, bp.l0, tile0, lane, wave);
-    stage_tile(p.x1, p.H1, p.W1, b, bp.l1, tile1, lane, wave);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __syncthreads();
-    const v2f zero2 = {0.f, 0.f};
-    const int pw = min(2 * wave + hw, 6);                 // 7 bins of the row: one per half-wave (the 8th slot idles)
-    const bool live = 2 * wave + hw < 7;
-    v2f v = zero2;
-    v += bp.l0.empty ? zero2 : bin_lds2<2>(tile0 + cp2, tabx[0], taby[0], pw, 0);
-    v += bp.l1.empty ? zero2 : bin_lds2<2>(tile1 + cp2, tabx[1], taby[1], pw, 0);
-    v += gsum[0];
-    v += gsum[1];
-    if (sem2) {
-      __syncthreads();                                    // every wave is done with the level-0 band
-      stage_tile(p.sem, p.H0, p.W0, b, bp.ls, tile0, lane, wave);
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (!bp.ls.empty) {
-        v2f a, bq, c, d;
-#define SEM4(GX_, GY_)                                                                   \
-        a = bin_lds2<GX_, GY_>(tile0 + cp2, tabx[2], taby[2], 2 * pw, 0);                \
-        bq = bin_lds2<GX_, GY_>(tile0 + cp2, tabx[2], taby[2], 2 * pw + 1, 0);           \
-        c = bin_lds2<GX_, GY_>(tile0 + cp2, tabx[2], taby[2], 2 * pw, 1);                \
-        d = bin_lds2<GX_, GY_>(tile0 + cp2, tabx[2], taby[2], 2 * pw + 1, 1);
-        if (gs.gw == 2 && gs.gh == 2) { SEM4(2, 2) } else if (gs.gw == 2) { SEM4(2, 1) } else { SEM4(1, 2) }
-#undef SEM4
-        v += (((a + bq) + c) + d) * 0.25f;
-      }
-    }
-    if (live) *reinterpret_cast<v2f*>(p.out + (long long)r * 49 * 64 + (ph * 7 + pw) * 64 + cp2) = v;
-    __syncthreads();                                      // tables / tiles are rewritten by the next job
+#pragma unroll
+    for (int k = 0; k < 49; ++k) acc[k] += gsum;
+    // semantic 14x14 grid with 2 samples per bin on an axis, average-pooled 2x2: 2*g samples per 7x7 bin and axis on the
+    // 14-grid's geometry (bin size bw/2 of the 7-grid)
+    if (sem2) sm_accumulate(p.sem, p.H0, p.W0, b, gs.x1, gs.y1, 2.f * gs.bw, 2.f * gs.bh, 2 * gs.gw, 2 * gs.gh, &tabs, ring, acc, lane);
+    float* out = p.out + (long long)r * 49 * 64;
+#pragma unroll
+    for (int k = 0; k < 49; ++k) out[k * 64 + lane] = acc[k];
   }
 }
 
@@ -437,12 +521,10 @@ __global__ __launch_bounds__(256) void roi_classify_kernel(RoiFeatParams p) {
   const bool sem_g1 = gs.gw == 1 && gs.gh == 1;
   const LevelPlan l0 = plan_level(g0, 7, 2, p.H0, p.W0, TP0, lane);
   const LevelPlan l1 = plan_level(g1, 7, 2, p.H1, p.W1, TP1, lane);
-  // 0: LDS path; 1: gather path (at most 2x2 semantic samples per bin); 2: one block per bin (big proposals)
-  int cls = (sem_g1 && l0.ok && l1.ok) ? 0 : (gs.gw <= 2 && gs.gh <= 2) ? 1 : 2;
-  if (cls == 1) {
-    for (int ph = 0; ph < 7; ++ph)
-      if (!plan_bands(p, g0, g1, gs, ph, lane).ok) cls = 2;
-  }
+  // 0: LDS tiles; 1: stream kernel (at most 2x2 semantic samples per 14x14 bin, sides up to SM_MAXSIDE px: footprints of at
+  // most 30 x 30 pixels on stride 4, bins spanning at most SM_J pixels); 2: one block per bin (big proposals)
+  const float rwn = roi[3] - roi[1], rhn = roi[4] - roi[2];
+  int cls = (sem_g1 && l0.ok && l1.ok) ? 0 : (gs.gw <= 2 && gs.gh <= 2 && rwn <= (float)SM_MAXSIDE && rhn <= (float)SM_MAXSIDE) ? 1 : 2;
   if (lane == 0) {
     p.fb_flag[r] = (unsigned char)cls;
     if (cls == 2) p.fb_list[atomicAdd(&p.fb_count[0], 1)] = r;
@@ -606,7 +688,7 @@ int launch_roi_feat(const RoiFeatParams& p, int P, int r_cap, hipStream_t s, hip
     hipLaunchKernelGGL(roi_classify_kernel, dim3(cdiv(r_cap, 4)), dim3(256), 0, s, p);
     const bool fork = side && ev_fork && ev_join;
     if (fork && (hipEventRecord(ev_fork, s) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess)) return NUHTC_E_HIP;
-    hipLaunchKernelGGL(roi_feat7_band_kernel, dim3(7 * (r_cap < 2048 ? r_cap : 2048)), dim3(256), 0, fork ? side : s, p);
+    hipLaunchKernelGGL(roi_feat7_stream_kernel, dim3(r_cap < 8192 ? r_cap : 8192), dim3(64), 0, fork ? side : s, p);
     if (fork && hipEventRecord(ev_join, side) != hipSuccess) return NUHTC_E_HIP;
     hipLaunchKernelGGL(roi_feat7_lds_kernel, dim3(FB_SLOTS * 49 + r_cap), dim3(256), 0, s, p);
     if (fork && hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) return NUHTC_E_HIP;
