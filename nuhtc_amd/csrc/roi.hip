@@ -260,6 +260,7 @@ __device__ __forceinline__ float bin_lds(const float* tile, int fw, const AxisEn
 // arithmetic per tap), not by LDS or memory.  `cp2` = 2 * (lane & 31) is the lane's first channel; the two half-waves
 // work on different bins, so the axis tables are read per lane.
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 template <int GX, int GY = GX>
 __device__ __forceinline__ v2f bin_lds2(const float* tile, const AxisEnt* tx, const AxisEnt* ty, int pw, int ph) {
   v2f acc = {0.f, 0.f};
@@ -336,15 +337,14 @@ __device__ __forceinline__ void roi_feat7_generic_block(const RoiFeatParams& p, 
 // pixels of 256 bytes per map) fits no LDS tile, and gathering the taps of every sample from L2 moves each pixel 4-16 times.
 // RoIAlign is separable, though: a bin is  sum_y sum_x wy[y] * wx[x] * F[y][x]  with per-axis weights that are the sums of
 // the bilinear tap weights of the bin's samples (divided by the samples per axis).  One wave therefore STREAMS a RoI's
-// footprint two rows at a time: rows (<= 32 pixels x 64 channels) are copied into a four-slot LDS ring by direct global->LDS
-// loads one pair ahead; each half-wave contracts its row along x into the 7 bin columns (6 merged taps per bin, static LDS
-// offsets from a per-bin base, two channels per lane in packed fp32) and scatters it into its 49 accumulators with the
-// row's 7 y-weights; the halves are added at the end.  Every footprint pixel is read once, there is no
+// footprint row by row: a row (<= 32 pixels x 64 channels) is copied into a two-slot LDS ring by direct global->LDS loads
+// one row ahead, contracted along x into the 7 bin columns (6 merged taps per bin, static LDS offsets from a per-bin base)
+// and scattered into the 49 accumulators with the row's 7 y-weights.  Every footprint pixel is read once, there is no
 // block barrier (one wave = one block), and the arithmetic per RoI drops from ~4700 tap evaluations to ~65 rows x 90 FMAs.
 // The sum runs in a different order than mmcv's sample loop (rounding differences of a few 1e-7 relative).
 #define SM_MAXSIDE 112      // RoI side (network px) up to which the stream kernel applies: footprint <= 30 px on stride 4
 #define SM_ROWPX 36         // LDS ring slot: 32 footprint pixels + room for the padded taps of the last bin
-#define SM_J 6              // merged taps per bin and axis (bin span in pixels: <= 4.3 * 3/4 + 2)
+#define SM_J 5              // merged taps per bin and axis: samples of a bin lie within bw * (S-1)/S <= 3 px, so they touch <= 5 pixels
 #define SM_FH 32            // rows of the dense y-weight table
 
 struct StreamTabs {
@@ -360,10 +360,9 @@ __device__ __forceinline__ AxisEnt sm_sample(float start, float bs, int S, int s
   return axis_entry(c, size, valid);
 }
 
-// one map of one RoI: adds RoIAlign(7x7, Sx x Sy samples per bin) of `map` into acc[49].  A lane owns two channels
-// (packed fp32) and a half-wave owns every second footprint row: the two halves are added up by the caller at the end.
+// one map of one RoI: adds RoIAlign(7x7, Sx x Sy samples per bin) of `map` into acc[49] (lane = channel)
 __device__ __forceinline__ void sm_accumulate(const float* __restrict__ map, int H, int W, int b, float x1, float y1, float bw, float bh,
-                                              int Sx, int Sy, StreamTabs* tb, float* ring, v2f (&acc)[49], int lane) {
+                                              int Sx, int Sy, StreamTabs* tb, float* ring, float (&acc)[49], int lane) {
   // ---- footprint bounds over the valid samples (lanes 0..27: x samples, 32..59: y samples)
   const bool is_y = lane >= 32;
   const int idx = lane & 31;
@@ -374,7 +373,7 @@ __device__ __forceinline__ void sm_accumulate(const float* __restrict__ map, int
   const int lo = half_min(valid ? e.lo : (1 << 30)), hi = half_max(valid ? e.hi : -1);
   const int fx0 = __shfl(lo, 0), fx1 = __shfl(hi, 0), fy0 = __shfl(lo, 32), fy1 = __shfl(hi, 32);
   if (fx1 < 0 || fy1 < 0) return;                       // every sample of an axis lies outside the map: the term is 0
-  const int fw = min(fx1 - fx0 + 1, 32), fh = min(fy1 - fy0 + 1, SM_FH);   // (roi_classify_kernel admits only RoIs within these limits)
+  const int fw = fx1 - fx0 + 1, fh = min(fy1 - fy0 + 1, SM_FH);     // (roi_classify_kernel admits only RoIs with fw <= 32, fh <= SM_FH)
   // ---- merged per-axis weights.  x: lane = (bin, tap) of the 7 x SM_J table; y: 4 entries of the 7 x SM_FH table per lane
   if (lane < 7) {
     int m = 1 << 30;
@@ -406,104 +405,97 @@ __device__ __forceinline__ void sm_accumulate(const float* __restrict__ map, int
       const AxisEnt q = sm_sample(y1, bh, Sy, ph * Sy + is, H, v);
       if (v) { if (q.lo == fy0 + yr) wsum += q.h; if (q.hi == fy0 + yr) wsum += q.l; }
     }
-    tb->wy[ph][yr] = yr < fh ? wsum / (float)Sy : 0.f;
+    tb->wy[ph][yr] = wsum / (float)Sy;
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
-  const int c2 = 2 * (lane & 31), hw = lane >> 5;
   float wxr[7][SM_J];
   int xbase[7];
 #pragma unroll
   for (int pw = 0; pw < 7; ++pw) {
-    xbase[pw] = tb->xlo[pw] * 64 + c2;
+    xbase[pw] = tb->xlo[pw] * 64 + lane;
 #pragma unroll
     for (int j = 0; j < SM_J; ++j) wxr[pw][j] = tb->wx[pw][j];
   }
-  // ---- stream the rows two at a time: slot (y & 3) of the ring holds row y; rows 2k+2, 2k+3 are requested before rows
-  // 2k, 2k+1 are used (half-wave 0 takes the even row of the pair, half-wave 1 the odd one)
+  // ---- stream the rows: slot (yr & 1) of the ring holds row yr.  Row yr + 1 is loaded into registers (4 pixels = 1 KB per
+  // wave instruction, 16 lanes x 16 bytes per pixel) before row yr is contracted and written to the other slot afterwards
+  // (a wave-wide global->LDS instruction costs the SIMD ~100 issue cycles here, a dwordx4 load + ds_write_b128 pair ~25)
   const float* base = map + (((long long)b * H + fy0) * W + fx0) * 64;
-  const int sub = lane >> 4, c4 = (lane & 15) * 4;     // one global->LDS instruction moves 4 pixels (16 lanes x 16 bytes each)
+  const int sub = lane >> 4, c4 = (lane & 15) * 4;
   const int n4 = (fw + 3) >> 2;
-  auto stage_row = [&](int yr) {                       // rows past the footprint repeat its last row (their weights are 0)
-    float* dst = ring + (yr & 3) * (SM_ROWPX * 64);
-    const float* src = base + (long long)(yr < fh ? yr : fh - 1) * W * 64;
-    for (int q = 0; q < n4; ++q) {
+  v4f stg[8];
+  auto load_row = [&](int yr) {
+    const float* src = base + (long long)yr * W * 64;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
       int px = 4 * q + sub;
-      px = px < fw ? px : fw - 1;                       // the last group repeats the row's last pixel (never past the map)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + px * 64 + c4),
-                                       (__attribute__((address_space(3))) void*)(dst + q * 256), 16, 0, 0);
+      px = px < fw ? px : fw - 1;                       // groups past the footprint repeat its last pixel (never past the map)
+      if (q < n4) stg[q] = *reinterpret_cast<const v4f*>(src + px * 64 + c4);
     }
   };
-  stage_row(0);
-  stage_row(1);
-  const int npairs = (fh + 1) >> 1;
-  for (int k = 0; k < npairs; ++k) {
-    if (k + 1 < npairs) {
-      stage_row(2 * k + 2);
-      stage_row(2 * k + 3);
-      // loads complete in order: all but the 2 * n4 just issued are done
-      switch (n4) {
-        case 8: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-        case 7: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-        case 5: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-      }
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+  auto store_row = [&](int yr) {
+    float* dst = ring + (yr & 1) * (SM_ROWPX * 64);
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (q < n4) *reinterpret_cast<v4f*>(dst + (4 * q + sub) * 64 + c4) = stg[q];
+  };
+  load_row(0);
+  store_row(0);
+  for (int yr = 0; yr < fh; ++yr) {
+    if (yr + 1 < fh) load_row(yr + 1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    const int yr = 2 * k + hw;
-    const float* row = ring + (yr & 3) * (SM_ROWPX * 64);
-    v2f T[7];
+    const float* row = ring + (yr & 1) * (SM_ROWPX * 64);
+    float T[7];
 #pragma unroll
     for (int pw = 0; pw < 7; ++pw) {
-      v2f t = {0.f, 0.f};
+      float t = 0.f;
 #pragma unroll
-      for (int j = 0; j < SM_J; ++j) t = __builtin_elementwise_fma(v2f{wxr[pw][j], wxr[pw][j]}, *reinterpret_cast<const v2f*>(row + xbase[pw] + j * 64), t);
+      for (int j = 0; j < SM_J; ++j) t = fmaf(wxr[pw][j], row[xbase[pw] + j * 64], t);
       T[pw] = t;
     }
 #pragma unroll
     for (int ph = 0; ph < 7; ++ph) {
-      const float wyv = tb->wy[ph][yr < SM_FH ? yr : SM_FH - 1];    // 0 for rows past the footprint
+      const float wyv = tb->wy[ph][yr];
 #pragma unroll
-      for (int pw = 0; pw < 7; ++pw) acc[ph * 7 + pw] = __builtin_elementwise_fma(v2f{wyv, wyv}, T[pw], acc[ph * 7 + pw]);
+      for (int pw = 0; pw < 7; ++pw) acc[ph * 7 + pw] = fmaf(wyv, T[pw], acc[ph * 7 + pw]);
     }
-    __builtin_amdgcn_wave_barrier();                   // the slots of this pair are refilled in the next iteration
+    if (yr + 1 < fh) store_row(yr + 1);                // (waits for the loads; the other slot's readers are this wave itself)
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
 __global__ __launch_bounds__(64) void roi_feat7_stream_kernel(RoiFeatParams p) {
-  __shared__ __attribute__((aligned(16))) float ring[4 * SM_ROWPX * 64];
+  __shared__ __attribute__((aligned(16))) float ring[2 * SM_ROWPX * 64];
   __shared__ StreamTabs tabs;
   const int lane = threadIdx.x;
-  const int c2 = 2 * (lane & 31), hw = lane >> 5;
   const int nm = p.fb_count[1];
   // ring pixels beyond a footprint's width are read with zero weights: clear the ring once so they never hold NaN bits
   // (afterwards they hold stale map values, which are finite)
-  for (int t = lane; t < 4 * SM_ROWPX * 64; t += 64) ring[t] = 0.f;
+  for (int t = lane; t < 2 * SM_ROWPX * 64; t += 64) ring[t] = 0.f;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
   for (int job = blockIdx.x; job < nm; job += gridDim.x) {
     const int r = p.mid_list[job];
     const float* roi = p.rois + (long long)r * 5;
     const int b = (int)roi[0];
-    v2f acc[49];
+    float acc[49];
 #pragma unroll
-    for (int k = 0; k < 49; ++k) acc[k] = v2f{0.f, 0.f};
+    for (int k = 0; k < 49; ++k) acc[k] = 0.f;
     const RoiGeom g0 = roi_geom(roi, 0.25f, 7, 2), g1 = roi_geom(roi, 0.125f, 7, 2), gs = roi_geom(roi, 0.25f, 14, 0);
     const bool sem2 = gs.gw == 2 || gs.gh == 2;          // (classify guarantees gw, gh in {1, 2})
-    // FPN level 0 (+ the semantic term when it is sampled at the same points: one sample per 14x14 bin), level 1
-    sm_accumulate(sem2 ? p.x0 : p.x0sem, p.H0, p.W0, b, g0.x1, g0.y1, g0.bw, g0.bh, 2, 2, &tabs, ring, acc, lane);
-    sm_accumulate(p.x1, p.H1, p.W1, b, g1.x1, g1.y1, g1.bw, g1.bh, 2, 2, &tabs, ring, acc, lane);
-    // semantic 14x14 grid with 2 samples per bin on an axis, average-pooled 2x2: 2*g samples per 7x7 bin and axis on the
-    // 14-grid's geometry (the 7-grid's bin is two 14-grid bins)
-    if (sem2) sm_accumulate(p.sem, p.H0, p.W0, b, gs.x1, gs.y1, 2.f * gs.bw, 2.f * gs.bh, 2 * gs.gw, 2 * gs.gh, &tabs, ring, acc, lane);
+    // FPN level 0 (+ the semantic term when it is sampled at the same points: one sample per 14x14 bin), level 1, and -- when
+    // the semantic 14x14 grid takes 2 samples per bin on an axis -- the semantic map itself: average-pooled 2x2 that is 2*g
+    // samples per 7x7 bin and axis on the 14-grid's geometry (a 7-grid bin is two 14-grid bins)
+    for (int m = 0; m < (sem2 ? 3 : 2); ++m) {
+      const float* map = m == 0 ? (sem2 ? p.x0 : p.x0sem) : m == 1 ? p.x1 : p.sem;
+      const RoiGeom& g = m == 0 ? g0 : m == 1 ? g1 : gs;
+      const float bmul = m == 2 ? 2.f : 1.f;
+      sm_accumulate(map, m == 1 ? p.H1 : p.H0, m == 1 ? p.W1 : p.W0, b, g.x1, g.y1, bmul * g.bw, bmul * g.bh, m == 2 ? 2 * gs.gw : 2,
+                    m == 2 ? 2 * gs.gh : 2, &tabs, ring, acc, lane);
+    }
     // attention-pooled levels 2, 3: one vector per RoI, added to every bin
-    v2f gsum = {0.f, 0.f};
+    float gsum = 0.f;
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
       const int Hl = l ? p.H3 : p.H2, Wl = l ? p.W3 : p.W2;
@@ -512,23 +504,13 @@ __global__ __launch_bounds__(64) void roi_feat7_stream_kernel(RoiFeatParams p) {
       cx = fminf(fmaxf(cx, 0.f), (float)(Wl - 1));
       cy = fminf(fmaxf(cy, 0.f), (float)(Hl - 1));
       const float* G = l ? p.G3 : p.G2;
-      gsum += *reinterpret_cast<const v2f*>(G + (((long long)b * Hl + (int)cy) * Wl + (int)cx) * 64 + c2);
+      gsum += G[(((long long)b * Hl + (int)cy) * Wl + (int)cx) * 64 + lane];
     }
-    // even rows + odd rows, then the pooled terms; half-wave 0 stores the even bins, half-wave 1 the odd ones
+#pragma unroll
+    for (int k = 0; k < 49; ++k) acc[k] += gsum;
     float* out = p.out + (long long)r * 49 * 64;
 #pragma unroll
-    for (int k = 0; k < 49; ++k) {
-      v2f o;
-      o.x = acc[k].x + __shfl_xor(acc[k].x, 32);
-      o.y = acc[k].y + __shfl_xor(acc[k].y, 32);
-      acc[k] = o + gsum;
-    }
-#pragma unroll
-    for (int k = 0; k < 49; k += 2) {
-      const v2f v = (hw && k + 1 < 49) ? acc[k + 1 < 49 ? k + 1 : k] : acc[k];
-      const int bin = hw ? k + 1 : k;
-      if (bin < 49) *reinterpret_cast<v2f*>(out + bin * 64 + c2) = v;
-    }
+    for (int k = 0; k < 49; ++k) out[k * 64 + lane] = acc[k];
   }
 }
 
