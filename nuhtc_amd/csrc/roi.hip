@@ -442,8 +442,7 @@ __device__ __forceinline__ void sm_accumulate(const float* __restrict__ map, int
   load_row(0);
   store_row(0);
   for (int yr = 0; yr < fh; ++yr) {
-    if (yr + 1 < fh) load_row(yr + 1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    if (yr + 1 < fh) load_row(yr + 1);                 // stays in flight while row yr is contracted
     __builtin_amdgcn_wave_barrier();
     const float* row = ring + (yr & 1) * (SM_ROWPX * 64);
     float T[7];
