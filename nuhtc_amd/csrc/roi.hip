@@ -360,10 +360,9 @@ __device__ __forceinline__ AxisEnt sm_sample(float start, float bs, int S, int s
   return axis_entry(c, size, valid);
 }
 
-// one map of one RoI: adds RoIAlign(7x7, Sx x Sy samples per bin) of `map` into acc[ph][i]: a lane owns two channels (packed
-// fp32, 8-byte LDS reads) and the bin columns pw = 4 * (lane / 32) + i, i < 4 (the 8th column does not exist: zero weights)
+// one map of one RoI: adds RoIAlign(7x7, Sx x Sy samples per bin) of `map` into acc[49] (lane = channel)
 __device__ __forceinline__ void sm_accumulate(const float* __restrict__ map, int H, int W, int b, float x1, float y1, float bw, float bh,
-                                              int Sx, int Sy, StreamTabs* tb, float* ring, v2f (&acc)[28], int lane) {
+                                              int Sx, int Sy, StreamTabs* tb, float* ring, float (&acc)[49], int lane) {
   // ---- footprint bounds over the valid samples (lanes 0..27: x samples, 32..59: y samples)
   const bool is_y = lane >= 32;
   const int idx = lane & 31;
@@ -410,16 +409,13 @@ __device__ __forceinline__ void sm_accumulate(const float* __restrict__ map, int
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
-  const int c2 = 2 * (lane & 31), hw = lane >> 5;
-  float wxr[4][SM_J];
-  int xbase[4];
+  float wxr[7][SM_J];
+  int xbase[7];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int pw = 4 * hw + i;
-    const bool live = pw < 7;
-    xbase[i] = (live ? tb->xlo[pw] : 0) * 64 + c2;
+  for (int pw = 0; pw < 7; ++pw) {
+    xbase[pw] = tb->xlo[pw] * 64 + lane;
 #pragma unroll
-    for (int j = 0; j < SM_J; ++j) wxr[i][j] = live ? tb->wx[pw][j] : 0.f;
+    for (int j = 0; j < SM_J; ++j) wxr[pw][j] = tb->wx[pw][j];
   }
   // ---- stream the rows: slot (yr & 1) of the ring holds row yr.  Row yr + 1 is loaded into registers (4 pixels = 1 KB per
   // wave instruction, 16 lanes x 16 bytes per pixel) before row yr is contracted and written to the other slot afterwards
@@ -449,19 +445,19 @@ __device__ __forceinline__ void sm_accumulate(const float* __restrict__ map, int
     if (yr + 1 < fh) load_row(yr + 1);                 // stays in flight while row yr is contracted
     __builtin_amdgcn_wave_barrier();
     const float* row = ring + (yr & 1) * (SM_ROWPX * 64);
-    v2f T[4];
+    float T[7];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      v2f t = {0.f, 0.f};
+    for (int pw = 0; pw < 7; ++pw) {
+      float t = 0.f;
 #pragma unroll
-      for (int j = 0; j < SM_J; ++j) t = __builtin_elementwise_fma(v2f{wxr[i][j], wxr[i][j]}, *reinterpret_cast<const v2f*>(row + xbase[i] + j * 64), t);
-      T[i] = t;
+      for (int j = 0; j < SM_J; ++j) t = fmaf(wxr[pw][j], row[xbase[pw] + j * 64], t);
+      T[pw] = t;
     }
 #pragma unroll
     for (int ph = 0; ph < 7; ++ph) {
       const float wyv = tb->wy[ph][yr];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[ph * 4 + i] = __builtin_elementwise_fma(v2f{wyv, wyv}, T[i], acc[ph * 4 + i]);
+      for (int pw = 0; pw < 7; ++pw) acc[ph * 7 + pw] = fmaf(wyv, T[pw], acc[ph * 7 + pw]);
     }
     if (yr + 1 < fh) store_row(yr + 1);                // (waits for the loads; the other slot's readers are this wave itself)
     __builtin_amdgcn_wave_barrier();
@@ -482,9 +478,9 @@ __global__ __launch_bounds__(64) void roi_feat7_stream_kernel(RoiFeatParams p) {
     const int r = p.mid_list[job];
     const float* roi = p.rois + (long long)r * 5;
     const int b = (int)roi[0];
-    v2f acc[28];
+    float acc[49];
 #pragma unroll
-    for (int k = 0; k < 28; ++k) acc[k] = v2f{0.f, 0.f};
+    for (int k = 0; k < 49; ++k) acc[k] = 0.f;
     const RoiGeom g0 = roi_geom(roi, 0.25f, 7, 2), g1 = roi_geom(roi, 0.125f, 7, 2), gs = roi_geom(roi, 0.25f, 14, 0);
     const bool sem2 = gs.gw == 2 || gs.gh == 2;          // (classify guarantees gw, gh in {1, 2})
     // FPN level 0 (+ the semantic term when it is sampled at the same points: one sample per 14x14 bin), level 1, and -- when
@@ -498,8 +494,7 @@ __global__ __launch_bounds__(64) void roi_feat7_stream_kernel(RoiFeatParams p) {
                     m == 2 ? 2 * gs.gh : 2, &tabs, ring, acc, lane);
     }
     // attention-pooled levels 2, 3: one vector per RoI, added to every bin
-    const int c2 = 2 * (lane & 31), hw = lane >> 5;
-    v2f gsum = {0.f, 0.f};
+    float gsum = 0.f;
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
       const int Hl = l ? p.H3 : p.H2, Wl = l ? p.W3 : p.W2;
@@ -508,16 +503,13 @@ __global__ __launch_bounds__(64) void roi_feat7_stream_kernel(RoiFeatParams p) {
       cx = fminf(fmaxf(cx, 0.f), (float)(Wl - 1));
       cy = fminf(fmaxf(cy, 0.f), (float)(Hl - 1));
       const float* G = l ? p.G3 : p.G2;
-      gsum += *reinterpret_cast<const v2f*>(G + (((long long)b * Hl + (int)cy) * Wl + (int)cx) * 64 + c2);
+      gsum += G[(((long long)b * Hl + (int)cy) * Wl + (int)cx) * 64 + lane];
     }
+#pragma unroll
+    for (int k = 0; k < 49; ++k) acc[k] += gsum;
     float* out = p.out + (long long)r * 49 * 64;
 #pragma unroll
-    for (int ph = 0; ph < 7; ++ph)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int pw = 4 * hw + i;
-        if (pw < 7) *reinterpret_cast<v2f*>(out + (ph * 7 + pw) * 64 + c2) = acc[ph * 4 + i] + gsum;
-      }
+    for (int k = 0; k < 49; ++k) out[k * 64 + lane] = acc[k];
   }
 }
 
