@@ -148,6 +148,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # A GPU that has been idle (a fresh box) runs its first second or so well below its sustained clocks: before the W
+    # contractual warm-up steps, untimed steps are run until the step time has settled (two consecutive groups of 10 steps
+    # within 2 % of each other, at most 6 s).  Nothing here is timed or counted.
+    settle_steps, prev = 0, None
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < 6.0:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            step_fn()
+        torch.cuda.synchronize()
+        cur = time.perf_counter() - t1
+        settle_steps += 10
+        if prev is not None and abs(cur - prev) <= 0.02 * prev:
+            break
+        prev = cur
     for _ in range(args.warmup):
         step_fn()
     eng.check()
@@ -320,7 +336,7 @@ def main():
     if rank == 0:
         out = {
             'metric': 'tiles/sec (256x256) whole-node', 'value': total_tiles / dt, 'unit': 'tiles/s', 'n_gpus': world,
-            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+            'steps': args.steps, 'warmup': args.warmup, 'settle_steps_before_warmup': settle_steps, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'htc_lite_swin PanNuke config, batch_size=16 256x256 tiles per GPU (BASELINE configs[1]), full path '
                                    'incl. proposals, cascade, masks, per-tile mask-NMS' + (' [fixed load: 1064 RoIs, 64 detections per tile]' if args.fixed_load else ''), 'batch_per_gpu': B,

@@ -198,3 +198,35 @@ def test_pipeline_matches_single_engine(hip_device):
     with pytest.raises(RuntimeError):
         for _ in range(4):
             pipe.submit(tiles[:4], hip.CH_SWAP)
+
+
+def test_mag20_scale_factor_4(hip_device):
+    """tools/infer_wsi.py:416-419 sets MultiScaleFlipAug.scale_factor = 80 / mag: a 20x slide runs at scale_factor 4 (a 64-px tile
+    is a 256-px network input; cv2's x4 8-bit resize, boxes / masks scaled back by 4).  Engine vs oracle, strict."""
+    from nuhtc_amd import synth, weights
+    from nuhtc_amd.config import Config, engine_options, set_test_scale_factor
+    from nuhtc_amd.engine import Engine
+    from oracle import model as O
+    import os
+    cfg = Config.fromfile(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'configs/nuhtc/htc_lite_swin_pannuke_infer.py'))
+    assert set_test_scale_factor(cfg, 20) == 4.0 and engine_options(cfg)['scale_factor'] == 4.0
+    sd = weights.bench_state_dict(6, obj_bias=0.0)
+    tiles = synth.nuclei_tiles(3, 64, start=50)
+    eng = Engine(sd, device=0, max_batch=4, tile=(64, 64), scale_factor=4.0)
+    got = eng(tiles, 1)
+    img = eng.buffer('img')[:3].cpu().numpy()                       # (B, 256, 256, 3) network input
+    ref_img = O.preprocess(tiles, 1, scale=4).permute(0, 2, 3, 1).numpy()
+    assert img.shape == ref_img.shape == (3, 256, 256, 3) and np.abs(img - ref_img).max() <= 1e-6
+    ref, it = O.Oracle(sd, scale=4.0)(tiles, 1, keep=True)
+    vals = P.oracle_paste_values(O, it, (64, 64), 4.0)
+    n = 0
+    for i, (g, r) in enumerate(zip(got, ref)):
+        rep, fails = P.compare_strict(r, g, values=vals[i])
+        print(f'mag 20 tile {i}: {P.fmt(rep)}', *rep['explained'], sep='\n    ')
+        assert not fails, (i, fails)
+        n += rep['n_got']
+    assert n > 0
+    # a scale the engine cannot take is refused at creation, not silently rounded
+    from nuhtc_amd.engine import HipError
+    with pytest.raises(HipError):
+        Engine(sd, device=0, max_batch=1, tile=(64, 64), scale_factor=2.7)
