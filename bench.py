@@ -149,21 +149,21 @@ def main():
         torch.cuda.synchronize()
 
     # A GPU that has been idle (a fresh box) runs its first second or so well below its sustained clocks: before the W
-    # contractual warm-up steps, untimed steps are run until the step time has settled (two consecutive groups of 10 steps
-    # within 2 % of each other, at most 6 s).  Nothing here is timed or counted.
-    settle_steps, prev = 0, None
+    # contractual warm-up steps, untimed steps are run until the step time has settled (three consecutive groups of 10 steps
+    # within 1 % of each other, at most 8 s).  Nothing here is timed or counted.
+    settle_steps, hist = 0, []
     t_settle = time.perf_counter()
-    while time.perf_counter() - t_settle < 6.0:
+    while time.perf_counter() - t_settle < 8.0:
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(10):
             step_fn()
         torch.cuda.synchronize()
-        cur = time.perf_counter() - t1
+        hist.append((time.perf_counter() - t1) / 10)
         settle_steps += 10
-        if prev is not None and abs(cur - prev) <= 0.02 * prev:
+        if len(hist) >= 3 and max(hist[-3:]) <= 1.01 * min(hist[-3:]):
             break
-        prev = cur
+    print('settle phase, ms per step by group of 10:', [round(h * 1e3, 2) for h in hist], file=sys.stderr)
     for _ in range(args.warmup):
         step_fn()
     eng.check()

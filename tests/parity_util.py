@@ -18,7 +18,8 @@ Everything tolerated is returned in the report so the tests print it; nothing is
 import numpy as np
 
 EPS = 2e-5        # score / IoU distance from a threshold that explains a flipped decision (measured fp32 differences: ~1e-6)
-EPS_MASK = 1e-5   # a flipped mask pixel must have its pasted probability this close to 0.5 (measured on MI355X: <= 2.5e-6)
+EPS_MASK = 1e-4   # mask probabilities of the two sides agree to 1e-4 (the stage tolerance of tests/test_hip_full.py): a pixel can flip
+                  # only where the pasted probability is that close to 0.5 (measured on MI355X: 1e-6 .. 2e-5)
 
 
 def box_iou(a, b):
