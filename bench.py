@@ -107,6 +107,7 @@ def main():
                          'the free-running proposal / detection counts of the synthetic weights')
     ap.add_argument('--roi-size', default='12,40', help='--fixed-load: RoI side range in network pixels (SURVEY: 12,40; 40x nuclei: ~40,100)')
     ap.add_argument('--gemm-shapes', action='store_true', help='add the per-shape GEMM timings to the JSON line')
+    ap.add_argument('--no-settle', action='store_true', help='skip the untimed settle phase (profiling passes that serialise kernels)')
     ap.add_argument('--roi-sort', action='store_true', help='--fixed-load (dev): hand the RoIs over sorted by position (locality experiment)')
     args = ap.parse_args()
 
@@ -153,7 +154,7 @@ def main():
     # within 1 % of each other, at most 8 s).  Nothing here is timed or counted.
     settle_steps, hist = 0, []
     t_settle = time.perf_counter()
-    while time.perf_counter() - t_settle < 8.0:
+    while not args.no_settle and time.perf_counter() - t_settle < 8.0:
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(10):
