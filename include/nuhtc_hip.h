@@ -130,6 +130,18 @@ int nuhtc_infer_fixed_load(nuhtc_engine* e, const uint8_t* tiles_dev, int B, int
  * Enqueues on `stream`; does not synchronise. */
 int nuhtc_mask_contours(nuhtc_engine* e, const nuhtc_dets* dets, int B, int cap, int16_t* xy_dev, int32_t* n_dev, void* stream);
 
+/* Compacts the kept detections of a finished nuhtc_infer (slots r < counts[b] with keep set), in (tile, slot) order, into
+ * dense device buffers of capacity `cap` rows, so that a slide loop fetches a batch's results with a few fixed-size
+ * asynchronous copies instead of one copy per detection (the fields tools/infer_wsi.py:486-539 reads out of `result`):
+ * n_dev [1] = number of kept detections (may exceed cap: then only the first cap rows were written and the caller falls
+ * back to reading the detection buffers directly); idx_dev [cap] = b * max_per_img + r; boxes_dev [cap][5]; labels_dev
+ * [cap]; cn_dev [cap] / xy_dev [cap][contour_cap][2] = contour length / vertices from nuhtc_mask_contours (contour_n /
+ * contour_xy may be NULL: cn = 0, no vertices); words_dev [cap][tile_h * tile_w / 32] = the bit-packed masks.
+ * Enqueues on `stream`; does not synchronise. */
+int nuhtc_export_kept(nuhtc_engine* e, const nuhtc_dets* dets, int B, const int32_t* contour_n, const int16_t* contour_xy, int contour_cap,
+                      int cap, int32_t* n_dev, int64_t* idx_dev, float* boxes_dev, int32_t* labels_dev, int32_t* cn_dev, int16_t* xy_dev,
+                      uint32_t* words_dev, void* stream);
+
 /* Overlap measure of nuhtc_merge_overlap. */
 enum {
   NUHTC_OVERLAP_MASK = 0,     /* IoU of the instance masks (pixel sets) */

@@ -101,6 +101,15 @@ int launch_gemm(const GemmParams& p, hipStream_t s);
 int launch_contours(const uint32_t* masks, const uint8_t* keep, const int32_t* counts, int B, int max_per_img, int H, int W,
                     int cap, int16_t* xy, int32_t* n, hipStream_t s);
 
+// compaction of the kept detections of a batch into dense export buffers (contour.hip, nuhtc_export_kept)
+struct ExportParams {
+  const float* boxes; const int32_t* labels; const int32_t* counts; const uint8_t* keep; const uint32_t* masks;
+  const int32_t* contour_n; const int16_t* contour_xy;
+  int B, K, words, ccap, cap;
+  int32_t* n_out; int64_t* idx; float* boxes_out; int32_t* labels_out; int32_t* cn_out; int16_t* xy_out; uint32_t* words_out;
+};
+int launch_export_kept(const ExportParams& p, int32_t* pos_scratch, hipStream_t s);
+
 // ----------------------------------------------------------------------------- Swin kernels (swin.hip)
 // xtab / ytab: dev int4 per output column / row {src index 0, src index 1, weight 0, weight 1} from cv_linear_tables()
 void cv_linear_tables(int ssize, int dsize, bool horizontal, std::vector<int>& tab);

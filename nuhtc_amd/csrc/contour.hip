@@ -192,3 +192,65 @@ int launch_contours(const uint32_t* masks, const uint8_t* keep, const int32_t* c
   hipLaunchKernelGGL(contour_kernel, dim3(cdiv(total, CT_WAVES)), dim3(64 * CT_WAVES), lds, s, p, total);
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
 }
+
+// ----------------------------------------------------------------------------- export of the kept detections
+// After nuhtc_infer (+ nuhtc_mask_contours): compacts the detections that survived the per-tile filter + mask-NMS, in
+// (tile, slot) order, into dense device buffers -- index, box + score, label, contour length, contour vertices, bit-packed
+// mask -- so the host fetches them with a handful of fixed-size asynchronous copies (tools/infer_wsi.py:486-539 reads the
+// same fields out of `result`).  One block: flags -> exclusive scan -> rows copied by whole waves.
+
+__global__ __launch_bounds__(1024) void export_scan_kernel(ExportParams p, int32_t* pos) {
+  __shared__ int part[1024];
+  const int tid = threadIdx.x, total = p.B * p.K;
+  const int per = (total + 1023) / 1024;
+  const int lo = tid * per, hi = min(lo + per, total);
+  int s = 0;
+  for (int i = lo; i < hi; ++i) {
+    const int b = i / p.K, r = i - b * p.K;
+    s += (r < p.counts[b] && p.keep[i]) ? 1 : 0;
+  }
+  part[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int t = 0; t < 1024; ++t) { const int v = part[t]; part[t] = acc; acc += v; }
+    *p.n_out = acc;
+  }
+  __syncthreads();
+  int acc = part[tid];
+  for (int i = lo; i < hi; ++i) {
+    const int b = i / p.K, r = i - b * p.K;
+    const bool k = r < p.counts[b] && p.keep[i];
+    pos[i] = k ? acc : -1;
+    acc += k ? 1 : 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void export_copy_kernel(ExportParams p, const int32_t* pos) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= p.B * p.K) return;
+  const int d = pos[i];
+  if (d < 0 || d >= p.cap) return;
+  if (lane == 0) { p.idx[d] = i; p.labels_out[d] = p.labels[i]; p.cn_out[d] = p.contour_n ? p.contour_n[i] : 0; }
+  if (lane < 5) p.boxes_out[d * 5 + lane] = p.boxes[(long long)i * 5 + lane];
+  const uint4* ms = reinterpret_cast<const uint4*>(p.masks + (long long)i * p.words);
+  uint4* md = reinterpret_cast<uint4*>(p.words_out + (long long)d * p.words);
+  for (int t = lane; t < p.words / 4; t += 64) md[t] = ms[t];
+  if (p.contour_xy) {
+    const uint32_t* xs = reinterpret_cast<const uint32_t*>(p.contour_xy + (long long)i * p.ccap * 2);   // one (x, y) pair per dword
+    uint32_t* xd = reinterpret_cast<uint32_t*>(p.xy_out + (long long)d * p.ccap * 2);
+    const int nv = p.contour_n ? max(p.contour_n[i], 0) : p.ccap;
+    for (int t = lane; t < min(nv, p.ccap); t += 64) xd[t] = xs[t];
+  }
+}
+
+int launch_export_kept(const ExportParams& p, int32_t* pos_scratch, hipStream_t s) {
+  if (p.B <= 0) return 0;
+  if (p.words % 4 != 0) return NUHTC_E_INVALID;
+  ProfScope ps("export", 0, 0, s);
+  hipLaunchKernelGGL(export_scan_kernel, dim3(1), dim3(1024), 0, s, p, pos_scratch);
+  hipLaunchKernelGGL(export_copy_kernel, dim3(cdiv(p.B * p.K, 4)), dim3(256), 0, s, p, pos_scratch);
+  return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
+}
+

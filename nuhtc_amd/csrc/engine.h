@@ -52,6 +52,7 @@ struct nuhtc_engine {
   int roi_cap = 0;          // rois per tile: max_cc_proposals + rpn_max_per_img
   int cand_cap = 0;         // rpn candidates per tile (<= 4 * nms_pre), det candidates per tile
   int* overflow = nullptr;  // dev int[4]
+  int32_t* export_pos = nullptr;   // nuhtc_export_kept scratch [max_batch * max_per_img]
   hipStream_t side = nullptr;       // proposal selection / NMS run here, concurrently with the semantic head on the caller's stream
   hipEvent_t ev_rpn = nullptr, ev_side = nullptr, ev_fpn = nullptr;
   struct RoiWs* rw = nullptr;

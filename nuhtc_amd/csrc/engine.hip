@@ -587,6 +587,26 @@ int nuhtc_mask_contours(nuhtc_engine* e, const nuhtc_dets* dets, int B, int cap,
   return 0;
 }
 
+
+int nuhtc_export_kept(nuhtc_engine* e, const nuhtc_dets* dets, int B, const int32_t* contour_n, const int16_t* contour_xy, int contour_cap, int cap,
+                      int32_t* n_dev, int64_t* idx_dev, float* boxes_dev, int32_t* labels_dev, int32_t* cn_dev, int16_t* xy_dev, uint32_t* words_dev,
+                      void* stream) {
+  if (!e) return NUHTC_E_INVALID;
+  if (!dets || !dets->boxes || !dets->labels || !dets->counts || !dets->keep || !dets->masks || B < 1 || B > e->cfg.max_batch || cap < 1 ||
+      !n_dev || !idx_dev || !boxes_dev || !labels_dev || !cn_dev || !words_dev || (contour_xy && (!xy_dev || contour_cap < 1)))
+    FAIL(e, NUHTC_E_INVALID, "bad nuhtc_export_kept arguments");
+  HIP_CHECK(e, hipSetDevice(e->device));
+  if (!e->export_pos) {
+    int rc = dev_alloc(e, (void**)&e->export_pos, (size_t)e->cfg.max_batch * e->cfg.max_per_img * sizeof(int32_t));
+    if (rc) return rc;
+  }
+  ExportParams p{dets->boxes, dets->labels, dets->counts, dets->keep, dets->masks, contour_n, contour_xy, B, e->cfg.max_per_img,
+                 e->cfg.tile_h * (e->cfg.tile_w / 32), contour_cap, cap, n_dev, idx_dev, boxes_dev, labels_dev, cn_dev, xy_dev, words_dev};
+  int rc = launch_export_kept(p, e->export_pos, (hipStream_t)stream);
+  if (rc) FAIL(e, rc, "export launch failed (tile_h * tile_w / 32 must be a multiple of 4)");
+  return 0;
+}
+
 int nuhtc_check(nuhtc_engine* e, void* stream) {
   if (!e) return NUHTC_E_INVALID;
   HIP_CHECK(e, hipSetDevice(e->device));

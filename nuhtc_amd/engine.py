@@ -165,28 +165,25 @@ class Engine:
         pinned host buffers.  No host synchronisation: every device -> host copy of a result would otherwise block
         the submitting thread behind the other batches in flight.  Read with export_read() once the stream (or an
         event recorded after this call) has completed."""
-        K, P, W = self.cfg.max_per_img, self.cfg.tile_h, self.cfg.tile_h * (self.cfg.tile_w // 32)
+        K, W = self.cfg.max_per_img, self.cfg.tile_h * (self.cfg.tile_w // 32)
         cap = int(cap or min(self.cfg.max_batch * K, 96 * self.cfg.max_batch))
         ex = getattr(self, '_ex', None)
         if ex is None or ex['cap'] != cap or ex['ccap'] != contour_cap:
             pin = lambda *shape, dtype: torch.zeros(*shape, dtype=dtype).pin_memory()
-            ex = self._ex = dict(cap=cap, ccap=contour_cap, nk=pin(1, dtype=torch.int32), idx=pin(cap, dtype=torch.int64),
-                                 boxes=pin(cap, 5, dtype=torch.float32), labels=pin(cap, dtype=torch.int32), cn=pin(cap, dtype=torch.int32),
-                                 xy=pin(cap, contour_cap, 2, dtype=torch.int16), words=pin(cap, W, dtype=torch.int32),
-                                 ar=torch.arange(K, device=self.device, dtype=torch.int32),
-                                 rows=torch.arange(self.cfg.max_batch, device=self.device, dtype=torch.int32))
+            dev = lambda *shape, dtype: torch.zeros(*shape, dtype=dtype, device=self.device)
+            names = dict(nk=((1,), torch.int32), idx=((cap,), torch.int64), boxes=((cap, 5), torch.float32), labels=((cap,), torch.int32),
+                         cn=((cap,), torch.int32), xy=((cap, contour_cap, 2), torch.int16), words=((cap, W), torch.int32))
+            ex = self._ex = dict(cap=cap, ccap=contour_cap, host={k: pin(*sh, dtype=dt) for k, (sh, dt) in names.items()},
+                                 dev={k: dev(*sh, dtype=dt) for k, (sh, dt) in names.items()})
         self.contours_async(B, contour_cap)
-        MB = self.cfg.max_batch          # the gather runs over all max_batch rows (fixed shapes); rows >= B hold stale results
-        kept = (self.keep != 0) & (ex['ar'][None, :] < self.counts[:, None]) & (ex['rows'][:, None] < B)
-        flat = kept.reshape(-1)
-        idx = torch.argsort((~flat).to(torch.uint8), stable=True)[:cap]       # kept detections first, (tile, slot) ascending
-        ex['nk'].copy_(flat.sum(dtype=torch.int32).reshape(1), non_blocking=True)
-        ex['idx'].copy_(idx, non_blocking=True)
-        ex['boxes'].copy_(self.boxes.reshape(MB * K, 5)[idx], non_blocking=True)
-        ex['labels'].copy_(self.labels.reshape(MB * K)[idx], non_blocking=True)
-        ex['cn'].copy_(self.contour_n.reshape(MB * K)[idx], non_blocking=True)
-        ex['xy'].copy_(self.contour_xy.reshape(MB * K, contour_cap, 2)[idx], non_blocking=True)
-        ex['words'].copy_(self.masks.reshape(MB * K, W)[idx], non_blocking=True)
+        d = ex['dev']
+        vp = lambda t: ctypes.c_void_p(t.data_ptr())
+        # compaction of the kept detections on the device (nuhtc_export_kept), then one asynchronous copy per field
+        self._check(self.lib.nuhtc_export_kept(self.h, ctypes.byref(self.dets), B, vp(self.contour_n), vp(self.contour_xy), contour_cap, cap,
+                                               vp(d['nk']), vp(d['idx']), vp(d['boxes']), vp(d['labels']), vp(d['cn']), vp(d['xy']), vp(d['words']),
+                                               self._stream()))
+        for k, h in ex['host'].items():
+            h.copy_(d[k], non_blocking=True)
         ex['B'] = B
 
     def export_read(self):
@@ -194,9 +191,9 @@ class Engine:
         (<= 0: traced by the host mirror), contour vertices, bit-packed mask words) of the pinned buffers export_async
         filled, or None when the batch held more kept detections than the buffers (use the synchronous path then).
         The views are valid until the next export_async of this engine."""
-        ex = self._ex
+        ex = self._ex['host']
         n = int(ex['nk'][0])
-        if n > ex['cap']:
+        if n > self._ex['cap']:
             return None
         K = self.cfg.max_per_img
         idx = ex['idx'][:n].numpy()
