@@ -270,7 +270,7 @@ def main():
     # algorithmic bytes of the kernels whose work depends on device-side counts (RoIs, detections): from the last step's counts
     R = int(roi_counts.sum())
     D = int(counts.sum())
-    rois2 = eng.buffer('rois_stage2')[:R].cpu().numpy() if not args.fixed_load else None
+    rois2 = eng.buffer('rois')[:R].cpu().numpy() if not args.fixed_load else None   # the cascade's RoI list (after its in-place refinements)
     px = lambda wh, s: (np.ceil(wh[:, 0] / s) + 2) * (np.ceil(wh[:, 1] / s) + 2)
     if rois2 is not None and R:
         wh = rois2[:, 3:5] - rois2[:, 1:3]
