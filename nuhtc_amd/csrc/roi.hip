@@ -469,6 +469,7 @@ __global__ __launch_bounds__(64) void roi_feat7_stream_kernel(RoiFeatParams p) {
   __shared__ StreamTabs tabs;
   const int lane = threadIdx.x;
   const int nm = p.fb_count[1];
+  if ((int)blockIdx.x >= nm) return;                    // (most launches of the usual small-RoI load have no mid-size RoI at all)
   // ring pixels beyond a footprint's width are read with zero weights: clear the ring once so they never hold NaN bits
   // (afterwards they hold stale map values, which are finite)
   for (int t = lane; t < 2 * SM_ROWPX * 64; t += 64) ring[t] = 0.f;
