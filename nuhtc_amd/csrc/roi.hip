@@ -157,6 +157,8 @@ __device__ __forceinline__ RoiGeom roi_geom(const float* roi, float scale, int P
 // both paths are bit-identical.  RoIs with a larger footprint fall back to the global-memory path.
 #define TP0 12
 #define TP1 7
+#define TS0 8      // small-tile variant of the LDS path
+#define TS1 5
 struct AxisEnt { int lo, hi; float l, h; };
 
 // per-axis part of mmcv's bilinear_interpolate for sample coordinate c on an axis of `size` pixels
@@ -528,6 +530,9 @@ __global__ __launch_bounds__(256) void roi_classify_kernel(RoiFeatParams p) {
   // most 30 x 30 pixels on stride 4, bins spanning at most SM_J pixels); 2: one block per bin (big proposals)
   const float rwn = roi[3] - roi[1], rhn = roi[4] - roi[2];
   int cls = (sem_g1 && l0.ok && l1.ok) ? 0 : (gs.gw <= 2 && gs.gh <= 2 && rwn <= (float)SM_MAXSIDE && rhn <= (float)SM_MAXSIDE) ? 1 : 2;
+  // class 0 is split by footprint: 0 = fits the small tiles (8x8 / 5x5 pixels: boxes up to ~24 px, the usual nucleus), 3 = needs
+  // the 12x12 / 7x7 tiles; the small variant takes a third of the LDS, so twice as many RoIs are in flight per CU
+  if (cls == 0 && !(l0.fw <= TS0 && l0.fh <= TS0 && l1.fw <= TS1 && l1.fh <= TS1)) cls = 3;
   if (lane == 0) {
     p.fb_flag[r] = (unsigned char)cls;
     if (cls == 2) p.fb_list[atomicAdd(&p.fb_count[0], 1)] = r;
@@ -535,19 +540,23 @@ __global__ __launch_bounds__(256) void roi_classify_kernel(RoiFeatParams p) {
   }
 }
 
+template <int T0, int T1, int FLAG, bool WITH_FALLBACK>
 __global__ __launch_bounds__(256) void roi_feat7_lds_kernel(RoiFeatParams p) {
-  __shared__ float tile0[TP0 * TP0 * 64];
-  __shared__ float tile1[TP1 * TP1 * 64];
+  __shared__ float tile0[T0 * T0 * 64];
+  __shared__ float tile1[(T1 * T1 * 64 > 3 * 64) ? T1 * T1 * 64 : 3 * 64];
   __shared__ AxisEnt tab[2][2][16];
   // one RoI per block: the 4 waves share the staged footprints and split the 49 bins, so each SIMD holds 4 waves of
   // 4 different RoIs (LDS allows 4 blocks per CU) and the LDS / global latencies of one hide behind the others
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (blockIdx.x < FB_SLOTS * 49) {                     // fallback blocks first (see roi_feat7_generic_block)
-    roi_feat7_generic_block(p, blockIdx.x / 49, blockIdx.x % 49, reinterpret_cast<float(*)[64]>(tile1));
-    return;
+  int r = blockIdx.x;
+  if (WITH_FALLBACK) {
+    if (blockIdx.x < FB_SLOTS * 49) {                   // fallback blocks first (see roi_feat7_generic_block)
+      roi_feat7_generic_block(p, blockIdx.x / 49, blockIdx.x % 49, reinterpret_cast<float(*)[64]>(tile1));
+      return;
+    }
+    r = blockIdx.x - FB_SLOTS * 49;
   }
-  const int r = blockIdx.x - FB_SLOTS * 49;
-  if (r >= *p.r_dev || p.fb_flag[r]) return;
+  if (r >= *p.r_dev || p.fb_flag[r] != FLAG) return;
   const float* roi = p.rois + (long long)r * 5;
   const int b = (int)roi[0];
   const int cp2 = 2 * (lane & 31), hw = lane >> 5;     // bin loop: 2 channels per lane, one bin per half-wave
@@ -565,8 +574,8 @@ __global__ __launch_bounds__(256) void roi_feat7_lds_kernel(RoiFeatParams p) {
   float* out = p.out + (long long)r * 49 * 64;
   const RoiGeom g0 = roi_geom(roi, 0.25f, 7, 2), g1 = roi_geom(roi, 0.125f, 7, 2), gs = roi_geom(roi, 0.25f, 14, 0);
   const bool sem_g1 = gs.gw == 1 && gs.gh == 1;
-  const LevelPlan l0 = plan_level(g0, 7, 2, p.H0, p.W0, TP0, lane);   // every wave computes the same plan
-  const LevelPlan l1 = plan_level(g1, 7, 2, p.H1, p.W1, TP1, lane);
+  const LevelPlan l0 = plan_level(g0, 7, 2, p.H0, p.W0, T0, lane);   // every wave computes the same plan
+  const LevelPlan l1 = plan_level(g1, 7, 2, p.H1, p.W1, T1, lane);
   // With one sample per bin the 14x14 semantic grid (fused_semantic_head -> adaptive_avg_pool2d to 7x7,
   // htc_roi_head_cus.py) samples exactly the 2x2-per-bin points of the 7x7 grid on the same stride-4 geometry, and both
   // results are averaged over the same 4 samples: by linearity one interpolation of the pre-added map x0 + sem serves both.
@@ -693,7 +702,8 @@ int launch_roi_feat(const RoiFeatParams& p, int P, int r_cap, hipStream_t s, hip
     if (fork && (hipEventRecord(ev_fork, s) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess)) return NUHTC_E_HIP;
     hipLaunchKernelGGL(roi_feat7_stream_kernel, dim3(r_cap < 8192 ? r_cap : 8192), dim3(64), 0, fork ? side : s, p);
     if (fork && hipEventRecord(ev_join, side) != hipSuccess) return NUHTC_E_HIP;
-    hipLaunchKernelGGL(roi_feat7_lds_kernel, dim3(FB_SLOTS * 49 + r_cap), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((roi_feat7_lds_kernel<TS0, TS1, 0, false>), dim3(r_cap), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((roi_feat7_lds_kernel<TP0, TP1, 3, true>), dim3(FB_SLOTS * 49 + r_cap), dim3(256), 0, s, p);
     if (fork && hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) return NUHTC_E_HIP;
   } else if (P == 14) hipLaunchKernelGGL(roi_feat14_kernel, dim3(r_cap, 7), dim3(256), 0, s, p);
   else return NUHTC_E_INVALID;
