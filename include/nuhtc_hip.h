@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NUHTC_ABI_VERSION 2
+#define NUHTC_ABI_VERSION 3
 
 enum {
   NUHTC_OK = 0,
@@ -45,6 +45,14 @@ enum {
  *   0: tools/infer.py      (file -> BGR -> to_rgb): tile channels are used as given (RGB vs RGB means)
  *   1: tools/infer_wsi.py  (RGB ndarray run through the BGR pipeline): channels are reversed first     */
 enum { NUHTC_CH_AS_IS = 0, NUHTC_CH_SWAP = 1 };
+
+/* How the fp32 matrix products of the path (Swin linears, convolutions, FCs) are executed.  Both are fp32 arithmetic: fp32
+ * operands and results, exact products, fp32 accumulation.
+ *   NUHTC_PIPE_BF16_SPLIT (default): every fp32 operand is split exactly into three bf16 numbers (8 + 8 + 8 significand bits)
+ *       and the product runs as six v_mfma_f32_32x32x16_bf16 per 16-deep step (the three cross terms below 2^-26 of the product
+ *       are dropped); measured error against fp64 is at or below that of the fp32 MFMA chain (csrc/gemm.hip).
+ *   NUHTC_PIPE_FP32: v_mfma_f32_32x32x2_f32, bitwise an fp32 fma chain (1/16 of the bf16 MFMA rate on gfx950). */
+enum { NUHTC_PIPE_BF16_SPLIT = 0, NUHTC_PIPE_FP32 = 1 };
 
 typedef struct nuhtc_engine nuhtc_engine;
 
@@ -76,6 +84,7 @@ typedef struct nuhtc_config {
   int32_t margin;            /* 2    */
   int32_t min_area;          /* 10   */
   float   mask_nms_thr;      /* 0.05 */
+  int32_t matrix_pipe;       /* NUHTC_PIPE_BF16_SPLIT (default) or NUHTC_PIPE_FP32 */
 } nuhtc_config;
 
 /* Fills `cfg` with the PanNuke defaults listed above. */
@@ -183,6 +192,10 @@ int nuhtc_get_buffer(nuhtc_engine* e, const char* name, void** dev_ptr, int64_t*
 /* C[M,N] = act(A[M,K] * W[N,K]^T + bias[N]);  act: 0 none, 1 relu, 2 gelu(erf).  K%32==0, N%32==0. */
 int nuhtc_op_gemm(nuhtc_engine* e, const float* A, const float* W, const float* bias, float* C, int M, int N, int K,
                   int act, void* stream);
+/* The same product on the bf16 matrix pipe with exactly split operands (NUHTC_PIPE_BF16_SPLIT); W_host = host copy of W_dev (the
+ * split of a constant weight is made on the host, as at nuhtc_finalize).  Synchronises `stream`. */
+int nuhtc_op_gemm_split(nuhtc_engine* e, const float* A, const float* W_dev, const float* W_host, const float* bias, float* C, int M,
+                        int N, int K, int act, void* stream);
 /* mmcv RoIAlign(avg, aligned=True) on an NHWC map: feat [N,H,W,C=64], rois [R,5] -> out [R,P,P,C]. */
 int nuhtc_op_roi_align(nuhtc_engine* e, const float* feat_nhwc, int N, int H, int W, const float* rois, int R, int P,
                        float spatial_scale, int sampling_ratio, float* out, void* stream);

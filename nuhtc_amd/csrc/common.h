@@ -69,6 +69,7 @@ enum StoreMode { ST_PLAIN = 0, ST_ROWMAP = 1, ST_DECONV2 = 2 };
 struct GemmParams {
   const float* A;
   const float* W;      // [N][K] row-major
+  const void* Wsplit;  // optional: W split into three bf16 planes (gemm_register_split); then the bf16 matrix pipe is used
   const float* bias;   // [N] or null
   float* C;
   int M, N, K;
@@ -95,6 +96,10 @@ struct GemmParams {
   unsigned long long* stamps;   // dev instrumentation (-DNUHTC_GEMM_STAMPS), null otherwise
 };
 int launch_gemm(const GemmParams& p, hipStream_t s);
+// exact three-way bf16 split of a constant weight matrix (host copy given), keyed by its fp32 device pointer: launch_gemm then
+// runs that product on the bf16 matrix pipe (gemm.hip).  gemm_unregister_split frees the split copy.
+int gemm_register_split(const float* w_dev, const float* w_host, int N, int K);
+void gemm_unregister_split(const float* w_dev);
 
 // ----------------------------------------------------------------------------- contours (contour.hip)
 // outer contour (cv2 RETR first contour, CHAIN_APPROX_SIMPLE) of every kept instance mask; n: 0 = none, -1 = overflow

@@ -24,6 +24,7 @@ struct nuhtc_engine {
   std::map<std::string, std::vector<int64_t>> schema;   // names / shapes nuhtc_load_weight accepts
   std::map<std::string, BufInfo> bufs;
   std::vector<void*> allocs;
+  std::vector<const float*> split_weights;   // weights registered with gemm_register_split (bf16 matrix pipe)
   size_t bytes_allocated = 0;
   bool finalized = false;
   bool debug_tokens = false;
@@ -58,6 +59,8 @@ struct nuhtc_engine {
   struct RoiWs* rw = nullptr;
 };
 
+// uploads a GEMM weight [N][K] and, unless cfg.matrix_pipe == NUHTC_PIPE_FP32, registers its exact bf16 split (gemm.hip)
+int upload_gemm_weight(nuhtc_engine* e, float** dst, const std::vector<float>& v, int N, int K);
 int finalize_roi(nuhtc_engine* e);
 int alloc_roi_workspace(nuhtc_engine* e);
 // rois_fixed != null -> fixed-load mode

@@ -30,6 +30,7 @@ void nuhtc_default_config(nuhtc_config* c) {
   const float st[3][4] = {{0.1f, 0.1f, 0.2f, 0.2f}, {0.05f, 0.05f, 0.1f, 0.1f}, {0.033f, 0.033f, 0.067f, 0.067f}};
   memcpy(c->stage_stds, st, sizeof(st));
   c->margin = 2; c->min_area = 10; c->mask_nms_thr = 0.05f;
+  c->matrix_pipe = NUHTC_PIPE_BF16_SPLIT;
 }
 
 const char* nuhtc_last_error(const nuhtc_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
@@ -54,6 +55,7 @@ int nuhtc_create(const nuhtc_config* cfg, int device, nuhtc_engine** out) {
   if (cfg->rpn_nms_pre < 1 || cfg->rpn_nms_pre > 4096 || cfg->rpn_max_per_img < 1 || cfg->rpn_max_per_img > 4096) { g_create_error = "rpn_nms_pre / rpn_max_per_img out of range (<=4096)"; return NUHTC_E_INVALID; }
   if (cfg->max_per_img < 1 || cfg->max_per_img > 2048) { g_create_error = "max_per_img out of range"; return NUHTC_E_INVALID; }
   if (cfg->max_cc_proposals < 0 || cfg->max_cc_proposals > 4096) { g_create_error = "max_cc_proposals out of range"; return NUHTC_E_INVALID; }
+  if (cfg->matrix_pipe != NUHTC_PIPE_BF16_SPLIT && cfg->matrix_pipe != NUHTC_PIPE_FP32) { g_create_error = "matrix_pipe must be NUHTC_PIPE_BF16_SPLIT or NUHTC_PIPE_FP32"; return NUHTC_E_INVALID; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { g_create_error = "no such HIP device"; return NUHTC_E_HIP; }
   hipDeviceProp_t prop;
@@ -74,6 +76,7 @@ void nuhtc_destroy(nuhtc_engine* e) {
   if (e->ev_rpn) hipEventDestroy(e->ev_rpn);
   if (e->ev_side) hipEventDestroy(e->ev_side);
   if (e->ev_fpn) hipEventDestroy(e->ev_fpn);
+  for (const float* w : e->split_weights) gemm_unregister_split(w);
   for (void* p : e->allocs) hipFree(p);
   delete e;
 }
@@ -146,6 +149,17 @@ static int upload(nuhtc_engine* e, float** dst, const std::vector<float>& v) {
   int rc = dev_alloc(e, (void**)dst, v.size() * sizeof(float));
   if (rc) return rc;
   HIP_CHECK(e, hipMemcpy(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int upload_gemm_weight(nuhtc_engine* e, float** dst, const std::vector<float>& v, int N, int K) {
+  int rc = upload(e, dst, v);
+  if (rc) return rc;
+  if (e->cfg.matrix_pipe == NUHTC_PIPE_FP32) return 0;
+  if ((size_t)N * K != v.size()) FAIL(e, NUHTC_E_INVALID, "upload_gemm_weight: shape mismatch");
+  rc = gemm_register_split(*dst, v.data(), N, K);
+  if (rc) FAIL(e, rc, "gemm_register_split failed");
+  e->split_weights.push_back(*dst);
   return 0;
 }
 
@@ -304,9 +318,9 @@ int nuhtc_finalize(nuhtc_engine* e) {
           for (int kj = 0; kj < WS2; ++kj) rbT[((size_t)h * WS2 + kj) * WS2 + qi] = rb[((size_t)h * WS2 + qi) * WS2 + kj];
       if ((rc = upload(e, &bw.relbT, rbT))) return rc;
       if ((rc = upload(e, &bw.n1g, n1w->data)) || (rc = upload(e, &bw.n1b, n1b->data)) || (rc = upload(e, &bw.relb, rb)) ||
-          (rc = upload(e, &bw.qkv_w, qw->data)) || (rc = upload(e, &bw.qkv_b, qb->data)) || (rc = upload(e, &bw.proj_w, pw->data)) ||
+          (rc = upload_gemm_weight(e, &bw.qkv_w, qw->data, 3 * C, C)) || (rc = upload(e, &bw.qkv_b, qb->data)) || (rc = upload_gemm_weight(e, &bw.proj_w, pw->data, C, C)) ||
           (rc = upload(e, &bw.proj_b, pb->data)) || (rc = upload(e, &bw.n2g, n2w->data)) || (rc = upload(e, &bw.n2b, n2b->data)) ||
-          (rc = upload(e, &bw.f1_w, f1w->data)) || (rc = upload(e, &bw.f1_b, f1b->data)) || (rc = upload(e, &bw.f2_w, f2w->data)) ||
+          (rc = upload_gemm_weight(e, &bw.f1_w, f1w->data, 4 * C, C)) || (rc = upload(e, &bw.f1_b, f1b->data)) || (rc = upload_gemm_weight(e, &bw.f2_w, f2w->data, C, 4 * C)) ||
           (rc = upload(e, &bw.f2_b, f2b->data)))
         return rc;
       e->blocks[s].push_back(bw);
@@ -327,7 +341,7 @@ int nuhtc_finalize(nuhtc_engine* e) {
           b2[q * C + ch] = nb->data[ch * 4 + q];
           for (int n = 0; n < 2 * C; ++n) w2[(size_t)n * 4 * C + q * C + ch] = rw->data[(size_t)n * 4 * C + ch * 4 + q];
         }
-      if ((rc = upload(e, &e->mg_g[s], g2)) || (rc = upload(e, &e->mg_b[s], b2)) || (rc = upload(e, &e->mg_w[s], w2))) return rc;
+      if ((rc = upload(e, &e->mg_g[s], g2)) || (rc = upload(e, &e->mg_b[s], b2)) || (rc = upload_gemm_weight(e, &e->mg_w[s], w2, 2 * C, 4 * C))) return rc;
     }
   }
   // ---- FPN
@@ -337,8 +351,8 @@ int nuhtc_finalize(nuhtc_engine* e) {
     RAW(lb, "neck.lateral_convs." + std::to_string(i) + ".conv.bias", 64);
     RAW(fw, "neck.fpn_convs." + std::to_string(i) + ".conv.weight", 64, 64, 3, 3);
     RAW(fb, "neck.fpn_convs." + std::to_string(i) + ".conv.bias", 64);
-    if ((rc = upload(e, &e->lat_w[i], lw->data)) || (rc = upload(e, &e->lat_b[i], lb->data)) ||
-        (rc = upload(e, &e->fpn_w[i], pack_conv3(*fw, 64, 64))) || (rc = upload(e, &e->fpn_b[i], fb->data)))
+    if ((rc = upload_gemm_weight(e, &e->lat_w[i], lw->data, 64, C)) || (rc = upload(e, &e->lat_b[i], lb->data)) ||
+        (rc = upload_gemm_weight(e, &e->fpn_w[i], pack_conv3(*fw, 64, 64), 64, 576)) || (rc = upload(e, &e->fpn_b[i], fb->data)))
       return rc;
   }
   // ---- RPN: 3x3 conv, then cls(3)+reg(12) fused into one N=32 pointwise layer (cols 0-2 cls, 3-14 reg, rest 0)
@@ -349,8 +363,8 @@ int nuhtc_finalize(nuhtc_engine* e) {
     std::vector<float> w(32 * 64, 0.f), b(32, 0.f);
     for (int n = 0; n < 3; ++n) { b[n] = kb->data[n]; for (int k = 0; k < 64; ++k) w[n * 64 + k] = kw->data[n * 64 + k]; }
     for (int n = 0; n < 12; ++n) { b[3 + n] = rb->data[n]; for (int k = 0; k < 64; ++k) w[(3 + n) * 64 + k] = rw->data[n * 64 + k]; }
-    if ((rc = upload(e, &e->rpn_w, pack_conv3(*cw, 64, 64))) || (rc = upload(e, &e->rpn_b, cb->data)) ||
-        (rc = upload(e, &e->rpn_hw, w)) || (rc = upload(e, &e->rpn_hb, b)))
+    if ((rc = upload_gemm_weight(e, &e->rpn_w, pack_conv3(*cw, 64, 64), 64, 576)) || (rc = upload(e, &e->rpn_b, cb->data)) ||
+        (rc = upload_gemm_weight(e, &e->rpn_hw, w, 32, 64)) || (rc = upload(e, &e->rpn_hb, b)))
       return rc;
   }
   // ---- semantic head
@@ -361,13 +375,13 @@ int nuhtc_finalize(nuhtc_engine* e) {
       RAW(lb, p + "lateral_convs." + std::to_string(i) + ".conv.bias", 64);
       RAW(cw, p + "convs." + std::to_string(i) + ".conv.weight", 64, 64, 3, 3);
       RAW(cb, p + "convs." + std::to_string(i) + ".conv.bias", 64);
-      if ((rc = upload(e, &e->sem_lw[i], lw->data)) || (rc = upload(e, &e->sem_lb[i], lb->data)) ||
-          (rc = upload(e, &e->sem_cw[i], pack_conv3(*cw, 64, 64))) || (rc = upload(e, &e->sem_cb[i], cb->data)))
+      if ((rc = upload_gemm_weight(e, &e->sem_lw[i], lw->data, 64, 64)) || (rc = upload(e, &e->sem_lb[i], lb->data)) ||
+          (rc = upload_gemm_weight(e, &e->sem_cw[i], pack_conv3(*cw, 64, 64), 64, 576)) || (rc = upload(e, &e->sem_cb[i], cb->data)))
         return rc;
     }
     RAW(ew, p + "conv_embedding.conv.weight", 64, 64, 1, 1); RAW(eb, p + "conv_embedding.conv.bias", 64);
     RAW(gw, p + "conv_logits.weight", 1, 64, 1, 1); RAW(gb, p + "conv_logits.bias", 1);
-    if ((rc = upload(e, &e->sem_ew, ew->data)) || (rc = upload(e, &e->sem_eb, eb->data)) || (rc = upload(e, &e->sem_gw, gw->data)) ||
+    if ((rc = upload_gemm_weight(e, &e->sem_ew, ew->data, 64, 64)) || (rc = upload(e, &e->sem_eb, eb->data)) || (rc = upload(e, &e->sem_gw, gw->data)) ||
         (rc = upload(e, &e->sem_gb, gb->data)))
       return rc;
   }
@@ -654,5 +668,21 @@ int nuhtc_op_gemm(nuhtc_engine* e, const float* A, const float* W, const float* 
   p.act = act;
   int rc = launch_gemm(p, (hipStream_t)stream);
   if (rc) FAIL(e, rc, "gemm launch failed (K%32, N%32 required)");
+  return 0;
+}
+
+int nuhtc_op_gemm_split(nuhtc_engine* e, const float* A, const float* W_dev, const float* W_host, const float* bias, float* C, int M, int N,
+                        int K, int act, void* stream) {
+  if (!e || !A || !W_dev || !W_host || !C) return NUHTC_E_INVALID;
+  HIP_CHECK(e, hipSetDevice(e->device));
+  int rc = gemm_register_split(W_dev, W_host, N, K);
+  if (rc) FAIL(e, rc, "gemm_register_split failed (K % 8)");
+  GemmParams p = gp(A, W_dev, bias, C, M, N, K);
+  p.act = act;
+  rc = launch_gemm(p, (hipStream_t)stream);
+  hipError_t he = hipStreamSynchronize((hipStream_t)stream);
+  gemm_unregister_split(W_dev);
+  if (rc) FAIL(e, rc, "gemm launch failed (K%32, N%32 required)");
+  if (he != hipSuccess) FAIL(e, NUHTC_E_HIP, "gemm kernel failed");
   return 0;
 }

@@ -7,6 +7,7 @@
 // htc_mask_head.py:22-39), the bbox-head FCs (convfc_bbox_head.py:158-196) and the attention-pool similarity /
 // aggregation products (nuhtc/models/roi_extractors_cus.py:228-235).
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <vector>
 #include <cstdio>
@@ -37,6 +38,138 @@ __device__ __forceinline__ float gelu_erf(float v) {
   qd = fmaf(qd, x2, -1.42647390514189e-02f);
   const float e = x * pn * __builtin_amdgcn_rcpf(qd);
   return 0.5f * v * (1.0f + e);
+}
+
+// ---- epilogue shared by the fp32 and the split-bf16 main loops
+template <int MT, int NT, int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[MT][NT], float* lds, float* __restrict__ C, int z, int m0, int n0,
+                                              int Meff) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int i32 = lane & 31, half = lane >> 5;
+  // ---- epilogue.  The accumulators hold a 32x32 sub-tile with the column on the lane and 16 rows in the registers, which
+  // would mean 16 single-dword stores (and residual loads) per lane per sub-tile: at K = 96..384 that store / load issue
+  // costs as much as the whole k-loop.  Each wave therefore transposes its sub-tile through a private 4 KB slice of the
+  // (now idle) staging LDS -- 16 conflict-free ds_write_b32, 4 ds_read_b128 -- so that a lane owns 4 consecutive columns
+  // of 4 rows: every global access of the epilogue (bias, residual, FPN top-down term, the store) is one 16-byte
+  // instruction covering 8 full 128-byte row segments per wave.
+  const float* ri = p.cos_ri ? p.cos_ri + (long long)z * p.sRi : nullptr;
+  const float* rj = p.cos_rj ? p.cos_rj + (long long)z * p.sRj : nullptr;
+  __syncthreads();                              // every wave is done reading the k-loop's LDS tiles
+  float* tb = lds + wave * (32 * 32);           // this wave's transpose tile [row][col]
+  const int rr = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) {
+    // bookkeeping of the 4 rows this lane stores (rows 8j + rr of the sub-tile): validity, scatter map, FPN parent /
+    // deconv base row; all map reads are issued together from clamped addresses
+    int mrow[4], drow[4], aux[4];
+    unsigned okmask = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + (wm * MT + mi) * 32 + 8 * j + rr;
+      if (m < Meff) okmask |= 1u << j;
+      mrow[j] = m < Meff ? m : Meff - 1;
+      drow[j] = mrow[j];
+      aux[j] = 0;
+    }
+    if (p.store == ST_ROWMAP) {
+      int d[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[j] = p.row_map[mrow[j]];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { if (d[j] < 0) okmask &= ~(1u << j); drow[j] = d[j] >= 0 ? d[j] : 0; }
+    }
+    if (p.up) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int hw = p.upH * p.upW;
+        const int b = mrow[j] / hw, q = mrow[j] - b * hw;
+        const int y = q / p.upW, x = q - y * p.upW;
+        aux[j] = (b * (p.upH >> 1) + (y >> 1)) * (p.upW >> 1) + (x >> 1);
+      }
+    } else if (p.store == ST_DECONV2) {
+      // rows m = (d, y, x) on a cH x cW grid; columns n = (kh*2+kw)*ldc + oc -> out[(d, 2y+kh, 2x+kw), oc]
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int hw = p.cH * p.cW;
+        const int b = mrow[j] / hw, q = mrow[j] - b * hw;
+        const int y = q / p.cW, x = q - y * p.cW;
+        aux[j] = (b * (2 * p.cH) + 2 * y) * (2 * p.cW) + 2 * x;
+      }
+    }
+    float riv[4];
+    if (p.act == ACT_COS) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) riv[j] = ri[mrow[j]];
+    }
+    // Vector-memory operations retire in issue order, so a load issued after a column tile's stores would wait for those
+    // stores to be acknowledged (thousands of cycles under load) before its data counts as landed.  Bias / column norms of
+    // every column tile are therefore loaded before the first store, and the row-dependent terms (residual, FPN parent)
+    // of tile t+1 are requested (into the registers tile t's terms just left) before tile t is stored: the wait for them
+    // never has a store ahead of it.
+    // (launch_gemm rejects bias together with the cosine epilogue and residual together with the FPN term, so one column
+    // vector per tile and one row-term array serve all epilogues)
+    const float* colp = p.act == ACT_COS ? rj : p.bias;
+    const float* rowp = p.res ? p.res : p.up;
+    const int rowld = p.res ? p.ldr : p.N;
+    unsigned rowoff[4];   // element offsets (launch_gemm checks they fit 32 bits)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rowoff[j] = (unsigned)(p.res ? drow[j] : aux[j]) * (unsigned)rowld + (unsigned)(n0 + wn * NT * 32 + c4);
+    v4f colv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      colv[t] = v4f{0.f, 0.f, 0.f, 0.f};
+      if (colp) colv[t] = *reinterpret_cast<const v4f*>(colp + n0 + (wn * NT + t) * 32 + c4);
+    }
+    v4f rowv[4];
+#define EPI_LOADS(t_)                                                                                                   \
+  if (rowp) {                                                                                                           \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                       \
+        rowv[j] = *reinterpret_cast<const v4f*>(rowp + rowoff[j] + (t_) * 32);                                          \
+  }
+    EPI_LOADS(0)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tb[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + i32] = acc[mi][t][r];
+      const int n = n0 + (wn * NT + t) * 32 + c4;            // this lane's 4 columns
+      // (DS operations of one wave execute in order: the reads below see the writes above, and the next sub-tile's writes
+      // cannot overtake these reads)
+      v4f v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = *reinterpret_cast<const v4f*>(tb + (8 * j + rr) * 32 + c4) * p.alpha;
+        if (p.bias) v[j] += colv[t];
+        if (p.act == ACT_RELU) {
+          v[j].x = fmaxf(v[j].x, 0.f); v[j].y = fmaxf(v[j].y, 0.f); v[j].z = fmaxf(v[j].z, 0.f); v[j].w = fmaxf(v[j].w, 0.f);
+        } else if (p.act == ACT_GELU) {
+          v[j].x = gelu_erf(v[j].x); v[j].y = gelu_erf(v[j].y); v[j].z = gelu_erf(v[j].z); v[j].w = gelu_erf(v[j].w);
+        } else if (p.act == ACT_COS) {
+          v[j].x = fmaxf(v[j].x * riv[j] * colv[t].x - p.cos_tau, 0.f) + p.cos_tau;
+          v[j].y = fmaxf(v[j].y * riv[j] * colv[t].y - p.cos_tau, 0.f) + p.cos_tau;
+          v[j].z = fmaxf(v[j].z * riv[j] * colv[t].z - p.cos_tau, 0.f) + p.cos_tau;
+          v[j].w = fmaxf(v[j].w * riv[j] * colv[t].w - p.cos_tau, 0.f) + p.cos_tau;
+        }
+        if (rowp) v[j] += rowv[j];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < NT) EPI_LOADS(t + 1)          // requested before this tile's stores are issued
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (!((okmask >> j) & 1u)) continue;
+        if (p.store == ST_DECONV2) {
+          const int tap = n / p.ldc, oc = n - tap * p.ldc;     // ldc % 4 == 0: the 4 columns share one tap
+          *reinterpret_cast<v4f*>(C + ((long long)aux[j] + (tap >> 1) * (2 * p.cW) + (tap & 1)) * p.ldc + oc) = v[j];
+        } else {
+          *reinterpret_cast<v4f*>(C + (long long)drow[j] * p.ldc + n) = v[j];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);   // keep the live ranges of one column tile from overlapping the next
+    }
+#undef EPI_LOADS
+  }
 }
 
 template <int MT, int NT, int WM, int WN, int BK, int AMODE>
@@ -282,129 +415,8 @@ __global__ __launch_bounds__(256, (MT * NT <= 3 ? 4 : 3)) void gemm_kernel(GemmP
 #undef MFMA_AT
 #undef MFMA_GROUP
 
-  // ---- epilogue.  The accumulators hold a 32x32 sub-tile with the column on the lane and 16 rows in the registers, which
-  // would mean 16 single-dword stores (and residual loads) per lane per sub-tile: at K = 96..384 that store / load issue
-  // costs as much as the whole k-loop.  Each wave therefore transposes its sub-tile through a private 4 KB slice of the
-  // (now idle) staging LDS -- 16 conflict-free ds_write_b32, 4 ds_read_b128 -- so that a lane owns 4 consecutive columns
-  // of 4 rows: every global access of the epilogue (bias, residual, FPN top-down term, the store) is one 16-byte
-  // instruction covering 8 full 128-byte row segments per wave.
-  const float* ri = p.cos_ri ? p.cos_ri + (long long)z * p.sRi : nullptr;
-  const float* rj = p.cos_rj ? p.cos_rj + (long long)z * p.sRj : nullptr;
   STAMP(st2 = __builtin_amdgcn_s_memtime();)
-  __syncthreads();                              // every wave is done reading the k-loop's LDS tiles
-  float* tb = lds + wave * (32 * 32);           // this wave's transpose tile [row][col]
-  const int rr = lane >> 3, c4 = (lane & 7) * 4;
-#pragma unroll
-  for (int mi = 0; mi < MT; ++mi) {
-    // bookkeeping of the 4 rows this lane stores (rows 8j + rr of the sub-tile): validity, scatter map, FPN parent /
-    // deconv base row; all map reads are issued together from clamped addresses
-    int mrow[4], drow[4], aux[4];
-    unsigned okmask = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int m = m0 + (wm * MT + mi) * 32 + 8 * j + rr;
-      if (m < Meff) okmask |= 1u << j;
-      mrow[j] = m < Meff ? m : Meff - 1;
-      drow[j] = mrow[j];
-      aux[j] = 0;
-    }
-    if (p.store == ST_ROWMAP) {
-      int d[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) d[j] = p.row_map[mrow[j]];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { if (d[j] < 0) okmask &= ~(1u << j); drow[j] = d[j] >= 0 ? d[j] : 0; }
-    }
-    if (p.up) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int hw = p.upH * p.upW;
-        const int b = mrow[j] / hw, q = mrow[j] - b * hw;
-        const int y = q / p.upW, x = q - y * p.upW;
-        aux[j] = (b * (p.upH >> 1) + (y >> 1)) * (p.upW >> 1) + (x >> 1);
-      }
-    } else if (p.store == ST_DECONV2) {
-      // rows m = (d, y, x) on a cH x cW grid; columns n = (kh*2+kw)*ldc + oc -> out[(d, 2y+kh, 2x+kw), oc]
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int hw = p.cH * p.cW;
-        const int b = mrow[j] / hw, q = mrow[j] - b * hw;
-        const int y = q / p.cW, x = q - y * p.cW;
-        aux[j] = (b * (2 * p.cH) + 2 * y) * (2 * p.cW) + 2 * x;
-      }
-    }
-    float riv[4];
-    if (p.act == ACT_COS) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) riv[j] = ri[mrow[j]];
-    }
-    // Vector-memory operations retire in issue order, so a load issued after a column tile's stores would wait for those
-    // stores to be acknowledged (thousands of cycles under load) before its data counts as landed.  Bias / column norms of
-    // every column tile are therefore loaded before the first store, and the row-dependent terms (residual, FPN parent)
-    // of tile t+1 are requested (into the registers tile t's terms just left) before tile t is stored: the wait for them
-    // never has a store ahead of it.
-    // (launch_gemm rejects bias together with the cosine epilogue and residual together with the FPN term, so one column
-    // vector per tile and one row-term array serve all epilogues)
-    const float* colp = p.act == ACT_COS ? rj : p.bias;
-    const float* rowp = p.res ? p.res : p.up;
-    const int rowld = p.res ? p.ldr : p.N;
-    unsigned rowoff[4];   // element offsets (launch_gemm checks they fit 32 bits)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) rowoff[j] = (unsigned)(p.res ? drow[j] : aux[j]) * (unsigned)rowld + (unsigned)(n0 + wn * NT * 32 + c4);
-    v4f colv[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      colv[t] = v4f{0.f, 0.f, 0.f, 0.f};
-      if (colp) colv[t] = *reinterpret_cast<const v4f*>(colp + n0 + (wn * NT + t) * 32 + c4);
-    }
-    v4f rowv[4];
-#define EPI_LOADS(t_)                                                                                                   \
-  if (rowp) {                                                                                                           \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                       \
-        rowv[j] = *reinterpret_cast<const v4f*>(rowp + rowoff[j] + (t_) * 32);                                          \
-  }
-    EPI_LOADS(0)
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) tb[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + i32] = acc[mi][t][r];
-      const int n = n0 + (wn * NT + t) * 32 + c4;            // this lane's 4 columns
-      // (DS operations of one wave execute in order: the reads below see the writes above, and the next sub-tile's writes
-      // cannot overtake these reads)
-      v4f v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        v[j] = *reinterpret_cast<const v4f*>(tb + (8 * j + rr) * 32 + c4) * p.alpha;
-        if (p.bias) v[j] += colv[t];
-        if (p.act == ACT_RELU) {
-          v[j].x = fmaxf(v[j].x, 0.f); v[j].y = fmaxf(v[j].y, 0.f); v[j].z = fmaxf(v[j].z, 0.f); v[j].w = fmaxf(v[j].w, 0.f);
-        } else if (p.act == ACT_GELU) {
-          v[j].x = gelu_erf(v[j].x); v[j].y = gelu_erf(v[j].y); v[j].z = gelu_erf(v[j].z); v[j].w = gelu_erf(v[j].w);
-        } else if (p.act == ACT_COS) {
-          v[j].x = fmaxf(v[j].x * riv[j] * colv[t].x - p.cos_tau, 0.f) + p.cos_tau;
-          v[j].y = fmaxf(v[j].y * riv[j] * colv[t].y - p.cos_tau, 0.f) + p.cos_tau;
-          v[j].z = fmaxf(v[j].z * riv[j] * colv[t].z - p.cos_tau, 0.f) + p.cos_tau;
-          v[j].w = fmaxf(v[j].w * riv[j] * colv[t].w - p.cos_tau, 0.f) + p.cos_tau;
-        }
-        if (rowp) v[j] += rowv[j];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (t + 1 < NT) EPI_LOADS(t + 1)          // requested before this tile's stores are issued
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (!((okmask >> j) & 1u)) continue;
-        if (p.store == ST_DECONV2) {
-          const int tap = n / p.ldc, oc = n - tap * p.ldc;     // ldc % 4 == 0: the 4 columns share one tap
-          *reinterpret_cast<v4f*>(C + ((long long)aux[j] + (tap >> 1) * (2 * p.cW) + (tap & 1)) * p.ldc + oc) = v[j];
-        } else {
-          *reinterpret_cast<v4f*>(C + (long long)drow[j] * p.ldc + n) = v[j];
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);   // keep the live ranges of one column tile from overlapping the next
-    }
-#undef EPI_LOADS
-  }
+  gemm_epilogue<MT, NT, WM, WN>(p, acc, lds, C, z, m0, n0, Meff);
 #ifdef NUHTC_GEMM_STAMPS
   st3 = __builtin_amdgcn_s_memtime();
   __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0)
@@ -416,6 +428,184 @@ __global__ __launch_bounds__(256, (MT * NT <= 3 ? 4 : 3)) void gemm_kernel(GemmP
   }
 #endif
 #undef STAMP
+}
+
+// ======================================================================================================================
+// fp32 GEMM on the bf16 matrix pipe by exact operand splitting.
+// gfx950's fp32 MFMA runs at 1/16 of the bf16 rate.  An fp32 number is exactly the sum of three bf16 numbers (24 significand
+// bits = 8 + 8 + 8; round-to-nearest splits, the residuals are exact fp32 subtractions), a bf16 x bf16 product is exact in
+// fp32, and v_mfma_f32_32x32x16_bf16 accumulates in fp32.  So  a*b = sum_ij a_i*b_j  over nine exact products; the three
+// smallest (a2*b3, a3*b2, a3*b3 <= 2^-26 |a*b|, below half an fp32 rounding unit) are dropped: SIX bf16 MFMAs of depth 16 (192
+// cycles) replace the eight fp32 MFMAs of depth 2 (512 cycles) of the same 32x32x16 product.  Measured against fp64
+// (tools/dev/probe/bf16split_probe.hip, K = 96 .. 3136, normal and wide-range operands): max error 1.2-1.6e-7 of sum|a*b|
+// against 1.4-2.1e-7 for the fp32 MFMA chain, identical with all nine products -- the result is fp32 arithmetic (exact
+// products, fp32 accumulation), only the summation order differs, and the 16-deep dot products round less often.
+//   W is split once at nuhtc_finalize (gemm_register_split) into Wsplit[n][k/8][plane 0..2][8 bf16]: the 96 bytes a column
+//   needs per 16-deep k-tile are contiguous in HBM and in the LDS image (112-byte column pitch: conflict-free b128 reads);
+//   A stays fp32 in HBM and LDS (same staging as the fp32 kernel, implicit 3x3-conv loader included) and is split in
+//   registers after the fragment read: 44 VALU instructions per k-tile and wave beside 6*NT MFMAs.
+// Block = 4 waves x 32 rows, NT column tiles of 32, BK = 16, double-buffered LDS, one barrier per k-tile; epilogue shared.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pk_bf16_rn(float lo, float hi) {   // two floats -> packed bf16 (round to nearest even)
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  bf2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned, v);
+}
+
+template <int NT, int AMODE>
+__global__ __launch_bounds__(256, 3) void gemm_split_kernel(GemmParams p) {
+  constexpr int MT = 1, WM = 4, WN = 1, BK = 16;
+  constexpr int BM = 128, BN = 32 * NT;
+  constexpr int KC = BK / 4, RPP = 256 / KC, NA = BM / RPP;       // A staging: float4 slots, 64 rows per pass, 2 passes
+  constexpr int LDK = BK + 4;                                      // A image [row][20 floats]
+  constexpr int BP = 28;                                           // B image [col][112 bytes = 28 floats]: 2 k-groups x 3 planes x 16 B + pad
+  constexpr int NCH = BN * 6, NB = (NCH + 255) / 256;              // B staging: 16-byte chunks per k-tile, passes of 256 threads
+  __shared__ __attribute__((aligned(16))) float lds[2 * (LDK * BM + BP * BN) > 4 * 32 * 32 ? 2 * (LDK * BM + BP * BN) : 4 * 32 * 32];
+  float* As = lds;                       // [2][BM][LDK]
+  float* Bs = lds + 2 * LDK * BM;        // [2][BN][BP]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int i32 = lane & 31, half = lane >> 5;
+  const int nTilesN = p.N / BN;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tile_m = (slot / nTilesN) * 8 + xcd, tile_n = slot % nTilesN;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int z = blockIdx.z;
+  int Meff = p.M;
+  if (p.m_dev) {
+    int md = *p.m_dev * p.m_mul;
+    Meff = md < Meff ? md : Meff;
+  }
+  if (m0 >= Meff) return;
+  const float* __restrict__ A = p.A + (long long)z * p.sA;
+  float* __restrict__ C = p.C + (long long)z * p.sC;
+  const char* __restrict__ Wsp = reinterpret_cast<const char*>(p.Wsplit);
+
+  // ---- A staging assignment (as in gemm_kernel: clamped rows, out-of-image conv taps read a page of zeros)
+  const int kc = tid % KC, rbase = tid / KC;
+  const float* a_ptr[NA];
+  unsigned a_ok[NA];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    int m = m0 + rbase + RPP * j;
+    m = m < Meff ? m : Meff - 1;
+    if (AMODE == A_PLAIN) {
+      a_ptr[j] = A + (long long)m * p.lda + kc * 4;
+      a_ok[j] = 0;
+    } else {
+      const int hw = p.cH * p.cW;
+      const int rr = m - (m / hw) * hw;
+      const int y = rr / p.cW, x = rr - y * p.cW;
+      unsigned bits = 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        if (yy >= 0 && yy < p.cH && xx >= 0 && xx < p.cW) bits |= 1u << t;
+      }
+      a_ok[j] = bits;
+      a_ptr[j] = A + (long long)m * p.cC + kc * 4;
+    }
+  }
+  // ---- B staging assignment: chunk q = tid + 256 j -> column q / 6, 16-byte piece q % 6 of its 96 bytes
+  const char* w_ptr[NB];
+  int w_lds[NB];
+  const long long wpitch = (long long)(p.K / 8) * 48;             // bytes per column of Wsplit
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    int q = tid + 256 * j;
+    q = q < NCH ? q : NCH - 1;
+    const int n = q / 6, c = q - n * 6;
+    w_ptr[j] = Wsp + (long long)(n0 + n) * wpitch + c * 16;
+    w_lds[j] = n * BP + c * 4;                                      // float index inside a Bs buffer
+  }
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  v4f ra[NA];
+  u32x4 rb[NB];
+  int cv_tap = 0, cv_c0 = 0;
+  long long cv_off = 0;
+#define S_LOAD_TILE(kt_)                                                                                       \
+  {                                                                                                            \
+    if (AMODE != A_PLAIN) {                                                                                    \
+      const int ky = cv_tap / 3 - 1, kx = cv_tap - (cv_tap / 3) * 3 - 1;                                       \
+      cv_off = (long long)(ky * p.cW + kx) * p.cC + cv_c0;                                                     \
+    }                                                                                                          \
+    _Pragma("unroll") for (int j = 0; j < NA; ++j) {                                                           \
+      if (AMODE == A_PLAIN) ra[j] = *reinterpret_cast<const v4f*>(a_ptr[j] + (kt_) * BK);                      \
+      else {                                                                                                   \
+        const bool ok = (a_ok[j] >> cv_tap) & 1u;                                                              \
+        ra[j] = *reinterpret_cast<const v4f*>(ok ? a_ptr[j] + cv_off : p.zeros);                               \
+      }                                                                                                        \
+    }                                                                                                          \
+    _Pragma("unroll") for (int j = 0; j < NB; ++j)                                                             \
+      if (64 * wave_u + 256 * j < NCH) rb[j] = *reinterpret_cast<const u32x4*>(w_ptr[j] + (long long)(kt_) * 96); \
+    if (AMODE != A_PLAIN) {                                                                                    \
+      cv_c0 += BK;                                                                                             \
+      if (cv_c0 == p.cC) { cv_c0 = 0; cv_tap = cv_tap < 8 ? cv_tap + 1 : 8; }                                  \
+    }                                                                                                          \
+  }
+#define S_STORE_TILE(buf_)                                                                                     \
+  {                                                                                                            \
+    _Pragma("unroll") for (int j = 0; j < NA; ++j)                                                             \
+      *reinterpret_cast<v4f*>(As + (buf_) * LDK * BM + (rbase + RPP * j) * LDK + kc * 4) = ra[j];              \
+    _Pragma("unroll") for (int j = 0; j < NB; ++j)                                                             \
+      if (64 * wave_u + 256 * j < NCH) *reinterpret_cast<u32x4*>(Bs + (buf_) * BP * BN + w_lds[j]) = rb[j];    \
+  }
+  f32x16 acc[1][NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][t][r] = 0.f;
+  const float* arow0 = As + (wave * 32 + i32) * LDK + half * 8;    // this lane's 8 consecutive k of its row
+  const float* brow0 = Bs + i32 * BP + half * 12;                  // its k-group of column i32: 3 planes x 16 B
+
+  const int nk = p.K / BK;
+  S_LOAD_TILE(0)
+  S_STORE_TILE(0)
+  __syncthreads();
+  if (nk > 1) S_LOAD_TILE(1)
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    // fragments of tile kt
+    const v4f a_lo = *reinterpret_cast<const v4f*>(arow0 + buf * LDK * BM), a_hi = *reinterpret_cast<const v4f*>(arow0 + buf * LDK * BM + 4);
+    u32x4 bq[NT][3];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) bq[t][pl] = *reinterpret_cast<const u32x4*>(brow0 + buf * BP * BN + t * 32 * BP + pl * 4);
+    // tile kt+1: registers -> the other LDS buffer (its readers finished before the last barrier); tile kt+2: HBM -> registers
+    if (kt + 1 < nk) S_STORE_TILE(buf ^ 1)
+    if (kt + 2 < nk) S_LOAD_TILE(kt + 2)
+    // split the A fragment: three bf16 planes (round to nearest at every level, exact residuals)
+    const float af[8] = {a_lo.x, a_lo.y, a_lo.z, a_lo.w, a_hi.x, a_hi.y, a_hi.z, a_hi.w};
+    u32x4 q1, q2, q3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float x = af[2 * i], y = af[2 * i + 1];
+      const unsigned w1 = pk_bf16_rn(x, y);
+      const float rx = x - __uint_as_float(w1 << 16), ry = y - __uint_as_float(w1 & 0xffff0000u);
+      const unsigned w2 = pk_bf16_rn(rx, ry);
+      const float sx = rx - __uint_as_float(w2 << 16), sy = ry - __uint_as_float(w2 & 0xffff0000u);
+      q1[i] = w1; q2[i] = w2; q3[i] = pk_bf16_rn(sx, sy);
+    }
+    const bf16x8 a1 = __builtin_bit_cast(bf16x8, q1), a2 = __builtin_bit_cast(bf16x8, q2), a3 = __builtin_bit_cast(bf16x8, q3);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const bf16x8 b1 = __builtin_bit_cast(bf16x8, bq[t][0]), b2 = __builtin_bit_cast(bf16x8, bq[t][1]), b3 = __builtin_bit_cast(bf16x8, bq[t][2]);
+      // smallest terms first
+      acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[0][t], 0, 0, 0);
+      acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[0][t], 0, 0, 0);
+      acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[0][t], 0, 0, 0);
+      acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[0][t], 0, 0, 0);
+      acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[0][t], 0, 0, 0);
+      acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[0][t], 0, 0, 0);
+    }
+    __syncthreads();        // tile kt+1 is in LDS for every wave; the buffer of tile kt may be overwritten next iteration
+  }
+#undef S_LOAD_TILE
+#undef S_STORE_TILE
+  gemm_epilogue<MT, NT, WM, WN>(p, acc, lds, C, z, m0, n0, Meff);
 }
 
 // block tile 128 x (32·NT): one 32-row strip per wave, NT accumulators (128x128 with 64x64 per wave, 256x64 and BK = 32 were
@@ -443,6 +633,58 @@ static const float* zero_page() {
   return z;
 }
 
+// ---- registry of split weights: fp32 weight pointer -> Wsplit[n][k/8][3][8 bf16] on the same device
+struct SplitEnt { void* dev; int N, K; };
+static std::map<const float*, SplitEnt> g_split;
+static std::mutex g_split_mu;
+
+static inline unsigned short bf16_rn_bits(float f) {     // round to nearest even (finite inputs)
+  unsigned u;
+  memcpy(&u, &f, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+static inline float bf16_bits_to_float(unsigned short h) {
+  unsigned u = (unsigned)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+int gemm_register_split(const float* w_dev, const float* w_host, int N, int K) {
+  if (!w_dev || !w_host || N <= 0 || K <= 0 || K % 8) return NUHTC_E_INVALID;
+  std::vector<unsigned short> sp((size_t)N * K * 3);
+  for (int n = 0; n < N; ++n)
+    for (int k = 0; k < K; ++k) {
+      const float b = w_host[(size_t)n * K + k];
+      const unsigned short b1 = bf16_rn_bits(b);
+      const float r1 = b - bf16_bits_to_float(b1);           // exact
+      const unsigned short b2 = bf16_rn_bits(r1);
+      const float r2 = r1 - bf16_bits_to_float(b2);          // exact
+      const unsigned short b3 = bf16_rn_bits(r2);
+      unsigned short* dst = sp.data() + (((size_t)n * (K / 8) + k / 8) * 3) * 8 + (k & 7);
+      dst[0] = b1; dst[8] = b2; dst[16] = b3;
+    }
+  void* d = nullptr;
+  if (hipMalloc(&d, sp.size() * 2) != hipSuccess || hipMemcpy(d, sp.data(), sp.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return NUHTC_E_HIP;
+  std::lock_guard<std::mutex> lock(g_split_mu);
+  g_split[w_dev] = SplitEnt{d, N, K};
+  return 0;
+}
+
+void gemm_unregister_split(const float* w_dev) {
+  std::lock_guard<std::mutex> lock(g_split_mu);
+  auto it = g_split.find(w_dev);
+  if (it != g_split.end()) { hipFree(it->second.dev); g_split.erase(it); }
+}
+
+template <int NT>
+static void launch_split(const GemmParams& q, int mtiles, hipStream_t s) {
+  dim3 grid(cdiv(mtiles, 8) * 8 * (q.N / (32 * NT)), 1, q.batch > 0 ? q.batch : 1);
+  if (q.amode == A_CONV3) hipLaunchKernelGGL((gemm_split_kernel<NT, A_CONV3>), grid, dim3(256), 0, s, q);
+  else hipLaunchKernelGGL((gemm_split_kernel<NT, A_PLAIN>), grid, dim3(256), 0, s, q);
+}
+
 int launch_gemm(const GemmParams& p, hipStream_t s) {
   if (p.M <= 0) return 0;
   if (p.K % 32 != 0 || p.N % 32 != 0) return NUHTC_E_INVALID;
@@ -464,6 +706,11 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
   }
   GemmParams q = p;
   if (q.alpha == 0.f) q.alpha = 1.f;
+  if (!q.Wsplit && (q.batch <= 1)) {       // a weight registered at finalize runs on the bf16 pipe with exactly split operands
+    std::lock_guard<std::mutex> lock(g_split_mu);
+    auto it = g_split.find(p.W);
+    if (it != g_split.end() && it->second.N == p.N && it->second.K == p.K) q.Wsplit = it->second.dev;
+  }
   if (q.amode == A_CONV3 && !q.zeros) {
     q.zeros = zero_page();
     if (!q.zeros) return NUHTC_E_HIP;
@@ -486,7 +733,12 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
   if (!stamp_buf && hipMalloc(&stamp_buf, 8ull * 8 * 4 * 65536) != hipSuccess) return NUHTC_E_HIP;
   q.stamps = stamp_buf;
 #endif
-  if (nt == 1) launch_cfg<1, 1, 4, 1>(q, cdiv(p.M, 128), s);
+  if (q.Wsplit) {
+    if (nt == 1) launch_split<1>(q, cdiv(p.M, 128), s);
+    else if (nt == 2) launch_split<2>(q, cdiv(p.M, 128), s);
+    else if (nt == 3) launch_split<3>(q, cdiv(p.M, 128), s);
+    else launch_split<4>(q, cdiv(p.M, 128), s);
+  } else if (nt == 1) launch_cfg<1, 1, 4, 1>(q, cdiv(p.M, 128), s);
   else if (nt == 2) launch_cfg<1, 2, 4, 1>(q, cdiv(p.M, 128), s);
   else if (nt == 3) launch_cfg<1, 3, 4, 1>(q, cdiv(p.M, 128), s);
   else launch_cfg<1, 4, 4, 1>(q, cdiv(p.M, 128), s);

@@ -119,7 +119,7 @@ int finalize_roi(nuhtc_engine* e) {
       for (int k2 = 0; k2 < 256; ++k2) hw[(nc + 2 + n) * 256 + k2] = wr->data[n * 256 + k2];
       hb[nc + 2 + n] = br->data[n];
     }
-    if ((rc = up(e, &e->fc1_w[k], w1p)) || (rc = up(e, &e->fc1_b[k], b1->data)) || (rc = up(e, &e->fc2_w[k], w2->data)) ||
+    if ((rc = upload_gemm_weight(e, &e->fc1_w[k], w1p, 256, 3136)) || (rc = up(e, &e->fc1_b[k], b1->data)) || (rc = upload_gemm_weight(e, &e->fc2_w[k], w2->data, 256, 256)) ||
         (rc = up(e, &e->fc2_b[k], b2->data)) || (rc = up(e, &e->head_w[k], hw)) || (rc = up(e, &e->head_b[k], hb)))
       return rc;
   }
@@ -128,7 +128,7 @@ int finalize_roi(nuhtc_engine* e) {
     for (int j = 0; j < 4; ++j) {
       RAWT(w, p + "convs." + std::to_string(j) + ".conv.weight", 64, 64, 3, 3);
       RAWT(b, p + "convs." + std::to_string(j) + ".conv.bias", 64);
-      if ((rc = up(e, &e->mk_w[j], pack3(*w, 64, 64))) || (rc = up(e, &e->mk_b[j], b->data))) return rc;
+      if ((rc = upload_gemm_weight(e, &e->mk_w[j], pack3(*w, 64, 64), 64, 576)) || (rc = up(e, &e->mk_b[j], b->data))) return rc;
     }
     RAWT(uw, p + "upsample.weight", 64, 64, 2, 2); RAWT(ub, p + "upsample.bias", 64);
     RAWT(lw, p + "conv_logits.weight", 1, 64, 1, 1); RAWT(lb, p + "conv_logits.bias", 1);
@@ -139,7 +139,7 @@ int finalize_roi(nuhtc_engine* e) {
         for (int t = 0; t < 4; ++t) w[((size_t)t * 64 + oc) * 64 + ic] = uw->data[((size_t)ic * 64 + oc) * 4 + t];
     for (int t = 0; t < 4; ++t)
       for (int oc = 0; oc < 64; ++oc) b[t * 64 + oc] = ub->data[oc];
-    if ((rc = up(e, &e->mk_up_w, w)) || (rc = up(e, &e->mk_up_b, b)) || (rc = up(e, &e->mk_lw, lw->data)) || (rc = up(e, &e->mk_lb, lb->data))) return rc;
+    if ((rc = upload_gemm_weight(e, &e->mk_up_w, w, 256, 64)) || (rc = up(e, &e->mk_up_b, b)) || (rc = up(e, &e->mk_lw, lw->data)) || (rc = up(e, &e->mk_lb, lb->data))) return rc;
   }
   return 0;
 }

@@ -248,12 +248,19 @@ class Engine:
         view = torch.as_tensor(_DevView(p.value, shp, _TYPESTR[dt.value]), device=self.device)
         return view.clone()
 
-    def op_gemm(self, A, W, bias=None, act=0):
+    def op_gemm(self, A, W, bias=None, act=0, pipe='fp32'):
+        """C = act(A @ W.T + bias) by the engine's GEMM kernel; pipe 'fp32' (v_mfma_f32_32x32x2_f32) or 'split' (exact 3-way bf16
+        split of both operands on v_mfma_f32_32x32x16_bf16)."""
         M, K = A.shape
         N = W.shape[0]
         C = torch.empty(M, N, dtype=torch.float32, device=self.device)
-        self._check(self.lib.nuhtc_op_gemm(self.h, A.data_ptr(), W.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                           C.data_ptr(), M, N, K, act, self._stream()))
+        bp = bias.data_ptr() if bias is not None else None
+        if pipe == 'fp32':
+            self._check(self.lib.nuhtc_op_gemm(self.h, A.data_ptr(), W.data_ptr(), bp, C.data_ptr(), M, N, K, act, self._stream()))
+        else:
+            wh = np.ascontiguousarray(W.detach().cpu().numpy(), dtype=np.float32)
+            self._check(self.lib.nuhtc_op_gemm_split(self.h, A.data_ptr(), W.data_ptr(), wh.ctypes.data_as(ctypes.c_void_p), bp, C.data_ptr(),
+                                                     M, N, K, act, self._stream()))
         return C
 
     def op_roi_align(self, feat_nhwc, rois, P, scale, sr):

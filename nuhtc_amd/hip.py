@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(HERE, 'libnuhtc_hip.so')
 OK, E_INVALID, E_HIP, E_STATE, E_CAPACITY, E_NOTFOUND = 0, -1, -2, -3, -4, -5
 CH_AS_IS, CH_SWAP = 0, 1
 OVERLAP_MASK, OVERLAP_POLYGON = 0, 1
+PIPE_BF16_SPLIT, PIPE_FP32 = 0, 1
 
 
 class Config(ctypes.Structure):
@@ -26,6 +27,7 @@ class Config(ctypes.Structure):
         ('watershed_proposal', ctypes.c_int32), ('max_cc_proposals', ctypes.c_int32),
         ('stage_stds', (ctypes.c_float * 4) * 3),
         ('margin', ctypes.c_int32), ('min_area', ctypes.c_int32), ('mask_nms_thr', ctypes.c_float),
+        ('matrix_pipe', ctypes.c_int32),
     ]
 
 
@@ -36,7 +38,7 @@ class Dets(ctypes.Structure):
 
 EXPORTS = ['nuhtc_default_config', 'nuhtc_create', 'nuhtc_destroy', 'nuhtc_last_error', 'nuhtc_load_weight',
            'nuhtc_finalize', 'nuhtc_infer', 'nuhtc_infer_fixed_load', 'nuhtc_check', 'nuhtc_get_buffer',
-           'nuhtc_op_gemm', 'nuhtc_op_roi_align', 'nuhtc_op_nms', 'nuhtc_profile_enable', 'nuhtc_profile_read',
+           'nuhtc_op_gemm', 'nuhtc_op_gemm_split', 'nuhtc_op_roi_align', 'nuhtc_op_nms', 'nuhtc_profile_enable', 'nuhtc_profile_read',
            'nuhtc_mask_contours', 'nuhtc_merge_overlap', 'nuhtc_export_kept']
 
 _lib = None
@@ -66,6 +68,7 @@ def load():
     lib.nuhtc_get_buffer.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int64),
                                      ctypes.POINTER(ci), ctypes.POINTER(ci)]
     lib.nuhtc_op_gemm.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
+    lib.nuhtc_op_gemm_split.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
     lib.nuhtc_op_roi_align.argtypes = [vp, vp, ci, ci, ci, vp, ci, ci, cf, ci, vp, vp]
     lib.nuhtc_op_nms.argtypes = [vp, vp, vp, ci, cf, vp, vp, vp]
     lib.nuhtc_mask_contours.argtypes = [vp, ctypes.POINTER(Dets), ci, ci, vp, vp, vp]

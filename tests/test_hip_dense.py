@@ -49,13 +49,44 @@ def test_gemm_op_shapes(hip_device):
         for act in (0, 1, 2):
             ref = A.double() @ W.double().T + b.double()
             ref = ref if act == 0 else (torch.relu(ref) if act == 1 else torch.nn.functional.gelu(ref))
-            out = eng.op_gemm(A.cuda(), W.cuda(), b.cuda(), act)
-            _cmp(f'gemm M{M} N{N} K{K} act{act}', out, ref.float(), errs, 1e-5, 2e-5)
+            for pipe in ('fp32', 'split'):
+                out = eng.op_gemm(A.cuda(), W.cuda(), b.cuda(), act, pipe=pipe)
+                _cmp(f'gemm[{pipe}] M{M} N{N} K{K} act{act}', out, ref.float(), errs, 1e-5, 2e-5)
     # A = I with an asymmetric B catches transposed fragment/C layouts
     I = torch.eye(96)
     Wb = torch.arange(96 * 96, dtype=torch.float32).reshape(96, 96) / 97.0
-    _cmp('gemm identity', eng.op_gemm(I.cuda(), Wb.cuda(), None, 0), Wb.T.contiguous(), errs, 0, 1e-6)
+    for pipe in ('fp32', 'split'):
+        _cmp(f'gemm[{pipe}] identity', eng.op_gemm(I.cuda(), Wb.cuda(), None, 0, pipe=pipe), Wb.T.contiguous(), errs, 0, 1e-6)
     assert not errs, '\n'.join(errs)
+
+
+def test_split_bf16_pipe_is_fp32_arithmetic(hip_device):
+    """The default matrix pipe (exact three-way bf16 split of both operands, six v_mfma_f32_32x32x16_bf16 per 16-deep step) against
+    an fp64 reference, beside the fp32 MFMA kernel on the same operands: its error, normalised by sum_k |a_k b_k|, must stay at
+    the level of an fp32 accumulation (a few 1e-7) and within 1.25x of the fp32 MFMA chain's -- normal operands and operands
+    spread over ~5 decades, K = 96 .. 3136 (the path's depths).  A bf16 (or 2-term) product would be 100-1000x off."""
+    g = G.load('small_b2')
+    eng, _ = _engine(g)
+    gen = torch.Generator().manual_seed(3)
+    rows = []
+    for wide in (False, True):
+        for (M, N, K) in [(256, 96, 96), (256, 384, 96), (256, 96, 384), (128, 192, 768), (128, 256, 3136), (256, 64, 576)]:
+            A = torch.randn(M, K, generator=gen)
+            W = torch.randn(N, K, generator=gen)
+            if wide:
+                A = A * torch.exp(2.0 * torch.randn(M, K, generator=gen))
+                W = W * torch.exp(2.0 * torch.randn(N, K, generator=gen))
+            ref = A.double() @ W.double().T
+            mag = A.double().abs() @ W.double().abs().T
+            e = {}
+            for pipe in ('fp32', 'split'):
+                out = eng.op_gemm(A.cuda(), W.cuda(), None, 0, pipe=pipe).cpu().double()
+                err = ((out - ref).abs() / mag)
+                e[pipe] = (float(err.max()), float((err ** 2).mean().sqrt()))
+            rows.append((wide, M, N, K, e))
+            print(f"{'wide  ' if wide else 'normal'} M{M} N{N} K{K}: fp32 mfma max {e['fp32'][0]:.2e} rms {e['fp32'][1]:.2e} | split max {e['split'][0]:.2e} rms {e['split'][1]:.2e}")
+            assert e['split'][1] <= 1.25 * e['fp32'][1] + 1e-9, (wide, M, N, K, e)
+            assert e['split'][0] <= (3e-6 if wide else 4e-7), (wide, M, N, K, e)
 
 
 @pytest.mark.parametrize('case', ['small_b2', 'small_wsi_b3', 'full_b1', 'five_b2'])
