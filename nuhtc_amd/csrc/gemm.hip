@@ -560,49 +560,136 @@ __global__ __launch_bounds__(256, 3) void gemm_split_kernel(GemmParams p) {
   const float* arow0 = As + (wave * 32 + i32) * LDK + half * 8;    // this lane's 8 consecutive k of its row
   const float* brow0 = Bs + i32 * BP + half * 12;                  // its k-group of column i32: 3 planes x 16 B
 
+  // ---- main loop, software-pipelined around the one barrier per k-tile.  The 6*NT MFMAs of tile kt (column tile after
+  // column tile) are split in two groups; everything else is a "filler" placed in the gap after an MFMA:
+  //   group A (first half)  | LDS writes of tile kt+1 (registers loaded a tile ago)
+  //   lgkmcnt(0) + barrier
+  //   group B (second half) | A fragment read of tile kt+1, HBM loads of tile kt+2, the split of that A fragment into the
+  //                         | NEXT set of bf16 planes, and -- as soon as a column tile's last MFMA has issued -- the read of its
+  //                         | B fragments for tile kt+1 into the same registers (one set of B registers, refilled in a rolling way)
+  // so no MFMA waits for LDS or for the split: its operands were produced half a tile earlier.
+  constexpr int NMF = 6 * NT, PB = NMF / 2;                        // MFMAs per tile; position of the barrier
+  constexpr int NST = NA + NB;                                     // staging stores (= loads) per tile
+  constexpr int GB = NMF - PB;                                     // gaps of group B
+  constexpr int NUB = 2 + NST + 4;                                 // filler units of group B: 2 A reads, loads, 4 split pairs
+  constexpr int FPA = (NST + PB - 1) / PB, FPB = (NUB + GB - 1) / GB;
+  v4f a_lo, a_hi;
+  u32x4 bq[NT][3];
+  u32x4 pc[3], pn[3];                                              // bf16 planes of the A fragment: current tile, next tile
+#define S_READ_B(t_, buf_)                                                                                     \
+  { _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                           \
+      bq[t_][pl] = *reinterpret_cast<const u32x4*>(brow0 + (buf_) * BP * BN + (t_) * 32 * BP + pl * 4); }
+#define S_READ_A(h_, buf_)                                                                                     \
+  { if ((h_) == 0) a_lo = *reinterpret_cast<const v4f*>(arow0 + (buf_) * LDK * BM);                            \
+    else a_hi = *reinterpret_cast<const v4f*>(arow0 + (buf_) * LDK * BM + 4); }
+  // split floats 2i, 2i+1 of the fragment into dword i of the three planes (round to nearest at every level, exact residuals)
+#define S_SPLIT_PAIR(i_, P_)                                                                                   \
+  {                                                                                                            \
+    const float x = (i_) == 0 ? a_lo.x : (i_) == 1 ? a_lo.z : (i_) == 2 ? a_hi.x : a_hi.z;                     \
+    const float y = (i_) == 0 ? a_lo.y : (i_) == 1 ? a_lo.w : (i_) == 2 ? a_hi.y : a_hi.w;                     \
+    const unsigned w1 = pk_bf16_rn(x, y);                                                                      \
+    const float rx = x - __uint_as_float(w1 << 16), ry = y - __uint_as_float(w1 & 0xffff0000u);                \
+    const unsigned w2 = pk_bf16_rn(rx, ry);                                                                    \
+    const float sx = rx - __uint_as_float(w2 << 16), sy = ry - __uint_as_float(w2 & 0xffff0000u);              \
+    P_[0][(i_)] = w1; P_[1][(i_)] = w2; P_[2][(i_)] = pk_bf16_rn(sx, sy);                                      \
+  }
+#define S_LOAD_ONE(f_, kt_)                                                                                    \
+  {                                                                                                            \
+    if ((f_) < NA) {                                                                                           \
+      const int j = (f_) < NA ? (f_) : 0;                                                                      \
+      if (AMODE == A_PLAIN) ra[j] = *reinterpret_cast<const v4f*>(a_ptr[j] + (kt_) * BK);                      \
+      else {                                                                                                   \
+        const bool ok = (a_ok[j] >> cv_tap) & 1u;                                                              \
+        ra[j] = *reinterpret_cast<const v4f*>(ok ? a_ptr[j] + cv_off : p.zeros);                               \
+      }                                                                                                        \
+    } else if ((f_) < NST) {                                                                                   \
+      const int j = (f_) >= NA && (f_) < NST ? (f_) - NA : 0;                                                  \
+      if (64 * wave_u + 256 * j < NCH) rb[j] = *reinterpret_cast<const u32x4*>(w_ptr[j] + (long long)(kt_) * 96); \
+    }                                                                                                          \
+  }
+#define S_STORE_ONE(f_, buf_)                                                                                  \
+  {                                                                                                            \
+    if ((f_) < NA) {                                                                                           \
+      const int j = (f_) < NA ? (f_) : 0;                                                                      \
+      *reinterpret_cast<v4f*>(As + (buf_) * LDK * BM + (rbase + RPP * j) * LDK + kc * 4) = ra[j];              \
+    } else if ((f_) < NST) {                                                                                   \
+      const int j = (f_) >= NA && (f_) < NST ? (f_) - NA : 0;                                                  \
+      if (64 * wave_u + 256 * j < NCH) *reinterpret_cast<u32x4*>(Bs + (buf_) * BP * BN + w_lds[j]) = rb[j];    \
+    }                                                                                                          \
+  }
+#define S_CONV_BEGIN()                                                                                         \
+  if (AMODE != A_PLAIN) {                                                                                      \
+    const int ky = cv_tap / 3 - 1, kx = cv_tap - (cv_tap / 3) * 3 - 1;                                         \
+    cv_off = (long long)(ky * p.cW + kx) * p.cC + cv_c0;                                                       \
+  }
+#define S_CONV_END()                                                                                           \
+  if (AMODE != A_PLAIN) {                                                                                      \
+    cv_c0 += BK;                                                                                               \
+    if (cv_c0 == p.cC) { cv_c0 = 0; cv_tap = cv_tap < 8 ? cv_tap + 1 : 8; }                                    \
+  }
+#define S_MFMA(i_)                                                                                             \
+  {                                                                                                            \
+    const int t = (i_) / 6, e = (i_) % 6;   /* smallest terms first: a3b1, a1b3, a2b2, a2b1, a1b2, a1b1 */     \
+    const int ia = e == 0 ? 2 : (e == 2 || e == 3) ? 1 : 0, ib = e == 1 ? 2 : (e == 2 || e == 4) ? 1 : 0;      \
+    acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pc[ia]), __builtin_bit_cast(bf16x8, bq[t][ib]), \
+                                                        acc[0][t], 0, 0, 0);                                   \
+  }
   const int nk = p.K / BK;
   S_LOAD_TILE(0)
   S_STORE_TILE(0)
   __syncthreads();
   if (nk > 1) S_LOAD_TILE(1)
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    // fragments of tile kt
-    const v4f a_lo = *reinterpret_cast<const v4f*>(arow0 + buf * LDK * BM), a_hi = *reinterpret_cast<const v4f*>(arow0 + buf * LDK * BM + 4);
-    u32x4 bq[NT][3];
+  S_READ_A(0, 0) S_READ_A(1, 0)
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) bq[t][pl] = *reinterpret_cast<const u32x4*>(brow0 + buf * BP * BN + t * 32 * BP + pl * 4);
-    // tile kt+1: registers -> the other LDS buffer (its readers finished before the last barrier); tile kt+2: HBM -> registers
-    if (kt + 1 < nk) S_STORE_TILE(buf ^ 1)
-    if (kt + 2 < nk) S_LOAD_TILE(kt + 2)
-    // split the A fragment: three bf16 planes (round to nearest at every level, exact residuals)
-    const float af[8] = {a_lo.x, a_lo.y, a_lo.z, a_lo.w, a_hi.x, a_hi.y, a_hi.z, a_hi.w};
-    u32x4 q1, q2, q3;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float x = af[2 * i], y = af[2 * i + 1];
-      const unsigned w1 = pk_bf16_rn(x, y);
-      const float rx = x - __uint_as_float(w1 << 16), ry = y - __uint_as_float(w1 & 0xffff0000u);
-      const unsigned w2 = pk_bf16_rn(rx, ry);
-      const float sx = rx - __uint_as_float(w2 << 16), sy = ry - __uint_as_float(w2 & 0xffff0000u);
-      q1[i] = w1; q2[i] = w2; q3[i] = pk_bf16_rn(sx, sy);
-    }
-    const bf16x8 a1 = __builtin_bit_cast(bf16x8, q1), a2 = __builtin_bit_cast(bf16x8, q2), a3 = __builtin_bit_cast(bf16x8, q3);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const bf16x8 b1 = __builtin_bit_cast(bf16x8, bq[t][0]), b2 = __builtin_bit_cast(bf16x8, bq[t][1]), b3 = __builtin_bit_cast(bf16x8, bq[t][2]);
-      // smallest terms first
-      acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[0][t], 0, 0, 0);
-      acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[0][t], 0, 0, 0);
-      acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[0][t], 0, 0, 0);
-      acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[0][t], 0, 0, 0);
-      acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[0][t], 0, 0, 0);
-      acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[0][t], 0, 0, 0);
-    }
-    __syncthreads();        // tile kt+1 is in LDS for every wave; the buffer of tile kt may be overwritten next iteration
+  for (int t = 0; t < NT; ++t) S_READ_B(t, 0)
+  {
+    u32x4 (&P0)[3] = pc;
+    S_SPLIT_PAIR(0, P0) S_SPLIT_PAIR(1, P0) S_SPLIT_PAIR(2, P0) S_SPLIT_PAIR(3, P0)
   }
+  int kt = 0;
+  // HN: tile kt+1 exists (its LDS writes, fragment reads and split); HN2: tile kt+2 exists (its HBM loads)
+#define S_BODY(HN, HN2)                                                                                        \
+  {                                                                                                            \
+    const int buf = kt & 1;                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < PB; ++i) {                                                           \
+      S_MFMA(i)                                                                                                \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+      if (HN) { _Pragma("unroll") for (int u = 0; u < FPA; ++u) { const int f = i * FPA + u; if (f < NST) S_STORE_ONE(f, buf ^ 1) } } \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+    }                                                                                                          \
+    __builtin_amdgcn_s_waitcnt(0xC07F);   /* lgkmcnt(0): this wave's LDS writes have landed */                 \
+    __builtin_amdgcn_s_barrier();                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    if (HN2) S_CONV_BEGIN()                                                                                    \
+    if (HN) { _Pragma("unroll") for (int t = 0; t < NT; ++t) if (6 * t + 6 <= PB) S_READ_B(t, buf ^ 1) }      \
+    _Pragma("unroll") for (int i = PB; i < NMF; ++i) {                                                         \
+      S_MFMA(i)                                                                                                \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+      _Pragma("unroll") for (int u = 0; u < FPB; ++u) {                                                        \
+        const int f = (i - PB) * FPB + u;                                                                      \
+        if (f < 2) { if (HN) S_READ_A(f, buf ^ 1) }                                                            \
+        else if (f < 2 + NST) { if (HN2) S_LOAD_ONE(f - 2, kt + 2) }                                           \
+        else if (f < NUB) { if (HN) S_SPLIT_PAIR(f - 2 - NST, pn) }                                            \
+      }                                                                                                        \
+      if (HN && i % 6 == 5 && i / 6 * 6 + 6 > PB) S_READ_B(i / 6, buf ^ 1)   /* this column tile is done: refill */ \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+    }                                                                                                          \
+    if (HN2) S_CONV_END()                                                                                      \
+    if (HN) { pc[0] = pn[0]; pc[1] = pn[1]; pc[2] = pn[2]; }                                                   \
+  }
+  for (; kt + 2 < nk; ++kt) S_BODY(1, 1)
+  if (kt + 1 < nk) { S_BODY(1, 0) ++kt; }
+  S_BODY(0, 0)
+#undef S_BODY
+#undef S_MFMA
+#undef S_CONV_BEGIN
+#undef S_CONV_END
+#undef S_LOAD_ONE
+#undef S_STORE_ONE
+#undef S_SPLIT_PAIR
+#undef S_READ_A
+#undef S_READ_B
+  __syncthreads();
 #undef S_LOAD_TILE
 #undef S_STORE_TILE
   gemm_epilogue<MT, NT, WM, WN>(p, acc, lds, C, z, m0, n0, Meff);
