@@ -30,6 +30,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA (no sparsity)
 PEAK_HBM_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
 DOMINANT = 'gemm_kernel<3>'      # all Swin-T linears (N % 96 == 0): 96 % of the path's FLOPs
 # kernel tags (csrc ProfScope) -> groups of SURVEY 8d; dense groups are priced against the fp32-MFMA roof, the others
@@ -98,6 +99,10 @@ def main():
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=4, help='cpu_baseline: tiles per timed oracle batch (3 timed batches)')
+    ap.add_argument('--pipe', default='split', choices=['split', 'fp32'],
+                    help="matrix pipe of the engine: 'split' (default: exact three-way bf16 operand split, six bf16 MFMAs per fp32 product step) "
+                         "or 'fp32' (v_mfma_f32_32x32x2_f32)")
+    ap.add_argument('--no-fp32-pipe', action='store_true', help='skip the secondary measurement of the same step on the fp32 MFMA kernels')
     ap.add_argument('--no-roi-load', action='store_true', help='skip the second workload (fixed load with 40-100 px RoIs)')
     ap.add_argument('--in-flight', type=int, default=0,
                     help='also report the streaming rate with this many batches in flight (e.g. 3; off by default so that the '
@@ -127,7 +132,8 @@ def main():
     from nuhtc_amd.engine import Engine
     torch.cuda.set_device(local_rank)
     sd = weights.bench_state_dict()
-    eng = Engine(sd, device=local_rank, max_batch=args.batch, tile=(256, 256))
+    pipe = hip.PIPE_BF16_SPLIT if args.pipe == 'split' else hip.PIPE_FP32
+    eng = Engine(sd, device=local_rank, max_batch=args.batch, tile=(256, 256), matrix_pipe=pipe)
     B = args.batch
     # every rank gets its own tiles (tile index space sharded contiguously across ranks)
     tiles_np = synth.nuclei_tiles(B, 256, start=rank * B)
@@ -205,7 +211,7 @@ def main():
     # numbers above belong to.
     pipelined = None
     if args.in_flight > 1:
-        engs = [eng] + [Engine(sd, device=local_rank, max_batch=args.batch, tile=(256, 256)) for _ in range(args.in_flight - 1)]
+        engs = [eng] + [Engine(sd, device=local_rank, max_batch=args.batch, tile=(256, 256), matrix_pipe=pipe) for _ in range(args.in_flight - 1)]
         streams = [torch.cuda.Stream() for _ in engs]
 
         def run(k):
@@ -339,18 +345,62 @@ def main():
         roi_ms = sum(v['ms'] for k, v in p2.items() if k.split('|')[0] in ('roi_feat7', 'roi_classify')) / 2
         roi_load = {'workload': 'fixed load: 1064 given RoIs per tile with sides 40-100 network px, 64 detections per tile (nuhtc_infer_fixed_load)',
                     'value': k2 * B * world / d2, 'unit': 'tiles/s', 'ms_per_step': d2 / k2 * 1e3, 'steps': k2, 'roi_feat7_ms_per_step': round(roi_ms, 3)}
+    # the same step on the fp32 MFMA kernels (NUHTC_PIPE_FP32), on the record beside the default pipe: same weights, same tiles
+    fp32_pipe = None
+    if args.pipe == 'split' and not args.no_fp32_pipe and not args.fixed_load:
+        e32 = Engine(sd, device=local_rank, max_batch=args.batch, tile=(256, 256), matrix_pipe=hip.PIPE_FP32)
+        k3 = max(5, min(30, args.steps))
+        for _ in range(3):
+            e32.infer_async(tiles, mode)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(k3):
+            e32.infer_async(tiles, mode)
+        sync_all()
+        d3 = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([d3], device='cuda')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            d3 = float(t.item())
+        hip.profile_enable(True)
+        for _ in range(2):
+            e32.infer_async(tiles, mode)
+        p3 = hip.profile_read()
+        hip.profile_enable(False)
+        g3 = [v for k, v in p3.items() if k.split('|')[0] == DOMINANT]
+        a3 = sum(v['flops'] for v in g3) / (sum(v['ms'] for v in g3) * 1e-3) / 1e12
+        # do the two pipes decide alike?  detections of the last batch, slot by slot
+        same_counts = bool(torch.equal(eng.counts[:B], e32.counts[:B]))
+        nmax = int(eng.counts[:B].max())
+        dbox = float((eng.boxes[:B, :nmax] - e32.boxes[:B, :nmax]).abs().max()) if same_counts and nmax else None
+        same_labels = bool(torch.equal(eng.labels[:B, :nmax], e32.labels[:B, :nmax])) if same_counts else False
+        fp32_pipe = {'value': k3 * B * world / d3, 'unit': 'tiles/s', 'ms_per_step': d3 / k3 * 1e3, 'steps': k3,
+                     'roofline_frac_dominant_kernel': a3 / PEAK_F32_MFMA_TFLOPS, 'achieved_tflops_dominant_kernel': a3,
+                     'same_detection_counts_as_default_pipe': same_counts, 'same_labels': same_labels, 'max_abs_box_or_score_difference': dbox,
+                     'note': 'NUHTC_PIPE_FP32: every matrix product on v_mfma_f32_32x32x2_f32 (the kernels of round 1)'}
+        e32.close()
     if rank == 0:
         out = {
             'metric': 'tiles/sec (256x256) whole-node', 'value': total_tiles / dt, 'unit': 'tiles/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'settle_steps_before_warmup': settle_steps, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'dtype_note': ('fp32 operands, results and accumulation everywhere; matrix products on the bf16 matrix pipe with every fp32 operand split exactly into '
+                           'three bf16 numbers (six exact bf16 products per fp32 product, the three cross terms below 2^-26 dropped): measured error against fp64 at or '
+                           'below the fp32 MFMA chain (tests/test_hip_dense.py::test_split_bf16_pipe_is_fp32_arithmetic)') if args.pipe == 'split' else
+                          'fp32 MFMA (v_mfma_f32_32x32x2_f32) for every matrix product',
             'config': {'workload': 'htc_lite_swin PanNuke config, batch_size=16 256x256 tiles per GPU (BASELINE configs[1]), full path '
                                    'incl. proposals, cascade, masks, per-tile mask-NMS' + (' [fixed load: 1064 RoIs, 64 detections per tile]' if args.fixed_load else ''), 'batch_per_gpu': B,
                        'weights': 'seeded synthetic (weights.bench_state_dict); pannuke.pth not distributed',
                        'tiles': 'synthetic nuclei tiles (nuhtc_amd.synth), resident in HBM',
                        'mean_rois_per_tile': float(roi_counts.mean()), 'mean_dets_per_tile': float(counts.mean())},
-            'roofline': {'bound': 'mfma', 'kernel': DOMINANT + ' (Swin-T linears, fp32 v_mfma_f32_32x32x2_f32)', 'achieved': achieved,
-                         'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_note,
+            'roofline': {'bound': 'mfma', 'kernel': DOMINANT + (' (Swin-T linears: gemm_split_kernel<3,0>, 6 x v_mfma_f32_32x32x16_bf16 per 32x32x16 fp32 product)' if args.pipe == 'split'
+                                                                else ' (Swin-T linears, fp32 v_mfma_f32_32x32x2_f32)'), 'achieved': achieved,
+                         'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS,
+                         'peak_note': 'achieved = ALGORITHMIC fp32 FLOP (2 M N K) / launch time; peak = dense fp32 MFMA (the dtype of the path)',
+                         'matrix_pipe': ({'instruction': 'v_mfma_f32_32x32x16_bf16', 'executed_tflops': 6 * achieved, 'peak': PEAK_BF16_MFMA_TFLOPS, 'frac': 6 * achieved / PEAK_BF16_MFMA_TFLOPS,
+                                          'fp32_equivalent_ceiling_tflops': PEAK_BF16_MFMA_TFLOPS / 6} if args.pipe == 'split' else
+                                         {'instruction': 'v_mfma_f32_32x32x2_f32', 'executed_tflops': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'frac': achieved / PEAK_F32_MFMA_TFLOPS}),
+                         'traffic': traffic, 'traffic_source': traffic_note,
                          'pipeline_frac': pipeline_frac, 'pipeline_gflop_per_tile': step_flops / B / 1e9,
                          'algorithmic_bytes_per_launch': dom['bytes'] / dom['launches'],
                          'avg_launch_ms': dur_ms, 'launches_per_step': dom['launches'] // prof_steps,
@@ -363,6 +413,8 @@ def main():
         }
         if roi_load:
             out['real_slide_roi_load'] = roi_load
+        if fp32_pipe:
+            out['fp32_mfma_pipe'] = fp32_pipe
         if pipelined:
             out['pipelined'] = pipelined
         if args.gemm_shapes:
