@@ -562,17 +562,21 @@ __global__ __launch_bounds__(256, 3) void gemm_split_kernel(GemmParams p) {
 
   // ---- main loop, software-pipelined around the one barrier per k-tile.  The 6*NT MFMAs of tile kt (column tile after
   // column tile) are split in two groups; everything else is a "filler" placed in the gap after an MFMA:
-  //   group A (first half)  | LDS writes of tile kt+1 (registers loaded a tile ago)
+  //   group A (first half)  | LDS writes of tile kt+1 (registers loaded a whole tile ago), then at once the HBM loads of tile kt+2
+  //                         | into the registers just freed: a k-tile lasts ~1700 cycles with three workgroups per CU (a third
+  //                         | of the fp32 kernel's), so the loads need the whole tile to land (PMC: with the loads in group B,
+  //                         | 39 % of the wave cycles were spent parked at waitcnt / the barrier)
   //   lgkmcnt(0) + barrier
-  //   group B (second half) | A fragment read of tile kt+1, HBM loads of tile kt+2, the split of that A fragment into the
-  //                         | NEXT set of bf16 planes, and -- as soon as a column tile's last MFMA has issued -- the read of its
-  //                         | B fragments for tile kt+1 into the same registers (one set of B registers, refilled in a rolling way)
+  //   group B (second half) | A fragment read of tile kt+1, the split of that A fragment into the NEXT set of bf16 planes, and
+  //                         | -- as soon as a column tile's last MFMA has issued -- the read of its B fragments for tile kt+1
+  //                         | into the same registers (one set of B registers, refilled in a rolling way)
   // so no MFMA waits for LDS or for the split: its operands were produced half a tile earlier.
   constexpr int NMF = 6 * NT, PB = NMF / 2;                        // MFMAs per tile; position of the barrier
   constexpr int NST = NA + NB;                                     // staging stores (= loads) per tile
   constexpr int GB = NMF - PB;                                     // gaps of group B
-  constexpr int NUB = 2 + NST + 4;                                 // filler units of group B: 2 A reads, loads, 4 split pairs
-  constexpr int FPA = (NST + PB - 1) / PB, FPB = (NUB + GB - 1) / GB;
+  constexpr int NUA = 2 * NST;                                     // filler units of group A: LDS writes of tile kt+1, then HBM loads of tile kt+2
+  constexpr int FPA = (NUA + PB - 1) / PB;
+  constexpr int FPB = GB >= 4 ? 1 : 2, SOFF = FPB * GB - 4;        // group B: the 4 split pairs sit in its last gaps (A fragment read right after the barrier)
   v4f a_lo, a_hi;
   u32x4 bq[NT][3];
   u32x4 pc[3], pn[3];                                              // bf16 planes of the A fragment: current tile, next tile
@@ -651,30 +655,34 @@ __global__ __launch_bounds__(256, 3) void gemm_split_kernel(GemmParams p) {
 #define S_BODY(HN, HN2)                                                                                        \
   {                                                                                                            \
     const int buf = kt & 1;                                                                                    \
+    if (HN2) S_CONV_BEGIN()                                                                                    \
     _Pragma("unroll") for (int i = 0; i < PB; ++i) {                                                           \
       S_MFMA(i)                                                                                                \
       __builtin_amdgcn_sched_barrier(0);                                                                       \
-      if (HN) { _Pragma("unroll") for (int u = 0; u < FPA; ++u) { const int f = i * FPA + u; if (f < NST) S_STORE_ONE(f, buf ^ 1) } } \
+      _Pragma("unroll") for (int u = 0; u < FPA; ++u) {                                                        \
+        const int f = i * FPA + u;                                                                             \
+        if (f < NST) { if (HN) S_STORE_ONE(f, buf ^ 1) }                                                       \
+        else if (f < NUA) { if (HN2) S_LOAD_ONE(f - NST, kt + 2) }                                             \
+      }                                                                                                        \
       __builtin_amdgcn_sched_barrier(0);                                                                       \
     }                                                                                                          \
+    if (HN2) S_CONV_END()                                                                                      \
     __builtin_amdgcn_s_waitcnt(0xC07F);   /* lgkmcnt(0): this wave's LDS writes have landed */                 \
     __builtin_amdgcn_s_barrier();                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
-    if (HN2) S_CONV_BEGIN()                                                                                    \
+    if (HN) { S_READ_A(0, buf ^ 1) S_READ_A(1, buf ^ 1) }                                                      \
     if (HN) { _Pragma("unroll") for (int t = 0; t < NT; ++t) if (6 * t + 6 <= PB) S_READ_B(t, buf ^ 1) }      \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
     _Pragma("unroll") for (int i = PB; i < NMF; ++i) {                                                         \
       S_MFMA(i)                                                                                                \
       __builtin_amdgcn_sched_barrier(0);                                                                       \
       _Pragma("unroll") for (int u = 0; u < FPB; ++u) {                                                        \
-        const int f = (i - PB) * FPB + u;                                                                      \
-        if (f < 2) { if (HN) S_READ_A(f, buf ^ 1) }                                                            \
-        else if (f < 2 + NST) { if (HN2) S_LOAD_ONE(f - 2, kt + 2) }                                           \
-        else if (f < NUB) { if (HN) S_SPLIT_PAIR(f - 2 - NST, pn) }                                            \
+        const int f = (i - PB) * FPB + u - SOFF;                                                               \
+        if (f >= 0 && f < 4) { if (HN) S_SPLIT_PAIR(f, pn) }                                                   \
       }                                                                                                        \
       if (HN && i % 6 == 5 && i / 6 * 6 + 6 > PB) S_READ_B(i / 6, buf ^ 1)   /* this column tile is done: refill */ \
       __builtin_amdgcn_sched_barrier(0);                                                                       \
     }                                                                                                          \
-    if (HN2) S_CONV_END()                                                                                      \
     if (HN) { pc[0] = pn[0]; pc[1] = pn[1]; pc[2] = pn[2]; }                                                   \
   }
   for (; kt + 2 < nk; ++kt) S_BODY(1, 1)
