@@ -454,11 +454,11 @@ __device__ __forceinline__ unsigned pk_bf16_rn(float lo, float hi) {   // two fl
   return __builtin_bit_cast(unsigned, v);
 }
 
-template <int NT, int AMODE>
-__global__ __launch_bounds__(256, 3) void gemm_split_kernel(GemmParams p) {
-  constexpr int MT = 1, WM = 4, WN = 1, BK = 16;
-  constexpr int BM = 128, BN = 32 * NT;
-  constexpr int KC = BK / 4, RPP = 256 / KC, NA = BM / RPP;       // A staging: float4 slots, 64 rows per pass, 2 passes
+template <int MT, int NT, int AMODE>
+__global__ __launch_bounds__(256, (MT == 1 ? 3 : 2)) void gemm_split_kernel(GemmParams p) {
+  constexpr int WM = 4, WN = 1, BK = 16;
+  constexpr int BM = 128 * MT, BN = 32 * NT;            // a wave owns MT row tiles of 32 (rows (wave * MT + mi) * 32 ..) x NT column tiles
+  constexpr int KC = BK / 4, RPP = 256 / KC, NA = BM / RPP;       // A staging: float4 slots, 64 rows per pass, 2 * MT passes
   constexpr int LDK = BK + 4;                                      // A image [row][20 floats]
   constexpr int BP = 28;                                           // B image [col][112 bytes = 28 floats]: 2 k-groups x 3 planes x 16 B + pad
   constexpr int NCH = BN * 6, NB = (NCH + 255) / 256;              // B staging: 16-byte chunks per k-tile, passes of 256 threads
@@ -552,12 +552,14 @@ __global__ __launch_bounds__(256, 3) void gemm_split_kernel(GemmParams p) {
     _Pragma("unroll") for (int j = 0; j < NB; ++j)                                                             \
       if (64 * wave_u + 256 * j < NCH) *reinterpret_cast<u32x4*>(Bs + (buf_) * BP * BN + w_lds[j]) = rb[j];    \
   }
-  f32x16 acc[1][NT];
+  f32x16 acc[MT][NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][t][r] = 0.f;
-  const float* arow0 = As + (wave * 32 + i32) * LDK + half * 8;    // this lane's 8 consecutive k of its row
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][t][r] = 0.f;
+  const float* arow0 = As + (wave * MT * 32 + i32) * LDK + half * 8;    // this lane's 8 consecutive k of its row (row tile mi: + mi * 32 * LDK)
   const float* brow0 = Bs + i32 * BP + half * 12;                  // its k-group of column i32: 3 planes x 16 B
 
   // ---- main loop, software-pipelined around the one barrier per k-tile.  The 6*NT MFMAs of tile kt (column tile after
@@ -571,26 +573,31 @@ __global__ __launch_bounds__(256, 3) void gemm_split_kernel(GemmParams p) {
   //                         | -- as soon as a column tile's last MFMA has issued -- the read of its B fragments for tile kt+1
   //                         | into the same registers (one set of B registers, refilled in a rolling way)
   // so no MFMA waits for LDS or for the split: its operands were produced half a tile earlier.
-  constexpr int NMF = 6 * NT, PB = NMF / 2;                        // MFMAs per tile; position of the barrier
+  constexpr int NMF = 6 * NT * MT, PB = NMF / 2;                   // MFMAs per tile (column tile outer, row tile, product); position of the barrier
+  constexpr int TM = 6 * MT;                                       // MFMAs per column tile
   constexpr int NST = NA + NB;                                     // staging stores (= loads) per tile
   constexpr int GB = NMF - PB;                                     // gaps of group B
   constexpr int NUA = 2 * NST;                                     // filler units of group A: LDS writes of tile kt+1, then HBM loads of tile kt+2
   constexpr int FPA = (NUA + PB - 1) / PB;
-  constexpr int FPB = GB >= 4 ? 1 : 2, SOFF = FPB * GB - 4;        // group B: the 4 split pairs sit in its last gaps (A fragment read right after the barrier)
-  v4f a_lo, a_hi;
+  constexpr int NSP = 4 * MT;                                      // split pairs per tile
+  constexpr int FPB = GB >= NSP ? 1 : 2, SOFF = FPB * GB - NSP;    // group B: the split pairs sit in its last gaps (A fragments are read right after the barrier)
+  v4f a_lo[MT], a_hi[MT];
   u32x4 bq[NT][3];
-  u32x4 pc[3], pn[3];                                              // bf16 planes of the A fragment: current tile, next tile
+  u32x4 pc[MT][3], pn[MT][3];                                      // bf16 planes of the A fragments: current tile, next tile
 #define S_READ_B(t_, buf_)                                                                                     \
   { _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                           \
       bq[t_][pl] = *reinterpret_cast<const u32x4*>(brow0 + (buf_) * BP * BN + (t_) * 32 * BP + pl * 4); }
-#define S_READ_A(h_, buf_)                                                                                     \
-  { if ((h_) == 0) a_lo = *reinterpret_cast<const v4f*>(arow0 + (buf_) * LDK * BM);                            \
-    else a_hi = *reinterpret_cast<const v4f*>(arow0 + (buf_) * LDK * BM + 4); }
+#define S_READ_A(h_, buf_)   /* unit h_ = 2 * mi + half of the 8 floats */                                     \
+  { const int mi = (h_) >> 1;                                                                                  \
+    if (((h_) & 1) == 0) a_lo[mi] = *reinterpret_cast<const v4f*>(arow0 + (buf_) * LDK * BM + mi * 32 * LDK);  \
+    else a_hi[mi] = *reinterpret_cast<const v4f*>(arow0 + (buf_) * LDK * BM + mi * 32 * LDK + 4); }
   // split floats 2i, 2i+1 of the fragment into dword i of the three planes (round to nearest at every level, exact residuals)
-#define S_SPLIT_PAIR(i_, P_)                                                                                   \
+#define S_SPLIT_PAIR(u_, PP_)   /* unit u_ = 4 * mi + pair */                                                  \
   {                                                                                                            \
-    const float x = (i_) == 0 ? a_lo.x : (i_) == 1 ? a_lo.z : (i_) == 2 ? a_hi.x : a_hi.z;                     \
-    const float y = (i_) == 0 ? a_lo.y : (i_) == 1 ? a_lo.w : (i_) == 2 ? a_hi.y : a_hi.w;                     \
+    const int mi = (u_) >> 2, i_ = (u_) & 3;                                                                   \
+    u32x4 (&P_)[3] = PP_[mi];                                                                                  \
+    const float x = (i_) == 0 ? a_lo[mi].x : (i_) == 1 ? a_lo[mi].z : (i_) == 2 ? a_hi[mi].x : a_hi[mi].z;     \
+    const float y = (i_) == 0 ? a_lo[mi].y : (i_) == 1 ? a_lo[mi].w : (i_) == 2 ? a_hi[mi].y : a_hi[mi].w;     \
     const unsigned w1 = pk_bf16_rn(x, y);                                                                      \
     const float rx = x - __uint_as_float(w1 << 16), ry = y - __uint_as_float(w1 & 0xffff0000u);                \
     const unsigned w2 = pk_bf16_rn(rx, ry);                                                                    \
@@ -633,23 +640,22 @@ __global__ __launch_bounds__(256, 3) void gemm_split_kernel(GemmParams p) {
   }
 #define S_MFMA(i_)                                                                                             \
   {                                                                                                            \
-    const int t = (i_) / 6, e = (i_) % 6;   /* smallest terms first: a3b1, a1b3, a2b2, a2b1, a1b2, a1b1 */     \
+    const int t = (i_) / TM, mi = ((i_) / 6) % MT, e = (i_) % 6;   /* smallest terms first: a3b1, a1b3, a2b2, a2b1, a1b2, a1b1 */ \
     const int ia = e == 0 ? 2 : (e == 2 || e == 3) ? 1 : 0, ib = e == 1 ? 2 : (e == 2 || e == 4) ? 1 : 0;      \
-    acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pc[ia]), __builtin_bit_cast(bf16x8, bq[t][ib]), \
-                                                        acc[0][t], 0, 0, 0);                                   \
+    acc[mi][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pc[mi][ia]), __builtin_bit_cast(bf16x8, bq[t][ib]), \
+                                                         acc[mi][t], 0, 0, 0);                                 \
   }
   const int nk = p.K / BK;
   S_LOAD_TILE(0)
   S_STORE_TILE(0)
   __syncthreads();
   if (nk > 1) S_LOAD_TILE(1)
-  S_READ_A(0, 0) S_READ_A(1, 0)
+#pragma unroll
+  for (int h = 0; h < 2 * MT; ++h) S_READ_A(h, 0)
 #pragma unroll
   for (int t = 0; t < NT; ++t) S_READ_B(t, 0)
-  {
-    u32x4 (&P0)[3] = pc;
-    S_SPLIT_PAIR(0, P0) S_SPLIT_PAIR(1, P0) S_SPLIT_PAIR(2, P0) S_SPLIT_PAIR(3, P0)
-  }
+#pragma unroll
+  for (int u = 0; u < NSP; ++u) S_SPLIT_PAIR(u, pc)
   int kt = 0;
   // HN: tile kt+1 exists (its LDS writes, fragment reads and split); HN2: tile kt+2 exists (its HBM loads)
 #define S_BODY(HN, HN2)                                                                                        \
@@ -670,20 +676,20 @@ __global__ __launch_bounds__(256, 3) void gemm_split_kernel(GemmParams p) {
     __builtin_amdgcn_s_waitcnt(0xC07F);   /* lgkmcnt(0): this wave's LDS writes have landed */                 \
     __builtin_amdgcn_s_barrier();                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
-    if (HN) { S_READ_A(0, buf ^ 1) S_READ_A(1, buf ^ 1) }                                                      \
-    if (HN) { _Pragma("unroll") for (int t = 0; t < NT; ++t) if (6 * t + 6 <= PB) S_READ_B(t, buf ^ 1) }      \
+    if (HN) { _Pragma("unroll") for (int h = 0; h < 2 * MT; ++h) S_READ_A(h, buf ^ 1) }                        \
+    if (HN) { _Pragma("unroll") for (int t = 0; t < NT; ++t) if (TM * t + TM <= PB) S_READ_B(t, buf ^ 1) }    \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
     _Pragma("unroll") for (int i = PB; i < NMF; ++i) {                                                         \
       S_MFMA(i)                                                                                                \
       __builtin_amdgcn_sched_barrier(0);                                                                       \
       _Pragma("unroll") for (int u = 0; u < FPB; ++u) {                                                        \
         const int f = (i - PB) * FPB + u - SOFF;                                                               \
-        if (f >= 0 && f < 4) { if (HN) S_SPLIT_PAIR(f, pn) }                                                   \
+        if (f >= 0 && f < NSP) { if (HN) S_SPLIT_PAIR(f, pn) }                                                 \
       }                                                                                                        \
-      if (HN && i % 6 == 5 && i / 6 * 6 + 6 > PB) S_READ_B(i / 6, buf ^ 1)   /* this column tile is done: refill */ \
+      if (HN && i % TM == TM - 1 && i / TM * TM + TM > PB) S_READ_B(i / TM, buf ^ 1)   /* this column tile is done: refill */ \
       __builtin_amdgcn_sched_barrier(0);                                                                       \
     }                                                                                                          \
-    if (HN) { pc[0] = pn[0]; pc[1] = pn[1]; pc[2] = pn[2]; }                                                   \
+    if (HN) { _Pragma("unroll") for (int mi = 0; mi < MT; ++mi) { pc[mi][0] = pn[mi][0]; pc[mi][1] = pn[mi][1]; pc[mi][2] = pn[mi][2]; } } \
   }
   for (; kt + 2 < nk; ++kt) S_BODY(1, 1)
   if (kt + 1 < nk) { S_BODY(1, 0) ++kt; }
@@ -773,11 +779,12 @@ void gemm_unregister_split(const float* w_dev) {
   if (it != g_split.end()) { hipFree(it->second.dev); g_split.erase(it); }
 }
 
-template <int NT>
-static void launch_split(const GemmParams& q, int mtiles, hipStream_t s) {
+template <int MT, int NT>
+static void launch_split(const GemmParams& q, hipStream_t s) {
+  const int mtiles = cdiv(q.M, 128 * MT);
   dim3 grid(cdiv(mtiles, 8) * 8 * (q.N / (32 * NT)), 1, q.batch > 0 ? q.batch : 1);
-  if (q.amode == A_CONV3) hipLaunchKernelGGL((gemm_split_kernel<NT, A_CONV3>), grid, dim3(256), 0, s, q);
-  else hipLaunchKernelGGL((gemm_split_kernel<NT, A_PLAIN>), grid, dim3(256), 0, s, q);
+  if (q.amode == A_CONV3) hipLaunchKernelGGL((gemm_split_kernel<MT, NT, A_CONV3>), grid, dim3(256), 0, s, q);
+  else hipLaunchKernelGGL((gemm_split_kernel<MT, NT, A_PLAIN>), grid, dim3(256), 0, s, q);
 }
 
 int launch_gemm(const GemmParams& p, hipStream_t s) {
@@ -832,10 +839,17 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
   q.stamps = stamp_buf;
 #endif
   if (q.Wsplit) {
-    if (nt == 1) launch_split<1>(q, cdiv(p.M, 128), s);
-    else if (nt == 2) launch_split<2>(q, cdiv(p.M, 128), s);
-    else if (nt == 3) launch_split<3>(q, cdiv(p.M, 128), s);
-    else launch_split<4>(q, cdiv(p.M, 128), s);
+    // 256-row block tiles (two row tiles per wave: half the weight bytes per flop from L2) where the launch still fills the
+    // chip with them; NUHTC_SPLIT_MT=1 / 2 forces one form (dev)
+    static int force_mt = -1;
+    if (force_mt < 0) { const char* e = getenv("NUHTC_SPLIT_MT"); force_mt = e ? atoi(e) : 0; }
+    const long long blocks2 = (long long)cdiv(p.M, 256) * (p.N / (32 * nt));
+    const bool mt2 = force_mt ? force_mt == 2 : (!p.m_dev && nt == 3 && blocks2 >= 512);
+    if (mt2 && nt == 3) launch_split<2, 3>(q, s);
+    else if (nt == 1) launch_split<1, 1>(q, s);
+    else if (nt == 2) launch_split<1, 2>(q, s);
+    else if (nt == 3) launch_split<1, 3>(q, s);
+    else launch_split<1, 4>(q, s);
   } else if (nt == 1) launch_cfg<1, 1, 4, 1>(q, cdiv(p.M, 128), s);
   else if (nt == 2) launch_cfg<1, 2, 4, 1>(q, cdiv(p.M, 128), s);
   else if (nt == 3) launch_cfg<1, 3, 4, 1>(q, cdiv(p.M, 128), s);
