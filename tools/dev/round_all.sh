@@ -16,7 +16,7 @@ cp /tmp/prof/*/*kernel_stats.csv $OUT/${R}_kernel_stats.csv; head -6 $OUT/${R}_k
 P="--steps 3 --warmup 1 --no-cpu-baseline --no-roi-load --no-settle"
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/hf -- python3 $GRAFT_REPO_ROOT/bench.py $P > /dev/null 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/hw -- python3 $GRAFT_REPO_ROOT/bench.py $P > /dev/null 2>&1
-python3 $GRAFT_REPO_ROOT/tools/dev/pmc_traffic.py '/tmp/h[fw]/**/*counter_collection.csv' 'gemm_split_kernel<3, 0>' $GRAFT_REPO_ROOT/nuhtc_amd/csrc/gemm.hip > $OUT/${R}_traffic.json; cat $OUT/${R}_traffic.json
+python3 $GRAFT_REPO_ROOT/tools/dev/pmc_traffic.py '/tmp/h[fw]/**/*counter_collection.csv' 'gemm_split_kernel<[12], 3, 0>' $GRAFT_REPO_ROOT/nuhtc_amd/csrc/gemm.hip > $OUT/${R}_traffic.json; cat $OUT/${R}_traffic.json
 python3 $GRAFT_REPO_ROOT/tools/dev/pmc_hbm_all.py '/tmp/h[fw]/**/*counter_collection.csv' 24 > $OUT/${R}_hbm_per_kernel.txt; head -30 $OUT/${R}_hbm_per_kernel.txt
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d /tmp/ut -- python3 $GRAFT_REPO_ROOT/bench.py $P > /dev/null 2>&1
 python3 $GRAFT_REPO_ROOT/tools/dev/pmc_util.py '/tmp/ut/**/*counter_collection.csv' > $OUT/${R}_pmc_util.txt; head -30 $OUT/${R}_pmc_util.txt
