@@ -479,6 +479,13 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : 2)) void gemm_split_kernel(Gemm
     Meff = md < Meff ? md : Meff;
   }
   if (m0 >= Meff) return;
+#ifdef NUHTC_GEMM_STAMPS
+  unsigned long long st0 = __builtin_amdgcn_s_memtime(), st1 = 0, st2 = 0, st3 = 0, st5 = 0, st6 = 0;
+  const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#define STAMP(x_) x_
+#else
+#define STAMP(x_)
+#endif
   const float* __restrict__ A = p.A + (long long)z * p.sA;
   float* __restrict__ C = p.C + (long long)z * p.sC;
   const char* __restrict__ Wsp = reinterpret_cast<const char*>(p.Wsplit);
@@ -604,7 +611,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : 2)) void gemm_split_kernel(Gemm
     const float sx = rx - __uint_as_float(w2 << 16), sy = ry - __uint_as_float(w2 & 0xffff0000u);              \
     P_[0][(i_)] = w1; P_[1][(i_)] = w2; P_[2][(i_)] = pk_bf16_rn(sx, sy);                                      \
   }
-#define S_LOAD_ONE(f_, kt_)                                                                                    \
+#define S_LOAD_ONE(f_, kt_)                                                                                   \
   {                                                                                                            \
     if ((f_) < NA) {                                                                                           \
       const int j = (f_) < NA ? (f_) : 0;                                                                      \
@@ -657,6 +664,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : 2)) void gemm_split_kernel(Gemm
 #pragma unroll
   for (int u = 0; u < NSP; ++u) S_SPLIT_PAIR(u, pc)
   int kt = 0;
+  STAMP(__builtin_amdgcn_s_waitcnt(0xC07F); st1 = __builtin_amdgcn_s_memtime();)
   // HN: tile kt+1 exists (its LDS writes, fragment reads and split); HN2: tile kt+2 exists (its HBM loads)
 #define S_BODY(HN, HN2)                                                                                        \
   {                                                                                                            \
@@ -667,6 +675,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : 2)) void gemm_split_kernel(Gemm
       __builtin_amdgcn_sched_barrier(0);                                                                       \
       _Pragma("unroll") for (int u = 0; u < FPA; ++u) {                                                        \
         const int f = i * FPA + u;                                                                             \
+        STAMP(if (f == 0 && HN) { unsigned long long w0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0x0070); st6 += __builtin_amdgcn_s_memtime() - w0; }) \
         if (f < NST) { if (HN) S_STORE_ONE(f, buf ^ 1) }                                                       \
         else if (f < NUA) { if (HN2) S_LOAD_ONE(f - NST, kt + 2) }                                             \
       }                                                                                                        \
@@ -674,7 +683,9 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : 2)) void gemm_split_kernel(Gemm
     }                                                                                                          \
     if (HN2) S_CONV_END()                                                                                      \
     __builtin_amdgcn_s_waitcnt(0xC07F);   /* lgkmcnt(0): this wave's LDS writes have landed */                 \
+    STAMP(st5 -= __builtin_amdgcn_s_memtime();)                                                                \
     __builtin_amdgcn_s_barrier();                                                                              \
+    STAMP(st5 += __builtin_amdgcn_s_memtime();)                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
     if (HN) { _Pragma("unroll") for (int h = 0; h < 2 * MT; ++h) S_READ_A(h, buf ^ 1) }                        \
     if (HN) { _Pragma("unroll") for (int t = 0; t < NT; ++t) if (TM * t + TM <= PB) S_READ_B(t, buf ^ 1) }    \
@@ -706,7 +717,20 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : 2)) void gemm_split_kernel(Gemm
   __syncthreads();
 #undef S_LOAD_TILE
 #undef S_STORE_TILE
+  STAMP(st2 = __builtin_amdgcn_s_memtime();)
   gemm_epilogue<MT, NT, WM, WN>(p, acc, lds, C, z, m0, n0, Meff);
+#ifdef NUHTC_GEMM_STAMPS
+  st3 = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0)
+  if (lane == 0 && p.stamps) {
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    unsigned long long* o = p.stamps + ((long long)blockIdx.x * 4 + wave) * 8;
+    o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = __builtin_amdgcn_s_memtime(); o[5] = hw; o[6] = st5;
+    o[7] = __builtin_amdgcn_s_memrealtime() - rt0;   /* 100 MHz ticks of this wave's life (replaces the load-wait stamp) */
+  }
+#endif
+#undef STAMP
 }
 
 // block tile 128 x (32·NT): one 32-row strip per wave, NT accumulators (128x128 with 64x64 per wave, 256x64 and BK = 32 were
@@ -806,6 +830,33 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
       if (nt > 2 && p.N % 64 == 0) nt = 2; else nt = 1;
     }
   }
+  {
+    // the split kernel pays the operand split once per row tile and column-tile pass, so narrow column tiles cost it more than
+    // they cost the fp32 kernel: 96-column tiles are kept at any grid size (measured on every N % 96 == 0 shape of the path,
+    // tools/dev/nt_sweep.sh: stage-4 linears 93 / 63 / 153 us against 104 / 70 / 177 with 32 columns), the others narrow
+    // only below 256 workgroups (NUHTC_SPLIT_FILL, dev)
+    static int sfill = -1;
+    if (sfill < 0) { const char* e = getenv("NUHTC_SPLIT_FILL"); sfill = e ? atoi(e) : 256; }
+    bool has_split = false;
+    if (p.batch <= 1 && p.K >= 96) {
+      std::lock_guard<std::mutex> lock(g_split_mu);
+      auto it = g_split.find(p.W);
+      has_split = it != g_split.end() && it->second.N == p.N && it->second.K == p.K;
+    }
+    if (has_split) {
+      int nt0 = (p.N % 96 == 0) ? 3 : (p.N % 128 == 0) ? 4 : (p.N % 64 == 0) ? 2 : 1;
+      long long mt = cdiv(p.M, 128);
+      if (p.m_dev) mt = (mt + 1) / 2;
+      if (nt0 != 3)
+        while (nt0 > 1 && mt * (p.N / (32 * nt0)) < sfill) { if (nt0 > 2 && p.N % 64 == 0) nt0 = 2; else nt0 = 1; }
+      nt = nt0;
+    }
+  }
+  {
+    static int force_nt = -1;   // dev: NUHTC_SPLIT_NT forces the column-tile width where N allows it
+    if (force_nt < 0) { const char* e = getenv("NUHTC_SPLIT_NT"); force_nt = e ? atoi(e) : 0; }
+    if (force_nt > 0 && p.N % (32 * force_nt) == 0) nt = force_nt;
+  }
   GemmParams q = p;
   if (q.alpha == 0.f) q.alpha = 1.f;
   // a weight registered at finalize runs on the bf16 pipe with exactly split operands; products of depth < 96 stay on the fp32
@@ -837,6 +888,7 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
   static unsigned long long* stamp_buf = nullptr;
   if (!stamp_buf && hipMalloc(&stamp_buf, 8ull * 8 * 4 * 65536) != hipSuccess) return NUHTC_E_HIP;
   q.stamps = stamp_buf;
+  hipMemsetAsync(stamp_buf, 0, 8ull * 8 * 4 * 65536, s);
 #endif
   if (q.Wsplit) {
     // 256-row block tiles (two row tiles per wave: half the weight bytes per flop from L2) where the launch still fills the

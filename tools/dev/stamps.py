@@ -9,6 +9,10 @@ base = t0[ok].min()
 print('waves', ok.sum(), 'span cycles(100MHz ticks?)', (t4[ok].max() - base))
 for name, x in (('prologue', t1 - t0), ('mainloop', t2 - t1), ('epilogue', t3 - t2), ('drain', t4 - t3), ('total', t4 - t0), ('loop:barrier wait', bar), ('loop:load wait', tile0)):
     x = x[ok]; print('%-22s mean %8.0f  p10 %8.0f  p50 %8.0f  p90 %8.0f' % (name, x.mean(), np.percentile(x, 10), np.percentile(x, 50), np.percentile(x, 90)))
+import os
+if os.environ.get('STAMPS_RT'):
+    life = (t4 - t0)[ok]; rt = tile0[ok]
+    print('s_memtime ticks per 100 MHz tick: mean %.2f -> %.2f GHz' % ((life / np.maximum(rt, 1)).mean(), (life.sum() / rt.sum()) / 10))
 # per CU timeline for one CU: (se, sh?, cu) from HW_ID
 cu = (hw >> 8) & 0xF; se = (hw >> 13) & 0x7; sh = (hw >> 12) & 1; simd = (hw >> 4) & 3; wid = hw & 0xF
 xcc = (hw >> 20) & 0xF

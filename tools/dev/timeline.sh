@@ -1,6 +1,6 @@
 # dev helper: kernel timeline of the last bench step (start offset, duration, queue) from a rocprofv3 kernel trace
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline > /tmp/tl.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roi-load --no-fp32-pipe --no-settle > /tmp/tl.log 2>&1
 python3 - <<'PY'
 import csv, glob
 rows = []
