@@ -104,9 +104,10 @@ def main():
                          "or 'fp32' (v_mfma_f32_32x32x2_f32)")
     ap.add_argument('--no-fp32-pipe', action='store_true', help='skip the secondary measurement of the same step on the fp32 MFMA kernels')
     ap.add_argument('--no-roi-load', action='store_true', help='skip the second workload (fixed load with 40-100 px RoIs)')
-    ap.add_argument('--in-flight', type=int, default=0,
-                    help='also report the streaming rate with this many batches in flight (e.g. 3; off by default so that the '
-                         'rocprofv3 summary of the default command sees every kernel without co-running kernels)')
+    ap.add_argument('--in-flight', type=int, default=4,
+                    help='also report the streaming rate with this many batches in flight (`pipelined`, after the timed region; 0 or 1 = '
+                         'off: the rocprofv3 / PMC passes of tools/dev/round_all.sh switch it off so that their summaries see every '
+                         'kernel without co-running kernels)')
     ap.add_argument('--fixed-load', action='store_true',
                     help='SURVEY 8d fixed-load mode: 1064 given RoIs and exactly 64 detections per tile (nuhtc_infer_fixed_load) instead of '
                          'the free-running proposal / detection counts of the synthetic weights')
@@ -217,7 +218,7 @@ def main():
         def run(k):
             for i in range(k):
                 with torch.cuda.stream(streams[i % len(engs)]):
-                    engs[i % len(engs)].infer_async(tiles, mode)
+                    step_fn(engs[i % len(engs)])
         for st in streams:
             st.wait_stream(torch.cuda.current_stream())
         run(args.warmup * len(engs))

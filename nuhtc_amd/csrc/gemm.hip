@@ -888,7 +888,6 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
   static unsigned long long* stamp_buf = nullptr;
   if (!stamp_buf && hipMalloc(&stamp_buf, 8ull * 8 * 4 * 65536) != hipSuccess) return NUHTC_E_HIP;
   q.stamps = stamp_buf;
-  hipMemsetAsync(stamp_buf, 0, 8ull * 8 * 4 * 65536, s);
 #endif
   if (q.Wsplit) {
     // 256-row block tiles (two row tiles per wave: half the weight bytes per flop from L2) where the launch still fills the
@@ -908,8 +907,9 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
   else launch_cfg<1, 4, 4, 1>(q, cdiv(p.M, 128), s);
 #ifdef NUHTC_GEMM_STAMPS
   {
-    static int cnt = 0;   // the 5th launch of the process is dumped to /tmp/stamps.txt
-    if (++cnt == 5) {
+    static int cnt = 0, dump_at = -1;   // the 5th launch of the process (or launch NUHTC_STAMP_AT) is dumped to /tmp/stamps.txt
+    if (dump_at < 0) { const char* e = getenv("NUHTC_STAMP_AT"); dump_at = e ? atoi(e) : 5; }
+    if (++cnt == dump_at) {
       hipDeviceSynchronize();
       int nb_ = cdiv(cdiv(p.M, 128), 8) * 8 * (p.N / (32 * nt));
       if (nb_ > 65536) nb_ = 65536;

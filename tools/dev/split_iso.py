@@ -10,10 +10,11 @@ shapes = [tuple(int(v) for v in a.split('x')) for a in sys.argv[1:]]
 out = []
 for (M, N, K) in shapes or [(16384, 384, 1536), (16384, 1536, 384), (16384, 1152, 384), (65536, 768, 192), (262144, 384, 96), (262144, 96, 384), (4096, 3072, 768), (16384, 3072, 3072)]:
     A = torch.randn(M, K, device='cuda'); W = torch.randn(N, K, device='cuda') / K ** 0.5; b = torch.randn(N, device='cuda')
+    if os.environ.get('ISO_ZERO') == '1': A.zero_(); W.zero_()
     for _ in range(2): eng.op_gemm(A, W, b, 0, pipe=pipe)
     torch.cuda.synchronize()
     hip.profile_enable(True)
-    n = 6
+    n = int(os.environ.get('ISO_N', 6))
     for _ in range(n): eng.op_gemm(A, W, b, 0, pipe=pipe)
     torch.cuda.synchronize()
     p = hip.profile_read(); hip.profile_enable(False)

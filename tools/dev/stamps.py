@@ -13,6 +13,13 @@ import os
 if os.environ.get('STAMPS_RT'):
     life = (t4 - t0)[ok]; rt = tile0[ok]
     print('s_memtime ticks per 100 MHz tick: mean %.2f -> %.2f GHz' % ((life / np.maximum(rt, 1)).mean(), (life.sum() / rt.sum()) / 10))
+# per-XCD spans: every XCD has its own counter base, so cluster the start stamps
+o = np.argsort(t0[ok]); ts = t0[ok][o]; te = t4[ok][o]
+cuts = np.nonzero(np.diff(ts) > 400000)[0] + 1
+spans = []
+for a, b_ in zip(np.r_[0, cuts], np.r_[cuts, len(ts)]):
+    spans.append((te[a:b_].max() - ts[a], np.percentile(ts[a:b_] - ts[a], [50, 90, 100]).astype(int).tolist(), b_ - a))
+print('per-XCD span (ticks), start offsets p50/p90/max, waves:', spans[:8])
 # per CU timeline for one CU: (se, sh?, cu) from HW_ID
 cu = (hw >> 8) & 0xF; se = (hw >> 13) & 0x7; sh = (hw >> 12) & 1; simd = (hw >> 4) & 3; wid = hw & 0xF
 xcc = (hw >> 20) & 0xF
