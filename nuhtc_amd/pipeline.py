@@ -15,7 +15,7 @@ from .engine import Engine
 
 
 class EnginePipeline:
-    def __init__(self, state_dict, device=0, depth=3, **engine_kw):
+    def __init__(self, state_dict, device=0, depth=4, **engine_kw):
         self.engines = [Engine(state_dict, device=device, **engine_kw) for _ in range(depth)]
         self.device = self.engines[0].device
         with torch.cuda.device(self.device):

@@ -23,7 +23,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--grid', type=int, default=100, help='tiles per side (default 100 -> 10 000 tiles)')
     ap.add_argument('--batch_size', type=int, default=16)
-    ap.add_argument('--depth', type=int, default=3, help='batches in flight per GPU')
+    ap.add_argument('--depth', type=int, default=4, help='batches in flight per GPU')
     ap.add_argument('--overlap_threshold', type=float, default=0.05)
     ap.add_argument('--workers', type=int, default=16, help='host processes rendering the synthetic canvas')
     ap.add_argument('--config', default=os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'configs/nuhtc/htc_lite_swin_pannuke_infer.py'))
@@ -50,7 +50,7 @@ def main():
     model = init_detector(args.config, ck, device=f'cuda:{local_rank}', max_batch=args.batch_size)
     model.opts.update(margin=2, min_area=10, mask_nms_thr=0.05)
     dev = torch.device('cuda', local_rank)
-    wsi.infer_tiles(model, tiles[0:3 * args.batch_size], tiles.coords[:3 * args.batch_size], args.batch_size, args.depth)   # warm-up
+    wsi.infer_tiles(model, tiles[0:args.depth * args.batch_size], tiles.coords[:args.depth * args.batch_size], args.batch_size, args.depth)   # warm-up
     sync = lambda: (torch.distributed.barrier() if world > 1 else None, torch.cuda.synchronize(dev))
     sync()
     t0 = time.perf_counter()
