@@ -208,6 +208,8 @@ int nuhtc_op_nms(nuhtc_engine* e, const float* boxes, const float* scores, int n
  * "tag launches total_ms algorithmic_flops algorithmic_bytes", then resets the records. */
 int nuhtc_profile_enable(int on);
 int nuhtc_profile_read(char* buf, size_t cap);
+/* Development: set an integer switch of the launch heuristics (the NUHTC_<NAME> environment variables) at run time. */
+int nuhtc_dev_knob(const char* name, int value);
 
 #ifdef __cplusplus
 }

@@ -59,6 +59,7 @@ struct ProfScope {
   int idx_;
 };
 bool prof_enabled();
+int dev_knob(const char* name, int dflt);   // development switch NUHTC_<name> (environment, or nuhtc_dev_knob at run time)
 
 // ----------------------------------------------------------------------------- GEMM (gemm.hip)
 // C[row_map(m), n] = epilogue( sum_k A(m,k) * W[n,k] )      fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32

@@ -455,7 +455,7 @@ __device__ __forceinline__ unsigned pk_bf16_rn(float lo, float hi) {   // two fl
 }
 
 template <int MT, int NT, int AMODE>
-__global__ __launch_bounds__(256, (MT == 1 ? 3 : 2)) void gemm_split_kernel(GemmParams p) {
+__global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void gemm_split_kernel(GemmParams p) {
   constexpr int WM = 4, WN = 1, BK = 16;
   constexpr int BM = 128 * MT, BN = 32 * NT;            // a wave owns MT row tiles of 32 (rows (wave * MT + mi) * 32 ..) x NT column tiles
   constexpr int KC = BK / 4, RPP = 256 / KC, NA = BM / RPP;       // A staging: float4 slots, 64 rows per pass, 2 * MT passes
@@ -822,8 +822,7 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
     // small problems: narrower column tiles until the launch has enough workgroups for the 256 CUs (a 128x96 tile
     // grid of a few hundred blocks leaves most SIMDs with one wave or none).  Launches whose row count lives on the
     // device (RoI / detection lists) are sized by capacity; about half of it is populated at the bench load.
-    static int fill = -1;
-    if (fill < 0) { const char* e = getenv("NUHTC_GEMM_FILL"); fill = e ? atoi(e) : 500; }
+    const int fill = dev_knob("GEMM_FILL", 500);
     long long mt = cdiv(p.M, 128) * (long long)(p.batch > 0 ? p.batch : 1);
     if (p.m_dev) mt = (mt + 1) / 2;
     while (nt > 1 && mt * (p.N / (32 * nt)) < fill) {
@@ -835,8 +834,7 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
     // they cost the fp32 kernel: 96-column tiles are kept at any grid size (measured on every N % 96 == 0 shape of the path,
     // tools/dev/nt_sweep.sh: stage-4 linears 93 / 63 / 153 us against 104 / 70 / 177 with 32 columns), the others narrow
     // only below 256 workgroups (NUHTC_SPLIT_FILL, dev)
-    static int sfill = -1;
-    if (sfill < 0) { const char* e = getenv("NUHTC_SPLIT_FILL"); sfill = e ? atoi(e) : 256; }
+    const int sfill = dev_knob("SPLIT_FILL", 256);
     bool has_split = false;
     if (p.batch <= 1 && p.K >= 96) {
       std::lock_guard<std::mutex> lock(g_split_mu);
@@ -853,8 +851,7 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
     }
   }
   {
-    static int force_nt = -1;   // dev: NUHTC_SPLIT_NT forces the column-tile width where N allows it
-    if (force_nt < 0) { const char* e = getenv("NUHTC_SPLIT_NT"); force_nt = e ? atoi(e) : 0; }
+    const int force_nt = dev_knob("SPLIT_NT", 0);   // dev: forces the column-tile width where N allows it
     if (force_nt > 0 && p.N % (32 * force_nt) == 0) nt = force_nt;
   }
   GemmParams q = p;
@@ -892,8 +889,7 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
   if (q.Wsplit) {
     // 256-row block tiles (two row tiles per wave: half the weight bytes per flop from L2) where the launch still fills the
     // chip with them; NUHTC_SPLIT_MT=1 / 2 forces one form (dev)
-    static int force_mt = -1;
-    if (force_mt < 0) { const char* e = getenv("NUHTC_SPLIT_MT"); force_mt = e ? atoi(e) : 0; }
+    const int force_mt = dev_knob("SPLIT_MT", 0);
     const long long blocks2 = (long long)cdiv(p.M, 256) * (p.N / (32 * nt));
     const bool mt2 = force_mt ? force_mt == 2 : (!p.m_dev && nt == 3 && blocks2 >= 512);
     if (mt2 && nt == 3) launch_split<2, 3>(q, s);

@@ -81,3 +81,25 @@ extern "C" int nuhtc_profile_read(char* buf, size_t cap) {
   memcpy(buf, out.c_str(), out.size() + 1);
   return 0;
 }
+
+// ---- development knobs: integer switches of the tile heuristics, initialised from the environment (NUHTC_<NAME>) on first use and
+// settable at run time so that two settings can be A/B-ed inside one process (tools/dev/knob_ab.py)
+#include <cstdlib>
+#include <mutex>
+static std::map<std::string, int> g_knobs;
+static std::mutex g_knob_mu;
+int dev_knob(const char* name, int dflt) {
+  std::lock_guard<std::mutex> lock(g_knob_mu);
+  auto it = g_knobs.find(name);
+  if (it != g_knobs.end()) return it->second;
+  const char* e = getenv((std::string("NUHTC_") + name).c_str());
+  const int v = e ? atoi(e) : dflt;
+  g_knobs[name] = v;
+  return v;
+}
+extern "C" int nuhtc_dev_knob(const char* name, int value) {
+  if (!name) return NUHTC_E_INVALID;
+  std::lock_guard<std::mutex> lock(g_knob_mu);
+  g_knobs[name] = value;
+  return 0;
+}

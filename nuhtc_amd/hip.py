@@ -38,7 +38,7 @@ class Dets(ctypes.Structure):
 
 EXPORTS = ['nuhtc_default_config', 'nuhtc_create', 'nuhtc_destroy', 'nuhtc_last_error', 'nuhtc_load_weight',
            'nuhtc_finalize', 'nuhtc_infer', 'nuhtc_infer_fixed_load', 'nuhtc_check', 'nuhtc_get_buffer',
-           'nuhtc_op_gemm', 'nuhtc_op_gemm_split', 'nuhtc_op_roi_align', 'nuhtc_op_nms', 'nuhtc_profile_enable', 'nuhtc_profile_read',
+           'nuhtc_op_gemm', 'nuhtc_op_gemm_split', 'nuhtc_op_roi_align', 'nuhtc_op_nms', 'nuhtc_profile_enable', 'nuhtc_profile_read', 'nuhtc_dev_knob',
            'nuhtc_mask_contours', 'nuhtc_merge_overlap', 'nuhtc_export_kept']
 
 _lib = None
@@ -75,6 +75,7 @@ def load():
     lib.nuhtc_merge_overlap.argtypes = [ci, vp, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int64, ci, ctypes.c_double, ci, ci, ci, ci, vp, vp]
     lib.nuhtc_export_kept.argtypes = [vp, ctypes.POINTER(Dets), ci, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.nuhtc_profile_enable.argtypes = [ci]
+    lib.nuhtc_dev_knob.argtypes = [ctypes.c_char_p, ci]
     lib.nuhtc_profile_read.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
     for name in EXPORTS:
         fn = getattr(lib, name)
@@ -95,6 +96,11 @@ def default_config():
 
 def profile_enable(on=True):
     load().nuhtc_profile_enable(1 if on else 0)
+
+
+def dev_knob(name, value):
+    """Development: set a switch of the launch heuristics (NUHTC_<NAME>) at run time."""
+    load().nuhtc_dev_knob(name.encode(), int(value))
 
 
 def profile_read():
