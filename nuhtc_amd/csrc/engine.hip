@@ -415,7 +415,16 @@ int nuhtc_finalize(nuhtc_engine* e) {
       (rc = ws(e, &e->sem_feat, "sem_feat", {B, g0.H, g0.W, 64}, 0)) || (rc = ws(e, &e->x0sem, "x0sem", {B, g0.H, g0.W, 64}, 0)) || (rc = ws(e, &e->sem_pred, "sem_pred", {B, g0.H, g0.W}, 0)))
     return rc;
   if ((rc = alloc_roi_workspace(e))) return rc;
-  HIP_CHECK(e, hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+  {
+    // The side stream carries the RPN branch (and the mid-size RoI class) beside the main stream's semantic branch.  Its NMS
+    // launches are large grids of one-wave workgroups that slow a co-running main-stream kernel tenfold while they last (a 20 us
+    // kernel of the component-proposal chain takes 200 us beside nms_mask_levels_kernel).  Running the branch at the lowest
+    // stream priority (NUHTC_SIDE_PRIO=1, dev) frees the main stream but stretches the RPN chain by the same amount, and the
+    // join then waits for it: measured 11.48-11.52 against 11.41-11.46 ms per step, so the default stays equal priority.
+    int least = 0, greatest = 0;
+    HIP_CHECK(e, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIP_CHECK(e, hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, dev_knob("SIDE_PRIO", 0) ? least : 0));
+  }
   HIP_CHECK(e, hipEventCreateWithFlags(&e->ev_rpn, hipEventDisableTiming));
   HIP_CHECK(e, hipEventCreateWithFlags(&e->ev_side, hipEventDisableTiming));
   HIP_CHECK(e, hipEventCreateWithFlags(&e->ev_fpn, hipEventDisableTiming));

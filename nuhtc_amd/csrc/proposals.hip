@@ -572,36 +572,49 @@ int nms_set_attributes() {
 struct Gauss5 { float k[25]; };
 
 // semantic logits (h x w) -> bilinear x4 (align_corners=True) -> 5x5 Gaussian (reflect pad) -> > 0
+// One block = a 64 x 32 output tile: the 68 x 36 up-sampled halo is evaluated once into LDS (ten independent evaluations per
+// thread, so the four taps of all of them are in flight together), then every thread blurs a column of 8 outputs (same taps, same
+// summation order as a plain row-major 5x5 loop: the mask is a sign test, the order is part of the result).
+constexpr int CCM_TW = 64, CCM_TH = 32;
 __global__ __launch_bounds__(256) void cc_mask_kernel(const float* __restrict__ pred, unsigned char* __restrict__ m, int h, int w, int H,
                                                       int W, Gauss5 gk) {
-  __shared__ float up[20][20 + 1];
+  __shared__ float up[CCM_TH + 4][CCM_TW + 4 + 1];
   const int b = blockIdx.z;
-  const int X0 = blockIdx.x * 16, Y0 = blockIdx.y * 16;
+  const int X0 = blockIdx.x * CCM_TW, Y0 = blockIdx.y * CCM_TH;
   const float* pb = pred + (long long)b * h * w;
   const float sy = h > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
   const float sx = w > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
-  for (int e = threadIdx.x; e < 400; e += 256) {
-    int ly = e / 20, lx = e - ly * 20;
+  constexpr int NE = (CCM_TH + 4) * (CCM_TW + 4);
+#pragma unroll 2
+  for (int e = threadIdx.x; e < NE; e += 256) {
+    int ly = e / (CCM_TW + 4), lx = e - ly * (CCM_TW + 4);
     int Y = Y0 + ly - 2, X = X0 + lx - 2;
     // reflect (no edge repeat): -1 -> 1, H -> H-2
     if (Y < 0) Y = -Y; if (Y >= H) Y = 2 * H - 2 - Y;
     if (X < 0) X = -X; if (X >= W) X = 2 * W - 2 - X;
+    Y = Y < 0 ? 0 : Y; X = X < 0 ? 0 : X;                    // halo cells beyond the reflected range (partial tiles) are never used
     float fy = sy * Y, fx = sx * X;
     int y0 = (int)fy, x0 = (int)fx;
+    y0 = y0 < h - 1 ? y0 : h - 1; x0 = x0 < w - 1 ? x0 : w - 1;
     int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
     float ly1 = fy - y0, lx1 = fx - x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
     up[ly][lx] = ly0 * (lx0 * pb[y0 * w + x0] + lx1 * pb[y0 * w + x1]) + ly1 * (lx0 * pb[y1 * w + x0] + lx1 * pb[y1 * w + x1]);
   }
   __syncthreads();
-  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-  const int Y = Y0 + ty, X = X0 + tx;
-  if (Y >= H || X >= W) return;
-  float acc = 0.f;
+  const int tx = threadIdx.x & 63, ty = (threadIdx.x >> 6) * 8;
+  const int X = X0 + tx;
+  if (X >= W) return;
 #pragma unroll
-  for (int i = 0; i < 5; ++i)
+  for (int r = 0; r < 8; ++r) {
+    const int Y = Y0 + ty + r;
+    if (Y >= H) break;
+    float acc = 0.f;
 #pragma unroll
-    for (int j = 0; j < 5; ++j) acc += gk.k[i * 5 + j] * up[ty + i][tx + j];
-  m[((long long)b * H + Y) * W + X] = acc > 0.f ? 1 : 0;
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int j = 0; j < 5; ++j) acc += gk.k[i * 5 + j] * up[ty + r + i][tx + j];
+    m[((long long)b * H + Y) * W + X] = acc > 0.f ? 1 : 0;
+  }
 }
 
 // 9-tap binary min (erode) / max (dilate) along x or y; outside the image counts as 0
@@ -801,7 +814,7 @@ int launch_cc_proposals(const CcParams& p, int B, hipStream_t s) {
       for (int j = 0; j < 5; ++j) gk.k[i * 5 + j] = k1[i] * k1[j];
   }
   unsigned char *A = p.mask_a, *Bm = p.mask_b;
-  hipLaunchKernelGGL(cc_mask_kernel, dim3(cdiv(W, 16), cdiv(H, 16), B), dim3(256), 0, s, p.sem_pred, A, p.h, p.w, H, W, gk);
+  hipLaunchKernelGGL(cc_mask_kernel, dim3(cdiv(W, CCM_TW), cdiv(H, CCM_TH), B), dim3(256), 0, s, p.sem_pred, A, p.h, p.w, H, W, gk);
   // open(5x5, 2) == erode 9x9 then dilate 9x9 (zero outside), separable
   hipLaunchKernelGGL((morph9_kernel<0, 0>), dim3(nb), dim3(256), 0, s, A, Bm, H, W, total);
   hipLaunchKernelGGL((morph9_kernel<0, 1>), dim3(nb), dim3(256), 0, s, Bm, A, H, W, total);

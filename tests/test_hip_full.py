@@ -214,6 +214,38 @@ def test_full_path_vs_oracle_and_golden(hip_device, case):
     assert not msgs, '\n'.join(msgs)
 
 
+def test_fp32_mfma_pipe_end_to_end(hip_device):
+    """matrix_pipe = NUHTC_PIPE_FP32 (every matrix product on v_mfma_f32_32x32x2_f32, round 1's kernels) against the oracle with the
+    same strict gates, and against the default pipe (exact bf16 split): same instances, same classes, same masks -- both pipes are
+    fp32 arithmetic, so they may only differ where the oracle comparison tolerates it.  An unknown pipe value is refused."""
+    from nuhtc_amd import hip
+    from nuhtc_amd.engine import HipError
+    from oracle import model as O
+    g = G.load('five_b2')
+    tiles = g['tiles']
+    B, mode = len(tiles), int(g['channel_mode'])
+    e32, sd = _engine(g, matrix_pipe=hip.PIPE_FP32)
+    esp, _ = _engine(g)
+    assert esp.cfg.matrix_pipe == hip.PIPE_BF16_SPLIT
+    e32.infer_async(e32.to_device(tiles), mode)
+    esp.infer_async(esp.to_device(tiles), mode)
+    got32, gotsp = e32.results(B), esp.results(B)
+    ref, it = O.Oracle(sd)(tiles, mode, keep=True)
+    vals = P.oracle_paste_values(O, it, tiles.shape[1:3])
+    msgs = []
+    for i in range(B):
+        rep, fails = P.compare_strict(ref[i], got32[i], values=vals[i], values_side='ref')
+        print(f'tile {i} fp32 pipe vs oracle: {P.fmt(rep)}')
+        msgs += [f'tile {i} fp32 pipe vs oracle: {f}' for f in fails]
+        rep, fails = P.compare_strict(gotsp[i], got32[i], values=None)
+        print(f'tile {i} fp32 pipe vs split pipe: {P.fmt(rep)}')
+        if rep['n_ref'] != rep['n_got'] or rep['matched'] != rep['n_ref']:
+            msgs.append(f'tile {i}: pipes disagree on the instances: {P.fmt(rep)}')
+    assert not msgs, '\n'.join(msgs)
+    with pytest.raises(HipError):
+        _engine(g, matrix_pipe=7)
+
+
 def test_capacity_overflow_is_reported(hip_device):
     g = G.load('full_b1')
     eng, _ = _engine(g, max_cc_proposals=2)
