@@ -5,7 +5,9 @@
 
 One step = one nuhtc_infer call on one batch of `--batch` synthetic 256x256x3 tiles already resident in HBM
 (the full path: pre-processing, Swin-T, FPN, RPN, proposals, 3-stage cascade, detection NMS, mask head, paste,
-per-tile mask-NMS).  Workload = BASELINE.json configs[1] ("PanNuke fold1 batch_size=16 256x256 tiles, 1xMI355X")
+per-tile mask-NMS).  The K timed steps run the way the slide loop runs them: `--in-flight` (default 4) batches on the GPU at
+once, one engine + HIP stream each (nuhtc_amd.pipeline); `sequential` is the rate of the same K steps one batch at a time
+(`--in-flight 0`), the mode every per-kernel figure of the line is measured in.  Workload = BASELINE.json configs[1] ("PanNuke fold1 batch_size=16 256x256 tiles, 1xMI355X")
 with seeded synthetic weights (models/pannuke.pth is not distributed) and synthetic nuclei tiles.
 With N > 1 (launched by torch.distributed.run, one rank per GPU) tiles are sharded across ranks (weak scaling:
 every rank processes its own batches, no data-path collective); the detection records of the last step -- the layout the
@@ -105,8 +107,8 @@ def main():
     ap.add_argument('--no-fp32-pipe', action='store_true', help='skip the secondary measurement of the same step on the fp32 MFMA kernels')
     ap.add_argument('--no-roi-load', action='store_true', help='skip the second workload (fixed load with 40-100 px RoIs)')
     ap.add_argument('--in-flight', type=int, default=4,
-                    help='also report the streaming rate with this many batches in flight (`pipelined`, after the timed region; 0 or 1 = '
-                         'off: the rocprofv3 / PMC passes of tools/dev/round_all.sh switch it off so that their summaries see every '
+                    help='batches on the GPU at once in the timed region (one engine + HIP stream each, as the slide loop runs); 0 or 1 = '
+                         'one batch at a time (the rocprofv3 / PMC passes of tools/dev/round_all.sh, so that their summaries see every '
                          'kernel without co-running kernels)')
     ap.add_argument('--fixed-load', action='store_true',
                     help='SURVEY 8d fixed-load mode: 1064 given RoIs and exactly 64 detections per tile (nuhtc_infer_fixed_load) instead of '
@@ -174,25 +176,47 @@ def main():
     print('settle phase, ms per step by group of 10:', [round(h * 1e3, 2) for h in hist], file=sys.stderr)
     from nuhtc_amd import parallel, wsi
 
-    def exchange():
-        """The exchange of the WSI path: the last step's kept detections in the record layout a slide ships (heads, ring
-        vertices, bit-packed mask crops), one all-gather (at N = 1 the packing runs too, the collective is a no-op)."""
-        eng.export_async(B)
+    def exchange(e):
+        """The exchange of the WSI path: the last step's kept detections (engine `e` ran it) in the record layout a slide ships
+        (heads, ring vertices, bit-packed mask crops), one all-gather (at N = 1 the packing runs too, the collective is a no-op)."""
+        e.export_async(B)
         torch.cuda.current_stream().synchronize()
         rec = dict(tile=[], box=[], score=[], label=[], mask=[], ring=[])
-        wsi._unpack(eng, B, 0, np.zeros((B, 2), np.int64), 256, rec, exported=True)
+        wsi._unpack(e, B, 0, np.zeros((B, 2), np.int64), 256, rec, exported=True)
         parts = wsi.pack_records(rec, tile_base=rank * B) + [torch.tensor([rank], dtype=torch.int32)]
         return parallel.gather_blobs([t.to(tiles.device) for t in parts])
 
-    for _ in range(args.warmup):
-        step_fn()
-    exchange()          # untimed: the first call allocates the pinned export buffers and loads lazily-built device code
-    eng.check()
+    # The timed region runs the K steps the way the slide loop runs them (nuhtc_amd.pipeline, tools/infer_wsi.py): `--in-flight`
+    # batches on the GPU at once, one engine + HIP stream each, consecutive steps on consecutive engines.  A dense launch is an
+    # MFMA-bound phase followed by an HBM-bound phase (DESIGN 5), and only another batch's kernels fill the idle resource.
+    # `--in-flight 0 / 1` times one batch at a time instead (the profiling passes: per-kernel durations need that); the
+    # one-batch-at-a-time rate of the same K steps is always measured right after and reported as `sequential`.
+    depth = max(1, args.in_flight)
+    engs = [eng] + [Engine(sd, device=local_rank, max_batch=args.batch, tile=(256, 256), matrix_pipe=pipe) for _ in range(depth - 1)]
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(depth - 1)]
+
+    def run(k):
+        for i in range(k):
+            with torch.cuda.stream(streams[i % depth]):
+                step_fn(engs[i % depth])
+    for st in streams[1:]:
+        st.wait_stream(torch.cuda.current_stream())
+    for e in engs[1:]:          # untimed: first-call allocations of the other engines (engine 0 went through the settle phase)
+        step_fn(e)
+    torch.cuda.synchronize()
+    run(args.warmup)
+    last = engs[(args.steps - 1) % depth]          # the engine that will run step K
+    for st in streams[1:]:
+        torch.cuda.current_stream().wait_stream(st)
+    exchange(last)      # untimed: the first call allocates the pinned export buffers and loads lazily-built device code
+    for e in engs:
+        e.check()
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step_fn()
-    gathered = exchange()                # once, inside the timed region
+    run(args.steps)
+    for st in streams[1:]:
+        torch.cuda.current_stream().wait_stream(st)
+    gathered = exchange(last)            # once, inside the timed region: the records of step K
     ranks_seen = sorted(int(g[-1][0]) for g in gathered)
     gathered_records = int(sum(g[0].shape[0] for g in gathered))
     gathered_bytes = int(sum(t.numel() * t.element_size() for g in gathered for t in g))
@@ -202,39 +226,32 @@ def main():
         t = torch.tensor([dt], device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    eng.check()
+    for e in engs:
+        e.check()
     total_tiles = args.steps * B * world
     counts = eng.counts[:B].cpu().numpy()
     roi_counts = eng.buffer('roi_counts')[:B].cpu().numpy()
 
-    # streaming rate: the same K steps with `--in-flight` batches on the GPU at once (one engine + HIP stream each, as the WSI
-    # path runs: nuhtc_amd.pipeline).  Reported beside `value`, which stays the one-batch-at-a-time rate the per-kernel
-    # numbers above belong to.
-    pipelined = None
-    if args.in_flight > 1:
-        engs = [eng] + [Engine(sd, device=local_rank, max_batch=args.batch, tile=(256, 256), matrix_pipe=pipe) for _ in range(args.in_flight - 1)]
-        streams = [torch.cuda.Stream() for _ in engs]
-
-        def run(k):
-            for i in range(k):
-                with torch.cuda.stream(streams[i % len(engs)]):
-                    step_fn(engs[i % len(engs)])
-        for st in streams:
-            st.wait_stream(torch.cuda.current_stream())
-        run(args.warmup * len(engs))
+    # the same K steps one batch at a time (what the per-kernel numbers below belong to)
+    sequential = None
+    if depth > 1:
+        for e in engs[1:]:
+            e.close()
+        engs = engs[:1]
         sync_all()
         t0 = time.perf_counter()
-        run(args.steps)
+        for _ in range(args.steps):
+            step_fn()
         sync_all()
-        dtp = time.perf_counter() - t0
+        dts = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([dtp], device='cuda')
+            t = torch.tensor([dts], device='cuda')
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dtp = float(t.item())
-        for e in engs:
-            e.check()
-        pipelined = {'in_flight': len(engs), 'value': total_tiles / dtp, 'unit': 'tiles/s', 'ms_per_step': dtp / args.steps * 1e3,
-                     'note': 'same K steps, consecutive batches overlapped on separate HIP streams (one engine each)'}
+            dts = float(t.item())
+        sequential = {'value': total_tiles / dts, 'unit': 'tiles/s', 'ms_per_step': dts / args.steps * 1e3, 'steps': args.steps,
+                      'note': 'the same K steps one batch at a time; roofline / kernel_ms_per_step / kernel_groups are measured in this mode'}
+    else:
+        dts = dt
 
     # live per-kernel timing (HIP events on the launch stream) over the same workload, separate steps so the
     # event records do not perturb the headline number
@@ -319,6 +336,7 @@ def main():
         groups['other'] = {'ms_per_step': round(sum(prof[t]['ms'] for t in other) / prof_steps, 3), 'tags': other}
     step_flops = sum(v['flops'] for v in prof.values()) / prof_steps          # FLOP the engine really executes per step
     pipeline_frac = step_flops / (dt / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS
+    pipeline_frac_seq = step_flops / (dts / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS
 
     # second workload, on the record every round: the same step at the RoI sizes of a real 40x slide (40-100 px after the x2
     # resize) instead of the synthetic weights' ~20 px boxes -- the 7x7 RoI features are the data-dependent part of the path
@@ -396,6 +414,7 @@ def main():
                                    'incl. proposals, cascade, masks, per-tile mask-NMS' + (' [fixed load: 1064 RoIs, 64 detections per tile]' if args.fixed_load else ''), 'batch_per_gpu': B,
                        'weights': 'seeded synthetic (weights.bench_state_dict); pannuke.pth not distributed',
                        'tiles': 'synthetic nuclei tiles (nuhtc_amd.synth), resident in HBM',
+                       'batches_in_flight': depth,
                        'mean_rois_per_tile': float(roi_counts.mean()), 'mean_dets_per_tile': float(counts.mean())},
             'roofline': {'bound': 'mfma', 'kernel': DOMINANT + (' (Swin-T linears: gemm_split_kernel<3,0>, 6 x v_mfma_f32_32x32x16_bf16 per 32x32x16 fp32 product)' if args.pipe == 'split'
                                                                 else ' (Swin-T linears, fp32 v_mfma_f32_32x32x2_f32)'), 'achieved': achieved,
@@ -405,7 +424,7 @@ def main():
                                           'fp32_equivalent_ceiling_tflops': PEAK_BF16_MFMA_TFLOPS / 6} if args.pipe == 'split' else
                                          {'instruction': 'v_mfma_f32_32x32x2_f32', 'executed_tflops': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'frac': achieved / PEAK_F32_MFMA_TFLOPS}),
                          'traffic': traffic, 'traffic_source': traffic_note,
-                         'pipeline_frac': pipeline_frac, 'pipeline_gflop_per_tile': step_flops / B / 1e9,
+                         'pipeline_frac': pipeline_frac, 'pipeline_frac_sequential': pipeline_frac_seq, 'pipeline_gflop_per_tile': step_flops / B / 1e9,
                          'algorithmic_bytes_per_launch': dom['bytes'] / dom['launches'],
                          'avg_launch_ms': dur_ms, 'launches_per_step': dom['launches'] // prof_steps,
                          'share_of_step_kernel_time': dom['ms'] / tot_ms},
@@ -419,8 +438,8 @@ def main():
             out['real_slide_roi_load'] = roi_load
         if fp32_pipe:
             out['fp32_mfma_pipe'] = fp32_pipe
-        if pipelined:
-            out['pipelined'] = pipelined
+        if sequential:
+            out['sequential'] = sequential
         if args.gemm_shapes:
             out['gemm_shapes'] = shapes
         if world == 1 and not args.no_cpu_baseline:
