@@ -108,7 +108,7 @@ def preprocess(tiles_u8, channel_mode=0, scale=2):
     mean = np.array(MEAN, np.float32)
     istd = (1.0 / np.array(STD, np.float64)).astype(np.float32) if False else None
     for t in np.asarray(tiles_u8):
-        r = cv2_resize_linear_u8(t, int(t.shape[1] * scale), int(t.shape[0] * scale)).astype(np.float32)
+        r = cv2_resize_linear_u8(t, int(t.shape[1] * scale + 0.5), int(t.shape[0] * scale + 0.5)).astype(np.float32)
         if channel_mode == 1:
             r = r[:, :, ::-1]
         # mmcv.imnormalize: cv2.subtract(img, mean) ; cv2.multiply(img, 1/std) with float64 scalars on f32 data
@@ -507,12 +507,17 @@ class Oracle:
         self.scale = scale
 
     @torch.no_grad()
-    def forward_tensor(self, img, ori_hw, fixed_rois=None, keep=False):
-        """img: (B,3,Hn,Wn) f32 network input. Returns list of (bbox_results, segm_results) like the reference
-        (+ dict of intermediates when keep=True)."""
+    def forward_tensor(self, img, ori_hw, fixed_rois=None, keep=False, img_hw=None):
+        """img: (B,3,Hn,Wn) f32 network input (the padded batch tensor). Returns list of (bbox_results, segm_results) like
+        the reference (+ dict of intermediates when keep=True).
+
+        img_hw = `img_meta['img_shape']`, the resized image BEFORE Pad(size_divisor=32) (default: the tensor's own size, i.e. no
+        padding): the reference clips RPN proposals (rpn_head.py:141,219), refined RoIs and detections (bbox_head.py:358,533) to
+        it and interpolates the semantic logits to it for the component proposals (htc_roi_head_cus.py:285,397), while anchors,
+        feature maps and RoI features live on the padded tensor; masks are pasted into `ori_shape` = ori_hw."""
         sd = self.sd
         B = img.shape[0]
-        img_hw = tuple(img.shape[-2:])
+        img_hw = tuple(img.shape[-2:]) if img_hw is None else tuple(int(v) for v in img_hw)
         c = backbone(sd, img)
         x = fpn(sd, c)
         rcls, rreg = rpn_convs(sd, x)
@@ -567,7 +572,9 @@ class Oracle:
 
     def __call__(self, tiles_u8, channel_mode=0, **kw):
         tiles_u8 = np.asarray(tiles_u8)
-        return self.forward_tensor(preprocess(tiles_u8, channel_mode, self.scale), tiles_u8.shape[1:3], **kw)
+        h, w = tiles_u8.shape[1:3]
+        img_hw = (int(h * self.scale + 0.5), int(w * self.scale + 0.5))       # mmcv.imrescale: new size = int(size * scale + 0.5)
+        return self.forward_tensor(preprocess(tiles_u8, channel_mode, self.scale), (h, w), img_hw=img_hw, **kw)
 
 
 # ----------------------------------------------------------------------------- a27-a28 per-tile filter + mask-NMS

@@ -171,7 +171,12 @@ def put(store, name, t):
 
 def run_case(name, tile_size, n_tiles, seed, channel_mode, five=False):
     model, cfg = mmcv_stub.build_reference_detector(CFG)
-    tiles = synth.nuclei_tiles(n_tiles, tile_size, start=100 * seed)
+    if isinstance(tile_size, tuple):      # (h, w) not multiples of 16: cut from the next larger square tile; Pad(size_divisor=32) acts
+        th, tw = tile_size
+        tiles = np.ascontiguousarray(synth.nuclei_tiles(n_tiles, -(-max(th, tw) // 32) * 32, start=100 * seed)[:, :th, :tw])
+    else:
+        th = tw = tile_size
+        tiles = synth.nuclei_tiles(n_tiles, tile_size, start=100 * seed)
     CLS_BIAS_ADD, sem_bias = calibrate(seed, tiles, channel_mode)
     sd = weights.seeded_state_dict(seed)
     sd['roi_head.semantic_head.conv_logits.bias'] = torch.tensor([float(sem_bias)])
@@ -192,7 +197,9 @@ def run_case(name, tile_size, n_tiles, seed, channel_mode, five=False):
 
     img = O.preprocess(tiles, channel_mode)
     Hn, Wn = img.shape[-2:]
-    metas = [dict(img_shape=(Hn, Wn, 3), ori_shape=(tile_size, tile_size, 3), pad_shape=(Hn, Wn, 3),
+    # Resize(scale_factor=2, keep_ratio=True) -> mmcv.imrescale: new size int(size * 2 + 0.5), scale_factor recomputed = 2 exactly;
+    # img_shape is the resized image, pad_shape the tensor after Pad(size_divisor=32) (transforms.py:207-236,570-)
+    metas = [dict(img_shape=(2 * th, 2 * tw, 3), ori_shape=(th, tw, 3), pad_shape=(Hn, Wn, 3),
                   scale_factor=np.array([2, 2, 2, 2], np.float32), flip=False, flip_direction=None)
              for _ in range(n_tiles)]
     cap = {}
@@ -264,7 +271,7 @@ def run_case(name, tile_size, n_tiles, seed, channel_mode, five=False):
         g[f'det{i}'] = np.concatenate(br, 0).astype(np.float32)
         g[f'lab{i}'] = np.concatenate([np.full(len(b), c, np.int32) for c, b in enumerate(br)])
         ms = [m for cl in sr for m in cl]
-        g[f'masks{i}'] = np.packbits(np.stack(ms).astype(np.uint8), axis=-1) if ms else np.zeros((0, tile_size, tile_size // 8), np.uint8)
+        g[f'masks{i}'] = np.packbits(np.stack(ms).astype(np.uint8), axis=-1) if ms else np.zeros((0, th, -(-tw // 8)), np.uint8)
         print(name, 'tile', i, 'rpn', len(cap['rpn_props'][i]), 'ws', len(cap['ws'][i]), 'dets', len(g[f'det{i}']),
               'classes', np.bincount(g[f'lab{i}'], minlength=5))
     os.makedirs(OUT, exist_ok=True)
@@ -280,6 +287,10 @@ CASES = [
     ('full_b1', 256, 1, 2, 0),
     # all five classes live, ~60 detections per 256x256 tile (a realistic PanNuke load), WSI channel mode, batch of 2
     ('five_b2', 256, 2, 3, 1, True),
+    # an image whose resized size is not a multiple of 32: 72 x 90 -> img_shape 144 x 180 -> pad_shape 160 x 192 (Pad acts;
+    # the reference clips boxes to img_shape, squeezes the padded semantic map into img_shape for the component proposals and
+    # pastes masks into ori_shape)
+    ('pad_b2', (72, 90), 2, 4, 0),
 ]
 
 if __name__ == '__main__':
