@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NUHTC_ABI_VERSION 3
+#define NUHTC_ABI_VERSION 4
 
 enum {
   NUHTC_OK = 0,
@@ -61,9 +61,14 @@ typedef struct nuhtc_engine nuhtc_engine;
 typedef struct nuhtc_config {
   int32_t abi_version;       /* = NUHTC_ABI_VERSION */
   int32_t num_classes;       /* 5 (PanNuke) / 4 (CoNSeP) ... ; 1..14              config:5   */
-  int32_t tile_h, tile_w;    /* input tile size in pixels (256)                              */
+  int32_t tile_h, tile_w;    /* size of the uint8 input buffers and of the output masks in pixels (256); tile_w % 32 == 0 */
+  int32_t valid_h, valid_w;  /* the image inside the buffer (top-left corner); 0 = the whole tile.  Like the reference's test
+                              * pipeline the image is resized (img_shape = scale * valid), normalised and zero-padded to the next
+                              * multiple of 32 (pad_shape, Pad(size_divisor=32), transforms.py:570-); boxes are clipped to img_shape,
+                              * the component proposals are computed at img_shape, masks are pasted into valid_h x valid_w
+                              * (ori_shape) and are zero outside it.  scale * valid must be integers. */
   int32_t max_batch;         /* workspace is sized for this many tiles per nuhtc_infer call  */
-  float   scale_factor;      /* 2.0 : MultiScaleFlipAug(scale_factor) = 80/mag (tools/infer_wsi.py:416-419); 1..8, tile*scale a multiple of 32 */
+  float   scale_factor;      /* 2.0 : MultiScaleFlipAug(scale_factor) = 80/mag (tools/infer_wsi.py:416-419); 1..8 */
   float   mean[3], std[3];   /* img_norm_cfg                                     config:8   */
   /* test_cfg.rpn                                                                config:256-261 */
   int32_t rpn_nms_pre;       /* 3000 */

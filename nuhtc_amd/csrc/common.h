@@ -119,7 +119,7 @@ int launch_export_kept(const ExportParams& p, int32_t* pos_scratch, hipStream_t 
 // ----------------------------------------------------------------------------- Swin kernels (swin.hip)
 // xtab / ytab: dev int4 per output column / row {src index 0, src index 1, weight 0, weight 1} from cv_linear_tables()
 void cv_linear_tables(int ssize, int dsize, bool horizontal, std::vector<int>& tab);
-int launch_preproc(const uint8_t* tiles, float* img, int B, int th, int tw, int Hn, int Wn, const int* xtab, const int* ytab, int swap,
+int launch_preproc(const uint8_t* tiles, float* img, int B, int th, int tw, int Hn, int Wn, int Hv, int Wv, const int* xtab, const int* ytab, int swap,
                    const float* mean_istd, hipStream_t s);
 int launch_patch_embed(const float* img, const float* w, const float* b, const float* g, const float* beta, float* tok,
                        int B, int Hn, int Wn, hipStream_t s);

@@ -29,7 +29,9 @@ struct nuhtc_engine {
   bool finalized = false;
   bool debug_tokens = false;
   int lastB = 0;
-  int Hn = 0, Wn = 0;
+  int Hn = 0, Wn = 0;     // network input = pad_shape: img_shape rounded up to a multiple of 32
+  int Hv = 0, Wv = 0;     // img_shape = scale_factor * valid image size (boxes are clipped to it)
+  int vh = 0, vw = 0;     // ori_shape = the image inside the tile buffer
   int *rs_xtab = nullptr, *rs_ytab = nullptr;   // cv2 linear-resize tables (swin.hip preproc)
 
   StageGeom st[4];

@@ -38,17 +38,19 @@ const char* nuhtc_last_error(const nuhtc_engine* e) { return e ? e->err.c_str() 
 int nuhtc_create(const nuhtc_config* cfg, int device, nuhtc_engine** out) {
   if (!cfg || !out) { g_create_error = "null argument"; return NUHTC_E_INVALID; }
   if (cfg->abi_version != NUHTC_ABI_VERSION) { g_create_error = "abi_version mismatch"; return NUHTC_E_INVALID; }
+  if (cfg->tile_h <= 0 || cfg->tile_w <= 0 || cfg->tile_w % 32) { g_create_error = "tile_h / tile_w must be positive and tile_w a multiple of 32 (bit-packed mask rows)"; return NUHTC_E_INVALID; }
+  if (cfg->valid_h < 0 || cfg->valid_w < 0 || cfg->valid_h > cfg->tile_h || cfg->valid_w > cfg->tile_w) { g_create_error = "valid_h / valid_w must lie in [0, tile] (0 = the whole tile)"; return NUHTC_E_INVALID; }
   {
-    // network input = mmcv.rescale_size: int(size*scale + 0.5); Pad(size_divisor=32) must be a no-op and the per-axis
-    // factors new/old (mmdet Resize: w_scale, h_scale) must both equal scale_factor, i.e. scale*tile is an integer
-    const double sh = (double)cfg->tile_h * cfg->scale_factor, sw = (double)cfg->tile_w * cfg->scale_factor;
-    if (!(cfg->scale_factor >= 1.0f && cfg->scale_factor <= 8.0f) || sh != floor(sh) || sw != floor(sw) || ((long long)sh % 32) || ((long long)sw % 32)) {
-      g_create_error = "scale_factor (80/mag) must be in [1,8] and give a network input (tile*scale) that is a multiple of 32";
+    // resized image = mmcv.rescale_size: int(size*scale + 0.5); the per-axis factors new/old (mmdet Resize: w_scale, h_scale) must
+    // both equal scale_factor, i.e. scale*size is an integer.  Pad(size_divisor=32) then rounds the network input up.
+    const int vh = cfg->valid_h ? cfg->valid_h : cfg->tile_h, vw = cfg->valid_w ? cfg->valid_w : cfg->tile_w;
+    const double sh = (double)vh * cfg->scale_factor, sw = (double)vw * cfg->scale_factor;
+    if (!(cfg->scale_factor >= 1.0f && cfg->scale_factor <= 8.0f) || sh != floor(sh) || sw != floor(sw)) {
+      g_create_error = "scale_factor (80/mag) must be in [1,8] and scale_factor * image size must be integers";
       return NUHTC_E_INVALID;
     }
+    if (sh < 32 || sw < 32) { g_create_error = "the resized image must be at least 32 x 32"; return NUHTC_E_INVALID; }
   }
-  if (cfg->tile_h % 16 || cfg->tile_w % 16 || cfg->tile_h <= 0 || cfg->tile_w <= 0) { g_create_error = "tile size must be a positive multiple of 16"; return NUHTC_E_INVALID; }
-  if (cfg->tile_w % 32) { g_create_error = "tile_w must be a multiple of 32 (bit-packed mask rows)"; return NUHTC_E_INVALID; }
   // class logits live in rows of 16 floats: num_classes + 2 (objectness pair) values per RoI, see bbox_tail_kernel
   if (cfg->num_classes < 1 || cfg->num_classes > 14) { g_create_error = "num_classes out of range (1..14)"; return NUHTC_E_INVALID; }
   if (cfg->max_batch < 1 || cfg->max_batch > 256) { g_create_error = "max_batch out of range"; return NUHTC_E_INVALID; }
@@ -261,13 +263,15 @@ int nuhtc_finalize(nuhtc_engine* e) {
   HIP_CHECK(e, hipSetDevice(e->device));
   const nuhtc_config& c = e->cfg;
   const int B = c.max_batch;
-  const int Hn = (int)(c.tile_h * (double)c.scale_factor + 0.5), Wn = (int)(c.tile_w * (double)c.scale_factor + 0.5);
+  e->vh = c.valid_h ? c.valid_h : c.tile_h; e->vw = c.valid_w ? c.valid_w : c.tile_w;
+  e->Hv = (int)(e->vh * (double)c.scale_factor + 0.5); e->Wv = (int)(e->vw * (double)c.scale_factor + 0.5);   // img_shape
+  const int Hn = (e->Hv + 31) / 32 * 32, Wn = (e->Wv + 31) / 32 * 32;                                            // pad_shape
   e->Hn = Hn; e->Wn = Wn;
   int rc;
   {
     std::vector<int> tx, ty;
-    cv_linear_tables(c.tile_w, Wn, true, tx);
-    cv_linear_tables(c.tile_h, Hn, false, ty);
+    cv_linear_tables(e->vw, e->Wv, true, tx);
+    cv_linear_tables(e->vh, e->Hv, false, ty);
     if ((rc = upload_i(e, &e->rs_xtab, tx)) || (rc = upload_i(e, &e->rs_ytab, ty))) return rc;
   }
   // ---- geometry
@@ -575,7 +579,7 @@ int nuhtc_infer(nuhtc_engine* e, const uint8_t* tiles, int B, int channel_mode, 
   e->lastB = B;
   float mi[6];
   for (int i = 0; i < 3; ++i) { mi[i] = e->cfg.mean[i]; mi[3 + i] = (float)(1.0 / (double)e->cfg.std[i]); }
-  RUN(launch_preproc(tiles, e->img, B, e->cfg.tile_h, e->cfg.tile_w, e->Hn, e->Wn, e->rs_xtab, e->rs_ytab, channel_mode == NUHTC_CH_SWAP, mi, s));
+  RUN(launch_preproc(tiles, e->img, B, e->cfg.tile_h, e->cfg.tile_w, e->Hn, e->Wn, e->Hv, e->Wv, e->rs_xtab, e->rs_ytab, channel_mode == NUHTC_CH_SWAP, mi, s));
   RUN(run_backbone(e, B, s));
   RUN(run_neck_heads(e, B, s));
   RUN(run_roi_path(e, B, nullptr, 0, 0, s, out));
@@ -592,7 +596,7 @@ int nuhtc_infer_fixed_load(nuhtc_engine* e, const uint8_t* tiles, int B, int cha
   e->lastB = B;
   float mi[6];
   for (int i = 0; i < 3; ++i) { mi[i] = e->cfg.mean[i]; mi[3 + i] = (float)(1.0 / (double)e->cfg.std[i]); }
-  RUN(launch_preproc(tiles, e->img, B, e->cfg.tile_h, e->cfg.tile_w, e->Hn, e->Wn, e->rs_xtab, e->rs_ytab, channel_mode == NUHTC_CH_SWAP, mi, s));
+  RUN(launch_preproc(tiles, e->img, B, e->cfg.tile_h, e->cfg.tile_w, e->Hn, e->Wn, e->Hv, e->Wv, e->rs_xtab, e->rs_ytab, channel_mode == NUHTC_CH_SWAP, mi, s));
   RUN(run_backbone(e, B, s));
   RUN(run_neck_heads(e, B, s));
   RUN(run_roi_path(e, B, rois, n_rois, n_dets, s, out));

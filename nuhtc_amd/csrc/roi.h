@@ -64,7 +64,8 @@ struct PasteParams {
   const float* prob;       // [D][28*28]
   const float* mask_rois;  // [D][5]
   const int *det_off, *det_counts;
-  int max_keep, H, W;
+  int max_keep, H, W;      // mask buffer rows / columns (W % 32 == 0)
+  int vH, vW;              // ori_shape: the canvas get_seg_masks pastes into (<= H, W); bits outside stay 0
   float scale, thr;
   unsigned* masks;         // [B][max_keep][H][W/32]
   int* areas;              // [B][max_keep]
@@ -78,6 +79,7 @@ struct TilePostParams {
   const unsigned* masks;
   unsigned char* keep;
   int max_keep, H, W, margin, min_area;
+  int vH, vW;              // image size the margin filter refers to (<= H, W)
   double thr;
 };
 

@@ -924,7 +924,7 @@ __global__ __launch_bounds__(256) void paste_kernel(PasteParams p) {
   const float x0 = box[0] / p.scale, y0 = box[1] / p.scale, x1 = box[2] / p.scale, y1 = box[3] / p.scale;
   // CPU semantics (skip_empty=True, one instance per chunk): only the integer hull of the box is sampled
   const int hx0 = max((int)floorf(x0) - 1, 0), hy0 = max((int)floorf(y0) - 1, 0);
-  const int hx1 = min((int)ceilf(x1) + 1, p.W), hy1 = min((int)ceilf(y1) + 1, p.H);
+  const int hx1 = min((int)ceilf(x1) + 1, p.vW), hy1 = min((int)ceilf(y1) + 1, p.vH);
   int area = 0;
   for (int wi = tid; wi < p.H * wpr; wi += 256) {
     const int y = wi / wpr, wx = wi - y * wpr;
@@ -995,8 +995,8 @@ __global__ __launch_bounds__(256) void tile_post_kernel(TilePostParams p) {
       int pos = 0;
       for (int i = 0; i < n; ++i) pos += (labels[i] < labels[j]) || (labels[i] == labels[j] && i < j);
       const float* d = dets + j * 5;
-      const bool ok = d[0] >= (float)p.margin && d[1] >= (float)p.margin && d[2] <= (float)(p.W - p.margin) &&
-                      d[3] <= (float)(p.H - p.margin) && areas[j] >= p.min_area;
+      const bool ok = d[0] >= (float)p.margin && d[1] >= (float)p.margin && d[2] <= (float)(p.vW - p.margin) &&
+                      d[3] <= (float)(p.vH - p.margin) && areas[j] >= p.min_area;
       // order: score desc, ties by class-major position desc (reverse of a stable ascending argsort)
       if (ok) key = ((unsigned long long)(~__float_as_uint(d[4])) << 32) | ((unsigned)(0xFFFF - pos) << 16) | (unsigned)j;
     }

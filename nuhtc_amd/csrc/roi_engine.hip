@@ -244,7 +244,7 @@ int run_roi_path(nuhtc_engine* e, int B, const float* rois_fixed, int n_rois, in
     for (int l = 0; l < 4; ++l) { lv.out[l] = e->rpn[l]; lv.h[l] = e->st[l].H; lv.w[l] = e->st[l].W; lv.stride[l] = 4 << l; }
     RpnSelParams sp;
     sp.nms_pre = c.rpn_nms_pre; sp.slot = w->rpn_slot; sp.cand_boxes = w->cand_boxes; sp.cand_scores = w->cand_scores; sp.cand_count = w->cand_count; sp.keys = w->rpn_keys; sp.key_stride = w->rpn_key_stride;
-    sp.img_h = Hn; sp.img_w = Wn; sp.min_size = c.rpn_min_bbox_size;
+    sp.img_h = e->Hv; sp.img_w = e->Wv; sp.min_size = c.rpn_min_bbox_size;      // max_shape = img_shape (rpn_head.py:141,219)
     // RPN selection + NMS depend only on the RPN maps: they run on the side stream, overlapping the semantic head /
     // connected-component kernels the caller's stream is still working through (fork at ev_rpn, join before build_rois)
     hipStream_t s2 = e->side;
@@ -262,7 +262,7 @@ int run_roi_path(nuhtc_engine* e, int B, const float* rois_fixed, int n_rois, in
     // ---- connected-component ("watershed") proposals (htc_roi_head_cus.py:283-342)
     if (c.watershed_proposal && c.max_cc_proposals > 0) {
       CcParams cp;
-      cp.sem_pred = e->sem_pred; cp.h = e->st[0].H; cp.w = e->st[0].W; cp.img_h = Hn; cp.img_w = Wn; cp.min_area = 10; cp.cap = c.max_cc_proposals;
+      cp.sem_pred = e->sem_pred; cp.h = e->st[0].H; cp.w = e->st[0].W; cp.img_h = e->Hv; cp.img_w = e->Wv; cp.min_area = 10;   /* interpolated to img_shape (htc_roi_head_cus.py:285,397) */ cp.cap = c.max_cc_proposals;
       cp.mask_a = w->cc_a; cp.mask_b = w->cc_b; cp.touch = w->cc_touch; cp.labels = w->cc_labels; cp.stats = w->cc_stats; cp.boxes = w->cc_boxes;
       cp.counts = w->cc_counts; cp.overflow = e->overflow; cp.list = w->cc_list; cp.nlist = w->cc_nlist;
       RUN(launch_cc_proposals(cp, B, s));
@@ -319,7 +319,7 @@ int run_roi_path(nuhtc_engine* e, int B, const float* rois_fixed, int n_rois, in
     tp.h = w->h2; tp.w = e->head_w[k]; tp.b = e->head_b[k]; tp.nc = c.num_classes; tp.r_dev = w->roi_total; tp.cls = w->cls[k]; tp.reg = w->reg[k];
     tp.refine = k < 2; tp.rois = w->rois;
     for (int j = 0; j < 4; ++j) tp.stds[j] = c.stage_stds[k][j];
-    tp.img_w = (float)Wn; tp.img_h = (float)Hn;
+    tp.img_w = (float)e->Wv; tp.img_h = (float)e->Hv;
     RUN(launch_bbox_tail(tp, Rcap, s));
   }
   // ---- ensemble + Seesaw activation + multiclass NMS (htc_roi_head_cus.py:2283-2303)
@@ -327,7 +327,7 @@ int run_roi_path(nuhtc_engine* e, int B, const float* rois_fixed, int n_rois, in
   dp.rois = w->rois; dp.cls0 = w->cls[0]; dp.cls1 = w->cls[1]; dp.cls2 = w->cls[2]; dp.reg2 = w->reg[2]; dp.roi_off = w->roi_off; dp.roi_cnt = w->roi_cnt;
   dp.nc = c.num_classes;
   for (int j = 0; j < 4; ++j) dp.stds[j] = c.stage_stds[2][j];
-  dp.img_w = (float)Wn; dp.img_h = (float)Hn; dp.scale = c.scale_factor; dp.score_thr = fixed ? -1.0f : c.score_thr;
+  dp.img_w = (float)e->Wv; dp.img_h = (float)e->Hv; dp.scale = c.scale_factor; dp.score_thr = fixed ? -1.0f : c.score_thr;
   dp.cand_boxes = w->dc_boxes; dp.cand_scores = w->dc_scores; dp.cand_ids = w->dc_ids; dp.cand_count = w->dc_count; dp.cap = w->det_cap;
   RUN(launch_det_candidates(dp, B, s));
   {
@@ -370,12 +370,12 @@ int run_roi_path(nuhtc_engine* e, int B, const float* rois_fixed, int n_rois, in
   RUN(launch_conv1x1_n1_dev(w->mup, e->mk_lw, e->mk_lb, w->mprob, Dcap * 784, w->det_total, 784, 1, s));
   PasteParams pp;
   pp.prob = w->mprob; pp.mask_rois = w->mask_rois; pp.det_off = w->det_off; pp.det_counts = out->counts; pp.max_keep = c.max_per_img;
-  pp.H = c.tile_h; pp.W = c.tile_w; pp.scale = c.scale_factor; pp.thr = c.mask_thr_binary; pp.masks = out->masks; pp.areas = out->areas;
+  pp.H = c.tile_h; pp.W = c.tile_w; pp.vH = e->vh; pp.vW = e->vw; pp.scale = c.scale_factor; pp.thr = c.mask_thr_binary; pp.masks = out->masks; pp.areas = out->areas;
   RUN(launch_paste(pp, B, s));
   if (out->keep && out->areas) {
     TilePostParams tp;
     tp.dets = out->boxes; tp.labels = out->labels; tp.areas = out->areas; tp.det_counts = out->counts; tp.masks = out->masks; tp.keep = out->keep;
-    tp.max_keep = c.max_per_img; tp.H = c.tile_h; tp.W = c.tile_w; tp.margin = c.margin; tp.min_area = c.min_area;
+    tp.max_keep = c.max_per_img; tp.H = c.tile_h; tp.W = c.tile_w; tp.vH = e->vh; tp.vW = e->vw; tp.margin = c.margin; tp.min_area = c.min_area;
     tp.thr = std::round((double)c.mask_nms_thr * 1e6) / 1e6;   // the reference compares against the Python double 0.05
     RUN(launch_tile_post(tp, B, s));
   }

@@ -41,7 +41,7 @@ void cv_linear_tables(int ssize, int dsize, bool horizontal, std::vector<int>& t
   }
 }
 
-__global__ void preproc_kernel(const uint8_t* __restrict__ tiles, float* __restrict__ img, int B, int th, int tw, int Hn, int Wn,
+__global__ void preproc_kernel(const uint8_t* __restrict__ tiles, float* __restrict__ img, int B, int th, int tw, int Hn, int Wn, int Hv, int Wv,
                                const int4* __restrict__ xtab, const int4* __restrict__ ytab, int swap, NormConst nc) {
   long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   long long total = (long long)B * Hn * Wn;
@@ -49,13 +49,17 @@ __global__ void preproc_kernel(const uint8_t* __restrict__ tiles, float* __restr
   int x = idx % Wn;
   int y = (idx / Wn) % Hn;
   int b = idx / ((long long)Wn * Hn);
+  float* o = img + idx * 3;
+  if (x >= Wv || y >= Hv) {   // Pad(size_divisor=32, pad_val=0) acts after Normalize: zeros right of / below the resized image
+    o[0] = 0.f; o[1] = 0.f; o[2] = 0.f;
+    return;
+  }
   const int4 tx = xtab[x], ty = ytab[y];
   const uint8_t* t = tiles + (long long)b * th * tw * 3;
   const uint8_t* p00 = t + ((long long)ty.x * tw + tx.x) * 3;
   const uint8_t* p01 = t + ((long long)ty.x * tw + tx.y) * 3;
   const uint8_t* p10 = t + ((long long)ty.y * tw + tx.x) * 3;
   const uint8_t* p11 = t + ((long long)ty.y * tw + tx.y) * 3;
-  float* o = img + idx * 3;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     int sc = swap ? 2 - c : c;
@@ -66,13 +70,13 @@ __global__ void preproc_kernel(const uint8_t* __restrict__ tiles, float* __restr
   }
 }
 
-int launch_preproc(const uint8_t* tiles, float* img, int B, int th, int tw, int Hn, int Wn, const int* xtab, const int* ytab, int swap,
+int launch_preproc(const uint8_t* tiles, float* img, int B, int th, int tw, int Hn, int Wn, int Hv, int Wv, const int* xtab, const int* ytab, int swap,
                    const float* mean_istd, hipStream_t s) {
   ProfScope ps("preproc", 0, (double)B * (3.0 * th * tw + 12.0 * Hn * Wn), s);
   NormConst nc;
   for (int i = 0; i < 3; ++i) { nc.mean[i] = mean_istd[i]; nc.istd[i] = mean_istd[3 + i]; }
   long long total = (long long)B * Hn * Wn;
-  hipLaunchKernelGGL(preproc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, tiles, img, B, th, tw, Hn, Wn,
+  hipLaunchKernelGGL(preproc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, tiles, img, B, th, tw, Hn, Wn, Hv, Wv,
                      (const int4*)xtab, (const int4*)ytab, swap, nc);
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
 }

@@ -37,7 +37,12 @@ class Engine:
         self.device = torch.device('cuda', device if isinstance(device, int) else torch.device(device).index or 0)
         cfg = hip.default_config()
         cfg.num_classes = num_classes
-        cfg.tile_h, cfg.tile_w = int(tile[0]), int(tile[1])
+        # `tile` is the image size (h, w), any size: the buffers the library sees are (h, w rounded up to a multiple of 32: bit-packed
+        # mask rows) with the image in the top-left corner; like the reference's test pipeline the library resizes the image, pads the
+        # network input to a multiple of 32 and clips boxes / pastes masks with the un-padded sizes (nuhtc_config.valid_h / valid_w)
+        self.image_hw = (int(tile[0]), int(tile[1]))
+        cfg.tile_h, cfg.tile_w = self.image_hw[0], -(-self.image_hw[1] // 32) * 32
+        cfg.valid_h, cfg.valid_w = self.image_hw
         cfg.max_batch = int(max_batch)
         for k, v in cfg_overrides.items():
             if not hasattr(cfg, k):
@@ -103,9 +108,12 @@ class Engine:
             tiles = torch.from_numpy(np.ascontiguousarray(tiles))
         if tiles.dtype != torch.uint8 or tiles.dim() != 4 or tiles.shape[-1] != 3:
             raise ValueError('tiles must be uint8 (B,H,W,3)')
-        if tuple(tiles.shape[1:3]) != (self.cfg.tile_h, self.cfg.tile_w):
-            raise ValueError(f'tile size {tuple(tiles.shape[1:3])} != engine tile size {(self.cfg.tile_h, self.cfg.tile_w)}')
-        return tiles.to(self.device, non_blocking=True).contiguous()
+        if tuple(tiles.shape[1:3]) != self.image_hw:
+            raise ValueError(f'tile size {tuple(tiles.shape[1:3])} != engine tile size {self.image_hw}')
+        tiles = tiles.to(self.device, non_blocking=True)
+        if self.cfg.tile_w != self.image_hw[1]:          # row pitch of the library's buffers: width rounded up to 32 (content ignored)
+            tiles = torch.nn.functional.pad(tiles, (0, 0, 0, self.cfg.tile_w - self.image_hw[1]))
+        return tiles.contiguous()
 
     # ------------------------------------------------------------------ hot path
     def infer_async(self, tiles_dev, channel_mode=hip.CH_AS_IS):
@@ -216,7 +224,7 @@ class Engine:
             bbox_res = [d[l == c] for c in range(nc)]
             if with_masks and n:
                 words = self.masks[b, :n].cpu().numpy().view(np.uint32)
-                bits = np.unpackbits(words.view(np.uint8).reshape(n, H, W // 8), axis=-1, bitorder='little').astype(bool)
+                bits = np.unpackbits(words.view(np.uint8).reshape(n, H, W // 8), axis=-1, bitorder='little').astype(bool)[..., :self.image_hw[1]]
                 segm_res = [[bits[j] for j in range(n) if l[j] == c] for c in range(nc)]
             else:
                 segm_res = [[] for _ in range(nc)]

@@ -18,7 +18,7 @@ PIPE_BF16_SPLIT, PIPE_FP32 = 0, 1
 class Config(ctypes.Structure):
     _fields_ = [
         ('abi_version', ctypes.c_int32), ('num_classes', ctypes.c_int32),
-        ('tile_h', ctypes.c_int32), ('tile_w', ctypes.c_int32), ('max_batch', ctypes.c_int32),
+        ('tile_h', ctypes.c_int32), ('tile_w', ctypes.c_int32), ('valid_h', ctypes.c_int32), ('valid_w', ctypes.c_int32), ('max_batch', ctypes.c_int32),
         ('scale_factor', ctypes.c_float), ('mean', ctypes.c_float * 3), ('std', ctypes.c_float * 3),
         ('rpn_nms_pre', ctypes.c_int32), ('rpn_max_per_img', ctypes.c_int32),
         ('rpn_nms_iou', ctypes.c_float), ('rpn_min_bbox_size', ctypes.c_float),

@@ -230,3 +230,85 @@ def test_mag20_scale_factor_4(hip_device):
     from nuhtc_amd.engine import HipError
     with pytest.raises(HipError):
         Engine(sd, device=0, max_batch=1, tile=(64, 64), scale_factor=2.7)
+
+
+def test_image_size_not_a_multiple_of_32(hip_device):
+    """A 72 x 90 image: the reference's test pipeline resizes it to 144 x 180 (img_shape), Pad(size_divisor=32) makes the network input
+    160 x 192 (pad_shape, zeros after normalisation), RPN proposals / refined boxes / detections are clipped to img_shape, the
+    component proposals are computed on the semantic logits interpolated to img_shape, masks are pasted into 72 x 90 (ori_shape).
+    Golden `pad_b2` is the reference's own output for this case; engine vs oracle stage by stage and engine vs oracle / golden end
+    to end with the strict gates.  Also through the public API (inference_detector on an ndarray of that size)."""
+    import torch
+    import golden_util as G
+    from nuhtc_amd.engine import Engine
+    from oracle import model as O
+    g = G.load('pad_b2')
+    sd = G.seeded_sd(g)
+    tiles = g['tiles']
+    B, (h, w) = len(tiles), tiles.shape[1:3]
+    assert (h, w) == (72, 90)
+    mode = int(g['channel_mode'])
+    eng = Engine(sd, device=0, max_batch=B, tile=(h, w))
+    assert (eng.cfg.tile_h, eng.cfg.tile_w, eng.cfg.valid_h, eng.cfg.valid_w) == (72, 96, 72, 90)
+    eng.infer_async(eng.to_device(tiles), mode)
+    got = eng.results(B)
+    msgs = []
+    # a1: resize + normalise + zero pad
+    img = eng.buffer('img')[:B].cpu().numpy()
+    ref_img = O.preprocess(tiles, mode).permute(0, 2, 3, 1).numpy()
+    assert img.shape == ref_img.shape == (B, 160, 192, 3)
+    assert np.abs(img - ref_img).max() <= 1e-6 and (img[:, 144:] == 0).all() and (img[:, :, 180:] == 0).all()
+    # dense stages on the padded tensor
+    with torch.no_grad():
+        x = O.fpn(sd, O.backbone(sd, torch.from_numpy(ref_img).permute(0, 3, 1, 2)))
+        sem_pred, sem_feat = O.semantic_head(sd, x)
+    for i in range(4):
+        err = float((eng.buffer(f'x{i}')[:B].cpu().permute(0, 3, 1, 2) - x[i]).abs().max())
+        print(f'x{i}: {err:.2e}')
+        assert err <= 2e-4, (i, err)
+    # a10-a12 / a14 from the engine's own maps: proposals live inside img_shape = 144 x 180
+    nchw = lambda t: t.cpu().permute(0, 3, 1, 2).contiguous()
+    rp = [nchw(eng.buffer(f'rpn{i}')[:B]) for i in range(4)]
+    rpn_ref = O.rpn_proposals([r[:, 0:3] for r in rp], [r[:, 3:15] for r in rp], (144, 180))
+    rpn_counts = eng.buffer('rpn_counts')[:B].cpu().numpy()
+    rpn = eng.buffer('rpn_props')[:B].cpu().numpy()
+    cc_ref = O.cc_proposals(eng.buffer('sem_pred')[:B].cpu()[:, None], (144, 180))
+    cc_counts = eng.buffer('cc_counts')[:B].cpu().numpy()
+    cc = eng.buffer('cc_props')[:B].cpu().numpy()
+    for i in range(B):
+        a, b = rpn_ref[i].numpy(), rpn[i, :rpn_counts[i]]
+        assert len(a) == len(b), (i, len(a), len(b))
+        assert b[:, 2].max() <= 180.0 and b[:, 3].max() <= 144.0 and b[:, :4].max() > 150.0
+        d = np.abs(G.canon_rows(a) - G.canon_rows(b)).max()
+        print(f'tile {i}: {len(b)} rpn proposals, max diff {d:.2e}; cc proposals oracle/hip {len(cc_ref[i])}/{cc_counts[i]}')
+        assert d <= 1e-3
+        assert np.array_equal(cc_ref[i].numpy()[:, :4], cc[i, :cc_counts[i]]), i
+    # end to end
+    ref, it = O.Oracle(sd)(tiles, mode, keep=True)
+    vals = P.oracle_paste_values(O, it, (h, w))
+    for i in range(B):
+        gd, gl = g[f'det{i}'], g[f'lab{i}']
+        gm = np.unpackbits(g[f'masks{i}'], axis=-1).astype(bool)[..., :w]
+        gold = ([gd[gl == c] for c in range(5)], [[gm[j] for j in range(len(gd)) if gl[j] == c] for c in range(5)])
+        assert all(m.shape == (h, w) for cl in got[i][1] for m in cl)
+        for tag, r, v in (('oracle', ref[i], vals[i]), ('golden', gold, None)):
+            rep, fails = P.compare_strict(r, got[i], values=v, values_side='ref')
+            print(f'pad_b2 tile {i} end-to-end vs {tag}: {P.fmt(rep)}', *rep['explained'], sep='\n    ')
+            msgs += [f'tile {i} vs {tag}: {f}' for f in fails]
+        assert sum(len(b) for b in got[i][0]) > 100
+    assert not msgs, '\n'.join(msgs)
+    # the public API on an array of that size (inference_detector pads nothing itself: the engine does what Pad does)
+    eng.close()
+    import os
+    import warnings
+    from nuhtc_amd import apis
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = apis.init_detector(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'configs/nuhtc/htc_lite_swin_pannuke_infer.py'),
+                                   None, 'cuda:0', max_batch=2)
+    model.state_dict = sd
+    bbox_res, segm_res = apis.inference_detector(model, tiles[0])
+    n = sum(len(b) for b in bbox_res)
+    assert n > 50 and all(m.shape == (h, w) and m.dtype == bool for cl in segm_res for m in cl)
+    allb = np.concatenate(bbox_res, 0)
+    assert allb[:, 2].max() <= w and allb[:, 3].max() <= h
