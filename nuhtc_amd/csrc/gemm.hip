@@ -879,7 +879,9 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
     tag = it->second.c_str();
   }
   // algorithmic work of the launch (a device-side row count is applied when the records are read)
-  ProfScope ps(tag, 2.0 * p.M * p.N * p.K * nb, 4.0 * nb * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N), s);
+  // bytes: A, W, C once each, plus the row term the epilogue adds (residual: M x N; FPN parent at half resolution: M x N / 4)
+  const double row_term = p.res ? (double)p.M * p.N : p.up ? 0.25 * p.M * p.N : 0.0;
+  ProfScope ps(tag, 2.0 * p.M * p.N * p.K * nb, 4.0 * nb * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N + row_term), s);
   ps.device_rows(p.m_dev, p.m_mul, p.M);
 #ifdef NUHTC_GEMM_STAMPS
   static unsigned long long* stamp_buf = nullptr;
