@@ -76,22 +76,60 @@ __global__ __launch_bounds__(1024) void rpn_level_kernel(RpnLevels lv, RpnSelPar
     return 1.0f / (1.0f + expf(-x));
   };
   int nsel;
+  // Keys of this (image, level) in registers: RPN_KPT per thread cover 49 152 anchors (level 0 of a 512 x 512 input); the loads of
+  // the strided logits are independent and issued together, and the four counting passes never go back to memory (one
+  // outstanding load per thread and pass was what this kernel spent its time on).  Larger levels use the scratch row.
+  constexpr int RPN_KPT = 48;
+  const bool in_regs = n <= RPN_KPT * 1024;
+  unsigned myk[RPN_KPT];
   if (n > k) {
-    // the scores sit 128 bytes apart in the head's NHWC output (3 logits of 32 channels): they are turned into sortable
-    // keys once, into a contiguous scratch row that the five passes below stream through
     unsigned* kk = p.keys + (long long)(b * 4 + L) * p.key_stride;
-    for (int idx = tid; idx < n; idx += 1024) kk[idx] = f2key(score_of(idx));
-    __syncthreads();
+    if (in_regs) {
+#pragma unroll
+      for (int j = 0; j < RPN_KPT; ++j) {
+        const int idx = tid + j * 1024;
+        myk[j] = idx < n ? f2key(score_of(idx)) : 0u;
+      }
+    } else {
+      for (int idx = tid; idx < n; idx += 1024) kk[idx] = f2key(score_of(idx));
+      __syncthreads();
+    }
     // radix select: find key T of rank k (descending) over 32-bit score keys
     unsigned prefix = 0, maskbits = 0;
     int need = k;   // still to take from the candidates matching `prefix` under `maskbits`
+    // RPN scores crowd into a few bins (most anchors score near 0): every wave first adds one count for each of its two most
+    // crowded bins, the rest is spread over the bins (the low-byte passes)
+    auto count = [&](unsigned key, bool in, int shift) {
+      const unsigned bin = (key >> shift) & 255;
+      bool mine = in;
+#pragma unroll
+      for (int round = 0; round < 2; ++round) {
+        const u64 todo = __ballot(mine);
+        if (!todo) break;
+        const int leader = __ffsll((long long)todo) - 1;
+        const unsigned b0 = __shfl(bin, leader);
+        const u64 grp = __ballot(mine && bin == b0);
+        if ((tid & 63) == leader) atomicAdd(&hist[b0], __popcll(grp));
+        mine = mine && bin != b0;
+      }
+      if (mine) atomicAdd(&hist[bin], 1);
+    };
     for (int pass = 0; pass < 4; ++pass) {
       const int shift = 24 - 8 * pass;
       for (int i = tid; i < 256; i += 1024) hist[i] = 0;
       __syncthreads();
-      for (int idx = tid; idx < n; idx += 1024) {
-        unsigned key = kk[idx];
-        if ((key & maskbits) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
+      if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < RPN_KPT; ++j) {
+          const int idx = tid + j * 1024;
+          if (j * 1024 < n) count(myk[j], idx < n && (myk[j] & maskbits) == prefix, shift);
+        }
+      } else {
+        for (int base = 0; base < n; base += 1024) {
+          const int idx = base + tid;
+          const unsigned key = idx < n ? kk[idx] : 0u;
+          count(key, idx < n && (key & maskbits) == prefix, shift);
+        }
       }
       __syncthreads();
       if (tid == 0) {
@@ -117,17 +155,26 @@ __global__ __launch_bounds__(1024) void rpn_level_kernel(RpnLevels lv, RpnSelPar
     __syncthreads();
     if ((k - need) + s_eq <= 4096) {
       // usual case: every key >= T fits the sort image; (key desc, index asc) order puts the `need` lowest-index ties
-      // first, so the list is simply cut at k after the sort
-      for (int idx = tid; idx < n; idx += 1024) {
-        const unsigned key = kk[idx];
-        if (key >= T) keys[atomicAdd(&s_cnt, 1)] = ((u64)(~key) << 32) | (unsigned)idx;
+      // first, so the list is simply cut at k after the sort.  One counter bump per wave.
+      auto emit = [&](int idx, unsigned key) {
+        const bool take = idx < n && key >= T;
+        const u64 m = __ballot(take);
+        int pos0 = 0;
+        if ((tid & 63) == 0 && m) pos0 = atomicAdd(&s_cnt, __popcll(m));
+        pos0 = __shfl(pos0, 0);
+        if (take) keys[pos0 + __popcll(m & ((1ull << (tid & 63)) - 1ull))] = ((u64)(~key) << 32) | (unsigned)idx;
+      };
+      if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < RPN_KPT; ++j)
+          if (j * 1024 < n) emit(tid + j * 1024, myk[j]);
+      } else {
+        for (int base = 0; base < n; base += 1024) emit(base + tid, base + tid < n ? kk[base + tid] : 0u);
       }
     } else {
       // a plateau of equal scores wider than the image: take exactly `need` of them by index rank (ordered block scans)
       int eq_before = 0;
-      for (int base = 0; base < n; base += 1024) {
-        int idx = base + tid;
-        unsigned key = idx < n ? kk[idx] : 0u;
+      auto emit = [&](int idx, unsigned key) {
         int is_eq = (idx < n && key == T) ? 1 : 0;
         int tot;
         int rank = block_exscan_1024(is_eq, sc16, &tot) + eq_before;
@@ -137,6 +184,13 @@ __global__ __launch_bounds__(1024) void rpn_level_kernel(RpnLevels lv, RpnSelPar
           keys[pos] = ((u64)(~key) << 32) | (unsigned)idx;
         }
         eq_before += tot;
+      };
+      if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < RPN_KPT; ++j)
+          if (j * 1024 < n) emit(tid + j * 1024, myk[j]);
+      } else {
+        for (int base = 0; base < n; base += 1024) emit(base + tid, base + tid < n ? kk[base + tid] : 0u);
       }
     }
     __syncthreads();
