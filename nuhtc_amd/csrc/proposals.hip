@@ -471,48 +471,56 @@ __global__ __launch_bounds__(1024) void nms_prepare_levels_kernel(NmsParams p) {
   }
 }
 
-__device__ __forceinline__ int seg_of_chunk(const NmsParams& p, int b, int chunk, int& start, int& cnt) {
-  for (int g = 0; g < p.n_groups; ++g) {
-    start = p.seg_start[b * p.n_groups + g];
-    cnt = p.seg_n[b * p.n_groups + g];
-    if (chunk * 64 >= start && chunk * 64 < start + ((cnt + 63) & ~63)) return g;
-  }
-  return -1;
-}
-
+// One wave per 64 x 64 tile of a group's upper triangle.  blockIdx.x enumerates only those tiles (group after group, row after
+// row): the full (cap/64)^2 grid was 374 k one-wave workgroups per launch of which 85 % returned at once, and that many
+// dispatches starved whatever ran beside it on the other stream.  Column areas are staged with the boxes; a column that no
+// row of the tile touches is skipped before the division (inter == 0 gives 0 > thr false whatever the union is).
 __global__ __launch_bounds__(64) void nms_mask_levels_kernel(NmsParams p) {
-  const int b = blockIdx.z, rb = blockIdx.y, cb = blockIdx.x;
-  if (cb < rb || cb * 64 >= p.n_total[b]) return;
-  int rs, rn, cs, cn;
-  const int gr = seg_of_chunk(p, b, rb, rs, rn);
-  if (gr < 0) return;
-  const int gc = seg_of_chunk(p, b, cb, cs, cn);
-  if (gc != gr) return;                                   // different levels never overlap
+  const int b = blockIdx.z;
+  int t = blockIdx.x, rs = 0, rn = 0, nc = 0, g = 0;
+  for (; g < p.n_groups; ++g) {
+    rs = p.seg_start[b * p.n_groups + g];
+    rn = p.seg_n[b * p.n_groups + g];
+    nc = (rn + 63) >> 6;
+    const int np = nc * (nc + 1) / 2;
+    if (t < np) break;
+    t -= np;
+  }
+  if (g == p.n_groups) return;
+  int r = 0;
+  while (t >= nc - r) { t -= nc - r; ++r; }
+  const int rb = (rs >> 6) + r, cb = rb + t;               // segments start on multiples of 64
   const int end = rs + rn;                                // one past the group's last row
   __shared__ float4 cbx[64];
+  __shared__ float car[64];
   const float4* sb = reinterpret_cast<const float4*>(p.sorted_boxes) + (long long)b * p.cap;
-  const int t = threadIdx.x;
+  const int lane = threadIdx.x;
   const int ncol = min(end - cb * 64, 64);
   if (ncol <= 0) return;
-  if (t < ncol) cbx[t] = sb[cb * 64 + t];
+  if (lane < ncol) {
+    const float4 c = sb[cb * 64 + lane];
+    cbx[lane] = c;
+    car[lane] = (c.z - c.x) * (c.w - c.y);
+  }
   __syncthreads();
-  const int row = rb * 64 + t;
-  if (row >= end) return;
-  const float4 a = sb[row];
+  const int row = rb * 64 + lane;
+  const bool live = row < end;
+  const float4 a = sb[live ? row : end - 1];
   const float sa = (a.z - a.x) * (a.w - a.y);
   u64 bits = 0;
-  const int start = (rb == cb) ? t + 1 : 0;
-  for (int j = start; j < ncol; ++j) {
+  const int start = (rb == cb) ? lane + 1 : 0;
+  for (int j = (rb == cb) ? 1 : 0; j < ncol; ++j) {
     const float4 c = cbx[j];
     float left = fmaxf(a.x, c.x), right = fminf(a.z, c.z);
     float top = fmaxf(a.y, c.y), bottom = fminf(a.w, c.w);
     float wdt = fmaxf(right - left, 0.f), hgt = fmaxf(bottom - top, 0.f);
     float inter = wdt * hgt;
-    float sb2 = (c.z - c.x) * (c.w - c.y);
-    float ovr = inter / (sa + sb2 - inter);
-    if (ovr > p.iou_thr) bits |= 1ull << j;
+    const bool mine = live && j >= start;
+    if (__ballot(mine && inter > 0.f) == 0) continue;
+    float ovr = inter / (sa + car[j] - inter);
+    if (mine && ovr > p.iou_thr) bits |= 1ull << j;
   }
-  p.mask[((long long)b * p.cap + row) * (p.cap / 64) + cb] = bits;
+  if (live) p.mask[((long long)b * p.cap + row) * (p.cap / 64) + cb] = bits;
 }
 
 // greedy reduce of one group (block = (image, group)): survivors of each 64-row chunk -> keepbits; at most max_keep per group
@@ -608,7 +616,8 @@ int launch_nms_levels(const NmsParams& p, int B, hipStream_t s) {
   while (slot_pow2 < p.slot) slot_pow2 <<= 1;
   size_t lds = (size_t)slot_pow2 * sizeof(u64);
   hipLaunchKernelGGL(nms_prepare_levels_kernel, dim3(B, p.n_groups), dim3(1024), lds, s, p);
-  hipLaunchKernelGGL(nms_mask_levels_kernel, dim3(p.cap / 64, p.cap / 64, B), dim3(64), 0, s, p);
+  const int slot_chunks = (p.slot + 63) / 64;      // a group holds at most `slot` candidates
+  hipLaunchKernelGGL(nms_mask_levels_kernel, dim3(p.n_groups * (slot_chunks * (slot_chunks + 1) / 2), 1, B), dim3(64), 0, s, p);
   hipLaunchKernelGGL(nms_reduce_levels_kernel, dim3(B, p.n_groups), dim3(256), 0, s, p);
   hipLaunchKernelGGL(nms_select_kernel, dim3(B), dim3(1024), 0, s, p);
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
