@@ -70,7 +70,9 @@ def test_split_bf16_pipe_is_fp32_arithmetic(hip_device):
     gen = torch.Generator().manual_seed(3)
     rows = []
     for wide in (False, True):
-        for (M, N, K) in [(256, 96, 96), (256, 384, 96), (256, 96, 384), (128, 192, 768), (128, 256, 3136), (256, 64, 576)]:
+        # the last shapes reach the other instantiations: 256-row block tiles (>= 512 of them), 128- and 64-column tiles at full grids
+        for (M, N, K) in [(256, 96, 96), (256, 384, 96), (256, 96, 384), (128, 192, 768), (128, 256, 3136), (256, 64, 576),
+                          (65536, 192, 96), (16384, 256, 128), (32768, 64, 192)]:
             A = torch.randn(M, K, generator=gen)
             W = torch.randn(N, K, generator=gen)
             if wide:
