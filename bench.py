@@ -26,8 +26,6 @@ import os
 import sys
 import time
 
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')   # before the first HIP call: see nuhtc_amd/__init__.py (streams of the batches in flight)
-
 import numpy as np
 import torch
 
