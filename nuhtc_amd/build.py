@@ -39,6 +39,7 @@ def build(force=False, verbose=False):
         objs.append(obj)
         cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-c', src, '-o', obj]
         cmd[4:4] = os.environ.get('NUHTC_EXTRA_CFLAGS', '').split()          # dev probes (-D...)
+        cmd[4:4] = os.environ.get('NUHTC_EXTRA_CFLAGS_' + os.path.basename(src).split('.')[0].upper(), '').split()   # ... per file
         if os.path.basename(src) in NO_CONTRACT:
             cmd.insert(4, '-ffp-contract=off')
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

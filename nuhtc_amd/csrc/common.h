@@ -60,6 +60,7 @@ struct ProfScope {
 };
 bool prof_enabled();
 int dev_knob(const char* name, int dflt);   // development switch NUHTC_<name> (environment, or nuhtc_dev_knob at run time)
+int& dev_knob_ref(const char* name, int dflt);   // the same, as a reference launch code looks up once and reads on every launch
 
 // ----------------------------------------------------------------------------- GEMM (gemm.hip)
 // C[row_map(m), n] = epilogue( sum_k A(m,k) * W[n,k] )      fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32

@@ -817,43 +817,6 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
   if (p.amode == A_CONV3 && (p.cC % 32 != 0 || p.K != 9 * p.cC)) return NUHTC_E_INVALID;
   if ((p.res && p.up) || (p.act == ACT_COS && p.bias)) return NUHTC_E_INVALID;
   if ((p.res && (long long)p.M * p.ldr >= (1ll << 31)) || (p.up && (long long)p.M * p.N >= (1ll << 31))) return NUHTC_E_INVALID;
-  int nt = (p.N % 96 == 0) ? 3 : (p.N % 128 == 0) ? 4 : (p.N % 64 == 0) ? 2 : 1;
-  {
-    // small problems: narrower column tiles until the launch has enough workgroups for the 256 CUs (a 128x96 tile
-    // grid of a few hundred blocks leaves most SIMDs with one wave or none).  Launches whose row count lives on the
-    // device (RoI / detection lists) are sized by capacity; about half of it is populated at the bench load.
-    const int fill = dev_knob("GEMM_FILL", 500);
-    long long mt = cdiv(p.M, 128) * (long long)(p.batch > 0 ? p.batch : 1);
-    if (p.m_dev) mt = (mt + 1) / 2;
-    while (nt > 1 && mt * (p.N / (32 * nt)) < fill) {
-      if (nt > 2 && p.N % 64 == 0) nt = 2; else nt = 1;
-    }
-  }
-  {
-    // the split kernel pays the operand split once per row tile and column-tile pass, so narrow column tiles cost it more than
-    // they cost the fp32 kernel: 96-column tiles are kept at any grid size (measured on every N % 96 == 0 shape of the path,
-    // tools/dev/nt_sweep.sh: stage-4 linears 93 / 63 / 153 us against 104 / 70 / 177 with 32 columns), the others narrow
-    // only below 256 workgroups (NUHTC_SPLIT_FILL, dev)
-    const int sfill = dev_knob("SPLIT_FILL", 256);
-    bool has_split = false;
-    if (p.batch <= 1 && p.K >= 96) {
-      std::lock_guard<std::mutex> lock(g_split_mu);
-      auto it = g_split.find(p.W);
-      has_split = it != g_split.end() && it->second.N == p.N && it->second.K == p.K;
-    }
-    if (has_split) {
-      int nt0 = (p.N % 96 == 0) ? 3 : (p.N % 128 == 0) ? 4 : (p.N % 64 == 0) ? 2 : 1;
-      long long mt = cdiv(p.M, 128);
-      if (p.m_dev) mt = (mt + 1) / 2;
-      if (nt0 != 3)
-        while (nt0 > 1 && mt * (p.N / (32 * nt0)) < sfill) { if (nt0 > 2 && p.N % 64 == 0) nt0 = 2; else nt0 = 1; }
-      nt = nt0;
-    }
-  }
-  {
-    const int force_nt = dev_knob("SPLIT_NT", 0);   // dev: forces the column-tile width where N allows it
-    if (force_nt > 0 && p.N % (32 * force_nt) == 0) nt = force_nt;
-  }
   GemmParams q = p;
   if (q.alpha == 0.f) q.alpha = 1.f;
   // a weight registered at finalize runs on the bf16 pipe with exactly split operands; products of depth < 96 stay on the fp32
@@ -863,6 +826,25 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
     std::lock_guard<std::mutex> lock(g_split_mu);
     auto it = g_split.find(p.W);
     if (it != g_split.end() && it->second.N == p.N && it->second.K == p.K) q.Wsplit = it->second.dev;
+  }
+  // column-tile width: the widest the shape allows, narrowed for small problems until the launch has enough workgroups for the
+  // 256 CUs (a 128x96 tile grid of a few hundred blocks leaves most SIMDs with one wave or none).  Launches whose row count lives
+  // on the device (RoI / detection lists) are sized by capacity; about half of it is populated at the bench load.
+  int nt = (p.N % 96 == 0) ? 3 : (p.N % 128 == 0) ? 4 : (p.N % 64 == 0) ? 2 : 1;
+  {
+    static const int& fill = dev_knob_ref("GEMM_FILL", 500);
+    static const int& sfill = dev_knob_ref("SPLIT_FILL", 256);
+    static const int& force_nt = dev_knob_ref("SPLIT_NT", 0);   // dev: forces the column-tile width where N allows it
+    long long mt = cdiv(p.M, 128) * (long long)(p.batch > 0 ? p.batch : 1);
+    if (p.m_dev) mt = (mt + 1) / 2;
+    // the split kernel pays the operand split once per row tile and column-tile pass, so narrow column tiles cost it more than
+    // they cost the fp32 kernel: 96-column tiles are kept at any grid size (measured on every N % 96 == 0 shape of the path,
+    // tools/dev/nt_sweep.sh: stage-4 linears 93 / 63 / 153 us against 104 / 70 / 177 with 32 columns), the others narrow only
+    // below 256 workgroups (NUHTC_SPLIT_FILL, dev)
+    const int limit = q.Wsplit ? sfill : fill;
+    if (!(q.Wsplit && nt == 3))
+      while (nt > 1 && mt * (p.N / (32 * nt)) < limit) { if (nt > 2 && p.N % 64 == 0) nt = 2; else nt = 1; }
+    if (force_nt > 0 && p.N % (32 * force_nt) == 0) nt = force_nt;
   }
   if (q.amode == A_CONV3 && !q.zeros) {
     q.zeros = zero_page();
@@ -891,7 +873,7 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
   if (q.Wsplit) {
     // 256-row block tiles (two row tiles per wave: half the weight bytes per flop from L2) where the launch still fills the
     // chip with them; NUHTC_SPLIT_MT=1 / 2 forces one form (dev)
-    const int force_mt = dev_knob("SPLIT_MT", 0);
+    static const int& force_mt = dev_knob_ref("SPLIT_MT", 0);
     const long long blocks2 = (long long)cdiv(p.M, 256) * (p.N / (32 * nt));
     const bool mt2 = force_mt ? force_mt == 2 : (!p.m_dev && nt == 3 && blocks2 >= 512);
     if (mt2 && nt == 3) launch_split<2, 3>(q, s);

@@ -86,20 +86,18 @@ extern "C" int nuhtc_profile_read(char* buf, size_t cap) {
 // settable at run time so that two settings can be A/B-ed inside one process (tools/dev/knob_ab.py)
 #include <cstdlib>
 #include <mutex>
-static std::map<std::string, int> g_knobs;
+static std::map<std::string, int> g_knobs;      // nodes never move: launch code keeps references to the values
 static std::mutex g_knob_mu;
-int dev_knob(const char* name, int dflt) {
+int& dev_knob_ref(const char* name, int dflt) {
   std::lock_guard<std::mutex> lock(g_knob_mu);
   auto it = g_knobs.find(name);
   if (it != g_knobs.end()) return it->second;
   const char* e = getenv((std::string("NUHTC_") + name).c_str());
-  const int v = e ? atoi(e) : dflt;
-  g_knobs[name] = v;
-  return v;
+  return g_knobs.emplace(name, e ? atoi(e) : dflt).first->second;
 }
+int dev_knob(const char* name, int dflt) { return dev_knob_ref(name, dflt); }
 extern "C" int nuhtc_dev_knob(const char* name, int value) {
   if (!name) return NUHTC_E_INVALID;
-  std::lock_guard<std::mutex> lock(g_knob_mu);
-  g_knobs[name] = value;
+  dev_knob_ref(name, value) = value;
   return 0;
 }
