@@ -181,8 +181,11 @@ def main():
         (heads, ring vertices, bit-packed mask crops), one all-gather (at N = 1 the packing runs too, the collective is a no-op)."""
         e.export_async(B)
         torch.cuda.current_stream().synchronize()
-        rec = dict(tile=[], box=[], score=[], label=[], mask=[], ring=[])
-        wsi._unpack(e, B, 0, np.zeros((B, 2), np.int64), 256, rec, exported=True)
+        parts = []
+        g = e.export_read()
+        if g['n']:
+            wsi._unpack_packed(e, g, 0, np.zeros((B, 2), np.int64), parts)
+        rec = wsi._records_from_parts(parts)
         parts = wsi.pack_records(rec, tile_base=rank * B) + [torch.tensor([rank], dtype=torch.int32)]
         return parallel.gather_blobs([t.to(tiles.device) for t in parts])
 

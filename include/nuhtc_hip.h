@@ -156,6 +156,16 @@ int nuhtc_export_kept(nuhtc_engine* e, const nuhtc_dets* dets, int B, const int3
                       int cap, int32_t* n_dev, int64_t* idx_dev, float* boxes_dev, int32_t* labels_dev, int32_t* cn_dev, int16_t* xy_dev,
                       uint32_t* words_dev, void* stream);
 
+/* Crops the masks nuhtc_export_kept compacted (words_dev [n][tile_h * tile_w / 32], n = min(*n_dev, cap)) to their bounding
+ * rectangles, on the device: crop_box_dev [cap][4] = x0, y0, x1, y1 in tile pixels (x1 / y1 exclusive; zeros for an empty mask),
+ * crop_area_dev [cap] = set pixels, crop_off_dev [cap + 1] = word offset of each crop in crop_words_dev (entry cap = total words the
+ * crops need: when it exceeds pool_cap the crops past the pool were not written and the caller cuts those from words_dev),
+ * crop_words_dev = rows of (w + 31) / 32 words with crop column x in bit x & 31 of word x >> 5 -- the layout nuhtc_merge_overlap
+ * takes.  Replaces the per-detection numpy slicing of the slide loop (tools/infer_wsi.py:533-566 works on such crops).
+ * Enqueues on `stream`; does not synchronise. */
+int nuhtc_export_crops(nuhtc_engine* e, const uint32_t* words_dev, const int32_t* n_dev, int cap, int32_t* crop_box_dev, int32_t* crop_area_dev,
+                       int32_t* crop_off_dev, uint32_t* crop_words_dev, int pool_cap, void* stream);
+
 /* Overlap measure of nuhtc_merge_overlap. */
 enum {
   NUHTC_OVERLAP_MASK = 0,     /* IoU of the instance masks (pixel sets) */

@@ -116,6 +116,8 @@ struct ExportParams {
   int32_t* n_out; int64_t* idx; float* boxes_out; int32_t* labels_out; int32_t* cn_out; int16_t* xy_out; uint32_t* words_out;
 };
 int launch_export_kept(const ExportParams& p, int32_t* pos_scratch, hipStream_t s);
+int launch_export_crops(const uint32_t* words, const int32_t* n_dev, int cap, int H, int wpr, int32_t* box, int32_t* area, int32_t* off, int32_t* size_scratch,
+                        uint32_t* pool, int pool_cap, hipStream_t s);
 
 // ----------------------------------------------------------------------------- Swin kernels (swin.hip)
 // xtab / ytab: dev int4 per output column / row {src index 0, src index 1, weight 0, weight 1} from cv_linear_tables()

@@ -254,3 +254,97 @@ int launch_export_kept(const ExportParams& p, int32_t* pos_scratch, hipStream_t 
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
 }
 
+
+// ---- tight crops of the exported masks ------------------------------------------------------------------------------------
+// The slide loop keeps, per kept detection, the mask cropped to its bounding rectangle (tools/infer_wsi.py:533-566 builds the
+// polygon from it, the cross-tile merge compares the crops).  Cropping 8 KB bit images one by one on the host was the slowest
+// part of the loop; here the exported masks (words_out of nuhtc_export_kept) are cropped on the device into one word pool:
+// bounds + popcount per detection (one wave each), an exclusive scan of the crop sizes, then the rows shifted so that crop
+// column 0 is bit 0 of word 0 (the layout nuhtc_merge_overlap takes).
+__global__ __launch_bounds__(256) void crop_bounds_kernel(const uint32_t* __restrict__ words, const int32_t* __restrict__ n_dev, int cap, int H, int wpr,
+                                                          int32_t* __restrict__ box, int32_t* __restrict__ area, int32_t* __restrict__ size) {
+  __shared__ unsigned colw[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int d = blockIdx.x * 4 + wave;
+  if (d >= cap) return;
+  const int n = min(*n_dev, cap);
+  if (d >= n) { if (lane == 0) { size[d] = 0; area[d] = 0; box[d * 4] = box[d * 4 + 1] = box[d * 4 + 2] = box[d * 4 + 3] = 0; } return; }
+  colw[wave][lane] = 0u;
+  const uint32_t* m = words + (long long)d * H * wpr;
+  int ymin = 1 << 30, ymax = -1, pc = 0;
+  for (int t = lane; t < H * wpr; t += 64) {
+    const unsigned w = m[t];
+    if (w) {
+      const int y = t / wpr;
+      ymin = min(ymin, y); ymax = max(ymax, y);
+      pc += __popc(w);
+      atomicOr(&colw[wave][t - y * wpr], w);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ymin = min(ymin, __shfl_xor(ymin, o)); ymax = max(ymax, __shfl_xor(ymax, o)); pc += __shfl_xor(pc, o);
+  }
+  // first / last set column: lane j looks at column word j (DS operations of a wave complete in order: the atomics above are done)
+  const unsigned cw = lane < wpr ? colw[wave][lane] : 0u;
+  int xmin = cw ? lane * 32 + __ffs((int)cw) - 1 : 1 << 30;
+  int xmax = cw ? lane * 32 + 31 - __clz((int)cw) : -1;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { xmin = min(xmin, __shfl_xor(xmin, o)); xmax = max(xmax, __shfl_xor(xmax, o)); }
+  if (lane == 0) {
+    const bool any = ymax >= 0;
+    box[d * 4 + 0] = any ? xmin : 0; box[d * 4 + 1] = any ? ymin : 0; box[d * 4 + 2] = any ? xmax + 1 : 0; box[d * 4 + 3] = any ? ymax + 1 : 0;
+    area[d] = pc;
+    size[d] = any ? (ymax + 1 - ymin) * ((xmax + 1 - xmin + 31) >> 5) : 0;
+  }
+}
+
+__global__ __launch_bounds__(1024) void crop_scan_kernel(const int32_t* __restrict__ size, int cap, int32_t* __restrict__ off) {
+  __shared__ int part[1024];
+  const int tid = threadIdx.x;
+  const int per = (cap + 1023) / 1024;
+  const int lo = tid * per, hi = min(lo + per, cap);
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += size[i];
+  part[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int t = 0; t < 1024; ++t) { const int v = part[t]; part[t] = acc; acc += v; }
+    off[cap] = acc;                       // total words the crops need
+  }
+  __syncthreads();
+  int acc = part[tid];
+  for (int i = lo; i < hi; ++i) { off[i] = acc; acc += size[i]; }
+}
+
+__global__ __launch_bounds__(256) void crop_write_kernel(const uint32_t* __restrict__ words, const int32_t* __restrict__ n_dev, int cap, int H, int wpr,
+                                                         const int32_t* __restrict__ box, const int32_t* __restrict__ off, uint32_t* __restrict__ pool, int pool_cap) {
+  const int lane = threadIdx.x & 63;
+  const int d = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (d >= min(*n_dev, cap)) return;
+  const int x0 = box[d * 4], y0 = box[d * 4 + 1], x1 = box[d * 4 + 2], y1 = box[d * 4 + 3];
+  const int cw = (x1 - x0 + 31) >> 5, h = y1 - y0;
+  const int o = off[d];
+  if (h <= 0 || o + h * cw > pool_cap) return;          // crops past the pool are the caller's to cut from the full masks
+  const uint32_t* m = words + (long long)d * H * wpr;
+  const int w0 = x0 >> 5, sh = x0 & 31;
+  for (int t = lane; t < h * cw; t += 64) {
+    const int r = t / cw, j = t - r * cw;
+    const uint32_t* row = m + (long long)(y0 + r) * wpr;
+    const unsigned lo = row[w0 + j] >> sh;
+    const unsigned hi = (sh && w0 + j + 1 < wpr) ? row[w0 + j + 1] << (32 - sh) : 0u;
+    pool[o + t] = lo | hi;
+  }
+}
+
+int launch_export_crops(const uint32_t* words, const int32_t* n_dev, int cap, int H, int wpr, int32_t* box, int32_t* area, int32_t* off, int32_t* size_scratch,
+                        uint32_t* pool, int pool_cap, hipStream_t s) {
+  if (cap <= 0) return 0;
+  if (wpr > 64) return NUHTC_E_INVALID;
+  ProfScope ps("export", 0, 0, s);
+  hipLaunchKernelGGL(crop_bounds_kernel, dim3(cdiv(cap, 4)), dim3(256), 0, s, words, n_dev, cap, H, wpr, box, area, size_scratch);
+  hipLaunchKernelGGL(crop_scan_kernel, dim3(1), dim3(1024), 0, s, size_scratch, cap, off);
+  hipLaunchKernelGGL(crop_write_kernel, dim3(cdiv(cap, 4)), dim3(256), 0, s, words, n_dev, cap, H, wpr, box, off, pool, pool_cap);
+  return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
+}

@@ -56,6 +56,7 @@ struct nuhtc_engine {
   int cand_cap = 0;         // rpn candidates per tile (<= 4 * nms_pre), det candidates per tile
   int* overflow = nullptr;  // dev int[4]
   int32_t* export_pos = nullptr;   // nuhtc_export_kept scratch [max_batch * max_per_img]
+  int32_t* crop_size = nullptr;    // nuhtc_export_crops scratch [max_batch * max_per_img]
   hipStream_t side = nullptr;       // proposal selection / NMS run here, concurrently with the semantic head on the caller's stream
   hipEvent_t ev_rpn = nullptr, ev_side = nullptr, ev_fpn = nullptr;
   struct RoiWs* rw = nullptr;

@@ -634,6 +634,24 @@ int nuhtc_export_kept(nuhtc_engine* e, const nuhtc_dets* dets, int B, const int3
   return 0;
 }
 
+int nuhtc_export_crops(nuhtc_engine* e, const uint32_t* words_dev, const int32_t* n_dev, int cap, int32_t* crop_box_dev, int32_t* crop_area_dev,
+                       int32_t* crop_off_dev, uint32_t* crop_words_dev, int pool_cap, void* stream) {
+  if (!e) return NUHTC_E_INVALID;
+  if (!words_dev || !n_dev || cap < 1 || !crop_box_dev || !crop_area_dev || !crop_off_dev || !crop_words_dev || pool_cap < 1)
+    FAIL(e, NUHTC_E_INVALID, "bad nuhtc_export_crops arguments");
+  HIP_CHECK(e, hipSetDevice(e->device));
+  const int max_cap = e->cfg.max_batch * e->cfg.max_per_img;
+  if (cap > max_cap) FAIL(e, NUHTC_E_INVALID, "nuhtc_export_crops: cap exceeds max_batch * max_per_img");
+  if (!e->crop_size) {
+    int rc = dev_alloc(e, (void**)&e->crop_size, (size_t)max_cap * sizeof(int32_t));
+    if (rc) return rc;
+  }
+  int rc = launch_export_crops(words_dev, n_dev, cap, e->cfg.tile_h, e->cfg.tile_w / 32, crop_box_dev, crop_area_dev, crop_off_dev, e->crop_size, crop_words_dev,
+                               pool_cap, (hipStream_t)stream);
+  if (rc) FAIL(e, rc, "crop export launch failed");
+  return 0;
+}
+
 int nuhtc_check(nuhtc_engine* e, void* stream) {
   if (!e) return NUHTC_E_INVALID;
   HIP_CHECK(e, hipSetDevice(e->device));

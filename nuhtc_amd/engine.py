@@ -167,22 +167,26 @@ class Engine:
             out.append(d)
         return out
 
-    def export_async(self, B, cap=None, contour_cap=256):
+    def export_async(self, B, cap=None, contour_cap=256, crop_words_per_det=128):
         """After infer_async: enqueue, on the current stream, everything the slide loop needs from the batch -- the outer
-        contours (nuhtc_mask_contours) and a gather of the kept detections, in (tile, slot) order, into fixed-capacity
-        pinned host buffers.  No host synchronisation: every device -> host copy of a result would otherwise block
-        the submitting thread behind the other batches in flight.  Read with export_read() once the stream (or an
-        event recorded after this call) has completed."""
+        contours (nuhtc_mask_contours), a gather of the kept detections, in (tile, slot) order (nuhtc_export_kept), and their
+        masks cropped to their bounding rectangles into one word pool (nuhtc_export_crops) -- into fixed-capacity pinned host
+        buffers.  No host synchronisation: every device -> host copy of a result would otherwise block the submitting thread
+        behind the other batches in flight.  Read with export_read() once the stream (or an event recorded after this call) has
+        completed.  The full 8 KB masks stay on the device (export_full_mask fetches one when a crop did not fit the pool)."""
         K, W = self.cfg.max_per_img, self.cfg.tile_h * (self.cfg.tile_w // 32)
         cap = int(cap or min(self.cfg.max_batch * K, 96 * self.cfg.max_batch))
+        pool = cap * int(crop_words_per_det)
         ex = getattr(self, '_ex', None)
-        if ex is None or ex['cap'] != cap or ex['ccap'] != contour_cap:
+        if ex is None or ex['cap'] != cap or ex['ccap'] != contour_cap or ex['pool'] != pool:
             pin = lambda *shape, dtype: torch.zeros(*shape, dtype=dtype).pin_memory()
             dev = lambda *shape, dtype: torch.zeros(*shape, dtype=dtype, device=self.device)
             names = dict(nk=((1,), torch.int32), idx=((cap,), torch.int64), boxes=((cap, 5), torch.float32), labels=((cap,), torch.int32),
-                         cn=((cap,), torch.int32), xy=((cap, contour_cap, 2), torch.int16), words=((cap, W), torch.int32))
-            ex = self._ex = dict(cap=cap, ccap=contour_cap, host={k: pin(*sh, dtype=dt) for k, (sh, dt) in names.items()},
+                         cn=((cap,), torch.int32), xy=((cap, contour_cap, 2), torch.int16), crop_box=((cap, 4), torch.int32),
+                         crop_area=((cap,), torch.int32), crop_off=((cap + 1,), torch.int32), crop_words=((pool,), torch.int32))
+            ex = self._ex = dict(cap=cap, ccap=contour_cap, pool=pool, host={k: pin(*sh, dtype=dt) for k, (sh, dt) in names.items()},
                                  dev={k: dev(*sh, dtype=dt) for k, (sh, dt) in names.items()})
+            ex['dev']['words'] = dev(cap, W, dtype=torch.int32)          # full masks of the kept detections: device only
         self.contours_async(B, contour_cap)
         d = ex['dev']
         vp = lambda t: ctypes.c_void_p(t.data_ptr())
@@ -190,6 +194,8 @@ class Engine:
         self._check(self.lib.nuhtc_export_kept(self.h, ctypes.byref(self.dets), B, vp(self.contour_n), vp(self.contour_xy), contour_cap, cap,
                                                vp(d['nk']), vp(d['idx']), vp(d['boxes']), vp(d['labels']), vp(d['cn']), vp(d['xy']), vp(d['words']),
                                                self._stream()))
+        self._check(self.lib.nuhtc_export_crops(self.h, vp(d['words']), vp(d['nk']), cap, vp(d['crop_box']), vp(d['crop_area']), vp(d['crop_off']),
+                                                vp(d['crop_words']), pool, self._stream()))
         for k, h in ex['host'].items():
             h.copy_(d[k], non_blocking=True)
         ex['B'] = B
@@ -205,8 +211,16 @@ class Engine:
             return None
         K = self.cfg.max_per_img
         idx = ex['idx'][:n].numpy()
+        off = ex['crop_off'].numpy()
         return dict(n=n, tile=idx // K, slot=idx % K, boxes=ex['boxes'][:n].numpy(), labels=ex['labels'][:n].numpy(), cn=ex['cn'][:n].numpy(),
-                    xy=ex['xy'][:n].numpy(), words=ex['words'][:n].numpy().view(np.uint32))
+                    xy=ex['xy'][:n].numpy(), crop_box=ex['crop_box'][:n].numpy(), crop_area=ex['crop_area'][:n].numpy(), crop_off=off[:n],
+                    crop_words=ex['crop_words'].numpy().view(np.uint32), crop_total=int(off[self._ex['cap']]), pool=self._ex['pool'])
+
+    def export_full_mask(self, k):
+        """(tile_h, tile_w) bool mask of exported detection k of the last export_async (synchronous device read: the rare crop that
+        did not fit the pool, or a contour the device could not trace)."""
+        words = self._ex['dev']['words'][k].cpu().numpy().view(np.uint32)
+        return np.unpackbits(words.view(np.uint8).reshape(self.cfg.tile_h, self.cfg.tile_w // 8), axis=-1, bitorder='little').astype(bool)
 
     def results(self, B, with_masks=True):
         """Device outputs of the last infer -> list of (bbox_results, segm_results) exactly like the reference

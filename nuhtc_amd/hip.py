@@ -38,7 +38,7 @@ class Dets(ctypes.Structure):
 
 EXPORTS = ['nuhtc_default_config', 'nuhtc_create', 'nuhtc_destroy', 'nuhtc_last_error', 'nuhtc_load_weight',
            'nuhtc_finalize', 'nuhtc_infer', 'nuhtc_infer_fixed_load', 'nuhtc_check', 'nuhtc_get_buffer',
-           'nuhtc_op_gemm', 'nuhtc_op_gemm_split', 'nuhtc_op_roi_align', 'nuhtc_op_nms', 'nuhtc_profile_enable', 'nuhtc_profile_read', 'nuhtc_dev_knob',
+           'nuhtc_op_gemm', 'nuhtc_op_gemm_split', 'nuhtc_op_roi_align', 'nuhtc_op_nms', 'nuhtc_profile_enable', 'nuhtc_profile_read', 'nuhtc_dev_knob', 'nuhtc_export_crops',
            'nuhtc_mask_contours', 'nuhtc_merge_overlap', 'nuhtc_export_kept']
 
 _lib = None
@@ -74,6 +74,7 @@ def load():
     lib.nuhtc_mask_contours.argtypes = [vp, ctypes.POINTER(Dets), ci, ci, vp, vp, vp]
     lib.nuhtc_merge_overlap.argtypes = [ci, vp, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int64, ci, ctypes.c_double, ci, ci, ci, ci, vp, vp]
     lib.nuhtc_export_kept.argtypes = [vp, ctypes.POINTER(Dets), ci, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.nuhtc_export_crops.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, ci, vp]
     lib.nuhtc_profile_enable.argtypes = [ci]
     lib.nuhtc_dev_knob.argtypes = [ctypes.c_char_p, ci]
     lib.nuhtc_profile_read.argtypes = [ctypes.c_char_p, ctypes.c_size_t]

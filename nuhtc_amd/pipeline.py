@@ -2,8 +2,11 @@
 GPU at once, each on its own engine (weights + workspace, 123 MB + ~0.3 GB per tile of max_batch) and its own HIP stream.
 While one batch is in the under-filled tail of a launch (stage-3/4 GEMMs, the single-block proposal / detection kernels)
 the other batch's kernels fill the idle CUs, and the host's result unpacking of batch i overlaps the GPU work of batch
-i+1.  Measured on MI355X at B=16 (bench.py `pipelined`): 13.4 ms per batch alone, ≈ 12.3 ms per batch with three in flight
-(1190 -> ≈ 1300 tiles/s); with two in flight the gain depends on which hardware queues the streams land on (0-13 %).
+i+1.  Measured on MI355X at B=16 (bench.py): 11.4 ms per batch alone, ≈ 10 ms per batch with four in flight (1400 -> ≈ 1600-1690
+tiles/s); two identical chains started together stay in phase and gain nothing.  Host batches are copied from pageable memory:
+that copy blocks the submitting thread for ≈ 4 ms per batch, but staging through pinned buffers made the slide loop twice as slow
+(the CPU writes 3 MB into pinned memory at ≈ 0.5 GB/s, and with the host running ahead the copies of four streams got in the way of
+the kernels: 1431 -> 688 tiles/s), so the plain copy stays.
 
 The reference has no counterpart (its DataLoader overlaps only the CPU tile reads with the GPU, tools/infer_wsi.py:466-476)."""
 import collections

@@ -40,6 +40,117 @@ def _gather_sync(eng, B):
                 words=eng.masks[sel[0], sel[1]].reshape(len(tile), -1).cpu().numpy().view(np.uint32))
 
 
+class PackedMasks:
+    """Mask crops of a slide's detections in the packed layout the device produces and nuhtc_merge_overlap takes: `boxes` int32 (n, 4)
+    crop rectangles in slide pixels (x1, y1 exclusive), `areas` int32 (n,), `bits` uint32 words (rows of (w + 31) // 32 words, crop
+    column x in bit x & 31 of word x >> 5), `off` int64 (n,) word offset of each crop.  Behaves like the list of
+    (bool crop, x0, y0) the per-detection path builds: len(), indexing and iteration decode crops on demand."""
+
+    def __init__(self, boxes, areas, bits, off):
+        self.boxes, self.areas, self.bits, self.off = boxes, areas, bits, off
+        self.arrays = None      # set by infer_tiles: the records' other fields as arrays (pack_records' fast path)
+
+    def __len__(self):
+        return len(self.areas)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        x0, y0, x1, y1 = (int(v) for v in self.boxes[i])
+        h, w = y1 - y0, x1 - x0
+        wpr = (w + 31) // 32
+        words = self.bits[int(self.off[i]):int(self.off[i]) + h * wpr].reshape(h, wpr)
+        return np.unpackbits(words.view(np.uint8), axis=-1, bitorder='little')[:, :w].astype(bool), x0, y0
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    def __add__(self, other):               # like the list it stands in for: concatenation gives a plain list of decoded crops
+        return list(self) + list(other)
+
+    def __radd__(self, other):
+        return list(other) + list(self)
+
+    def subset(self, keep):
+        """The crops `keep` (indices) re-packed contiguously."""
+        keep = np.asarray(keep, np.int64)
+        b = self.boxes[keep]
+        sizes = ((b[:, 3] - b[:, 1]).astype(np.int64) * ((b[:, 2] - b[:, 0] + 31) // 32)) if len(keep) else np.zeros(0, np.int64)
+        new_off = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64) if len(keep) else np.zeros(0, np.int64)
+        idx = np.arange(int(sizes.sum()), dtype=np.int64) + np.repeat(self.off[keep] - new_off, sizes)
+        return PackedMasks(b, self.areas[keep], self.bits[idx] if len(idx) else np.zeros(0, np.uint32), new_off)
+
+
+def _unpack_packed(eng, g, i0, coords, parts):
+    """Vectorised twin of _unpack for a batch exported with device crops (Engine.export_async -> nuhtc_export_crops): appends one
+    dict of arrays (the batch's records in the order _unpack produces) to `parts`."""
+    from . import contours as host
+    n = g['n']
+    tile, slot, boxes, labels = g['tile'], g['slot'], g['boxes'], g['labels']
+    cls_major = np.lexsort((slot, labels, tile))
+    order = cls_major[np.lexsort((np.arange(n), boxes[cls_major, 4], -tile[cls_major]))[::-1]]
+    cb = g['crop_box'][order].astype(np.int64)
+    order = order[cb[:, 2] > cb[:, 0]]                      # a mask without a set pixel is no record (tools/infer_wsi.py never sees one)
+    if len(order) == 0:
+        return
+    cb = g['crop_box'][order].astype(np.int64)
+    org = np.asarray(coords)[i0 + tile[order]].astype(np.int64)          # (m, 2) tile origins (x, y)
+    org4 = np.concatenate([org, org], 1)
+    sizes = (cb[:, 3] - cb[:, 1]) * ((cb[:, 2] - cb[:, 0] + 31) // 32)
+    src = g['crop_off'][order].astype(np.int64)
+    fits = src + sizes <= g['pool']
+    if fits.all():
+        idx = np.arange(int(sizes.sum()), dtype=np.int64) + np.repeat(src - (np.cumsum(sizes) - sizes), sizes)
+        bits = g['crop_words'][idx]
+    else:                                                                 # crops past the pool: cut from the full masks on the device
+        chunks = []
+        for k, ok in zip(order, fits):
+            if ok:
+                chunks.append(g['crop_words'][int(g['crop_off'][k]):int(g['crop_off'][k]) + int(sizes[len(chunks)])])
+            else:
+                x0, y0, x1, y1 = g['crop_box'][k]
+                m = eng.export_full_mask(int(k))[y0:y1, x0:x1]
+                chunks.append(pack_masks([(m, 0, 0)])[2])
+        bits = np.concatenate(chunks)
+    cn = g['cn'][order].astype(np.int64)
+    ccap = g['xy'].shape[1]
+    xy = np.zeros((len(order), ccap + 1, 2), np.int64)
+    xy[:, :ccap] = g['xy'][order]
+    for j in np.flatnonzero(cn <= 0):                                     # contour over the device capacities: host mirror on the crop
+        x0, y0, x1, y1 = cb[j]
+        wpr = (x1 - x0 + 31) // 32
+        o = int(np.cumsum(sizes)[j] - sizes[j])
+        m = np.unpackbits(bits[o:o + sizes[j]].reshape(y1 - y0, wpr).view(np.uint8), axis=-1, bitorder='little')[:, :x1 - x0].astype(bool)
+        c = host.trace_outer_contour(m) + np.array([x0, y0], np.int64)
+        if len(c) + 1 > xy.shape[1]:
+            xy = np.concatenate([xy, np.zeros((len(order), len(c) + 1 - xy.shape[1], 2), np.int64)], 1)
+        xy[j, :len(c)] = c
+        cn[j] = len(c)
+    xy[np.arange(len(order)), cn] = xy[:, 0]                              # mask2inst closes the ring (tools/infer_wsi.py:51-58)
+    xy += org[:, None, :]
+    parts.append(dict(tile=i0 + tile[order], box=boxes[order, :4].astype(np.float64) + org4, score=boxes[order, 4].astype(np.float64),
+                      label=labels[order].astype(np.int64), crop_box=(cb + org4).astype(np.int32), area=g['crop_area'][order].astype(np.int32),
+                      bits=bits, sizes=sizes, ring_n=cn + 1, ring_xy=xy))
+
+
+def _records_from_parts(parts):
+    """Per-batch arrays of _unpack_packed -> the record dict of infer_tiles (lists for the scalar fields and the rings, PackedMasks
+    for the mask crops, which also carries the scalar fields as whole-slide arrays for the vectorised consumers)."""
+    if not parts:
+        return dict(tile=[], box=[], score=[], label=[], mask=[], ring=[])
+    cat = lambda k: np.concatenate([p[k] for p in parts], 0)
+    tile, box, score, label, ring_n = cat('tile'), cat('box'), cat('score'), cat('label'), cat('ring_n')
+    sizes = cat('sizes')
+    off = (np.cumsum(sizes) - sizes).astype(np.int64)
+    masks = PackedMasks(cat('crop_box'), cat('area'), cat('bits'), off)
+    width = max(p['ring_xy'].shape[1] for p in parts)
+    ring_xy = np.concatenate([np.pad(p['ring_xy'], ((0, 0), (0, width - p['ring_xy'].shape[1]), (0, 0))) for p in parts], 0)
+    rec = dict(tile=tile.tolist(), box=list(box), score=score.tolist(), label=label.tolist(), mask=masks,
+               ring=[ring_xy[i, :ring_n[i]] for i in range(len(tile))])
+    masks.arrays = dict(tile=tile, box=box, score=score, label=label, ring_n=ring_n, ring_xy=ring_xy)   # the scalar fields as whole-slide arrays
+    return rec
+
+
 def _unpack(eng, B, i0, coords, P, rec, exported=False):
     """Kept detections of one finished batch -> records in slide coordinates.  `exported`: the batch was submitted with
     export=True (its results already sit in the engine's pinned buffers); otherwise they are fetched here."""
@@ -49,6 +160,12 @@ def _unpack(eng, B, i0, coords, P, rec, exported=False):
         g = _gather_sync(eng, B)
     n = g['n']
     if n == 0:
+        return
+    if 'crop_box' in g:                     # exported with device crops: the array path, appended in list form
+        parts = []
+        _unpack_packed(eng, g, i0, coords, parts)
+        if parts:
+            _extend(rec, _records_from_parts(parts))
         return
     tile, slot, boxes, labels = g['tile'], g['slot'], g['boxes'], g['labels']
     # per tile: class-major order like np.concatenate(result[0]) in the reference, then score order from mask_nms
@@ -94,12 +211,20 @@ def infer_tiles(model, tiles, coords, batch_size=16, depth=4):
     import torch
     P = tiles.shape[1]
     rec = dict(tile=[], box=[], score=[], label=[], mask=[], ring=[])
+    parts = []
     pipe = model.pipeline(tiles.shape[1:3], depth)
 
     def finish():
         eng, B, stream, i0 = pipe.collect()
         with torch.cuda.stream(stream):
-            _unpack(eng, B, i0, coords, P, rec, exported=True)
+            g = eng.export_read()
+            if g is not None and not rec['tile']:
+                if g['n']:
+                    _unpack_packed(eng, g, i0, coords, parts)      # device crops: whole-batch array operations
+            else:                                                 # more kept detections than the export buffers hold: per-detection path
+                if parts:
+                    _extend(rec, _records_from_parts(parts)); parts.clear()
+                _unpack(eng, B, i0, coords, P, rec, exported=False)
 
     for i in range(0, len(tiles), batch_size):
         if pipe.full():
@@ -107,12 +232,25 @@ def infer_tiles(model, tiles, coords, batch_size=16, depth=4):
         pipe.submit(tiles[i:i + batch_size], hip.CH_SWAP, tag=i, export=True)
     while pipe.pending:
         finish()
+    if parts and not rec['tile']:
+        return _records_from_parts(parts)
+    if parts:
+        _extend(rec, _records_from_parts(parts))
     return rec
+
+
+def _extend(rec, more):
+    """Append the records `more` to the list-form record dict `rec` (mask crops decoded)."""
+    for k in ('tile', 'box', 'score', 'label', 'ring'):
+        rec[k].extend(more[k])
+    rec['mask'].extend(list(more['mask']))
 
 
 def pack_masks(masks):
     """[(bool crop, x0, y0)] -> (boxes int32 [n,4] (x1,y1 exclusive), areas int32 [n], bits uint32 [...], bit_off int64 [n]):
     the crop layout nuhtc_merge_overlap takes (rows of (w+31)//32 words, pixel x in bit x&31 of word x>>5)."""
+    if isinstance(masks, PackedMasks):
+        return masks.boxes, masks.areas, (masks.bits if len(masks.bits) else np.zeros(1, np.uint32)), masks.off
     n = len(masks)
     boxes = np.zeros((n, 4), np.int32)
     areas = np.zeros(n, np.int32)
@@ -183,6 +321,20 @@ def pack_records(rec, keep=None, tile_base=0, rles=None):
     bits  int32   (words,): the bit-packed mask crops (the merge's input)
     blob  uint8   (bytes,): optional COCO RLE strings, concatenated"""
     import torch
+    if isinstance(rec['mask'], PackedMasks) and rec['mask'].arrays is not None:          # records of the packed path: whole-slide array operations
+        a = rec['mask'].arrays
+        kp = np.arange(len(a['score']), dtype=np.int64) if keep is None else np.asarray(list(keep), np.int64)
+        n = len(kp)
+        head = np.zeros((n, 9), np.float64)
+        head[:, :4], head[:, 4], head[:, 5], head[:, 6], head[:, 7] = a['box'][kp], a['score'][kp], a['label'][kp], a['ring_n'][kp], tile_base + a['tile'][kp]
+        head[:, 8] = [len(r) for r in rles] if rles else 0
+        rx = a['ring_xy'][kp]
+        verts = rx[np.arange(rx.shape[1])[None, :] < a['ring_n'][kp][:, None]].astype(np.int32).reshape(-1, 2)
+        m = rec['mask'].subset(kp)
+        crops = np.concatenate([m.boxes.astype(np.int64), m.areas[:, None].astype(np.int64), m.off[:, None]], 1) if n else np.zeros((0, 6), np.int64)
+        blob = np.frombuffer(b''.join(rles), np.uint8).copy() if rles else np.zeros(0, np.uint8)
+        return [torch.from_numpy(head), torch.from_numpy(verts), torch.from_numpy(crops), torch.from_numpy(m.bits.view(np.int32).copy()),
+                torch.from_numpy(blob)]
     keep = list(range(len(rec['score']))) if keep is None else list(keep)
     n = len(keep)
     head = np.zeros((n, 9), np.float64)

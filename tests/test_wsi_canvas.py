@@ -178,3 +178,39 @@ def test_consep_1000px_crop_36_padded_tiles(hip_device, tmp_path):
     for (m, x0, y0) in rec['mask']:
         assert x0 >= 0 and y0 >= 0 and x0 + m.shape[1] <= 960 + 256 and y0 + m.shape[0] <= 960 + 256
     print(f'consep crop: {n} nuclei after per-tile mask-NMS, {len(kept)} after the cross-tile merge (polygon IoU), {len(kept_m)} (mask IoU)')
+
+
+@pytest.mark.gpu
+def test_device_crops_equal_per_detection_unpack(model):
+    """The slide loop's array path (masks cropped on the device by nuhtc_export_crops, records built with whole-batch array
+    operations) against the per-detection path (full masks fetched, cropped one by one on the host): same records in the same
+    order -- tile, box, score, label, mask crop and origin, closed ring -- and the same packed gather tensors and merge result."""
+    import torch
+    from nuhtc_amd import hip, synth, wsi
+    G = 4
+    full, _ = synth.nuclei_canvas(G)
+    tiles = synth.CanvasTiles(full, 0, G, 0, G * G)
+    rec = wsi.infer_tiles(model, tiles, tiles.coords, 8)
+    assert isinstance(rec['mask'], wsi.PackedMasks) and len(rec['tile']) > 50
+    ref = dict(tile=[], box=[], score=[], label=[], mask=[], ring=[])
+    pipe = model.pipeline(tiles.shape[1:3], 4)
+
+    def finish():
+        eng, B, stream, i0 = pipe.collect()
+        with torch.cuda.stream(stream):
+            wsi._unpack(eng, B, i0, tiles.coords, 256, ref, exported=False)
+    for i in range(0, len(tiles), 8):
+        if pipe.full():
+            finish()
+        pipe.submit(tiles[i:i + 8], hip.CH_SWAP, tag=i, export=True)
+    while pipe.pending:
+        finish()
+    assert rec['tile'] == ref['tile'] and rec['score'] == ref['score'] and rec['label'] == ref['label']
+    assert all(np.array_equal(a, b) for a, b in zip(rec['box'], ref['box']))
+    assert all(np.array_equal(a, b) for a, b in zip(rec['ring'], ref['ring']))
+    for (m, x0, y0), (m2, x2, y2) in zip(rec['mask'], ref['mask']):
+        assert (x0, y0) == (x2, y2) and np.array_equal(m, m2)
+    for keep in (None, list(range(0, len(ref['tile']), 3))):
+        for a, b in zip(wsi.pack_records(rec, keep), wsi.pack_records(ref, keep)):
+            assert a.shape == b.shape and bool((a == b).all())
+    assert np.array_equal(wsi.merge_overlap(rec, 0.05), wsi.merge_overlap(ref, 0.05))
