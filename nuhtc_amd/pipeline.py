@@ -6,7 +6,8 @@ i+1.  Measured on MI355X at B=16 (bench.py): 11.4 ms per batch alone, ≈ 10 ms 
 tiles/s); two identical chains started together stay in phase and gain nothing.  Host batches are copied from pageable memory:
 that copy blocks the submitting thread for ≈ 4 ms per batch, but staging through pinned buffers made the slide loop twice as slow
 (the CPU writes 3 MB into pinned memory at ≈ 0.5 GB/s, and with the host running ahead the copies of four streams got in the way of
-the kernels: 1431 -> 688 tiles/s), so the plain copy stays.
+the kernels: 1431 -> 688 tiles/s; a staging buffer of ordinary memory page-locked with hipHostRegister: 613; the pageable copy on
+an idle per-slot copy stream: 1223), so the plain copy on the slot's stream stays.
 
 The reference has no counterpart (its DataLoader overlaps only the CPU tile reads with the GPU, tools/infer_wsi.py:466-476)."""
 import collections
