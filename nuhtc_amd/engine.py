@@ -179,13 +179,21 @@ class Engine:
         pool = cap * int(crop_words_per_det)
         ex = getattr(self, '_ex', None)
         if ex is None or ex['cap'] != cap or ex['ccap'] != contour_cap or ex['pool'] != pool:
-            pin = lambda *shape, dtype: torch.zeros(*shape, dtype=dtype).pin_memory()
             dev = lambda *shape, dtype: torch.zeros(*shape, dtype=dtype, device=self.device)
             names = dict(nk=((1,), torch.int32), idx=((cap,), torch.int64), boxes=((cap, 5), torch.float32), labels=((cap,), torch.int32),
-                         cn=((cap,), torch.int32), xy=((cap, contour_cap, 2), torch.int16), crop_box=((cap, 4), torch.int32),
-                         crop_area=((cap,), torch.int32), crop_off=((cap + 1,), torch.int32), crop_words=((pool,), torch.int32))
-            ex = self._ex = dict(cap=cap, ccap=contour_cap, pool=pool, host={k: pin(*sh, dtype=dt) for k, (sh, dt) in names.items()},
-                                 dev={k: dev(*sh, dtype=dt) for k, (sh, dt) in names.items()})
+                         cn=((cap,), torch.int32), crop_box=((cap, 4), torch.int32), crop_area=((cap,), torch.int32),
+                         crop_off=((cap + 1,), torch.int32), crop_words=((pool,), torch.int32), xy=((cap, contour_cap, 2), torch.int16))
+            # every field is a view into ONE device buffer and ONE pinned host buffer: a batch's results leave the device in a single
+            # copy (each asynchronous copy on a compute stream costs a hand-over between the copy engine and the kernels)
+            offs, total = {}, 0
+            for k, (sh, dt) in names.items():
+                offs[k] = total
+                total += (int(np.prod(sh)) * torch.empty(0, dtype=dt).element_size() + 255) // 256 * 256
+            blob_dev = torch.zeros(total, dtype=torch.uint8, device=self.device)
+            blob_host = torch.zeros(total, dtype=torch.uint8).pin_memory()
+            view = lambda blob, k: blob[offs[k]:offs[k] + int(np.prod(names[k][0])) * torch.empty(0, dtype=names[k][1]).element_size()].view(names[k][1]).view(*names[k][0])
+            ex = self._ex = dict(cap=cap, ccap=contour_cap, pool=pool, blob_dev=blob_dev, blob_host=blob_host,
+                                 host={k: view(blob_host, k) for k in names}, dev={k: view(blob_dev, k) for k in names})
             ex['dev']['words'] = dev(cap, W, dtype=torch.int32)          # full masks of the kept detections: device only
         self.contours_async(B, contour_cap)
         d = ex['dev']
@@ -196,8 +204,7 @@ class Engine:
                                                self._stream()))
         self._check(self.lib.nuhtc_export_crops(self.h, vp(d['words']), vp(d['nk']), cap, vp(d['crop_box']), vp(d['crop_area']), vp(d['crop_off']),
                                                 vp(d['crop_words']), pool, self._stream()))
-        for k, h in ex['host'].items():
-            h.copy_(d[k], non_blocking=True)
+        ex['blob_host'].copy_(ex['blob_dev'], non_blocking=True)
         ex['B'] = B
 
     def export_read(self):
