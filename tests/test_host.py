@@ -203,3 +203,40 @@ def test_unpack_record_order_and_crops():
         assert (x0, y0) == (ox + xs.min(), oy + ys.min()) and np.array_equal(crop, full[ys.min():ys.max() + 1, xs.min():xs.max() + 1])
         ring = rec['ring'][r]
         assert ring.shape == (5, 2) and np.array_equal(ring[0], ring[-1]) and np.array_equal(ring[:4], g['xy'][k, :4].astype(np.int64) + [ox, oy])
+
+
+def test_packed_masks_behave_like_the_crop_list():
+    """wsi.PackedMasks (the slide loop's device-crop records) against the list of (bool crop, x0, y0) it stands in for: decoding,
+    pack_masks, subset re-packing and the two pack_records paths give the same tensors."""
+    from nuhtc_amd import wsi
+    rng = np.random.default_rng(5)
+    crops = []
+    for i in range(40):
+        h, w = int(rng.integers(1, 70)), int(rng.integers(1, 70))
+        m = rng.random((h, w)) < 0.6
+        m[0, rng.integers(0, w)] = m[-1, rng.integers(0, w)] = True          # tight crops: first / last row and column hold a pixel
+        m[rng.integers(0, h), 0] = m[rng.integers(0, h), -1] = True
+        crops.append((m, int(rng.integers(0, 5000)), int(rng.integers(0, 5000))))
+    boxes, areas, bits, off = wsi.pack_masks(crops)
+    pm = wsi.PackedMasks(boxes, areas, bits, off)
+    assert len(pm) == 40
+    for (m, x0, y0), (m2, x2, y2) in zip(crops, pm):
+        assert (x0, y0) == (x2, y2) and np.array_equal(m, m2)
+    for a, b in zip(wsi.pack_masks(pm), (boxes, areas, bits, off)):
+        assert np.array_equal(a, b)
+    keep = [3, 4, 9, 30, 39]
+    for a, b in zip(wsi.pack_masks(pm.subset(keep)), wsi.pack_masks([crops[i] for i in keep])):
+        assert np.array_equal(a, b)
+    assert (pm + [crops[0]])[-1][1] == crops[0][1] and len([crops[0]] + pm) == 41
+    # the two record forms through pack_records
+    n = len(crops)
+    ring_n = rng.integers(4, 12, n)
+    ring_xy = rng.integers(0, 6000, (n, 12, 2)).astype(np.int64)
+    rec_list = dict(tile=list(range(n)), box=[rng.random(4) * 6000 for _ in range(n)], score=rng.random(n).tolist(), label=rng.integers(0, 5, n).tolist(),
+                    mask=crops, ring=[ring_xy[i, :ring_n[i]] for i in range(n)])
+    pm.arrays = dict(tile=np.arange(n), box=np.stack(rec_list['box']), score=np.array(rec_list['score']), label=np.array(rec_list['label']),
+                     ring_n=ring_n, ring_xy=ring_xy)
+    rec_packed = dict(rec_list, mask=pm)
+    for kp in (None, keep):
+        for a, b in zip(wsi.pack_records(rec_packed, kp, tile_base=7), wsi.pack_records(rec_list, kp, tile_base=7)):
+            assert a.shape == b.shape and bool((a == b).all())
