@@ -93,6 +93,26 @@ def cpu_baseline(sd, tiles, eng=None, mode=1, batch=4, timed=3):
     return out
 
 
+def self_launch(n):
+    """Run this script as `n` ranks (one per GPU) under torch.distributed.run as a CHILD process and relay its output: the JSON line
+    of rank 0 goes to stdout, everything else to stderr.  Returns the job's exit code.  Nothing here initialises the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in p.stdout:
+        (sys.stdout if line.startswith('{"metric"') else sys.stderr).write(line)
+        sys.stdout.flush()
+    return p.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -119,17 +139,29 @@ def main():
     ap.add_argument('--roi-sort', action='store_true', help='--fixed-load (dev): hand the RoIs over sorted by position (locality experiment)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process becomes the launcher (one rank per GPU under
+        # torch.distributed.run, the reference's pattern: tools/test.py:183,239 -> init_dist) BEFORE anything here touches the GPU,
+        # relays rank 0's JSON line and exits with the job's code.  It never re-execs: the ranks are child processes.
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or unset WORLD_SIZE and let bench.py launch them)')
+    # test hooks for a box with fewer GPUs than ranks (tests/test_hip_api.py): every rank on device 0, gloo instead of RCCL
+    if os.environ.get('NUHTC_ONE_DEVICE') == '1':
+        local_rank = 0
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        backend = os.environ.get('NUHTC_DIST_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from nuhtc_amd import hip, synth, weights
     from nuhtc_amd.engine import Engine
@@ -151,6 +183,13 @@ def main():
         step_fn = lambda e=eng: e.infer_fixed_load_async(tiles, rois, 64, mode)
     else:
         step_fn = lambda e=eng: e.infer_async(tiles, mode)
+
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     def sync_all():
         torch.cuda.synchronize()
@@ -225,10 +264,7 @@ def main():
     gathered_bytes = int(sum(t.numel() * t.element_size() for g in gathered for t in g))
     sync_all()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(dt)
     for e in engs:
         e.check()
     total_tiles = args.steps * B * world
@@ -247,14 +283,23 @@ def main():
             step_fn()
         sync_all()
         dts = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([dts], device='cuda')
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dts = float(t.item())
+        dts = max_over_ranks(dts)
         sequential = {'value': total_tiles / dts, 'unit': 'tiles/s', 'ms_per_step': dts / args.steps * 1e3, 'steps': args.steps,
                       'note': 'the same K steps one batch at a time; roofline / kernel_ms_per_step / kernel_groups are measured in this mode'}
     else:
         dts = dt
+
+    # the shader clock this box holds under the sequential step (the chip lowers its clock under matrix load and boxes differ:
+    # a per-kernel fraction is only comparable between runs together with this figure): a one-wave probe on its own stream
+    # (s_memtime against the 100 MHz s_memrealtime) beside untimed steps
+    k_clk = max(3, min(20, args.steps))
+    probe = hip.ClockProbe(local_rank)
+    torch.cuda.synchronize()
+    probe.start(0.8 * k_clk * dts / args.steps * 1e3)
+    for _ in range(k_clk):
+        step_fn()
+    shader_clock_ghz = probe.ghz()
+    torch.cuda.synchronize()
 
     # live per-kernel timing (HIP events on the launch stream) over the same workload, separate steps so the
     # event records do not perturb the headline number
@@ -355,10 +400,7 @@ def main():
             eng.infer_fixed_load_async(tiles, rois_b, 64, mode)
         sync_all()
         d2 = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([d2], device='cuda')
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            d2 = float(t.item())
+        d2 = max_over_ranks(d2)
         hip.profile_enable(True)
         for _ in range(2):
             eng.infer_fixed_load_async(tiles, rois_b, 64, mode)
@@ -380,10 +422,7 @@ def main():
             e32.infer_async(tiles, mode)
         sync_all()
         d3 = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([d3], device='cuda')
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            d3 = float(t.item())
+        d3 = max_over_ranks(d3)
         hip.profile_enable(True)
         for _ in range(2):
             e32.infer_async(tiles, mode)
@@ -429,6 +468,9 @@ def main():
                          'traffic': traffic, 'traffic_source': traffic_note,
                          'pipeline_frac': pipeline_frac, 'pipeline_frac_sequential': pipeline_frac_seq, 'pipeline_gflop_per_tile': step_flops / B / 1e9,
                          'algorithmic_bytes_per_launch': dom['bytes'] / dom['launches'],
+                         'shader_clock_ghz_under_step': shader_clock_ghz,
+                         'shader_clock_note': 's_memtime / s_memrealtime of a one-wave probe running beside untimed sequential steps (2.4 GHz nominal); '
+                                              'the dense launches are clock-limited, so fractions of different boxes compare only at equal clock',
                          'avg_launch_ms': dur_ms, 'launches_per_step': dom['launches'] // prof_steps,
                          'share_of_step_kernel_time': dom['ms'] / tot_ms},
             'kernel_ms_per_step': breakdown,

@@ -49,8 +49,12 @@ enum { NUHTC_CH_AS_IS = 0, NUHTC_CH_SWAP = 1 };
 /* How the fp32 matrix products of the path (Swin linears, convolutions, FCs) are executed.  Both are fp32 arithmetic: fp32
  * operands and results, exact products, fp32 accumulation.
  *   NUHTC_PIPE_BF16_SPLIT (default): every fp32 operand is split exactly into three bf16 numbers (8 + 8 + 8 significand bits)
- *       and the product runs as six v_mfma_f32_32x32x16_bf16 per 16-deep step (the three cross terms below 2^-26 of the product
- *       are dropped); measured error against fp64 is at or below that of the fp32 MFMA chain (csrc/gemm.hip).
+ *       and the product runs as six v_mfma_f32_32x32x16_bf16 per 16-deep step.  The six products are exact; the three cross terms
+ *       a2*b3, a3*b2 (each <= 2^-24 |a*b|: round-to-nearest splits give |a2| <= 2^-8 |a|, |a3| <= 2^-16 |a|) and a3*b3 (<= 2^-32)
+ *       are dropped, i.e. at worst 2^-23 |a*b| per product, one fp32 rounding unit -- not bit-identical to an fp32 fma chain.
+ *       Measured error against fp64 is at or below that of the fp32 MFMA chain (csrc/gemm.hip, DESIGN.md 4,
+ *       tests/test_hip_dense.py), and parity with the reference is instance-exact with every disagreement explained by a
+ *       threshold (tests/parity_util.py), not bitwise.
  *   NUHTC_PIPE_FP32: v_mfma_f32_32x32x2_f32, bitwise an fp32 fma chain (1/16 of the bf16 MFMA rate on gfx950). */
 enum { NUHTC_PIPE_BF16_SPLIT = 0, NUHTC_PIPE_FP32 = 1 };
 
@@ -223,7 +227,12 @@ int nuhtc_op_nms(nuhtc_engine* e, const float* boxes, const float* scores, int n
  * "tag launches total_ms algorithmic_flops algorithmic_bytes", then resets the records. */
 int nuhtc_profile_enable(int on);
 int nuhtc_profile_read(char* buf, size_t cap);
-/* Development: set an integer switch of the launch heuristics (the NUHTC_<NAME> environment variables) at run time. */
+/* Shader clock under load (measurement): enqueues on `stream` a one-wave kernel that spins for `ticks_100mhz` periods of the 100 MHz
+ * reference clock and writes out_dev[0] = shader cycles elapsed, out_dev[1] = reference ticks elapsed.  Launched on a stream of
+ * its own beside the kernels being timed, out[0] / out[1] x 100 MHz is the clock the chip held under them.  Does not synchronise. */
+int nuhtc_clock_probe(int device, uint64_t ticks_100mhz, uint64_t* out_dev, void* stream);
+/* Development builds (-DNUHTC_DEV) only: set an integer switch of the launch heuristics (the NUHTC_<NAME> environment variables) at
+ * run time.  The default build compiles every switch to its default and returns NUHTC_E_STATE here. */
 int nuhtc_dev_knob(const char* name, int value);
 
 #ifdef __cplusplus

@@ -102,6 +102,8 @@ int launch_gemm(const GemmParams& p, hipStream_t s);
 // runs that product on the bf16 matrix pipe (gemm.hip).  gemm_unregister_split frees the split copy.
 int gemm_register_split(const float* w_dev, const float* w_host, int N, int K);
 void gemm_unregister_split(const float* w_dev);
+int gemm_make_split(const float* w_host, int N, int K, void** out_dev);      // unregistered split (caller hipFree()s it)
+const void* gemm_find_split(const float* w_dev, int N, int K);
 
 // ----------------------------------------------------------------------------- contours (contour.hip)
 // outer contour (cv2 RETR first contour, CHAIN_APPROX_SIMPLE) of every kept instance mask; n: 0 = none, -1 = overflow

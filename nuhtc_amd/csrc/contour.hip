@@ -234,9 +234,15 @@ __global__ __launch_bounds__(256) void export_copy_kernel(ExportParams p, const 
   if (d < 0 || d >= p.cap) return;
   if (lane == 0) { p.idx[d] = i; p.labels_out[d] = p.labels[i]; p.cn_out[d] = p.contour_n ? p.contour_n[i] : 0; }
   if (lane < 5) p.boxes_out[d * 5 + lane] = p.boxes[(long long)i * 5 + lane];
-  const uint4* ms = reinterpret_cast<const uint4*>(p.masks + (long long)i * p.words);
-  uint4* md = reinterpret_cast<uint4*>(p.words_out + (long long)d * p.words);
-  for (int t = lane; t < p.words / 4; t += 64) md[t] = ms[t];
+  if (p.words % 4 == 0) {         // every mask starts on a 16-byte boundary
+    const uint4* ms = reinterpret_cast<const uint4*>(p.masks + (long long)i * p.words);
+    uint4* md = reinterpret_cast<uint4*>(p.words_out + (long long)d * p.words);
+    for (int t = lane; t < p.words / 4; t += 64) md[t] = ms[t];
+  } else {                        // odd word counts (e.g. a 65 x 96 tile): dword copies
+    const uint32_t* ms = p.masks + (long long)i * p.words;
+    uint32_t* md = p.words_out + (long long)d * p.words;
+    for (int t = lane; t < p.words; t += 64) md[t] = ms[t];
+  }
   if (p.contour_xy) {
     const uint32_t* xs = reinterpret_cast<const uint32_t*>(p.contour_xy + (long long)i * p.ccap * 2);   // one (x, y) pair per dword
     uint32_t* xd = reinterpret_cast<uint32_t*>(p.xy_out + (long long)d * p.ccap * 2);
@@ -247,7 +253,6 @@ __global__ __launch_bounds__(256) void export_copy_kernel(ExportParams p, const 
 
 int launch_export_kept(const ExportParams& p, int32_t* pos_scratch, hipStream_t s) {
   if (p.B <= 0) return 0;
-  if (p.words % 4 != 0) return NUHTC_E_INVALID;
   ProfScope ps("export", 0, 0, s);
   hipLaunchKernelGGL(export_scan_kernel, dim3(1), dim3(1024), 0, s, p, pos_scratch);
   hipLaunchKernelGGL(export_copy_kernel, dim3(cdiv(p.B * p.K, 4)), dim3(256), 0, s, p, pos_scratch);

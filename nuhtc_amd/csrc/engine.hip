@@ -630,7 +630,7 @@ int nuhtc_export_kept(nuhtc_engine* e, const nuhtc_dets* dets, int B, const int3
   ExportParams p{dets->boxes, dets->labels, dets->counts, dets->keep, dets->masks, contour_n, contour_xy, B, e->cfg.max_per_img,
                  e->cfg.tile_h * (e->cfg.tile_w / 32), contour_cap, cap, n_dev, idx_dev, boxes_dev, labels_dev, cn_dev, xy_dev, words_dev};
   int rc = launch_export_kept(p, e->export_pos, (hipStream_t)stream);
-  if (rc) FAIL(e, rc, "export launch failed (tile_h * tile_w / 32 must be a multiple of 4)");
+  if (rc) FAIL(e, rc, "export launch failed");
   return 0;
 }
 
@@ -706,13 +706,15 @@ int nuhtc_op_gemm_split(nuhtc_engine* e, const float* A, const float* W_dev, con
                         int K, int act, void* stream) {
   if (!e || !A || !W_dev || !W_host || !C) return NUHTC_E_INVALID;
   HIP_CHECK(e, hipSetDevice(e->device));
-  int rc = gemm_register_split(W_dev, W_host, N, K);
-  if (rc) FAIL(e, rc, "gemm_register_split failed (K % 8)");
+  void* sp = nullptr;              // a private split of this call's weight: the registry of the engines' weights is not touched
+  int rc = gemm_make_split(W_host, N, K, &sp);
+  if (rc) FAIL(e, rc, "gemm_make_split failed (K % 8)");
   GemmParams p = gp(A, W_dev, bias, C, M, N, K);
   p.act = act;
+  p.Wsplit = sp;
   rc = launch_gemm(p, (hipStream_t)stream);
   hipError_t he = hipStreamSynchronize((hipStream_t)stream);
-  gemm_unregister_split(W_dev);
+  hipFree(sp);
   if (rc) FAIL(e, rc, "gemm launch failed (K%32, N%32 required)");
   if (he != hipSuccess) FAIL(e, NUHTC_E_HIP, "gemm kernel failed");
   return 0;

@@ -435,7 +435,8 @@ __global__ __launch_bounds__(256, (MT * NT <= 3 ? 4 : 3)) void gemm_kernel(GemmP
 // gfx950's fp32 MFMA runs at 1/16 of the bf16 rate.  An fp32 number is exactly the sum of three bf16 numbers (24 significand
 // bits = 8 + 8 + 8; round-to-nearest splits, the residuals are exact fp32 subtractions), a bf16 x bf16 product is exact in
 // fp32, and v_mfma_f32_32x32x16_bf16 accumulates in fp32.  So  a*b = sum_ij a_i*b_j  over nine exact products; the three
-// smallest (a2*b3, a3*b2, a3*b3 <= 2^-26 |a*b|, below half an fp32 rounding unit) are dropped: SIX bf16 MFMAs of depth 16 (192
+// smallest are dropped (round-to-nearest splits: |a2| <= 2^-8 |a|, |a3| <= 2^-16 |a|, so a2*b3 and a3*b2 are <= 2^-24 |a*b| each
+// and a3*b3 <= 2^-32: at worst 2^-23 |a*b| per product, one fp32 rounding unit): SIX bf16 MFMAs of depth 16 (192
 // cycles) replace the eight fp32 MFMAs of depth 2 (512 cycles) of the same 32x32x16 product.  Measured against fp64
 // (tools/dev/probe/bf16split_probe.hip, K = 96 .. 3136, normal and wide-range operands): max error 1.2-1.6e-7 of sum|a*b|
 // against 1.4-2.1e-7 for the fp32 MFMA chain, identical with all nine products -- the result is fp32 arithmetic (exact
@@ -763,9 +764,10 @@ struct SplitEnt { void* dev; int N, K; };
 static std::map<const float*, SplitEnt> g_split;
 static std::mutex g_split_mu;
 
-static inline unsigned short bf16_rn_bits(float f) {     // round to nearest even (finite inputs)
+static inline unsigned short bf16_rn_bits(float f) {     // round to nearest even; a NaN stays a NaN (the integer carry would turn some into 0 / Inf)
   unsigned u;
   memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x0040u);
   u += 0x7fffu + ((u >> 16) & 1u);
   return (unsigned short)(u >> 16);
 }
@@ -776,8 +778,9 @@ static inline float bf16_bits_to_float(unsigned short h) {
   return f;
 }
 
-int gemm_register_split(const float* w_dev, const float* w_host, int N, int K) {
-  if (!w_dev || !w_host || N <= 0 || K <= 0 || K % 8) return NUHTC_E_INVALID;
+// host split of a constant weight matrix -> device buffer Wsplit[n][k/8][plane][8 bf16] (caller frees with hipFree)
+int gemm_make_split(const float* w_host, int N, int K, void** out) {
+  if (!w_host || !out || N <= 0 || K <= 0 || K % 8) return NUHTC_E_INVALID;
   std::vector<unsigned short> sp((size_t)N * K * 3);
   for (int n = 0; n < N; ++n)
     for (int k = 0; k < K; ++k) {
@@ -791,10 +794,29 @@ int gemm_register_split(const float* w_dev, const float* w_host, int N, int K) {
       dst[0] = b1; dst[8] = b2; dst[16] = b3;
     }
   void* d = nullptr;
-  if (hipMalloc(&d, sp.size() * 2) != hipSuccess || hipMemcpy(d, sp.data(), sp.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return NUHTC_E_HIP;
+  if (hipMalloc(&d, sp.size() * 2) != hipSuccess) return NUHTC_E_HIP;
+  if (hipMemcpy(d, sp.data(), sp.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { hipFree(d); return NUHTC_E_HIP; }
+  *out = d;
+  return 0;
+}
+
+int gemm_register_split(const float* w_dev, const float* w_host, int N, int K) {
+  if (!w_dev) return NUHTC_E_INVALID;
+  void* d = nullptr;
+  int rc = gemm_make_split(w_host, N, K, &d);
+  if (rc) return rc;
   std::lock_guard<std::mutex> lock(g_split_mu);
+  auto it = g_split.find(w_dev);
+  if (it != g_split.end()) hipFree(it->second.dev);         // a re-registered pointer (freed and reallocated weight): drop the stale split
   g_split[w_dev] = SplitEnt{d, N, K};
   return 0;
+}
+
+// the registered split of a weight (null when there is none): engines cache it at finalize so launches skip the lookup
+const void* gemm_find_split(const float* w_dev, int N, int K) {
+  std::lock_guard<std::mutex> lock(g_split_mu);
+  auto it = g_split.find(w_dev);
+  return (it != g_split.end() && it->second.N == N && it->second.K == K) ? it->second.dev : nullptr;
 }
 
 void gemm_unregister_split(const float* w_dev) {

@@ -82,8 +82,9 @@ extern "C" int nuhtc_profile_read(char* buf, size_t cap) {
   return 0;
 }
 
-// ---- development knobs: integer switches of the tile heuristics, initialised from the environment (NUHTC_<NAME>) on first use and
-// settable at run time so that two settings can be A/B-ed inside one process (tools/dev/knob_ab.py)
+// ---- development knobs: integer switches of the tile heuristics.  In a -DNUHTC_DEV build they are initialised from the environment
+// (NUHTC_<NAME>) on first use and settable at run time so that two settings can be A/B-ed inside one process (tools/dev/knob_ab.py);
+// the default build compiles them to their defaults: no environment reads, nuhtc_dev_knob refuses.
 #include <cstdlib>
 #include <mutex>
 static std::map<std::string, int> g_knobs;      // nodes never move: launch code keeps references to the values
@@ -92,12 +93,43 @@ int& dev_knob_ref(const char* name, int dflt) {
   std::lock_guard<std::mutex> lock(g_knob_mu);
   auto it = g_knobs.find(name);
   if (it != g_knobs.end()) return it->second;
+#ifdef NUHTC_DEV
   const char* e = getenv((std::string("NUHTC_") + name).c_str());
   return g_knobs.emplace(name, e ? atoi(e) : dflt).first->second;
+#else
+  return g_knobs.emplace(name, dflt).first->second;
+#endif
 }
 int dev_knob(const char* name, int dflt) { return dev_knob_ref(name, dflt); }
 extern "C" int nuhtc_dev_knob(const char* name, int value) {
   if (!name) return NUHTC_E_INVALID;
+#ifdef NUHTC_DEV
   dev_knob_ref(name, value) = value;
   return 0;
+#else
+  (void)value;
+  return NUHTC_E_STATE;      // not a development build (-DNUHTC_DEV)
+#endif
+}
+
+// ---- shader clock under load: one wave spins for `ticks` periods of the 100 MHz reference clock (s_memrealtime) and reports how
+// many shader cycles (s_memtime) went by.  Launched on a stream of its own beside the kernels being measured it occupies one
+// wave slot of one CU; cycles / ticks x 100 MHz is the clock the chip held while those kernels ran (bench.py: roofline.shader_clock).
+__global__ void clock_probe_kernel(unsigned long long ticks, unsigned long long* out) {
+  if (threadIdx.x != 0) return;
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long r = r0;
+  while (r - r0 < ticks) {
+    __builtin_amdgcn_s_sleep(32);
+    r = __builtin_amdgcn_s_memrealtime();
+  }
+  out[0] = __builtin_amdgcn_s_memtime() - c0;
+  out[1] = r - r0;
+}
+
+extern "C" int nuhtc_clock_probe(int device, uint64_t ticks_100mhz, uint64_t* out_dev, void* stream) {
+  if (!out_dev || ticks_100mhz == 0 || ticks_100mhz > 1000000000ull) return NUHTC_E_INVALID;
+  if (hipSetDevice(device) != hipSuccess) return NUHTC_E_HIP;
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long)ticks_100mhz, (unsigned long long*)out_dev);
+  return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
 }

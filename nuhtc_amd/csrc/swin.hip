@@ -329,79 +329,7 @@ int launch_merge_ln(const float* x, const float* g, const float* b, float* y, in
 }
 
 // ----------------------------------------------------------------------------- window attention
-__global__ __launch_bounds__(256) void window_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ bias,
-                                                          const float* __restrict__ mask, const int* __restrict__ out_map, float* __restrict__ out, int nPairs,
-                                                          int nWperImg, int C, int nH) {
-  __shared__ float4 kv[4][2][WS2 * 8];   // per wave: K then V, [49][32] as float4
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int pair = blockIdx.x * 4 + wave;
-  if (pair >= nPairs) return;   // whole wave exits; no block-wide barrier below
-  const int win = pair / nH, head = pair - win * nH;
-  const float* base = qkv + (long long)win * WS2 * 3 * C + head * HEAD_DIM;
-  float4* Kl = kv[wave][0];
-  float4* Vl = kv[wave][1];
-  // stage K and V: 8 lanes per row, 8 rows per pass
-  for (int r = lane >> 3; r < WS2; r += 8) {
-    int c4 = lane & 7;
-    Kl[r * 8 + c4] = *reinterpret_cast<const float4*>(base + (long long)r * 3 * C + C + c4 * 4);
-    Vl[r * 8 + c4] = *reinterpret_cast<const float4*>(base + (long long)r * 3 * C + 2 * C + c4 * 4);
-  }
-  const int i = lane < WS2 ? lane : WS2 - 1;   // idle lanes shadow the last row (results discarded)
-  float q[HEAD_DIM];
-  {
-    const float scale = 0.17677669529663687f;   // 32^-0.5
-    const float4* qp = reinterpret_cast<const float4*>(base + (long long)i * 3 * C);
-#pragma unroll
-    for (int d = 0; d < 8; ++d) {
-      float4 t = qp[d];
-      q[4 * d] = t.x * scale; q[4 * d + 1] = t.y * scale; q[4 * d + 2] = t.z * scale; q[4 * d + 3] = t.w * scale;
-    }
-  }
-  __builtin_amdgcn_s_waitcnt(0);   // LDS writes of this wave are complete before its reads (same wave: in order)
-  __builtin_amdgcn_wave_barrier();
-  const float* brow = bias + ((long long)head * WS2 + i) * WS2;
-  const float* mrow = mask ? mask + ((long long)(win % nWperImg) * WS2 + i) * WS2 : nullptr;
-  float sc[WS2];
-  float mx = -3.0e38f;
-#pragma unroll
-  for (int j = 0; j < WS2; ++j) {
-    float a = 0.f;
-#pragma unroll
-    for (int d = 0; d < 8; ++d) {
-      float4 k4 = Kl[j * 8 + d];
-      a = fmaf(q[4 * d], k4.x, a); a = fmaf(q[4 * d + 1], k4.y, a); a = fmaf(q[4 * d + 2], k4.z, a); a = fmaf(q[4 * d + 3], k4.w, a);
-    }
-    a += brow[j];
-    if (mrow) a += mrow[j];
-    sc[j] = a;
-    mx = fmaxf(mx, a);
-  }
-  float sum = 0.f;
-#pragma unroll
-  for (int j = 0; j < WS2; ++j) { sc[j] = expf(sc[j] - mx); sum += sc[j]; }
-  float o[HEAD_DIM];
-#pragma unroll
-  for (int d = 0; d < HEAD_DIM; ++d) o[d] = 0.f;
-#pragma unroll
-  for (int j = 0; j < WS2; ++j) {
-    const float pj = sc[j] / sum;
-#pragma unroll
-    for (int d = 0; d < 8; ++d) {
-      float4 v4 = Vl[j * 8 + d];
-      o[4 * d] = fmaf(pj, v4.x, o[4 * d]); o[4 * d + 1] = fmaf(pj, v4.y, o[4 * d + 1]);
-      o[4 * d + 2] = fmaf(pj, v4.z, o[4 * d + 2]); o[4 * d + 3] = fmaf(pj, v4.w, o[4 * d + 3]);
-    }
-  }
-  long long orow = (long long)win * WS2 + lane;
-  if (lane < WS2 && out_map) orow = out_map[orow];
-  if (lane < WS2 && orow >= 0) {
-    float4* op = reinterpret_cast<float4*>(out + orow * C + head * HEAD_DIM);
-#pragma unroll
-    for (int d = 0; d < 8; ++d) op[d] = make_float4(o[4 * d], o[4 * d + 1], o[4 * d + 2], o[4 * d + 3]);
-  }
-}
-
-// ---- MFMA variant: one wave per (window, head), no LDS, no barriers ---------------------------------------------------
+// ---- one wave per (window, head), no LDS, no barriers ---------------------------------------------------
 // Sᵀ = K·(s·Q)ᵀ and Oᵀ = Vᵀ·Pᵀ on v_mfma_f32_32x32x2_f32 with the 49 tokens padded to 2 x 32.  Computing the transposed
 // products puts the query on the lane and the keys in the accumulator registers, so (a) the softmax over keys is a
 // within-lane reduction plus one lane^32 exchange, and (b) the probability tile is already in B-operand position for the
@@ -537,11 +465,8 @@ int launch_window_attn(const float* qkv, const float* bias, const float* biasT, 
   ProfScope ps("window_attn", 4.0 * 49 * 49 * 32 * nWinTotal * nH, 16.0 * 49 * C * nWinTotal, s);
   int nPairs = nWinTotal * nH;
   if (nPairs <= 0) return 0;
-  static int use_mfma = -1;
-  if (use_mfma < 0) { const char* e = getenv("NUHTC_ATTN_VALU"); use_mfma = (e && atoi(e)) ? 0 : 1; }
-  if (use_mfma && biasT)
-    hipLaunchKernelGGL(window_attn_mfma_kernel, dim3(cdiv(nPairs, 4)), dim3(256), 0, s, qkv, biasT, mask, out_map, out, nPairs, nWperImg, C, nH);
-  else
-    hipLaunchKernelGGL(window_attn_kernel, dim3(cdiv(nPairs, 4)), dim3(256), 0, s, qkv, bias, mask, out_map, out, nPairs, nWperImg, C, nH);
+  if (!biasT) return NUHTC_E_INVALID;
+  (void)bias;
+  hipLaunchKernelGGL(window_attn_mfma_kernel, dim3(cdiv(nPairs, 4)), dim3(256), 0, s, qkv, biasT, mask, out_map, out, nPairs, nWperImg, C, nH);
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
 }

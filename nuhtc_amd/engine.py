@@ -86,6 +86,9 @@ class Engine:
     # ------------------------------------------------------------------ plumbing
     def _check(self, rc):
         if rc:
+            if not self.h:
+                raise HipError('this engine was closed (Engine.close(), or evicted from the Detector cache of max_engines sizes): '
+                               'ask the Detector for the engine again instead of keeping it')
             raise HipError(f'libnuhtc_hip error {rc}: {self.lib.nuhtc_last_error(self.h).decode()}')
 
     def close(self):
@@ -175,7 +178,10 @@ class Engine:
         behind the other batches in flight.  Read with export_read() once the stream (or an event recorded after this call) has
         completed.  The full 8 KB masks stay on the device (export_full_mask fetches one when a crop did not fit the pool)."""
         K, W = self.cfg.max_per_img, self.cfg.tile_h * (self.cfg.tile_w // 32)
-        cap = int(cap or min(self.cfg.max_batch * K, 96 * self.cfg.max_batch))
+        # default capacity: 96 kept detections per tile on average at the x2 resize of a 40x slide, scaled with the nuclei per tile at
+        # larger factors (20x slides: x4 -> four times the nuclei per 256-px tile); a batch over it falls back for that batch only
+        per_tile = 96 * max(1, int(round((float(self.cfg.scale_factor) / 2.0) ** 2)))
+        cap = int(cap or min(self.cfg.max_batch * K, per_tile * self.cfg.max_batch))
         pool = cap * int(crop_words_per_det)
         ex = getattr(self, '_ex', None)
         if ex is None or ex['cap'] != cap or ex['ccap'] != contour_cap or ex['pool'] != pool:

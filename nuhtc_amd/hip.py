@@ -39,7 +39,7 @@ class Dets(ctypes.Structure):
 EXPORTS = ['nuhtc_default_config', 'nuhtc_create', 'nuhtc_destroy', 'nuhtc_last_error', 'nuhtc_load_weight',
            'nuhtc_finalize', 'nuhtc_infer', 'nuhtc_infer_fixed_load', 'nuhtc_check', 'nuhtc_get_buffer',
            'nuhtc_op_gemm', 'nuhtc_op_gemm_split', 'nuhtc_op_roi_align', 'nuhtc_op_nms', 'nuhtc_profile_enable', 'nuhtc_profile_read', 'nuhtc_dev_knob', 'nuhtc_export_crops',
-           'nuhtc_mask_contours', 'nuhtc_merge_overlap', 'nuhtc_export_kept']
+           'nuhtc_mask_contours', 'nuhtc_merge_overlap', 'nuhtc_export_kept', 'nuhtc_clock_probe']
 
 _lib = None
 
@@ -76,6 +76,7 @@ def load():
     lib.nuhtc_export_kept.argtypes = [vp, ctypes.POINTER(Dets), ci, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.nuhtc_export_crops.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, ci, vp]
     lib.nuhtc_profile_enable.argtypes = [ci]
+    lib.nuhtc_clock_probe.argtypes = [ci, ctypes.c_uint64, vp, vp]
     lib.nuhtc_dev_knob.argtypes = [ctypes.c_char_p, ci]
     lib.nuhtc_profile_read.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
     for name in EXPORTS:
@@ -101,7 +102,9 @@ def profile_enable(on=True):
 
 def dev_knob(name, value):
     """Development: set a switch of the launch heuristics (NUHTC_<NAME>) at run time."""
-    load().nuhtc_dev_knob(name.encode(), int(value))
+    rc = load().nuhtc_dev_knob(name.encode(), int(value))
+    if rc:
+        raise RuntimeError('nuhtc_dev_knob: not a development build (NUHTC_EXTRA_CFLAGS=-DNUHTC_DEV python -m nuhtc_amd.build --force)')
 
 
 def profile_read():
@@ -115,3 +118,24 @@ def profile_read():
         tag, n, ms, fl, by = line.rsplit(' ', 4)
         out[tag] = dict(launches=int(n), ms=float(ms), flops=float(fl), bytes=float(by))
     return out
+
+
+class ClockProbe:
+    """Shader clock held while other kernels run: start() enqueues the one-wave probe on a stream of its own for `ms` milliseconds,
+    ghz() waits for it and returns cycles / reference ticks x 0.1 GHz."""
+
+    def __init__(self, device=0):
+        import torch
+        self.device = device
+        self.stream = torch.cuda.Stream(device=device)
+        self.out = torch.zeros(2, dtype=torch.int64, device=torch.device('cuda', device))
+
+    def start(self, ms):
+        rc = load().nuhtc_clock_probe(self.device, int(ms * 1e5), ctypes.c_void_p(self.out.data_ptr()), ctypes.c_void_p(self.stream.cuda_stream))
+        if rc:
+            raise RuntimeError(f'nuhtc_clock_probe failed ({rc})')
+
+    def ghz(self):
+        self.stream.synchronize()
+        c, r = (int(v) for v in self.out.cpu())
+        return 0.1 * c / r if r else None

@@ -13,9 +13,11 @@ def init_from_env(backend=None):
     world = int(os.environ.get('WORLD_SIZE', 1))
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if os.environ.get('NUHTC_ONE_DEVICE') == '1':       # test hook: several ranks on a one-GPU box (with NUHTC_DIST_BACKEND=gloo)
+        local_rank = 0
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
+        backend = backend or os.environ.get('NUHTC_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend, device_id=torch.device('cuda', local_rank))
@@ -59,6 +61,8 @@ def gather_blobs(parts, group=None):
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return [parts]
     world = dist.get_world_size(group)
+    if dist.get_backend(group) == 'gloo':       # gloo moves host memory: hand it host tensors
+        parts = [p.cpu() for p in parts]
     dev = parts[0].device
     head = torch.tensor([p.shape[0] for p in parts], dtype=torch.int64, device=dev)
     heads = [torch.zeros_like(head) for _ in range(world)]

@@ -172,12 +172,13 @@ def _unpack(eng, B, i0, coords, P, rec, exported=False):
     # (stable descending sort by score of the class-major list); tiles ascending
     cls_major = np.lexsort((slot, labels, tile))
     order = cls_major[np.lexsort((np.arange(n), boxes[cls_major, 4], -tile[cls_major]))[::-1]]
-    W = P // 32
+    P, PW = eng.cfg.tile_h, eng.cfg.tile_w          # mask buffers: tile_h rows of tile_w / 32 words (tile_w = width padded to 32)
+    W = PW // 32
     for k in order:
         b, bx = int(tile[k]), boxes[k]
         # a pasted mask lives inside the integer hull of its box (fcn_mask_head.py:344-412): unpack only those rows
         hy0, hy1 = max(int(np.floor(bx[1])) - 1, 0), min(int(np.ceil(bx[3])) + 1, P)
-        hx0, hx1 = max(int(np.floor(bx[0])) - 1, 0), min(int(np.ceil(bx[2])) + 1, P)
+        hx0, hx1 = max(int(np.floor(bx[0])) - 1, 0), min(int(np.ceil(bx[2])) + 1, PW)
         if hy1 <= hy0 or hx1 <= hx0:
             continue
         rows_w = g['words'][k].reshape(P, W)[hy0:hy1]
@@ -210,7 +211,6 @@ def infer_tiles(model, tiles, coords, batch_size=16, depth=4):
     (n+1,2) int64 contour in slide px, traced on the GPU: nuhtc_mask_contours))."""
     import torch
     P = tiles.shape[1]
-    rec = dict(tile=[], box=[], score=[], label=[], mask=[], ring=[])
     parts = []
     pipe = model.pipeline(tiles.shape[1:3], depth)
 
@@ -218,13 +218,16 @@ def infer_tiles(model, tiles, coords, batch_size=16, depth=4):
         eng, B, stream, i0 = pipe.collect()
         with torch.cuda.stream(stream):
             g = eng.export_read()
-            if g is not None and not rec['tile']:
+            if g is not None:
                 if g['n']:
                     _unpack_packed(eng, g, i0, coords, parts)      # device crops: whole-batch array operations
-            else:                                                 # more kept detections than the export buffers hold: per-detection path
-                if parts:
-                    _extend(rec, _records_from_parts(parts)); parts.clear()
-                _unpack(eng, B, i0, coords, P, rec, exported=False)
+            else:
+                # this batch alone held more kept detections than the export buffers: its records come through the per-detection
+                # path and join the others as one more part (later batches keep the packed path)
+                one = dict(tile=[], box=[], score=[], label=[], mask=[], ring=[])
+                _unpack(eng, B, i0, coords, P, one, exported=False)
+                if one['tile']:
+                    parts.append(_part_from_lists(one))
 
     for i in range(0, len(tiles), batch_size):
         if pipe.full():
@@ -232,11 +235,21 @@ def infer_tiles(model, tiles, coords, batch_size=16, depth=4):
         pipe.submit(tiles[i:i + batch_size], hip.CH_SWAP, tag=i, export=True)
     while pipe.pending:
         finish()
-    if parts and not rec['tile']:
-        return _records_from_parts(parts)
-    if parts:
-        _extend(rec, _records_from_parts(parts))
-    return rec
+    return _records_from_parts(parts)
+
+
+def _part_from_lists(rec):
+    """List-form records of one batch (the per-detection path) -> the array form _unpack_packed produces."""
+    n = len(rec['tile'])
+    cb, area, bits, off = pack_masks(rec['mask'])
+    sizes = (cb[:, 3] - cb[:, 1]).astype(np.int64) * ((cb[:, 2] - cb[:, 0] + 31) // 32)
+    ring_n = np.array([len(r) for r in rec['ring']], np.int64)
+    ring_xy = np.zeros((n, int(ring_n.max()), 2), np.int64)
+    for i, r in enumerate(rec['ring']):
+        ring_xy[i, :len(r)] = r
+    return dict(tile=np.asarray(rec['tile'], np.int64), box=np.stack(rec['box']).astype(np.float64), score=np.asarray(rec['score'], np.float64),
+                label=np.asarray(rec['label'], np.int64), crop_box=cb.astype(np.int32), area=area.astype(np.int32),
+                bits=bits[:int(sizes.sum())], sizes=sizes, ring_n=ring_n, ring_xy=ring_xy)
 
 
 def _extend(rec, more):

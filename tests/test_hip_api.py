@@ -291,3 +291,81 @@ def test_real_checkpoint_parity_script(hip_device, tmp_path):
                        cwd=ROOT, capture_output=True, text=True, timeout=600)
     print(r.stdout[-1500:])
     assert r.returncode == 0 and 'PARITY OK' in r.stdout, r.stderr[-1500:]
+
+
+def _two_rank_env():
+    """Two ranks on a one-GPU box: both on device 0, gloo instead of RCCL (RCCL refuses two ranks on one device)."""
+    env = dict(os.environ)
+    env.update(NUHTC_ONE_DEVICE='1', NUHTC_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='4')
+    return env
+
+
+def test_infer_wsi_two_ranks_equal_one_rank_byte_for_byte(hip_device, tmp_path):
+    """The multi-rank path end to end (north star: tiles sharded across ranks, one gather, merge on rank 0): tools/infer_wsi.py as
+    two processes under torch.distributed.run writes the same files as one process, byte for byte -- per-tile GeoJSON, point
+    GeoJSON and the merged slide -- and each rank cut only its own tiles (lazy sharded reads of the memory-mapped slide)."""
+    import subprocess
+    import sys
+    import torch
+    from nuhtc_amd import synth, weights
+    img = np.concatenate([np.concatenate([synth.nuclei_tile(40 + 3 * r + c, 128) for c in range(3)], 1) for r in range(2)], 0)   # 256 x 384
+    src = tmp_path / 'slide.npy'
+    np.save(src, img)
+    ck = tmp_path / 'w.pth'
+    torch.save(dict(state_dict=weights.bench_state_dict(0, obj_bias=0.0)), ck)
+    common = [os.path.join(ROOT, 'tools/infer_wsi.py'), str(src), CFG, str(ck), '--patch_size', '64', '--step_size', '48', '--batch_size', '4',
+              '--merge', '--mode', 'qupath']
+    subprocess.check_call([sys.executable] + common + ['--save_dir', str(tmp_path / 'one')])
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                          '--master-port', '29731'] + common + ['--save_dir', str(tmp_path / 'two')], env=_two_rank_env(),
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    print(out.stdout[-2000:])
+    assert out.returncode == 0
+    assert '48 tiles on 2 rank(s)' in out.stdout
+    for f in ('slide.geojson', 'slide_point.geojson', 'slide_merged.geojson'):
+        a = open(tmp_path / 'one/nuclei/slide' / f, 'rb').read()
+        b = open(tmp_path / 'two/nuclei/slide' / f, 'rb').read()
+        assert len(a) > 1000 and a == b, f
+
+
+def test_bench_launches_its_own_ranks(hip_device):
+    """`python bench.py --gpus 2` without a launcher: bench.py starts the two ranks itself (children under torch.distributed.run),
+    relays rank 0's JSON line and exits 0; the line says n_gpus 2, both ranks came back through the gather, and the whole-job value
+    counts both ranks' tiles.  (Both ranks share the one GPU of the test box, over gloo: the rate itself means nothing here.)"""
+    import json
+    import subprocess
+    import sys
+    env = _two_rank_env()
+    env.pop('WORLD_SIZE', None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--no-settle', '--no-fp32-pipe',
+                          '--no-roi-load', '--batch', '4'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    print(out.stderr[-3000:])
+    assert out.returncode == 0
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['exchange']['ranks_seen'] == [0, 1] and d['scaling'] == 'weak' and 'cpu_baseline' not in d
+    assert abs(d['value'] - 2 * 4 * 3 / (d['ms_per_step'] * 3e-3)) < 1e-6 * d['value']
+
+
+def test_batch_64_slide_equals_batch_8(hip_device, tmp_path):
+    """BASELINE configs[4]'s shape (tools/infer_wsi.py, patch 256, step 192, batch_size 64): a pipeline of four max_batch=64 engines over
+    a 12 x 12-tile slide gives, record for record, what batch_size 8 gives (tiles are independent: the batch size is a throughput
+    knob, tools/infer_wsi.py:466-476), through the CLI with --merge."""
+    import subprocess
+    import sys
+    import torch
+    from nuhtc_amd import synth, weights
+    G = 12
+    full, _ = synth.nuclei_canvas(G)
+    src = tmp_path / 'slide.npy'
+    np.save(src, full)
+    ck = tmp_path / 'w.pth'
+    torch.save(dict(state_dict=weights.bench_state_dict(0)), ck)
+    outs = {}
+    for bs in (64, 8):
+        subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools/infer_wsi.py'), str(src), CFG, str(ck), '--patch_size', '256', '--step_size', '192',
+                               '--batch_size', str(bs), '--save_dir', str(tmp_path / f'b{bs}'), '--merge'])
+        outs[bs] = {f: open(tmp_path / f'b{bs}/nuclei/slide' / f, 'rb').read() for f in ('slide.geojson', 'slide_merged.geojson')}
+    assert len(outs[64]['slide.geojson']) > 100000
+    assert outs[64] == outs[8]

@@ -128,3 +128,71 @@ def test_dense_stages_vs_oracle_and_golden(hip_device, case):
     _cmp('sem_feat', eng.buffer('sem_feat')[:B].permute(0, 3, 1, 2), sf, errs, 5e-4, 5e-4)
     G.check_sub(g, 'sem_feat', eng.buffer('sem_feat')[:B].permute(0, 3, 1, 2).contiguous(), 2e-3, 2e-3)
     assert not errs, '\n'.join(errs)
+
+
+def _split_vs_fp32(eng, A, W, label, max_rel, rms_ratio=1.25):
+    """Both pipes on the same operands against fp64; errors relative to sum_k |a_k b_k| (per output), printed class by class."""
+    ref = A.double() @ W.double().T
+    mag = A.double().abs() @ W.double().abs().T
+    e = {}
+    for pipe in ('fp32', 'split'):
+        out = eng.op_gemm(A.cuda(), W.cuda(), None, 0, pipe=pipe).cpu().double()
+        assert torch.isfinite(out).all(), (label, pipe)
+        err = (out - ref).abs() / mag
+        e[pipe] = (float(err.max()), float((err ** 2).mean().sqrt()))
+    print(f"{label}: fp32 mfma max {e['fp32'][0]:.2e} rms {e['fp32'][1]:.2e} | split max {e['split'][0]:.2e} rms {e['split'][1]:.2e}")
+    assert e['split'][0] <= max_rel, (label, e)
+    assert e['split'][1] <= rms_ratio * e['fp32'][1] + 1e-9, (label, e)
+    return e
+
+
+def test_split_pipe_hard_operand_classes(hip_device):
+    """The classes a 'this is fp32 arithmetic' claim has to survive: catastrophic cancellation, operands whose
+    first round-to-nearest split crosses a binade, third planes that are subnormal, the top of the exponent range, and Inf / NaN
+    propagation -- split pipe beside the fp32 MFMA chain, both against fp64, class by class."""
+    g = G.load('small_b2')
+    eng, _ = _engine(g)
+    gen = torch.Generator().manual_seed(11)
+    M, N, K = 256, 96, 384
+    # (1) cancellation: pairs (a, a) x (w, -w (1 + d)), d ~ 1e-6: sum a*b ~ 1e-6 of sum |a*b|.  The error is measured against
+    # sum |a*b| (the only bound any fp32 summation has); what must hold is that the split pipe does not lose the small net sum's
+    # leading digits more than the fp32 chain does
+    a = torch.randn(M, K // 2, generator=gen)
+    w = torch.randn(N, K // 2, generator=gen)
+    d = 1e-6 * torch.randn(N, K // 2, generator=gen)
+    A = torch.stack([a, a], 2).reshape(M, K)
+    W = torch.stack([w, -w * (1 + d)], 2).reshape(N, K)
+    _split_vs_fp32(eng, A, W, 'cancellation (net sum ~1e-6 of sum|ab|)', 4e-7)
+    # (2) first split rounds up across a binade: values just below a power of two (a1 = 2^k, negative residual planes)
+    k2 = torch.randint(-6, 7, (M, K), generator=gen).float()
+    A = torch.exp2(k2) * (2.0 - torch.rand(M, K, generator=gen) * 2e-3) * (torch.randint(0, 2, (M, K), generator=gen) * 2 - 1)
+    W = torch.exp2(torch.randint(-6, 7, (N, K), generator=gen).float()) * (2.0 - torch.rand(N, K, generator=gen) * 2e-3)
+    _split_vs_fp32(eng, A, W, 'just below powers of two (split rounds up a binade)', 4e-7)
+    # (3) subnormal third planes: |a| ~ 2^-110 puts a3 ~ 2^-126 .. 2^-134 below the smallest normal bf16 / fp32; the products
+    # (~2^-110) and the results are normal numbers
+    A = torch.randn(M, K, generator=gen) * 2.0 ** -110
+    W = torch.randn(N, K, generator=gen)
+    _split_vs_fp32(eng, A, W, 'third plane of A subnormal (|a| ~ 2^-110)', 4e-7)
+    A = torch.randn(M, K, generator=gen)
+    W = torch.randn(N, K, generator=gen) * 2.0 ** -110
+    _split_vs_fp32(eng, A, W, 'third plane of W subnormal (|w| ~ 2^-110)', 4e-7)
+    # (4) top of the range: |a| up to the largest bf16 (0x7f7f0000 = 3.3895e38; above it the first split rounds to Inf, a documented
+    # domain limit of the pipe), weights small enough that the sums stay finite
+    A = (torch.rand(M, K, generator=gen) * 0.5 + 0.5) * 3.38e38 * (torch.randint(0, 2, (M, K), generator=gen) * 2 - 1)
+    W = torch.randn(N, K, generator=gen) * 1e-4
+    _split_vs_fp32(eng, A, W, 'top binade (|a| up to 3.38e38)', 4e-7)
+    # (5) Inf / NaN: a non-finite operand makes exactly the outputs it touches non-finite on both pipes (an Inf may come out as NaN on
+    # the split pipe: Inf - bf16(Inf) is NaN in the residual planes), every other output stays finite and accurate
+    A = torch.randn(M, K, generator=gen)
+    W = torch.randn(N, K, generator=gen)
+    A[3, 5] = float('inf'); A[100, 17] = float('-inf'); A[200, 300] = float('nan')
+    W[7, 9] = float('nan'); W[50, 383] = float('inf')
+    ref = torch.nan_to_num(A, nan=0.0, posinf=0.0, neginf=0.0).double() @ torch.nan_to_num(W, nan=0.0, posinf=0.0, neginf=0.0).double().T
+    bad = torch.zeros(M, N, dtype=torch.bool)
+    bad[[3, 100, 200], :] = True
+    bad[:, [7, 50]] = True
+    for pipe in ('fp32', 'split'):
+        out = eng.op_gemm(A.cuda(), W.cuda(), None, 0, pipe=pipe).cpu()
+        assert torch.equal(~torch.isfinite(out), bad), pipe
+        err = ((out.double() - ref).abs() / (A.double().abs().nan_to_num(0, 0, 0) @ W.double().abs().nan_to_num(0, 0, 0).T))[~bad]
+        assert float(err.max()) <= 4e-7, (pipe, float(err.max()))

@@ -5,9 +5,11 @@
                                --margin 2 --min_area 10 --save_dir out --mode qupath]
     python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/infer_wsi.py ...   (one rank per GPU)
 
-<source>: .npy image (H,W,3) uint8 that is tiled on a grid (np.arange(0, size, step), zero padded; with --seg only the
-tissue found by nuhtc_amd.tissue is tiled, as the reference's seg_and_patch does), or .npz with
-`tiles` (N,P,P,3) and `coords` (N,2).  OpenSlide reading is out of scope (no openslide offline).
+<source>: .npy image (H,W,3) uint8 (memory-mapped) that is tiled on a grid (np.arange(0, size, step), zero padded; with --seg only the
+tissue found by nuhtc_amd.tissue is tiled, as the reference's seg_and_patch does; with --coords the given level-0 origins, the role
+of the reference's patches/<name>.h5), a store directory (nuhtc_amd.tilestore.write_store), or .npz with `tiles` (N,P,P,3) and
+`coords` (N,2).  Every rank cuts only the tiles of its own shard.  OpenSlide / HDF5 reading is out of scope (neither library
+exists offline).
 Output (like the reference, :659-693), for every detection that survives the per-tile filter + mask-NMS:
   --mode qupath : <save_dir>/nuclei/<name>/<name>.geojson and <name>_point.geojson (flat lists of QuPath features); run
                   tools/nuclei_merge.py on the .geojson for the cross-tile merge (or pass --merge to do it here on rank 0)
@@ -41,6 +43,7 @@ def parse_args():
     p.add_argument('--mode', default='qupath', choices=['qupath', 'dsa', 'coco', 'sql', 'all'])
     p.add_argument('--seg', action='store_true', help='segment tissue first and tile only the tissue contours (reference --seg --patch)')
     p.add_argument('--seg_downsample', type=int, default=64, help='downsample factor of the segmentation level (reference: pyramid level nearest 64x)')
+    p.add_argument('--coords', default=None, help='coordinate file of a .npy slide: .npy (N,2) or .npz with `coords` [+ `patch_size`] -- the role of the reference\'s patches/<name>.h5')
     p.add_argument('--merge', action='store_true', help='also run the cross-tile merge (nuclei_merge.py) on rank 0')
     p.add_argument('--overlap_threshold', type=float, default=0.05)
     p.add_argument('--save_dir', default='wsi_out')
@@ -53,19 +56,25 @@ def main():
     from nuhtc_amd import contours, parallel, wsi
     from nuhtc_amd.apis import init_detector
     rank, local_rank, world = parallel.init_from_env()
-    if args.source.endswith('.npz'):
-        z = np.load(args.source)
-        tiles, coords = z['tiles'], z['coords']
-    elif args.seg:
-        from nuhtc_amd import tissue
-        slide = np.load(args.source)
-        coords, conts, _ = tissue.tissue_tile_coords(slide, args.patch_size, args.step_size, scale=args.seg_downsample)
-        tiles = tissue.read_tiles(slide, coords, args.patch_size)
-        if rank == 0:
-            print(f'tissue segmentation: {len(conts)} contour(s), {len(coords)} tiles')
-    else:
-        tiles, coords = wsi.tile_grid(np.load(args.source), args.patch_size, args.step_size)
-    lo, hi = parallel.shard_range(len(tiles), rank, world)
+    # tile source with per-rank lazy reads (nuhtc_amd.tilestore): the slide stays memory-mapped, every rank knows all
+    # coordinates (16 bytes per tile) and cuts only the tiles of its own shard; tissue segmentation runs on rank 0 only
+    from nuhtc_amd import tilestore
+    coords_fn = None
+    if args.seg:
+        def coords_fn(slide):
+            c = [None]
+            if rank == 0:
+                from nuhtc_amd import tissue
+                c[0], conts, _ = tissue.tissue_tile_coords(slide, args.patch_size, args.step_size, scale=args.seg_downsample)
+                print(f'tissue segmentation: {len(conts)} contour(s), {len(c[0])} tiles')
+            if world > 1:
+                import torch.distributed as dist
+                dist.broadcast_object_list(c, src=0)
+            return c[0]
+    bag = tilestore.open_source(args.source, args.patch_size, args.step_size, coords=args.coords, coords_fn=coords_fn)
+    coords = bag.coords
+    lo, hi = parallel.shard_range(len(bag), rank, world)
+    tiles = bag.read(lo, hi)                                  # this rank's tiles only
     from nuhtc_amd.config import Config, set_test_scale_factor
     cfg = Config.fromfile(args.config)
     sf = set_test_scale_factor(cfg, args.mag)          # reference :416-419: scale_factor = 80 / mag
@@ -74,13 +83,13 @@ def main():
     model = init_detector(cfg, args.checkpoint, device=f'cuda:{local_rank}' if world > 1 else args.device, max_batch=args.batch_size)
     model.CLASSES = ('T', 'I', 'C', 'D', 'E')[:model.opts['num_classes']]
     model.opts.update(margin=args.margin, min_area=args.min_area, mask_nms_thr=0.05)
-    rec = wsi.infer_tiles(model, tiles[lo:hi], coords[lo:hi], args.batch_size)
+    rec = wsi.infer_tiles(model, tiles, coords[lo:hi], args.batch_size)
     # contours are traced on the rank that owns the tile; two variable-length gathers: records, then ring vertices
     rings = rec['ring']                                              # traced on the GPU (nuhtc_mask_contours)
     keep = [i for i, r in enumerate(rings) if len(r) >= 4]          # reference drops contours with < 3 points (:536)
     n = len(keep)
     want = lambda m: args.mode in (m, 'all')
-    P = tiles.shape[1]
+    P = bag.patch_size
     rles = []
     if want('coco'):                                                  # RLE of the instance inside its tile (:611-613)
         from nuhtc_amd import cocomask
@@ -98,7 +107,7 @@ def main():
     bparts = [g[4] if want('coco') else None for g in gathered]
     if rank == 0:
         from nuhtc_amd import outputs
-        name = os.path.splitext(os.path.basename(args.source))[0]
+        name = os.path.splitext(os.path.basename(os.path.normpath(args.source)))[0]
         out_dir = os.path.join(args.save_dir, 'nuclei', name)
         os.makedirs(out_dir, exist_ok=True)
         feats, points, dsa, annts, per_tile = [], [], [], [], {}
@@ -127,7 +136,7 @@ def main():
                                   'iscrowd': 0, 'segmentation': rle})
                 if sql:
                     sql.add(annidx, elementidx, ring, label, score, model.CLASSES)
-        msg = f'{len(tiles)} tiles on {world} rank(s): {sum(len(v) for v in per_tile.values())} nuclei after per-tile mask-NMS'
+        msg = f'{len(bag)} tiles on {world} rank(s): {sum(len(v) for v in per_tile.values())} nuclei after per-tile mask-NMS'
         if want('qupath'):
             outputs.write_json(os.path.join(out_dir, name + '.geojson'), feats)
             outputs.write_json(os.path.join(out_dir, name + '_point.geojson'), points)
@@ -145,7 +154,7 @@ def main():
             imgs = []
             for annidx in sorted(per_tile):
                 imgs.append(outputs.coco_tile_image(annidx, P, P, per_tile[annidx], model.CLASSES))
-                Image.fromarray(tiles[annidx]).save(os.path.join(img_dir, f'{annidx}.png'))
+                Image.fromarray(bag[annidx][0]).save(os.path.join(img_dir, f'{annidx}.png'))
             outputs.write_json(os.path.join(out_dir, 'coco_nuclei.json'),
                                {'images': imgs, 'annotations': annts, 'categories': outputs.coco_categories(model.CLASSES)})
         if sql:
