@@ -172,7 +172,8 @@ def _unpack(eng, B, i0, coords, P, rec, exported=False):
     # (stable descending sort by score of the class-major list); tiles ascending
     cls_major = np.lexsort((slot, labels, tile))
     order = cls_major[np.lexsort((np.arange(n), boxes[cls_major, 4], -tile[cls_major]))[::-1]]
-    P, PW = eng.cfg.tile_h, eng.cfg.tile_w          # mask buffers: tile_h rows of tile_w / 32 words (tile_w = width padded to 32)
+    cfg = getattr(eng, 'cfg', None)                 # mask buffers: tile_h rows of tile_w / 32 words (tile_w = width padded to 32)
+    P, PW = (cfg.tile_h, cfg.tile_w) if cfg is not None else (P, P)
     W = PW // 32
     for k in order:
         b, bx = int(tile[k]), boxes[k]
