@@ -215,6 +215,11 @@ int nuhtc_op_gemm(nuhtc_engine* e, const float* A, const float* W, const float* 
  * split of a constant weight is made on the host, as at nuhtc_finalize).  Synchronises `stream`. */
 int nuhtc_op_gemm_split(nuhtc_engine* e, const float* A, const float* W_dev, const float* W_host, const float* bias, float* C, int M,
                         int N, int K, int act, void* stream);
+/* The fused FFN half of a Swin block (csrc/mlp.hip; mmdet swin.py:365-367): out[T,C] = x + W2 gelu(W1 LN(x) + b1) + b2 with
+ * LN = LayerNorm(C, eps 1e-5, ln_g, ln_b), W1 [4C][C], W2 [C][4C] given as HOST arrays (packed like nuhtc_finalize packs them),
+ * everything else device memory.  C must be a width the fused kernel serves (96).  Synchronises `stream`. */
+int nuhtc_op_swin_mlp(nuhtc_engine* e, const float* x_dev, const float* ln_g_dev, const float* ln_b_dev, const float* w1_host,
+                      const float* b1_dev, const float* w2_host, const float* b2_dev, float* out_dev, int T, int C, void* stream);
 /* mmcv RoIAlign(avg, aligned=True) on an NHWC map: feat [N,H,W,C=64], rois [R,5] -> out [R,P,P,C]. */
 int nuhtc_op_roi_align(nuhtc_engine* e, const float* feat_nhwc, int N, int H, int W, const float* rois, int R, int P,
                        float spatial_scale, int sampling_ratio, float* out, void* stream);

@@ -18,8 +18,15 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
 
 
+def _flags():
+    return ' '.join(f'{k}={os.environ[k]}' for k in sorted(os.environ) if k.startswith('NUHTC_EXTRA_CFLAGS'))
+
+
 def needs_build():
     if not os.path.exists(LIB):
+        return True
+    stamp = os.path.join(HERE, 'build', 'flags.txt')       # a library built with other extra flags (a -DNUHTC_DEV build) is rebuilt
+    if (open(stamp).read() if os.path.exists(stamp) else '') != _flags():
         return True
     t = os.path.getmtime(LIB)
     deps = sources() + glob.glob(os.path.join(CSRC, '*.h')) + [os.path.join(HERE, '..', 'include', 'nuhtc_hip.h')]
@@ -51,6 +58,8 @@ def build(force=False, verbose=False):
             print(out.decode())
     cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB]
     subprocess.check_call(cmd)
+    with open(os.path.join(objdir, 'flags.txt'), 'w') as f:
+        f.write(_flags())
     return LIB
 
 

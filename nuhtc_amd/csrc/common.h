@@ -105,6 +105,14 @@ void gemm_unregister_split(const float* w_dev);
 int gemm_make_split(const float* w_host, int N, int K, void** out_dev);      // unregistered split (caller hipFree()s it)
 const void* gemm_find_split(const float* w_dev, int N, int K);
 
+// ----------------------------------------------------------------------------- fused FFN half of a Swin block (mlp.hip)
+// x_out = x_in + W2 gelu(W1 LN(x_in) + b1) + b2 in one kernel on the split-bf16 pipe; `wstream` from mlp_pack_stream (device copy)
+bool mlp_supported(int C);
+size_t mlp_stream_bytes(int C);
+void mlp_pack_stream(const float* w1, const float* w2, int C, std::vector<unsigned short>& out);
+int launch_swin_mlp(const float* x_in, float* x_out, const float* ln_g, const float* ln_b, const void* wstream, const float* b1, const float* b2,
+                    int T, int C, hipStream_t s);
+
 // ----------------------------------------------------------------------------- contours (contour.hip)
 // outer contour (cv2 RETR first contour, CHAIN_APPROX_SIMPLE) of every kept instance mask; n: 0 = none, -1 = overflow
 int launch_contours(const uint32_t* masks, const uint8_t* keep, const int32_t* counts, int B, int max_per_img, int H, int W,

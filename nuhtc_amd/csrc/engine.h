@@ -14,6 +14,7 @@ struct StageGeom {
 
 struct BlockW {
   float *n1g, *n1b, *relb, *relbT, *qkv_w, *qkv_b, *proj_w, *proj_b, *n2g, *n2b, *f1_w, *f1_b, *f2_w, *f2_b;
+  void* mlp_stream;    // fused FFN half (mlp.hip): chunk-major split planes of f1_w / f2_w, null where the three separate launches run
 };
 
 struct nuhtc_engine {

@@ -327,6 +327,12 @@ int nuhtc_finalize(nuhtc_engine* e) {
           (rc = upload_gemm_weight(e, &bw.f1_w, f1w->data, 4 * C, C)) || (rc = upload(e, &bw.f1_b, f1b->data)) || (rc = upload_gemm_weight(e, &bw.f2_w, f2w->data, C, 4 * C)) ||
           (rc = upload(e, &bw.f2_b, f2b->data)))
         return rc;
+      if (e->cfg.matrix_pipe == NUHTC_PIPE_BF16_SPLIT && mlp_supported(C)) {
+        std::vector<unsigned short> st;
+        mlp_pack_stream(f1w->data.data(), f2w->data.data(), C, st);
+        if ((rc = dev_alloc(e, &bw.mlp_stream, st.size() * 2))) return rc;
+        HIP_CHECK(e, hipMemcpy(bw.mlp_stream, st.data(), st.size() * 2, hipMemcpyHostToDevice));
+      }
       e->blocks[s].push_back(bw);
     }
     {
@@ -488,6 +494,10 @@ int run_backbone(nuhtc_engine* e, int B, hipStream_t s) {
         RUN(launch_gemm(p, s));
       }
       // x += W2·gelu(W1·LN2(x))      (swin.py:365-367, mmcv FFN)
+      static const int& fused_mlp = dev_knob_ref("FUSED_MLP", 1);
+      if (w.mlp_stream && fused_mlp) {      // one kernel: LN2, both linears, GELU and the residual (mlp.hip)
+        RUN(launch_swin_mlp(x, x, w.n2g, w.n2b, w.mlp_stream, w.f1_b, w.f2_b, T, C, s));
+      } else {
       RUN(launch_layernorm(x, nullptr, w.n2g, w.n2b, e->xw, T, C, s));
       {
         GemmParams p = gp(e->xw, w.f1_w, w.f1_b, e->hid, T, 4 * C, C);
@@ -498,6 +508,7 @@ int run_backbone(nuhtc_engine* e, int B, hipStream_t s) {
         GemmParams p = gp(e->hid, w.f2_w, w.f2_b, x, T, C, 4 * C);
         p.res = x; p.ldr = C;
         RUN(launch_gemm(p, s));
+      }
       }
       if (e->debug_tokens) {
         auto it = e->bufs.find("tok_s" + std::to_string(st) + "b" + std::to_string(b));
@@ -717,5 +728,23 @@ int nuhtc_op_gemm_split(nuhtc_engine* e, const float* A, const float* W_dev, con
   hipFree(sp);
   if (rc) FAIL(e, rc, "gemm launch failed (K%32, N%32 required)");
   if (he != hipSuccess) FAIL(e, NUHTC_E_HIP, "gemm kernel failed");
+  return 0;
+}
+
+int nuhtc_op_swin_mlp(nuhtc_engine* e, const float* x_dev, const float* ln_g_dev, const float* ln_b_dev, const float* w1_host, const float* b1_dev,
+                      const float* w2_host, const float* b2_dev, float* out_dev, int T, int C, void* stream) {
+  if (!e || !x_dev || !ln_g_dev || !ln_b_dev || !w1_host || !b1_dev || !w2_host || !b2_dev || !out_dev || T < 1) return NUHTC_E_INVALID;
+  if (!mlp_supported(C)) FAIL(e, NUHTC_E_INVALID, "nuhtc_op_swin_mlp: unsupported channel count");
+  HIP_CHECK(e, hipSetDevice(e->device));
+  std::vector<unsigned short> st;
+  mlp_pack_stream(w1_host, w2_host, C, st);
+  void* d = nullptr;
+  HIP_CHECK(e, hipMalloc(&d, st.size() * 2));
+  if (hipMemcpy(d, st.data(), st.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { hipFree(d); FAIL(e, NUHTC_E_HIP, "weight stream upload failed"); }
+  int rc = launch_swin_mlp(x_dev, out_dev, ln_g_dev, ln_b_dev, d, b1_dev, b2_dev, T, C, (hipStream_t)stream);
+  hipError_t he = hipStreamSynchronize((hipStream_t)stream);
+  hipFree(d);
+  if (rc) FAIL(e, rc, "swin_mlp launch failed");
+  if (he != hipSuccess) FAIL(e, NUHTC_E_HIP, "swin_mlp kernel failed");
   return 0;
 }

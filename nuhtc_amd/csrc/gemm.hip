@@ -14,31 +14,7 @@
 
 #include "common.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float v4f __attribute__((ext_vector_type(4)));
-
-// erf-GELU (torch.nn.GELU default, mmcv FFN act_cfg).  erf by the clamped odd rational x·P(x²)/Q(x²) (degrees 6 / 4 in x²:
-// 11 fma + 1 rcp), max abs error 4.5e-7 over all floats -- half the instructions of the libm erff, which was 10-15 % of
-// the FFN fc1 launches at K = 96..192.
-__device__ __forceinline__ float gelu_erf(float v) {
-  float x = v * 0.70710678118654752440f;
-  x = fminf(fmaxf(x, -4.0f), 4.0f);
-  const float x2 = x * x;
-  float pn = -2.72614225801306e-10f;
-  pn = fmaf(pn, x2, 2.77068142495902e-08f);
-  pn = fmaf(pn, x2, -2.10102402082508e-06f);
-  pn = fmaf(pn, x2, -5.69250639462346e-05f);
-  pn = fmaf(pn, x2, -7.34990630326855e-04f);
-  pn = fmaf(pn, x2, -2.95459980854025e-03f);
-  pn = fmaf(pn, x2, -1.60960333262415e-02f);
-  float qd = -1.45660718464996e-05f;
-  qd = fmaf(qd, x2, -2.13374055278905e-04f);
-  qd = fmaf(qd, x2, -1.68282697438203e-03f);
-  qd = fmaf(qd, x2, -7.37332916720468e-03f);
-  qd = fmaf(qd, x2, -1.42647390514189e-02f);
-  const float e = x * pn * __builtin_amdgcn_rcpf(qd);
-  return 0.5f * v * (1.0f + e);
-}
+#include "split_math.h"   // vector typedefs, gelu_erf, the bf16 split helpers
 
 // ---- epilogue shared by the fp32 and the split-bf16 main loops
 template <int MT, int NT, int WM, int WN>
@@ -446,15 +422,6 @@ __global__ __launch_bounds__(256, (MT * NT <= 3 ? 4 : 3)) void gemm_kernel(GemmP
 //   A stays fp32 in HBM and LDS (same staging as the fp32 kernel, implicit 3x3-conv loader included) and is split in
 //   registers after the fragment read: 44 VALU instructions per k-tile and wave beside 6*NT MFMAs.
 // Block = 4 waves x 32 rows, NT column tiles of 32, BK = 16, double-buffered LDS, one barrier per k-tile; epilogue shared.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ unsigned pk_bf16_rn(float lo, float hi) {   // two floats -> packed bf16 (round to nearest even)
-  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-  bf2 v = {(__bf16)lo, (__bf16)hi};
-  return __builtin_bit_cast(unsigned, v);
-}
-
 template <int MT, int NT, int AMODE>
 __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void gemm_split_kernel(GemmParams p) {
   constexpr int WM = 4, WN = 1, BK = 16;

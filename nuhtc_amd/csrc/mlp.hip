@@ -1,0 +1,307 @@
+// Fused FFN half of a Swin block:  x <- x + W2 · gelu(W1 · LN2(x) + b1) + b2      (mmdet swin.py:365-367, mmcv FFN; LN = norm2)
+// in ONE kernel: the 4C-wide hidden tensor never leaves the CU, LN2 is computed on the token tile the product reads, and the
+// operand split of the activations is done once per token tile instead of once per column-tile pass.  HBM traffic per token:
+// x read (+ a second, cache-served read for the residual) and x written, against LN2 (r + w) + fc1 (r + 4 w) + fc2 (4 r + r + w)
+// of the three separate launches.
+//
+// Arithmetic: the same exact three-way bf16 split as gemm_split_kernel (six v_mfma_f32_32x32x16_bf16 per 16-deep step, fp32
+// accumulation).  Both products are computed TRANSPOSED, with the token on the lane:
+//     Hᵀ[32 hidden][32 tokens] = W1[chunk] · Xnᵀ           A operand = W1 rows (LDS), B operand = the token tile's planes (registers)
+//     Outᵀ[C][32 tokens]      += W2[:, chunk] · gelu(Hᵀ)    A operand = W2 rows (LDS), B operand = planes of the accumulator of Hᵀ
+// An accumulator register r of lane (token, half) holds row (r & 3) + 8 (r >> 2) + 4 half of a 32-row tile; the MFMA's k index of
+// lane-half `half`, element e is free to mean any hidden unit as long as both operands agree, so with the weights' k axis
+// pre-permuted on the host (k' = 16 u + 8 half + e  <->  k = 16 u + 8 (e / 4) + 4 half + e % 4) registers 8u .. 8u+7 of the Hᵀ
+// accumulator ARE the B operand of k-step u of the second product: GELU and the split happen in place, no shuffle, no LDS.  The
+// same permutation on W1's k axis makes the x tile's load layout (16-byte pieces at channels 32 t + 8 q + 4 half) both the B operand
+// of the first product and the layout of the output accumulators, so the residual add and the store need no transpose either.
+//
+// Block = NW waves x 32 tokens; the weights stream through LDS in chunks of 32 hidden units ([W1 rows of the chunk | W2 columns
+// of the chunk], contiguous in HBM: nuhtc_finalize packs `Wstream`), double buffered, one barrier per chunk.
+#include <cstring>
+#include <mutex>
+#include <set>
+
+#include "common.h"
+#include "split_math.h"
+
+struct MlpParams {
+  const float* x_in;      // [T][C]
+  float* x_out;           // [T][C] (may alias x_in: a wave reads only the rows it writes)
+  const float* ln_g;      // [C]
+  const float* ln_b;      // [C]
+  const char* wstream;    // per chunk: 32 rows x (C/8) k-groups x 3 planes x 8 bf16 of W1p, then C rows x 4 k-groups x 3 planes x 8 bf16 of W2p
+  const float* b1;        // [4C]
+  const float* b2;        // [C]
+  int T;
+};
+
+template <int C>
+struct MlpGeom {
+  static constexpr int HID = 4 * C, NCHUNK = HID / 32, KS1 = C / 16, CT = C / 32;
+  static constexpr int R1 = (C / 8) * 48;           // bytes of a W1 row (all k-groups, 3 planes)
+  static constexpr int P1 = R1 + 16;                // LDS pitch: an odd number of 16-byte units = conflict-free ds_read_b128
+  static constexpr int R2 = 4 * 48, P2 = R2 + 16;   // a W2 row of one chunk: 4 k-groups
+  static constexpr int CHUNK_BYTES = 32 * R1 + C * R2;
+  static constexpr int PIECES = CHUNK_BYTES / 16;
+  static constexpr int W1BUF = 32 * P1, W2BUF = C * P2;   // bytes of one W1 / W2 chunk image
+  static constexpr int W2OFF = 2 * W1BUF;           // W1 images: 2 slots (chunk & 1); W2 images: 3 slots (chunk % 3, see the stagger)
+  static constexpr int VEC_OFF = W2OFF + 3 * W2BUF; // then: ln_g[C], ln_b[C], b2[C], b1[HID] as floats
+  static constexpr int LDS_BYTES = VEC_OFF + (3 * C + HID) * 4;
+  static_assert((P1 / 16) % 2 == 1 && (P2 / 16) % 2 == 1, "odd pitch");
+};
+
+template <int C, int NW, bool STAG>
+__global__ __launch_bounds__(64 * NW, 1) void swin_mlp_kernel(MlpParams p) {
+  using G = MlpGeom<C>;
+  constexpr int NT = 64 * NW;
+  constexpr int NP = (G::PIECES + NT - 1) / NT;     // 16-byte staging pieces per thread and chunk
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i32 = lane & 31, half = lane >> 5;
+  float* vec = reinterpret_cast<float*>(lds + G::VEC_OFF);
+  const float* ldg = vec;
+  const float* ldb = vec + C;
+  const float* lb2 = vec + 2 * C;
+  const float* lb1 = vec + 3 * C;
+
+  // ---- staging assignment: piece q = tid + NT * j of a chunk -> LDS offset inside the chunk's W1 image (q in the W1 part) or W2 image
+  int st_lds[NP];
+  bool st_w2[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    int q = tid + NT * j;
+    q = q < G::PIECES ? q : G::PIECES - 1;
+    st_w2[j] = q >= 32 * (G::R1 / 16);
+    if (!st_w2[j]) {
+      const int row = q / (G::R1 / 16), col = q - row * (G::R1 / 16);
+      st_lds[j] = row * G::P1 + col * 16;
+    } else {
+      const int q2 = q - 32 * (G::R1 / 16);
+      const int row = q2 / (G::R2 / 16), col = q2 - row * (G::R2 / 16);
+      st_lds[j] = G::W2OFF + row * G::P2 + col * 16;
+    }
+  }
+  const char* wsrc = p.wstream + (long long)tid * 16;
+  u32x4 stg[NP];
+#define MLP_LOAD_CHUNK(c_)                                                                                        \
+  { _Pragma("unroll") for (int j = 0; j < NP; ++j)                                                                \
+      if (NT * j + NT <= G::PIECES || tid + NT * j < G::PIECES)                                                   \
+        stg[j] = *reinterpret_cast<const u32x4*>(wsrc + (long long)(c_) * G::CHUNK_BYTES + (long long)NT * j * 16); }
+#define MLP_STORE_CHUNK(c_)   /* chunk c_: W1 image slot c_ & 1, W2 image slot c_ % 3 */                          \
+  { const int o1 = ((c_) & 1) * G::W1BUF, o2 = ((c_) % 3) * G::W2BUF;                                             \
+    _Pragma("unroll") for (int j = 0; j < NP; ++j)                                                                \
+      if (NT * j + NT <= G::PIECES || tid + NT * j < G::PIECES)                                                   \
+        *reinterpret_cast<u32x4*>(lds + st_lds[j] + (st_w2[j] ? o2 : o1)) = stg[j]; }
+
+  MLP_LOAD_CHUNK(0)
+  for (int i = tid; i < C; i += NT) { vec[i] = p.ln_g[i]; vec[C + i] = p.ln_b[i]; vec[2 * C + i] = p.b2[i]; }
+  for (int i = tid; i < G::HID; i += NT) vec[3 * C + i] = p.b1[i];
+
+  // ---- this lane's token row (clamped: rows past T are computed on the last row and never stored)
+  const long long tok = (long long)blockIdx.x * (32 * NW) + wave * 32 + i32;
+  const bool tok_ok = tok < p.T;
+  const float* xrow = p.x_in + (tok_ok ? tok : (long long)p.T - 1) * C + 4 * half;
+
+  // ---- LN2 of the token tile + operand split: xp[s][plane] = B operand of k-step s (8 channels: 32t + 8q + 4 half + i, q = 2(s&1) + e/4)
+  u32x4 xp[G::KS1][3];
+  {
+    v4f xv[G::CT][4];
+#pragma unroll
+    for (int t = 0; t < G::CT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xv[t][q] = *reinterpret_cast<const v4f*>(xrow + 32 * t + 8 * q);
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < G::CT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sum += (xv[t][q].x + xv[t][q].y) + (xv[t][q].z + xv[t][q].w);
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum / (float)C;
+    float var = 0.f;
+#pragma unroll
+    for (int t = 0; t < G::CT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        xv[t][q] -= mean;
+        var = fmaf(xv[t][q].x, xv[t][q].x, fmaf(xv[t][q].y, xv[t][q].y, fmaf(xv[t][q].z, xv[t][q].z, fmaf(xv[t][q].w, xv[t][q].w, var))));
+      }
+    var += __shfl_xor(var, 32);
+    const float rstd = 1.0f / sqrtf(var / (float)C + 1e-5f);
+    MLP_STORE_CHUNK(0)
+    __syncthreads();               // chunk 0 and the vectors are in LDS
+    MLP_LOAD_CHUNK(1)
+#pragma unroll
+    for (int t = 0; t < G::CT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const v4f gg = *reinterpret_cast<const v4f*>(ldg + 32 * t + 8 * q + 4 * half);
+        const v4f bb = *reinterpret_cast<const v4f*>(ldb + 32 * t + 8 * q + 4 * half);
+        const v4f v = xv[t][q] * rstd * gg + bb;
+        const int s = 2 * t + (q >> 1), d0 = 2 * (q & 1);
+        NUHTC_SPLIT3_INTO(xp[s], d0, v.x, v.y)
+        NUHTC_SPLIT3_INTO(xp[s], d0 + 1, v.z, v.w)
+      }
+  }
+
+  f32x16 acc[G::CT];
+#pragma unroll
+  for (int t = 0; t < G::CT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const char* w1_lane = lds + i32 * G::P1 + half * 48;                       // + slot * W1BUF + s * 96 + plane * 16
+  const char* w2_lane = lds + G::W2OFF + i32 * G::P2 + half * 48;            // + slot * W2BUF + t * 32 * P2 + u * 96 + plane * 16
+  f32x16 h;
+  u32x4 hp[2][3];
+  // Hᵀ chunk = W1[chunk] · Xnᵀ
+#define MLP_GEMM1(c_)                                                                                             \
+  { _Pragma("unroll") for (int r = 0; r < 16; ++r) h[r] = 0.f;                                                    \
+    const char* wb = w1_lane + ((c_) & 1) * G::W1BUF;                                                             \
+    _Pragma("unroll") for (int s = 0; s < G::KS1; ++s) {                                                          \
+      u32x4 wf[3];                                                                                                \
+      _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) wf[pl] = *reinterpret_cast<const u32x4*>(wb + s * 96 + pl * 16); \
+      h = mfma_split6(wf, xp[s], h);                                                                              \
+    } }
+  // + b1, GELU, split in place: registers 8u .. 8u+7 are the B operand of k-step u of the second product
+#define MLP_ACT(c_)                                                                                               \
+  { _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                               \
+      const v4f bb = *reinterpret_cast<const v4f*>(lb1 + (c_) * 32 + 8 * q + 4 * half);                           \
+      const float v0 = gelu_erf(h[4 * q] + bb.x), v1 = gelu_erf(h[4 * q + 1] + bb.y);                             \
+      const float v2 = gelu_erf(h[4 * q + 2] + bb.z), v3 = gelu_erf(h[4 * q + 3] + bb.w);                         \
+      const int u = q >> 1, d0 = 2 * (q & 1);                                                                     \
+      NUHTC_SPLIT3_INTO(hp[u], d0, v0, v1)                                                                        \
+      NUHTC_SPLIT3_INTO(hp[u], d0 + 1, v2, v3)                                                                    \
+    } }
+  // Outᵀ += W2[:, chunk] · gelu(Hᵀ)
+#define MLP_GEMM2(c_)                                                                                             \
+  { const char* wb = w2_lane + ((c_) % 3) * G::W2BUF;                                                             \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                                 \
+      _Pragma("unroll") for (int t = 0; t < G::CT; ++t) {                                                         \
+        u32x4 wf[3];                                                                                              \
+        _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) wf[pl] = *reinterpret_cast<const u32x4*>(wb + t * 32 * G::P2 + u * 96 + pl * 16); \
+        acc[t] = mfma_split6(wf, hp[u], acc[t]);                                                                  \
+      } }
+
+  // Stagger: the two waves of a SIMD run the same chunk loop between the same barriers, so without it both are in their matrix
+  // phase together and in their GELU / split (VALU) phase together.  The second half of the waves (4..7: the SIMD partners of
+  // 0..3) defers the second product of a chunk by one iteration -- B(j-1), A(j), V(j) against A(j), V(j), B(j) -- so that one
+  // partner's VALU phase runs beside the other's MFMAs.  Their W2 image of chunk j-1 must survive iteration j: three W2 slots.
+  const bool stag = STAG && __builtin_amdgcn_readfirstlane(wave) >= NW / 2;
+#pragma unroll 1
+  for (int ch = 0; ch < G::NCHUNK; ++ch) {
+    if (stag && ch > 0) MLP_GEMM2(ch - 1)
+    MLP_GEMM1(ch)
+    MLP_ACT(ch)
+    if (!stag) MLP_GEMM2(ch)
+    // next chunk into its slots (their last readers passed the barrier at the end of the previous iteration)
+    if (ch + 1 < G::NCHUNK) {
+      MLP_STORE_CHUNK(ch + 1)
+      if (ch + 2 < G::NCHUNK) MLP_LOAD_CHUNK(ch + 2)
+    }
+    __syncthreads();
+  }
+  if (stag) MLP_GEMM2(G::NCHUNK - 1)
+#undef MLP_GEMM1
+#undef MLP_ACT
+#undef MLP_GEMM2
+#undef MLP_LOAD_CHUNK
+#undef MLP_STORE_CHUNK
+
+  // ---- epilogue: + b2 + x (re-read: served by L2 / Infinity Cache, the tile was read a few microseconds ago), store
+  if (tok_ok) {
+    float* orow = p.x_out + tok * C + 4 * half;
+#pragma unroll
+    for (int t = 0; t < G::CT; ++t) {
+      v4f res[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) res[q] = *reinterpret_cast<const v4f*>(xrow + 32 * t + 8 * q);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const v4f bb = *reinterpret_cast<const v4f*>(lb2 + 32 * t + 8 * q + 4 * half);
+        v4f o = {acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+        o = o + bb + res[q];
+        *reinterpret_cast<v4f*>(orow + 32 * t + 8 * q) = o;
+      }
+    }
+  }
+}
+
+// ---- host side: the weight stream of one block (permuted k axes, split planes, chunk-major)
+static inline unsigned short mlp_bf16_rn(float f) {
+  unsigned u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x0040u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+static inline float mlp_bf16_f(unsigned short h) {
+  unsigned u = (unsigned)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+static inline void mlp_split3(float b, unsigned short* dst) {   // dst[0], dst[8], dst[16] = planes 1..3 of one element of a k-group
+  const unsigned short b1 = mlp_bf16_rn(b);
+  const float r1 = b - mlp_bf16_f(b1);
+  const unsigned short b2 = mlp_bf16_rn(r1);
+  const float r2 = r1 - mlp_bf16_f(b2);
+  dst[0] = b1; dst[8] = b2; dst[16] = mlp_bf16_rn(r2);
+}
+// position k' of a permuted 16-group -> original position: k' = 8 hh + e  <->  8 (e / 4) + 4 hh + e % 4
+static inline int mlp_perm16(int kp) { const int hh = (kp >> 3) & 1, e = kp & 7; return 8 * (e >> 2) + 4 * hh + (e & 3); }
+
+size_t mlp_stream_bytes(int C) { return (size_t)(4 * C / 32) * ((size_t)32 * (C / 8) * 48 + (size_t)C * 4 * 48); }
+
+// w1 [4C][C], w2 [C][4C] (row-major, fp32) -> the stream swin_mlp_kernel reads
+void mlp_pack_stream(const float* w1, const float* w2, int C, std::vector<unsigned short>& out) {
+  const int HID = 4 * C, nch = HID / 32;
+  out.assign(mlp_stream_bytes(C) / 2, 0);
+  unsigned short* o = out.data();
+  for (int j = 0; j < nch; ++j) {
+    for (int r = 0; r < 32; ++r)
+      for (int kg = 0; kg < C / 8; ++kg) {
+        for (int e = 0; e < 8; ++e) {
+          const int kp = 8 * kg + e, k = (kp & ~15) + mlp_perm16(kp & 15);
+          mlp_split3(w1[(size_t)(32 * j + r) * C + k], o + e);
+        }
+        o += 24;
+      }
+    for (int c = 0; c < C; ++c)
+      for (int kg = 0; kg < 4; ++kg) {
+        for (int e = 0; e < 8; ++e) {
+          const int kp = 8 * kg + e, k = 32 * j + (kp & ~15) + mlp_perm16(kp & 15);
+          mlp_split3(w2[(size_t)c * HID + k], o + e);
+        }
+        o += 24;
+      }
+  }
+}
+
+bool mlp_supported(int C) { return C == 96; }
+
+int launch_swin_mlp(const float* x_in, float* x_out, const float* ln_g, const float* ln_b, const void* wstream, const float* b1, const float* b2,
+                    int T, int C, hipStream_t s) {
+  if (T <= 0) return 0;
+  if (!mlp_supported(C) || !wstream) return NUHTC_E_INVALID;
+  MlpParams p{x_in, x_out, ln_g, ln_b, reinterpret_cast<const char*>(wstream), b1, b2, T};
+  // algorithmic work: both products; bytes: x read and written once (+ the weight stream once)
+  ProfScope ps("swin_mlp", 16.0 * T * C * C, 8.0 * T * C + (double)mlp_stream_bytes(C), s);
+  constexpr int NW = 8;
+  static const int& stagger = dev_knob_ref("MLP_STAGGER", 1);
+  auto kern = stagger ? &swin_mlp_kernel<96, NW, true> : &swin_mlp_kernel<96, NW, false>;
+  {
+    static std::set<std::pair<int, const void*>> done;      // the kernel needs more than the default 64 KB of dynamic LDS: raised once per device
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return NUHTC_E_HIP;
+    const auto key = std::make_pair(dev, reinterpret_cast<const void*>(kern));
+    if (!done.count(key)) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, MlpGeom<96>::LDS_BYTES) != hipSuccess)
+        return NUHTC_E_HIP;
+      done.insert(key);
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(cdiv(T, 32 * NW)), dim3(64 * NW), MlpGeom<96>::LDS_BYTES, s, p);
+  return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
+}

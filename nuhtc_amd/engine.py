@@ -298,6 +298,16 @@ class Engine:
                                                      M, N, K, act, self._stream()))
         return C
 
+    def op_swin_mlp(self, x, ln_g, ln_b, w1, b1, w2, b2):
+        """x + W2 gelu(W1 LN(x) + b1) + b2 by the fused FFN kernel (csrc/mlp.hip); x (T, C) and the vectors on the device, w1 / w2 anywhere."""
+        T, C = x.shape
+        out = torch.empty_like(x)
+        w1h = np.ascontiguousarray(w1.detach().cpu().numpy(), dtype=np.float32)
+        w2h = np.ascontiguousarray(w2.detach().cpu().numpy(), dtype=np.float32)
+        self._check(self.lib.nuhtc_op_swin_mlp(self.h, x.data_ptr(), ln_g.data_ptr(), ln_b.data_ptr(), w1h.ctypes.data_as(ctypes.c_void_p), b1.data_ptr(),
+                                               w2h.ctypes.data_as(ctypes.c_void_p), b2.data_ptr(), out.data_ptr(), T, C, self._stream()))
+        return out
+
     def op_roi_align(self, feat_nhwc, rois, P, scale, sr):
         N, H, W, C = feat_nhwc.shape
         R = rois.shape[0]

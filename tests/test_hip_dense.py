@@ -196,3 +196,41 @@ def test_split_pipe_hard_operand_classes(hip_device):
         assert torch.equal(~torch.isfinite(out), bad), pipe
         err = ((out.double() - ref).abs() / (A.double().abs().nan_to_num(0, 0, 0) @ W.double().abs().nan_to_num(0, 0, 0).T))[~bad]
         assert float(err.max()) <= 4e-7, (pipe, float(err.max()))
+
+
+def test_fused_mlp_kernel_vs_fp64(hip_device):
+    """csrc/mlp.hip (LN2 + fc1 + GELU + fc2 + residual in one kernel, hidden tensor in registers) against an fp64 evaluation of
+    mmdet swin.py:365-367 and beside the three separate launches' arithmetic (fp32 torch): its error must be at the fp32 level.
+    Token counts that are not a multiple of the 256-token block, large activations, and in-place use."""
+    g = G.load('small_b2')
+    eng, _ = _engine(g)
+    gen = torch.Generator().manual_seed(5)
+    C = 96
+    for T, scale in [(256, 1.0), (1000, 1.0), (31, 3.0), (4096 + 17, 10.0)]:
+        x = torch.randn(T, C, generator=gen) * scale + 0.3
+        ln_g = 1 + 0.1 * torch.randn(C, generator=gen)
+        ln_b = 0.1 * torch.randn(C, generator=gen)
+        w1 = torch.randn(4 * C, C, generator=gen) / C ** 0.5
+        b1 = 0.1 * torch.randn(4 * C, generator=gen)
+        w2 = torch.randn(C, 4 * C, generator=gen) / (4 * C) ** 0.5
+        b2 = 0.1 * torch.randn(C, generator=gen)
+
+        def ref(dt):
+            xd = x.to(dt)
+            xn = torch.nn.functional.layer_norm(xd, (C,), ln_g.to(dt), ln_b.to(dt), 1e-5)
+            h = torch.nn.functional.gelu(xn @ w1.to(dt).T + b1.to(dt))
+            return xd + h @ w2.to(dt).T + b2.to(dt)
+        r64, r32 = ref(torch.float64), ref(torch.float32)
+        dev = lambda t: t.cuda()
+        out = eng.op_swin_mlp(dev(x), dev(ln_g), dev(ln_b), w1, dev(b1), w2, dev(b2)).cpu()
+        e_hip = float((out.double() - r64).abs().max())
+        e_f32 = float((r32.double() - r64).abs().max())
+        mag = float(r64.abs().max())
+        print(f'fused mlp T{T} scale {scale}: max abs err {e_hip:.2e} (torch fp32 chain {e_f32:.2e}), |out| max {mag:.2f}')
+        assert torch.isfinite(out).all()
+        assert e_hip <= max(4.0 * e_f32, 2e-6 * mag), (T, e_hip, e_f32)
+        # in place (the engine's use): out aliases x
+        xd = dev(x).clone()
+        eng._check(eng.lib.nuhtc_op_swin_mlp(eng.h, xd.data_ptr(), dev(ln_g).data_ptr(), dev(ln_b).data_ptr(), w1.numpy().ctypes.data, dev(b1).data_ptr(),
+                                             w2.numpy().ctypes.data, dev(b2).data_ptr(), xd.data_ptr(), T, C, eng._stream()))
+        assert torch.equal(xd.cpu(), out)
