@@ -105,6 +105,11 @@ void gemm_unregister_split(const float* w_dev);
 int gemm_make_split(const float* w_host, int N, int K, void** out_dev);      // unregistered split (caller hipFree()s it)
 const void* gemm_find_split(const float* w_dev, int N, int K);
 
+// 3x3 convolution 64 -> 64 with the input halo resident in LDS as bf16 planes (conv.hip); launch_gemm routes A_CONV3 products with a
+// split weight there
+bool conv3_split_supported(const GemmParams& p);
+int launch_conv3_split(const GemmParams& p, hipStream_t s);
+
 // ----------------------------------------------------------------------------- fused FFN half of a Swin block (mlp.hip)
 // x_out = x_in + W2 gelu(W1 LN(x_in) + b1) + b2 in one kernel on the split-bf16 pipe; `wstream` from mlp_pack_stream (device copy)
 bool mlp_supported(int C);

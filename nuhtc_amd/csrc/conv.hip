@@ -1,0 +1,234 @@
+// 3x3 convolution, 64 -> 64 channels, NHWC fp32, on the bf16 matrix pipe with exactly split operands (the arithmetic of
+// gemm_split_kernel: six v_mfma_f32_32x32x16_bf16 per 16-deep step, fp32 accumulation, same k order tap-major / channel-minor).
+// Serves the FPN output convs (mmdet fpn.py:173-179), the RPN conv (rpn_head.py:62-68), the four semantic-head convs
+// (fused_semantic_head.py:97-111) and the mask-head convs (htc_mask_head.py:22-39).
+//
+// The implicit-GEMM loader of gemm_split_kernel re-reads every input pixel nine times (once per tap) from L2 and re-splits it
+// nine times in the MFMA waves' instruction stream.  Here a workgroup owns an 8 x 16 tile of output pixels: the (8+2) x (16+2)
+// input halo is read ONCE, split ONCE into its three bf16 planes and kept in LDS; all nine taps then read their A fragments
+// from that image at shifted pixel addresses -- the main loop has no vector-ALU work and no activation traffic at all, only LDS
+// fragment reads and MFMAs, with the 64 x 64 weights of one tap streamed through a double-buffered LDS image beside them.
+// The product is computed transposed (Outᵀ[32 channels][32 pixels] = W · Aᵀ: weights are the MFMA's A operand, pixels its B operand)
+// so that a lane ends up with 4 x 4 consecutive channels of ONE pixel: bias, activation and 16-byte NHWC stores need no transpose.
+//
+// LDS image of the halo: pixel pitch 400 B (64 channels x 3 planes x 2 B + 16: an odd number of 16-byte units) and row pitch
+// 7424 B (a multiple of 256 B), which makes the fragment reads of a wave -- 16 consecutive pixels of two adjacent rows --
+// conflict-free for ds_read_b128 (lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31}); weight image: 400 B per output channel.
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+
+#include "common.h"
+#include "split_math.h"
+
+#define CV_TH 8
+#define CV_TW 16
+#define CV_PIX 400                         // bytes per halo pixel in LDS
+#define CV_ROW 7424                        // bytes per halo row: (CV_TW + 2) * CV_PIX = 7200, padded to a multiple of 256
+#define CV_A_BYTES ((CV_TH + 2) * CV_ROW)  // 74240
+#define CV_WCOL 400                        // bytes per output channel of one tap's weights (8 k-groups x 48 B + 16)
+#define CV_W_BYTES (64 * CV_WCOL)          // 25600
+#define CV_LDS (CV_A_BYTES + 2 * CV_W_BYTES)
+
+struct Conv3Params {
+  const float* in;        // [nimg][H][W][64]
+  float* out;             // [nimg][H][W][64]
+  const char* wsplit;     // [64 out][72 k-groups][3 planes][8 bf16], k = tap * 64 + channel (gemm_make_split of the packed conv weight)
+  const float* bias;      // [64] or null
+  const int* nimg_dev;    // optional device-side image count (images >= *nimg_dev are skipped)
+  int nimg, H, W, act;
+  int tiles_x, tiles_y;
+};
+
+__global__ __launch_bounds__(512, 1) void conv3_split_kernel(Conv3Params p) {
+  extern __shared__ __attribute__((aligned(256))) char lds[];
+  char* Apl = lds;
+  char* Wb = lds + CV_A_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i32 = lane & 31, half = lane >> 5;
+  // Persistent workgroups (one per CU): workgroup b serves XCD b & 7 (workgroups are dealt round-robin over the 8 XCDs, which
+  // have an L2 each) and walks that XCD's contiguous share of the tile list with stride gridDim / 8: neighbouring tiles, which
+  // share halo rows, meet in one L2.  With a device-side image count only the real images are shared out.
+  const int nimg = p.nimg_dev ? min(p.nimg, *p.nimg_dev) : p.nimg;
+  const int tiles_img = p.tiles_y * p.tiles_x;
+  const int ntile = nimg * tiles_img;
+  const int per_xcd = (ntile + 7) >> 3;
+  const int xcd = blockIdx.x & 7, xstride = gridDim.x >> 3;
+  const int t_end = min((xcd + 1) * per_xcd, ntile);
+  int tile = xcd * per_xcd + (blockIdx.x >> 3);
+  if (tile >= t_end) return;
+
+  // ---- weight staging: 3 x 16-byte pieces per thread and tap (column q / 24, piece q % 24 of the tap's 384 bytes of that column)
+  const char* wsrc[3];
+  int wdst[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int q = tid + 512 * j, n = q / 24, c = q - n * 24;
+    wsrc[j] = p.wsplit + (long long)n * (72 * 48) + c * 16;
+    wdst[j] = n * CV_WCOL + c * 16;
+  }
+  u32x4 wst[3];
+#define CV_RAW_BARRIER() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) */ __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+#define CV_W_LOAD(tap_) { _Pragma("unroll") for (int j = 0; j < 3; ++j) wst[j] = *reinterpret_cast<const u32x4*>(wsrc[j] + (tap_) * 384); }
+#define CV_W_STORE(tap_) { _Pragma("unroll") for (int j = 0; j < 3; ++j) *reinterpret_cast<u32x4*>(Wb + ((tap_) & 1) * CV_W_BYTES + wdst[j]) = wst[j]; }
+
+  // ---- halo staging: item = (pixel, 16-byte piece of its 256 bytes); 180 * 16 = 2880 items over 512 threads.  The loads of the
+  // NEXT tile are issued before the main loop of the current one and stay in registers across it.
+  constexpr int NPX = (CV_TH + 2) * (CV_TW + 2), NIT = NPX * 16, NJ = (NIT + 511) / 512;
+  v4f hv[NJ];
+  int hdst[NJ];          // LDS offset of the item's 8 bytes of plane 0 (-1: no item)
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int it = tid + 512 * j;
+    const int px = it >> 4, c4 = it & 15;
+    const int hy = px / (CV_TW + 2), hx = px - hy * (CV_TW + 2);
+    hdst[j] = it < NIT ? hy * CV_ROW + hx * CV_PIX + (c4 >> 1) * 48 + (c4 & 1) * 8 : -1;
+  }
+#define CV_HALO_LOAD(tile_)                                                                                       \
+  { const int img_ = (tile_) / tiles_img, tr_ = (tile_) - img_ * tiles_img;                                       \
+    const int ty_ = tr_ / p.tiles_x, tx_ = tr_ - ty_ * p.tiles_x;                                                 \
+    const float* map_ = p.in + (long long)img_ * p.H * p.W * 64;                                                  \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                              \
+      const int it = tid + 512 * j;                                                                               \
+      const int px = it >> 4, c4 = it & 15;                                                                       \
+      const int hy = px / (CV_TW + 2), hx = px - hy * (CV_TW + 2);                                                \
+      const int y = ty_ * CV_TH - 1 + hy, x = tx_ * CV_TW - 1 + hx;                                               \
+      const bool ok = it < NIT && y >= 0 && y < p.H && x >= 0 && x < p.W;                                         \
+      hv[j] = ok ? *reinterpret_cast<const v4f*>(map_ + ((long long)y * p.W + x) * 64 + c4 * 4) : v4f{0.f, 0.f, 0.f, 0.f}; \
+    } }
+
+  CV_HALO_LOAD(tile)
+  CV_W_LOAD(0)
+
+  // ---- this wave: pixels (row 2 (wave & 3) + (i32 >> 4), column i32 & 15) of the tile x output channels 32 (wave >> 2) ..
+  const int prow = 2 * (wave & 3) + (i32 >> 4), pcol = i32 & 15;
+  const char* a_lane = Apl + prow * CV_ROW + pcol * CV_PIX + half * 48;            // + (ky * CV_ROW + kx * CV_PIX) + s * 96 + plane * 16
+  const char* w_lane = Wb + (32 * (wave >> 2) + i32) * CV_WCOL + half * 48;        // + buf * CV_W_BYTES + s * 96 + plane * 16
+
+  for (; tile < t_end; tile += xstride) {
+    const int img = tile / tiles_img, tr = tile - img * tiles_img;
+    const int ty = tr / p.tiles_x, tx = tr - ty * p.tiles_x;
+    const int y0 = ty * CV_TH, x0 = tx * CV_TW;
+    // ---- split the halo once, three planes into LDS; weights of tap 0
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if (hdst[j] >= 0) {
+        char* dst = Apl + hdst[j];
+        const Split3 a = split3_pair(hv[j].x, hv[j].y), b = split3_pair(hv[j].z, hv[j].w);
+        *reinterpret_cast<uint2*>(dst) = make_uint2(a.p1, b.p1);
+        *reinterpret_cast<uint2*>(dst + 16) = make_uint2(a.p2, b.p2);
+        *reinterpret_cast<uint2*>(dst + 32) = make_uint2(a.p3, b.p3);
+      }
+    }
+    CV_W_STORE(0)
+    CV_RAW_BARRIER()       // LDS writes only: nothing waits for the global stores of the previous tile's epilogue
+    CV_W_LOAD(1)
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // ---- main loop over 9 taps x 4 k-steps, software-pipelined: the six fragments of step i+1 are read between the MFMAs of
+    // step i (one ds_read_b128 after each MFMA), so no MFMA waits for LDS.  Per tap: the weights of tap+1 go into the other
+    // weight image at its first step (registers loaded a tap earlier), the barrier sits before its last step, whose reads
+    // are the first ones of tap+1.
+    u32x4 fw[2][3], fa[2][3];
+#define CV_READ_ONE(k_, buf_, tap_, s_)                                                                            \
+    { const int ky_ = (tap_) / 3, kx_ = (tap_) - ky_ * 3;                                                          \
+      if ((k_) < 3) fw[buf_][k_] = *reinterpret_cast<const u32x4*>(w_lane + ((tap_) & 1) * CV_W_BYTES + (s_) * 96 + (k_) * 16);    \
+      else fa[buf_][(k_) - 3] = *reinterpret_cast<const u32x4*>(a_lane + ky_ * CV_ROW + kx_ * CV_PIX + (s_) * 96 + ((k_) - 3) * 16); }
+#define CV_MFMA_ONE(k_, buf_)                                                                                      \
+    { constexpr int iw_[6] = {0, 2, 1, 0, 1, 0}, ia_[6] = {2, 0, 1, 1, 0, 0};   /* (activation, weight) plane order of gemm_split_kernel */ \
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[buf_][iw_[k_]]), __builtin_bit_cast(bf16x8, fa[buf_][ia_[k_]]), acc, 0, 0, 0); }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) CV_READ_ONE(k, 0, 0, 0)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+      for (int sidx = 0; sidx < 4; ++sidx) {
+        constexpr int dummy = 0; (void)dummy;
+        const int i = tap * 4 + sidx;
+        if (sidx == 0 && tap < 8) {
+          CV_W_STORE(tap + 1)
+          if (tap < 7) CV_W_LOAD(tap + 2)
+        }
+        // next tile's halo: requested behind the last weight load of this tile (vector-memory operations complete in issue order: a
+        // weight load queued behind these would make its tap wait for them), three taps before the epilogue
+        if (sidx == 1 && tap == 6 && tile + xstride < t_end) CV_HALO_LOAD(tile + xstride)
+        if (sidx == 3 && tap < 8) CV_RAW_BARRIER()   // only this wave's LDS operations are waited for: the next tile's halo loads stay in flight
+        const int ntap = sidx == 3 ? tap + 1 : tap, ns = sidx == 3 ? 0 : sidx + 1;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          CV_MFMA_ONE(k, i & 1)
+          __builtin_amdgcn_sched_barrier(0);
+          if (i < 35) CV_READ_ONE(k, (i + 1) & 1, ntap, ns)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+#undef CV_READ_ONE
+#undef CV_MFMA_ONE
+
+    // ---- epilogue: register r of lane (pixel, half) is output channel 32 (wave >> 2) + (r & 3) + 8 (r >> 2) + 4 half
+    const int y = y0 + prow, x = x0 + pcol;
+    if (y < p.H && x < p.W) {
+      const int cb = 32 * (wave >> 2) + 4 * half;
+      float* o = p.out + (((long long)img * p.H + y) * p.W + x) * 64 + cb;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v4f v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+        if (p.bias) v += *reinterpret_cast<const v4f*>(p.bias + cb + 8 * q);
+        if (p.act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<v4f*>(o + 8 * q) = v;
+      }
+    }
+    CV_W_LOAD(0)
+    CV_RAW_BARRIER()       // every wave is done reading this tile's halo and weight images before the next tile overwrites them
+  }
+#undef CV_RAW_BARRIER
+#undef CV_W_LOAD
+#undef CV_W_STORE
+#undef CV_HALO_LOAD
+}
+
+bool conv3_split_supported(const GemmParams& p) {
+  return p.amode == A_CONV3 && p.Wsplit && p.cC == 64 && p.N == 64 && p.K == 576 && p.lda == 576 && p.ldc == 64 && !p.res && !p.up && p.store == ST_PLAIN &&
+         (p.act == ACT_NONE || p.act == ACT_RELU) && p.alpha == 1.f && p.batch <= 1 && p.M % (p.cH * p.cW) == 0 && (!p.m_dev || p.m_mul == p.cH * p.cW);
+}
+
+int launch_conv3_split(const GemmParams& g, hipStream_t s) {
+  Conv3Params p;
+  memset(&p, 0, sizeof(p));
+  p.in = g.A; p.out = g.C; p.wsplit = reinterpret_cast<const char*>(g.Wsplit); p.bias = g.bias; p.nimg_dev = g.m_dev;
+  p.nimg = g.M / (g.cH * g.cW); p.H = g.cH; p.W = g.cW; p.act = g.act;
+  p.tiles_x = cdiv(g.cW, CV_TW); p.tiles_y = cdiv(g.cH, CV_TH);
+  const int ntile = p.nimg * p.tiles_x * p.tiles_y;
+  if (ntile <= 0) return 0;
+  {
+    static std::map<int, bool> done;       // more than the default 64 KB of dynamic LDS: raised once per device
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return NUHTC_E_HIP;
+    if (!done[dev]) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CV_LDS) != hipSuccess) return NUHTC_E_HIP;
+      done[dev] = true;
+    }
+  }
+  int ncu = 256;
+  {
+    static std::map<int, int> cus;
+    static std::mutex mu2;
+    std::lock_guard<std::mutex> lock(mu2);
+    int dev = 0;
+    hipGetDevice(&dev);
+    auto it = cus.find(dev);
+    if (it == cus.end()) {
+      hipDeviceProp_t prop;
+      it = cus.emplace(dev, hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256).first;
+    }
+    ncu = it->second;
+  }
+  const int grid = std::min(((ntile + 7) >> 3) * 8, (ncu + 7) / 8 * 8);        // one workgroup per CU (LDS), a multiple of the 8 XCDs
+  hipLaunchKernelGGL(conv3_split_kernel, dim3(grid), dim3(512), CV_LDS, s, p);
+  return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
+}

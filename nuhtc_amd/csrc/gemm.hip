@@ -839,14 +839,16 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
     q.zeros = zero_page();
     if (!q.zeros) return NUHTC_E_HIP;
   }
+  static const int& conv_halo = dev_knob_ref("CONV_HALO", 1);
+  const bool halo = conv_halo && conv3_split_supported(q);      // 3x3 convolutions: halo tile in LDS, split once (conv.hip)
   const double nb = p.batch > 0 ? p.batch : 1;
   const char* tag = "gemm";
   if (prof_enabled()) {   // per-shape tags, e.g. "gemm_kernel<3>|N288|K96" (strings live for the process lifetime)
     static std::map<long long, std::string> names;
-    long long key = ((long long)nt << 40) | ((long long)p.N << 20) | p.K | ((long long)(p.amode == A_CONV3) << 44);
+    long long key = ((long long)nt << 40) | ((long long)p.N << 20) | p.K | ((long long)(p.amode == A_CONV3) << 44) | ((long long)halo << 45);
     auto it = names.find(key);
     if (it == names.end())
-      it = names.emplace(key, "gemm_kernel<" + std::to_string(nt) + ">|N" + std::to_string(p.N) + "|K" + std::to_string(p.K) + (p.amode == A_CONV3 ? "|conv3" : "")).first;
+      it = names.emplace(key, "gemm_kernel<" + std::to_string(nt) + ">|N" + std::to_string(p.N) + "|K" + std::to_string(p.K) + (p.amode == A_CONV3 ? (halo ? "|conv3halo" : "|conv3") : "")).first;
     tag = it->second.c_str();
   }
   // algorithmic work of the launch (a device-side row count is applied when the records are read)
@@ -859,7 +861,10 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
   if (!stamp_buf && hipMalloc(&stamp_buf, 8ull * 8 * 4 * 65536) != hipSuccess) return NUHTC_E_HIP;
   q.stamps = stamp_buf;
 #endif
-  if (q.Wsplit) {
+  if (halo) {
+    const int rc = launch_conv3_split(q, s);
+    if (rc) return rc;
+  } else if (q.Wsplit) {
     // 256-row block tiles (two row tiles per wave: half the weight bytes per flop from L2) where the launch still fills the
     // chip with them; NUHTC_SPLIT_MT=1 / 2 forces one form (dev)
     static const int& force_mt = dev_knob_ref("SPLIT_MT", 0);

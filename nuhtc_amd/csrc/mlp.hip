@@ -33,6 +33,7 @@ struct MlpParams {
   const float* b1;        // [4C]
   const float* b2;        // [C]
   int T;
+  unsigned long long* stamps;   // dev instrumentation (-DNUHTC_MLP_STAMPS), null otherwise
 };
 
 template <int C>
@@ -56,6 +57,12 @@ __global__ __launch_bounds__(64 * NW, 1) void swin_mlp_kernel(MlpParams p) {
   constexpr int NT = 64 * NW;
   constexpr int NP = (G::PIECES + NT - 1) / NT;     // 16-byte staging pieces per thread and chunk
   extern __shared__ __attribute__((aligned(16))) char lds[];
+#ifdef NUHTC_MLP_STAMPS   // dev: per-wave phase times (tools/dev/mlp_stamps.py)
+  unsigned long long sk0 = __builtin_amdgcn_s_memtime(), sk1 = 0, sA = 0, sV = 0, sB = 0, sS = 0, sW = 0, sk2 = 0, stt = 0;
+#define MSTAMP(x_) x_
+#else
+#define MSTAMP(x_)
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i32 = lane & 31, half = lane >> 5;
   float* vec = reinterpret_cast<float*>(lds + G::VEC_OFF);
@@ -187,20 +194,29 @@ __global__ __launch_bounds__(64 * NW, 1) void swin_mlp_kernel(MlpParams p) {
   // 0..3) defers the second product of a chunk by one iteration -- B(j-1), A(j), V(j) against A(j), V(j), B(j) -- so that one
   // partner's VALU phase runs beside the other's MFMAs.  Their W2 image of chunk j-1 must survive iteration j: three W2 slots.
   const bool stag = STAG && __builtin_amdgcn_readfirstlane(wave) >= NW / 2;
+  MSTAMP(sk1 = __builtin_amdgcn_s_memtime();)
 #pragma unroll 1
   for (int ch = 0; ch < G::NCHUNK; ++ch) {
+    MSTAMP(stt = __builtin_amdgcn_s_memtime();)
     if (stag && ch > 0) MLP_GEMM2(ch - 1)
+    MSTAMP(__builtin_amdgcn_sched_barrier(0); { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); sB += n_ - stt; stt = n_; } __builtin_amdgcn_sched_barrier(0);)
     MLP_GEMM1(ch)
+    MSTAMP(__builtin_amdgcn_sched_barrier(0); { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); sA += n_ - stt; stt = n_; } __builtin_amdgcn_sched_barrier(0);)
     MLP_ACT(ch)
+    MSTAMP(__builtin_amdgcn_sched_barrier(0); { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); sV += n_ - stt; stt = n_; } __builtin_amdgcn_sched_barrier(0);)
     if (!stag) MLP_GEMM2(ch)
+    MSTAMP(__builtin_amdgcn_sched_barrier(0); { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); sB += n_ - stt; stt = n_; } __builtin_amdgcn_sched_barrier(0);)
     // next chunk into its slots (their last readers passed the barrier at the end of the previous iteration)
     if (ch + 1 < G::NCHUNK) {
       MLP_STORE_CHUNK(ch + 1)
       if (ch + 2 < G::NCHUNK) MLP_LOAD_CHUNK(ch + 2)
     }
+    MSTAMP(__builtin_amdgcn_sched_barrier(0); { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); sS += n_ - stt; stt = n_; } __builtin_amdgcn_sched_barrier(0);)
     __syncthreads();
+    MSTAMP(__builtin_amdgcn_sched_barrier(0); { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); sW += n_ - stt; stt = n_; } __builtin_amdgcn_sched_barrier(0);)
   }
   if (stag) MLP_GEMM2(G::NCHUNK - 1)
+  MSTAMP(sk2 = __builtin_amdgcn_s_memtime();)
 #undef MLP_GEMM1
 #undef MLP_ACT
 #undef MLP_GEMM2
@@ -224,6 +240,14 @@ __global__ __launch_bounds__(64 * NW, 1) void swin_mlp_kernel(MlpParams p) {
       }
     }
   }
+#ifdef NUHTC_MLP_STAMPS
+  __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0): the stores have been issued and acknowledged
+  if (lane == 0 && p.stamps) {
+    unsigned long long* o = p.stamps + ((long long)blockIdx.x * NW + wave) * 8;
+    o[0] = sk1 - sk0; o[1] = sA; o[2] = sV; o[3] = sB; o[4] = sS; o[5] = sW; o[6] = __builtin_amdgcn_s_memtime() - sk2; o[7] = sk0;
+  }
+#endif
+#undef MSTAMP
 }
 
 // ---- host side: the weight stream of one block (permuted k axes, split planes, chunk-major)
@@ -283,7 +307,12 @@ int launch_swin_mlp(const float* x_in, float* x_out, const float* ln_g, const fl
                     int T, int C, hipStream_t s) {
   if (T <= 0) return 0;
   if (!mlp_supported(C) || !wstream) return NUHTC_E_INVALID;
-  MlpParams p{x_in, x_out, ln_g, ln_b, reinterpret_cast<const char*>(wstream), b1, b2, T};
+  MlpParams p{x_in, x_out, ln_g, ln_b, reinterpret_cast<const char*>(wstream), b1, b2, T, nullptr};
+#ifdef NUHTC_MLP_STAMPS
+  static unsigned long long* stamp_buf = nullptr;
+  if (!stamp_buf && hipMalloc(&stamp_buf, 8ull * 8 * 8 * 4096) != hipSuccess) return NUHTC_E_HIP;
+  p.stamps = stamp_buf;
+#endif
   // algorithmic work: both products; bytes: x read and written once (+ the weight stream once)
   ProfScope ps("swin_mlp", 16.0 * T * C * C, 8.0 * T * C + (double)mlp_stream_bytes(C), s);
   constexpr int NW = 8;
@@ -303,5 +332,21 @@ int launch_swin_mlp(const float* x_in, float* x_out, const float* ln_g, const fl
     }
   }
   hipLaunchKernelGGL(kern, dim3(cdiv(T, 32 * NW)), dim3(64 * NW), MlpGeom<96>::LDS_BYTES, s, p);
+#ifdef NUHTC_MLP_STAMPS
+  {
+    static int cnt = 0, dump_at = -1;   // launch NUHTC_STAMP_AT (default 40) of the process is dumped to /tmp/mlp_stamps.txt
+    if (dump_at < 0) { const char* e = getenv("NUHTC_STAMP_AT"); dump_at = e ? atoi(e) : 40; }
+    if (++cnt == dump_at) {
+      hipDeviceSynchronize();
+      int nb = cdiv(T, 32 * NW);
+      if (nb > 4096) nb = 4096;
+      std::vector<unsigned long long> h((size_t)nb * NW * 8);
+      hipMemcpy(h.data(), stamp_buf, h.size() * 8, hipMemcpyDeviceToHost);
+      FILE* f = fopen("/tmp/mlp_stamps.txt", "w");
+      for (int b = 0; b < nb; ++b) for (int w = 0; w < NW; ++w) { auto* o = &h[((size_t)b * NW + w) * 8]; fprintf(f, "%d %d %llu %llu %llu %llu %llu %llu %llu %llu\n", b, w, o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]); }
+      fclose(f);
+    }
+  }
+#endif
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
 }

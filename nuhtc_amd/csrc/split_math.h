@@ -57,3 +57,12 @@ __device__ __forceinline__ f32x16 mfma_split6(const u32x4 (&a)[3], const u32x4 (
 #undef NUHTC_M6
   return acc;
 }
+
+// the same six products with the operand roles of the transposed kernels (a = weights as the MFMA's A operand, b = activations as
+// its B operand) in the order gemm_split_kernel issues them (activation plane, weight plane): (3,1) (1,3) (2,2) (2,1) (1,2) (1,1)
+__device__ __forceinline__ f32x16 mfma_split6_wa(const u32x4 (&w)[3], const u32x4 (&act)[3], f32x16 acc) {
+#define NUHTC_M6(iw_, ia_) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[iw_]), __builtin_bit_cast(bf16x8, act[ia_]), acc, 0, 0, 0);
+  NUHTC_M6(0, 2) NUHTC_M6(2, 0) NUHTC_M6(1, 1) NUHTC_M6(0, 1) NUHTC_M6(1, 0) NUHTC_M6(0, 0)
+#undef NUHTC_M6
+  return acc;
+}

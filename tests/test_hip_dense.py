@@ -221,8 +221,8 @@ def test_fused_mlp_kernel_vs_fp64(hip_device):
             h = torch.nn.functional.gelu(xn @ w1.to(dt).T + b1.to(dt))
             return xd + h @ w2.to(dt).T + b2.to(dt)
         r64, r32 = ref(torch.float64), ref(torch.float32)
-        dev = lambda t: t.cuda()
-        out = eng.op_swin_mlp(dev(x), dev(ln_g), dev(ln_b), w1, dev(b1), w2, dev(b2)).cpu()
+        d = {k: v.cuda() for k, v in dict(x=x, g=ln_g, b=ln_b, b1=b1, b2=b2).items()}      # kept alive across the raw-pointer call below
+        out = eng.op_swin_mlp(d['x'], d['g'], d['b'], w1, d['b1'], w2, d['b2']).cpu()
         e_hip = float((out.double() - r64).abs().max())
         e_f32 = float((r32.double() - r64).abs().max())
         mag = float(r64.abs().max())
@@ -230,7 +230,8 @@ def test_fused_mlp_kernel_vs_fp64(hip_device):
         assert torch.isfinite(out).all()
         assert e_hip <= max(4.0 * e_f32, 2e-6 * mag), (T, e_hip, e_f32)
         # in place (the engine's use): out aliases x
-        xd = dev(x).clone()
-        eng._check(eng.lib.nuhtc_op_swin_mlp(eng.h, xd.data_ptr(), dev(ln_g).data_ptr(), dev(ln_b).data_ptr(), w1.numpy().ctypes.data, dev(b1).data_ptr(),
-                                             w2.numpy().ctypes.data, dev(b2).data_ptr(), xd.data_ptr(), T, C, eng._stream()))
+        xd = d['x'].clone()
+        w1h, w2h = w1.numpy(), w2.numpy()
+        eng._check(eng.lib.nuhtc_op_swin_mlp(eng.h, xd.data_ptr(), d['g'].data_ptr(), d['b'].data_ptr(), w1h.ctypes.data, d['b1'].data_ptr(),
+                                             w2h.ctypes.data, d['b2'].data_ptr(), xd.data_ptr(), T, C, eng._stream()))
         assert torch.equal(xd.cpu(), out)
