@@ -38,6 +38,7 @@ struct Conv3Params {
   const int* nimg_dev;    // optional device-side image count (images >= *nimg_dev are skipped)
   int nimg, H, W, act;
   int tiles_x, tiles_y;
+  unsigned long long* stamps;   // dev instrumentation (-DNUHTC_CONV_STAMPS), null otherwise
 };
 
 __global__ __launch_bounds__(512, 1) void conv3_split_kernel(Conv3Params p) {
@@ -99,12 +100,24 @@ __global__ __launch_bounds__(512, 1) void conv3_split_kernel(Conv3Params p) {
 
   CV_HALO_LOAD(tile)
   CV_W_LOAD(0)
+  // bias of this lane's 16 output channels: loaded once per workgroup (a load in the epilogue would queue behind the next tile's
+  // halo loads and expose their HBM latency: vector-memory operations complete in order)
+  v4f bias4[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    bias4[q] = p.bias ? *reinterpret_cast<const v4f*>(p.bias + 32 * (wave >> 2) + 4 * half + 8 * q) : v4f{0.f, 0.f, 0.f, 0.f};
 
   // ---- this wave: pixels (row 2 (wave & 3) + (i32 >> 4), column i32 & 15) of the tile x output channels 32 (wave >> 2) ..
   const int prow = 2 * (wave & 3) + (i32 >> 4), pcol = i32 & 15;
   const char* a_lane = Apl + prow * CV_ROW + pcol * CV_PIX + half * 48;            // + (ky * CV_ROW + kx * CV_PIX) + s * 96 + plane * 16
   const char* w_lane = Wb + (32 * (wave >> 2) + i32) * CV_WCOL + half * 48;        // + buf * CV_W_BYTES + s * 96 + plane * 16
 
+#ifdef NUHTC_CONV_STAMPS
+  unsigned long long sSplit = 0, sMain = 0, sEpi = 0, sBar = 0, stt = __builtin_amdgcn_s_memtime(), sk0 = stt, nTiles = 0;
+#define CSTAMP(v_) { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); v_ += n_ - stt; stt = n_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define CSTAMP(v_)
+#endif
   for (; tile < t_end; tile += xstride) {
     const int img = tile / tiles_img, tr = tile - img * tiles_img;
     const int ty = tr / p.tiles_x, tx = tr - ty * p.tiles_x;
@@ -121,17 +134,19 @@ __global__ __launch_bounds__(512, 1) void conv3_split_kernel(Conv3Params p) {
       }
     }
     CV_W_STORE(0)
+    CSTAMP(sSplit)
     CV_RAW_BARRIER()       // LDS writes only: nothing waits for the global stores of the previous tile's epilogue
+    CSTAMP(sBar)
     CV_W_LOAD(1)
 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    // ---- main loop over 9 taps x 4 k-steps, software-pipelined: the six fragments of step i+1 are read between the MFMAs of
-    // step i (one ds_read_b128 after each MFMA), so no MFMA waits for LDS.  Per tap: the weights of tap+1 go into the other
-    // weight image at its first step (registers loaded a tap earlier), the barrier sits before its last step, whose reads
-    // are the first ones of tap+1.
-    u32x4 fw[2][3], fa[2][3];
+    // ---- main loop over 9 taps x 4 k-steps, software-pipelined TWO steps deep: the six fragments of step i+2 are read between
+    // the first MFMAs of step i (three register sets), so the one lgkmcnt wait per step finds reads that were issued a whole
+    // step (192 MFMA cycles) earlier.  Per tap: the weights of tap+1 go into the other weight image at its first step (registers
+    // loaded a tap earlier); the barrier sits before its third step, whose reads are the first ones of tap+1.
+    u32x4 fw[3][3], fa[3][3];
 #define CV_READ_ONE(k_, buf_, tap_, s_)                                                                            \
     { const int ky_ = (tap_) / 3, kx_ = (tap_) - ky_ * 3;                                                          \
       if ((k_) < 3) fw[buf_][k_] = *reinterpret_cast<const u32x4*>(w_lane + ((tap_) & 1) * CV_W_BYTES + (s_) * 96 + (k_) * 16);    \
@@ -142,10 +157,11 @@ __global__ __launch_bounds__(512, 1) void conv3_split_kernel(Conv3Params p) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) CV_READ_ONE(k, 0, 0, 0)
 #pragma unroll
+    for (int k = 0; k < 6; ++k) CV_READ_ONE(k, 1, 0, 1)
+#pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
 #pragma unroll
       for (int sidx = 0; sidx < 4; ++sidx) {
-        constexpr int dummy = 0; (void)dummy;
         const int i = tap * 4 + sidx;
         if (sidx == 0 && tap < 8) {
           CV_W_STORE(tap + 1)
@@ -154,13 +170,13 @@ __global__ __launch_bounds__(512, 1) void conv3_split_kernel(Conv3Params p) {
         // next tile's halo: requested behind the last weight load of this tile (vector-memory operations complete in issue order: a
         // weight load queued behind these would make its tap wait for them), three taps before the epilogue
         if (sidx == 1 && tap == 6 && tile + xstride < t_end) CV_HALO_LOAD(tile + xstride)
-        if (sidx == 3 && tap < 8) CV_RAW_BARRIER()   // only this wave's LDS operations are waited for: the next tile's halo loads stay in flight
-        const int ntap = sidx == 3 ? tap + 1 : tap, ns = sidx == 3 ? 0 : sidx + 1;
+        if (sidx == 2 && tap < 8) CV_RAW_BARRIER()   // only this wave's LDS operations are waited for: the next tile's halo loads stay in flight
+        const int ntap = sidx >= 2 ? tap + 1 : tap, ns = (sidx + 2) & 3;
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-          CV_MFMA_ONE(k, i & 1)
+          CV_MFMA_ONE(k, i % 3)
           __builtin_amdgcn_sched_barrier(0);
-          if (i < 35) CV_READ_ONE(k, (i + 1) & 1, ntap, ns)
+          if (i < 34 && k < 3) { CV_READ_ONE(2 * k, (i + 2) % 3, ntap, ns) CV_READ_ONE(2 * k + 1, (i + 2) % 3, ntap, ns) }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -168,6 +184,7 @@ __global__ __launch_bounds__(512, 1) void conv3_split_kernel(Conv3Params p) {
 #undef CV_READ_ONE
 #undef CV_MFMA_ONE
 
+    CSTAMP(sMain)
     // ---- epilogue: register r of lane (pixel, half) is output channel 32 (wave >> 2) + (r & 3) + 8 (r >> 2) + 4 half
     const int y = y0 + prow, x = x0 + pcol;
     if (y < p.H && x < p.W) {
@@ -176,14 +193,26 @@ __global__ __launch_bounds__(512, 1) void conv3_split_kernel(Conv3Params p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         v4f v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-        if (p.bias) v += *reinterpret_cast<const v4f*>(p.bias + cb + 8 * q);
+        v += bias4[q];
         if (p.act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         *reinterpret_cast<v4f*>(o + 8 * q) = v;
       }
     }
     CV_W_LOAD(0)
+    CSTAMP(sEpi)
     CV_RAW_BARRIER()       // every wave is done reading this tile's halo and weight images before the next tile overwrites them
+#ifdef NUHTC_CONV_STAMPS
+    CSTAMP(sBar)
+    ++nTiles;
+#endif
   }
+#ifdef NUHTC_CONV_STAMPS
+  if (lane == 0 && p.stamps) {
+    unsigned long long* o = p.stamps + ((long long)blockIdx.x * 8 + wave) * 8;
+    o[0] = sSplit; o[1] = sMain; o[2] = sEpi; o[3] = sBar; o[4] = nTiles; o[5] = __builtin_amdgcn_s_memtime() - sk0; o[6] = sk0; o[7] = 0;
+  }
+#endif
+#undef CSTAMP
 #undef CV_RAW_BARRIER
 #undef CV_W_LOAD
 #undef CV_W_STORE
@@ -229,6 +258,26 @@ int launch_conv3_split(const GemmParams& g, hipStream_t s) {
     ncu = it->second;
   }
   const int grid = std::min(((ntile + 7) >> 3) * 8, (ncu + 7) / 8 * 8);        // one workgroup per CU (LDS), a multiple of the 8 XCDs
+#ifdef NUHTC_CONV_STAMPS
+  static unsigned long long* stamp_buf = nullptr;
+  if (!stamp_buf && hipMalloc(&stamp_buf, 8ull * 8 * 8 * 512) != hipSuccess) return NUHTC_E_HIP;
+  p.stamps = stamp_buf;
+#endif
   hipLaunchKernelGGL(conv3_split_kernel, dim3(grid), dim3(512), CV_LDS, s, p);
+#ifdef NUHTC_CONV_STAMPS
+  {
+    static int cnt = 0, dump_at = -1;   // launch NUHTC_STAMP_AT of the process is dumped to /tmp/conv_stamps.txt
+    if (dump_at < 0) { const char* e = getenv("NUHTC_STAMP_AT"); dump_at = e ? atoi(e) : 200; }
+    if (++cnt == dump_at) {
+      hipDeviceSynchronize();
+      std::vector<unsigned long long> h((size_t)grid * 8 * 8);
+      hipMemcpy(h.data(), stamp_buf, h.size() * 8, hipMemcpyDeviceToHost);
+      FILE* f = fopen("/tmp/conv_stamps.txt", "w");
+      fprintf(f, "# H %d W %d nimg %d ntile %d grid %d\n", p.H, p.W, p.nimg, ntile, grid);
+      for (int b = 0; b < grid; ++b) for (int w = 0; w < 8; ++w) { auto* o = &h[((size_t)b * 8 + w) * 8]; fprintf(f, "%d %d %llu %llu %llu %llu %llu %llu %llu\n", b, w, o[0], o[1], o[2], o[3], o[4], o[5], o[6]); }
+      fclose(f);
+    }
+  }
+#endif
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
 }
