@@ -38,10 +38,10 @@ DOMINANT = 'gemm_kernel<3>'      # all Swin-T linears (N % 96 == 0): 96 % of the
 # kernel tags (csrc ProfScope) -> groups of SURVEY 8d; dense groups are priced against the fp32-MFMA roof, the others
 # against HBM with their ALGORITHMIC bytes (what the op must read + write once)
 GROUPS = {
-    'dense_swin_linears': ('mfma', ['gemm_kernel<3>']),
+    'dense_swin_linears': ('mfma', ['gemm_kernel<3>', 'swin_mlp', 'swin_lnqkv']),   # 96-column GEMMs + the fused stage-1 kernels (csrc/mlp.hip)
     'dense_convs_fcs': ('mfma', ['gemm_kernel<1>', 'gemm_kernel<2>', 'gemm_kernel<4>', 'patch_embed', 'attn_pool']),
     'attention': ('mfma', ['window_attn']),
-    'layernorm_gathers': ('hbm', ['layernorm', 'merge_ln', 'preproc', 'sem_fuse']),
+    'layernorm_gathers': ('hbm', ['layernorm', 'merge_ln', 'preproc', 'sem_fuse', 'qkv_pad_rows']),
     'roi_gather': ('hbm', ['roi_feat7', 'roi_feat14']),
     'nms_scan': ('hbm', ['nms', 'rpn_select', 'cc_proposals', 'det_candidates', 'bbox_tail', 'paste', 'tile_post', 'build_rois']),
 }

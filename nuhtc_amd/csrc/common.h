@@ -118,6 +118,12 @@ void mlp_pack_stream(const float* w1, const float* w2, int C, std::vector<unsign
 int launch_swin_mlp(const float* x_in, float* x_out, const float* ln_g, const float* ln_b, const void* wstream, const float* b1, const float* b2,
                     int T, int C, hipStream_t s);
 
+// fused LN1 + QKV linear (mlp.hip, C = 96): qkv window image rows of the T real tokens + the bias rows of the padding tokens
+bool lnqkv_supported(int C);
+void lnqkv_pack_stream(const float* w, int C, std::vector<unsigned short>& out);
+int launch_swin_lnqkv(const float* x, float* qkv, const int* src_tok, const int* dst_row, const int* pad_rows, int n_pad, const float* ln_g, const float* ln_b,
+                      const void* wstream, const float* bias, int T, int C, hipStream_t s);
+
 // ----------------------------------------------------------------------------- contours (contour.hip)
 // outer contour (cv2 RETR first contour, CHAIN_APPROX_SIMPLE) of every kept instance mask; n: 0 = none, -1 = overflow
 int launch_contours(const uint32_t* masks, const uint8_t* keep, const int32_t* counts, int B, int max_per_img, int H, int W,
@@ -149,9 +155,10 @@ int launch_layernorm_windows(const float* x, const int* src_map, const int* dst_
                              float* pad_dst, const float* pad_val, int rows, int C, hipStream_t s);
 // PatchMerging gather + LN(4C): out[(b,y2,x2), (kh*2+kw)*C + c] (weights pre-permuted to this order)
 int launch_merge_ln(const float* x, const float* g, const float* b, float* y, int B, int H, int W, int C, hipStream_t s);
-// window attention: qkv [nWin*49, 3C] -> out rows of C; bias [nH,49,49]; mask [nW,49,49] or null; window row r is written to
-// out row out_map[r] (skipped when negative), or to row r when out_map is null
-int launch_window_attn(const float* qkv, const float* bias, const float* biasT, const float* mask, const int* out_map, float* out,
+// window attention: qkv [nWin*49, 3C] -> out rows of C; biasP [nH][4096] / maskP [nW][4096]: the relative-position bias and the
+// shift mask packed per lane (engine.hip pack_attn_terms), mask_any [nW] flags the windows with a non-zero mask (maskP null: no shift);
+// window row r is written to out row out_map[r] (skipped when negative), or to row r when out_map is null
+int launch_window_attn(const float* qkv, const float* biasP, const float* maskP, const int* mask_any, const int* out_map, float* out,
                        int nWinTotal, int nWperImg, int C, int nH, hipStream_t s);
 
 // ----------------------------------------------------------------------------- dense heads (dense.hip)

@@ -9,11 +9,15 @@ struct StageGeom {
   int* cidx[2];        // dev: window-row -> index among the non-padding window rows (-1 = padding); tile b's rows are [b*H*W, (b+1)*H*W)
   int* ctok[2];        // dev: that compact index -> token index, [max_batch*H*W]
   int* vrow[2];        // dev: that compact index -> window row
-  float* mask;         // dev: shift mask [nW][49][49]
+  int* prow[2];        // dev: the padding rows of the window image (map < 0), per-tile lists back to back; npad per tile
+  int npad;
+  float* mask;         // dev: shift mask, packed per lane [nW][4096] (engine.hip pack_attn_terms)
+  int* mask_any;       // dev: [nW] 1 where the window's mask has a non-zero entry
 };
 
 struct BlockW {
-  float *n1g, *n1b, *relb, *relbT, *qkv_w, *qkv_b, *proj_w, *proj_b, *n2g, *n2b, *f1_w, *f1_b, *f2_w, *f2_b;
+  float *n1g, *n1b, *relbT /* relative-position bias packed per lane [nH][4096] */, *qkv_w, *qkv_b, *proj_w, *proj_b, *n2g, *n2b, *f1_w, *f1_b, *f2_w, *f2_b;
+  void* qkv_stream;    // fused LN1 + QKV (mlp.hip): k-permuted split planes of qkv_w, null where LN + GEMM run separately
   void* mlp_stream;    // fused FFN half (mlp.hip): chunk-major split planes of f1_w / f2_w, null where the three separate launches run
 };
 

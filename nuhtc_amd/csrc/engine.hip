@@ -204,6 +204,20 @@ static std::vector<float> pack_conv3(const HostTensor& w, int O, int I) {
 }
 
 // =============================================================================== finalize
+// window_attn_mfma_kernel reads the additive score terms (relative-position bias, shift mask) per lane: the lane of query i = 32 ti + l32
+// in half-wave `half` needs, for key tile tj, the 16 accumulator registers r <-> key 32 tj + (r & 3) + 8 (r >> 2) + 4 half.  Packed
+// as [ti][half][l32][tj][16] (4096 floats per 49 x 49 table) a lane's terms of a query tile are 32 contiguous floats = a few 16-byte loads.
+static void pack_attn_terms(const float* qk /* [49][49] query-major */, float* out /* 4096 */) {
+  for (int ti = 0; ti < 2; ++ti)
+    for (int half = 0; half < 2; ++half)
+      for (int l = 0; l < 32; ++l)
+        for (int tj = 0; tj < 2; ++tj)
+          for (int r = 0; r < 16; ++r) {
+            const int i = ti * 32 + l, j = tj * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            out[(((ti * 2 + half) * 32 + l) * 2 + tj) * 16 + r] = (i < WS2 && j < WS2) ? qk[i * WS2 + j] : 0.f;
+          }
+}
+
 static int build_stage_maps(nuhtc_engine* e, int s) {
   StageGeom& g = e->st[s];
   const int B = e->cfg.max_batch;
@@ -237,6 +251,13 @@ static int build_stage_maps(nuhtc_engine* e, int s) {
     if (rc) return rc;
     rc = upload_i(e, &g.vrow[sh], vr);
     if (rc) return rc;
+    std::vector<int> pr;                  // padding rows: tile b's are [b * npad, (b + 1) * npad)
+    for (size_t r = 0; r < m.size(); ++r)
+      if (m[r] < 0) pr.push_back((int)r);
+    g.npad = (int)(pr.size() / (size_t)B);
+    if (pr.empty()) pr.push_back(0);
+    rc = upload_i(e, &g.prow[sh], pr);
+    if (rc) return rc;
   }
   // shift mask on the padded grid (swin.py:197-218)
   std::vector<int> ids((size_t)g.Hp * g.Wp);
@@ -254,7 +275,16 @@ static int build_stage_maps(nuhtc_engine* e, int s) {
           mask[((size_t)w * WS2 + p) * WS2 + q] = ip == iq ? 0.f : -100.f;
         }
     }
-  return upload(e, &g.mask, mask);
+  std::vector<float> mp((size_t)g.nW * 4096);
+  std::vector<int> any(g.nW, 0);
+  for (int w = 0; w < g.nW; ++w) {
+    pack_attn_terms(mask.data() + (size_t)w * WS2 * WS2, mp.data() + (size_t)w * 4096);
+    for (int i = 0; i < WS2 * WS2; ++i)
+      if (mask[(size_t)w * WS2 * WS2 + i] != 0.f) { any[w] = 1; break; }
+  }
+  int rc = upload(e, &g.mask, mp);
+  if (rc) return rc;
+  return upload_i(e, &g.mask_any, any);
 }
 
 int nuhtc_finalize(nuhtc_engine* e) {
@@ -316,17 +346,20 @@ int nuhtc_finalize(nuhtc_engine* e) {
       std::vector<float> rb((size_t)nH * WS2 * WS2);
       for (int h = 0; h < nH; ++h)
         for (int i = 0; i < WS2 * WS2; ++i) rb[(size_t)h * WS2 * WS2 + i] = tab->data[(size_t)rel[i] * nH + h];
-      std::vector<float> rbT((size_t)nH * WS2 * WS2);   // [head][key][query] for the MFMA attention kernel
-      for (int h = 0; h < nH; ++h)
-        for (int qi = 0; qi < WS2; ++qi)
-          for (int kj = 0; kj < WS2; ++kj) rbT[((size_t)h * WS2 + kj) * WS2 + qi] = rb[((size_t)h * WS2 + qi) * WS2 + kj];
+      std::vector<float> rbT((size_t)nH * 4096);        // per-lane packed terms of the attention kernel (pack_attn_terms)
+      for (int h = 0; h < nH; ++h) pack_attn_terms(rb.data() + (size_t)h * WS2 * WS2, rbT.data() + (size_t)h * 4096);
       if ((rc = upload(e, &bw.relbT, rbT))) return rc;
-      if ((rc = upload(e, &bw.n1g, n1w->data)) || (rc = upload(e, &bw.n1b, n1b->data)) || (rc = upload(e, &bw.relb, rb)) ||
-          (rc = upload_gemm_weight(e, &bw.qkv_w, qw->data, 3 * C, C)) || (rc = upload(e, &bw.qkv_b, qb->data)) || (rc = upload_gemm_weight(e, &bw.proj_w, pw->data, C, C)) ||
+      if ((rc = upload(e, &bw.n1g, n1w->data)) || (rc = upload(e, &bw.n1b, n1b->data)) ||           (rc = upload_gemm_weight(e, &bw.qkv_w, qw->data, 3 * C, C)) || (rc = upload(e, &bw.qkv_b, qb->data)) || (rc = upload_gemm_weight(e, &bw.proj_w, pw->data, C, C)) ||
           (rc = upload(e, &bw.proj_b, pb->data)) || (rc = upload(e, &bw.n2g, n2w->data)) || (rc = upload(e, &bw.n2b, n2b->data)) ||
           (rc = upload_gemm_weight(e, &bw.f1_w, f1w->data, 4 * C, C)) || (rc = upload(e, &bw.f1_b, f1b->data)) || (rc = upload_gemm_weight(e, &bw.f2_w, f2w->data, C, 4 * C)) ||
           (rc = upload(e, &bw.f2_b, f2b->data)))
         return rc;
+      if (e->cfg.matrix_pipe == NUHTC_PIPE_BF16_SPLIT && lnqkv_supported(C)) {
+        std::vector<unsigned short> st;
+        lnqkv_pack_stream(qw->data.data(), C, st);
+        if ((rc = dev_alloc(e, &bw.qkv_stream, st.size() * 2))) return rc;
+        HIP_CHECK(e, hipMemcpy(bw.qkv_stream, st.data(), st.size() * 2, hipMemcpyHostToDevice));
+      }
       if (e->cfg.matrix_pipe == NUHTC_PIPE_BF16_SPLIT && mlp_supported(C)) {
         std::vector<unsigned short> st;
         mlp_pack_stream(f1w->data.data(), f2w->data.data(), C, st);
@@ -481,13 +514,18 @@ int run_backbone(nuhtc_engine* e, int B, hipStream_t s) {
       // (xw, T rows), the QKV GEMM scatters its rows into the window image, whose padding rows are the QKV bias
       // (LN of a zero-padded token is 0 after swin.py:341-343's F.pad, so its qkv is the bias), attention writes the
       // non-padding rows of its output compactly again and proj scatters them back to token order.
+      static const int& fused_qkv = dev_knob_ref("FUSED_QKV", 1);
+      if (w.qkv_stream && fused_qkv) {       // one kernel: LN1, window gather, QKV linear (mlp.hip) + the bias rows of the padding tokens
+        RUN(launch_swin_lnqkv(x, e->qkv, g.ctok[sh], g.vrow[sh], g.prow[sh], B * g.npad, w.n1g, w.n1b, w.qkv_stream, w.qkv_b, T, C, s));
+      } else {
       RUN(launch_layernorm_windows(x, g.map[sh], g.cidx[sh], w.n1g, w.n1b, e->xw, e->qkv, w.qkv_b, Mw, C, s));
       {
         GemmParams p = gp(e->xw, w.qkv_w, w.qkv_b, e->qkv, T, 3 * C, C);
         p.store = ST_ROWMAP; p.row_map = g.vrow[sh];
         RUN(launch_gemm(p, s));
       }
-      RUN(launch_window_attn(e->qkv, w.relb, w.relbT, sh ? g.mask : nullptr, g.cidx[sh], e->att, B * g.nW, g.nW, C, g.nH, s));
+      }
+      RUN(launch_window_attn(e->qkv, w.relbT, sh ? g.mask : nullptr, sh ? g.mask_any : nullptr, g.cidx[sh], e->att, B * g.nW, g.nW, C, g.nH, s));
       {
         GemmParams p = gp(e->att, w.proj_w, w.proj_b, x, T, C, C);
         p.store = ST_ROWMAP; p.row_map = g.ctok[sh]; p.res = x; p.ldr = C;

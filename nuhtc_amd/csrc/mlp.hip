@@ -250,6 +250,182 @@ __global__ __launch_bounds__(64 * NW, 1) void swin_mlp_kernel(MlpParams p) {
 #undef MSTAMP
 }
 
+// ======================================================================================================================
+// Fused LN1 + QKV linear of a Swin block (C = 96):  qkv[vrow[r]] = Wqkv · LN1(x[ctok[r]]) + b   for the T real tokens r in window
+// order (mmdet swin.py:341-356,88: norm1, pad, roll, window partition, qkv).  Replaces layernorm_windows + the K = 96 GEMM (three
+// column-tile passes that each re-read and re-split the normalised rows): one read of x, LN and the operand split once per token
+// tile, the 288 output features in three chunks of 96 (q, k, v) whose weights stream through a double-buffered LDS image.
+// Same transposed arrangement as swin_mlp_kernel: token on the lane, W rows as the MFMA's A operand, so a lane owns 4 x 4
+// consecutive features of its token per 32-feature tile and stores them as 16-byte pieces.  The padding rows of the window image
+// (their qkv is the bias) are filled by qkv_pad_rows_kernel.
+struct LnQkvParams {
+  const float* x;         // [tokens][C]
+  float* qkv;             // window image [rows][3C]
+  const int* src_tok;     // [T] compact window-order row -> token
+  const int* dst_row;     // [T] compact row -> row of the window image
+  const float* ln_g;
+  const float* ln_b;
+  const char* wstream;    // per chunk of 96 features: 96 rows x (C/8) k-groups x 3 planes x 8 bf16 of the k-permuted weight
+  const float* bias;      // [3C]
+  int T;
+};
+
+template <int C>
+struct QkvGeom {
+  static constexpr int KS1 = C / 16, CT = C / 32;
+  static constexpr int R1 = (C / 8) * 48, P1 = R1 + 16;
+  static constexpr int CHUNK_ROWS = C;                 // 96 features = 3 tiles of 32
+  static constexpr int CHUNK_BYTES = CHUNK_ROWS * R1, PIECES = CHUNK_BYTES / 16;
+  static constexpr int WBUF = CHUNK_ROWS * P1;
+  static constexpr int VEC_OFF = 2 * WBUF;             // then ln_g[C], ln_b[C], bias[3C]
+  static constexpr int LDS_BYTES = VEC_OFF + 5 * C * 4;
+};
+
+template <int C, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void swin_lnqkv_kernel(LnQkvParams p) {
+  using G = QkvGeom<C>;
+  constexpr int NT = 64 * NW;
+  constexpr int NP = (G::PIECES + NT - 1) / NT;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i32 = lane & 31, half = lane >> 5;
+  float* vec = reinterpret_cast<float*>(lds + G::VEC_OFF);
+  const float* ldg = vec;
+  const float* ldb = vec + C;
+  const float* lbias = vec + 2 * C;
+
+  int st_lds[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    int q = tid + NT * j;
+    q = q < G::PIECES ? q : G::PIECES - 1;
+    const int row = q / (G::R1 / 16), col = q - row * (G::R1 / 16);
+    st_lds[j] = row * G::P1 + col * 16;
+  }
+  const char* wsrc = p.wstream + (long long)tid * 16;
+  u32x4 stg[NP];
+#define QKV_LOAD_CHUNK(c_)                                                                                        \
+  { _Pragma("unroll") for (int j = 0; j < NP; ++j)                                                                \
+      if (NT * j + NT <= G::PIECES || tid + NT * j < G::PIECES)                                                   \
+        stg[j] = *reinterpret_cast<const u32x4*>(wsrc + (long long)(c_) * G::CHUNK_BYTES + (long long)NT * j * 16); }
+#define QKV_STORE_CHUNK(c_)                                                                                       \
+  { _Pragma("unroll") for (int j = 0; j < NP; ++j)                                                                \
+      if (NT * j + NT <= G::PIECES || tid + NT * j < G::PIECES)                                                   \
+        *reinterpret_cast<u32x4*>(lds + ((c_) & 1) * G::WBUF + st_lds[j]) = stg[j]; }
+#define QKV_RAW_BARRIER() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) */ __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+
+  QKV_LOAD_CHUNK(0)
+  for (int i = tid; i < C; i += NT) { vec[i] = p.ln_g[i]; vec[C + i] = p.ln_b[i]; }
+  for (int i = tid; i < 3 * C; i += NT) vec[2 * C + i] = p.bias[i];
+
+  const long long r = (long long)blockIdx.x * (32 * NW) + wave * 32 + i32;      // compact window-order row of this lane
+  const bool r_ok = r < p.T;
+  const long long rc = r_ok ? r : (long long)p.T - 1;
+  const float* xrow = p.x + (long long)p.src_tok[rc] * C + 4 * half;
+  float* orow = p.qkv + (long long)p.dst_row[rc] * (3 * C) + 4 * half;
+
+  u32x4 xp[G::KS1][3];
+  {
+    v4f xv[G::CT][4];
+#pragma unroll
+    for (int t = 0; t < G::CT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xv[t][q] = *reinterpret_cast<const v4f*>(xrow + 32 * t + 8 * q);
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < G::CT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sum += (xv[t][q].x + xv[t][q].y) + (xv[t][q].z + xv[t][q].w);
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum / (float)C;
+    float var = 0.f;
+#pragma unroll
+    for (int t = 0; t < G::CT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        xv[t][q] -= mean;
+        var = fmaf(xv[t][q].x, xv[t][q].x, fmaf(xv[t][q].y, xv[t][q].y, fmaf(xv[t][q].z, xv[t][q].z, fmaf(xv[t][q].w, xv[t][q].w, var))));
+      }
+    var += __shfl_xor(var, 32);
+    const float rstd = 1.0f / sqrtf(var / (float)C + 1e-5f);
+    QKV_STORE_CHUNK(0)
+    __syncthreads();
+    QKV_LOAD_CHUNK(1)
+#pragma unroll
+    for (int t = 0; t < G::CT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const v4f gg = *reinterpret_cast<const v4f*>(ldg + 32 * t + 8 * q + 4 * half);
+        const v4f bb = *reinterpret_cast<const v4f*>(ldb + 32 * t + 8 * q + 4 * half);
+        const v4f v = xv[t][q] * rstd * gg + bb;
+        const int s = 2 * t + (q >> 1), d0 = 2 * (q & 1);
+        NUHTC_SPLIT3_INTO(xp[s], d0, v.x, v.y)
+        NUHTC_SPLIT3_INTO(xp[s], d0 + 1, v.z, v.w)
+      }
+  }
+
+  // ---- 3 chunks x 3 feature tiles x KS1 k-steps; weight fragments read two steps ahead (three register sets)
+  const char* w_lane = lds + i32 * G::P1 + half * 48;          // + slot * WBUF + tile * 32 * P1 + s * 96 + plane * 16
+  constexpr int NSTEP = 3 * G::CT * G::KS1;                    // steps of 6 MFMAs over the whole kernel (54)
+  constexpr int SPC = G::CT * G::KS1;                          // steps per chunk (18)
+  u32x4 fw[3][3];
+#define QKV_READ(k_, set_, step_)                                                                                 \
+  { const int ch_ = (step_) / SPC, tl_ = ((step_) % SPC) / G::KS1, s_ = (step_) % G::KS1;                         \
+    fw[set_][k_] = *reinterpret_cast<const u32x4*>(w_lane + (ch_ & 1) * G::WBUF + tl_ * 32 * G::P1 + s_ * 96 + (k_) * 16); }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) QKV_READ(k, 0, 0)
+#pragma unroll
+  for (int k = 0; k < 3; ++k) QKV_READ(k, 1, 1)
+  f32x16 h;
+#pragma unroll
+  for (int step = 0; step < NSTEP; ++step) {
+    const int ch = step / SPC, tl = (step % SPC) / G::KS1, s = step % G::KS1;
+    if (s == 0) {
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) h[rr] = 0.f;
+    }
+    // weights of chunk ch+1: into the other image at the first step of chunk ch (registers loaded a chunk earlier); the barrier
+    // sits before the step whose look-ahead reads are the first ones of chunk ch+1 (two steps before the chunk's end)
+    if (step % SPC == 0 && ch < 2) {
+      QKV_STORE_CHUNK(ch + 1)
+      if (ch < 1) QKV_LOAD_CHUNK(ch + 2)
+    }
+    if (step % SPC == SPC - 2 && ch < 2) QKV_RAW_BARRIER()
+    {
+      constexpr int iw_[6] = {0, 2, 1, 0, 1, 0}, ia_[6] = {2, 0, 1, 1, 0, 0};   // (activation, weight) plane order of gemm_split_kernel
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[step % 3][iw_[k]]), __builtin_bit_cast(bf16x8, xp[s][ia_[k]]), h, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k < 3 && step + 2 < NSTEP) QKV_READ(k, (step + 2) % 3, step + 2)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (s == G::KS1 - 1 && r_ok) {      // feature tile done: + bias, store (features ch * C + 32 tl + 8 q + 4 half + 0..3)
+      const int f0 = ch * C + 32 * tl;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const v4f bb = *reinterpret_cast<const v4f*>(lbias + f0 + 8 * q + 4 * half);
+        const v4f o = v4f{h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]} + bb;
+        *reinterpret_cast<v4f*>(orow + f0 + 8 * q) = o;
+      }
+    }
+  }
+#undef QKV_READ
+#undef QKV_LOAD_CHUNK
+#undef QKV_STORE_CHUNK
+#undef QKV_RAW_BARRIER
+}
+
+// rows of the window image that hold padding tokens: qkv = bias (LN of a zero-padded token is 0, swin.py:341-343)
+__global__ __launch_bounds__(256) void qkv_pad_rows_kernel(float* __restrict__ qkv, const int* __restrict__ rows, int n, const float* __restrict__ bias, int C3) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= n) return;
+  v4f* dst = reinterpret_cast<v4f*>(qkv + (long long)rows[i] * C3);
+  const v4f* src = reinterpret_cast<const v4f*>(bias);
+  for (int c = lane; c < C3 / 4; c += 64) dst[c] = src[c];
+}
+
 // ---- host side: the weight stream of one block (permuted k axes, split planes, chunk-major)
 static inline unsigned short mlp_bf16_rn(float f) {
   unsigned u;
@@ -348,5 +524,46 @@ int launch_swin_mlp(const float* x_in, float* x_out, const float* ln_g, const fl
     }
   }
 #endif
+  return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
+}
+
+// ---- LN1 + QKV (C = 96)
+bool lnqkv_supported(int C) { return C == 96; }
+size_t lnqkv_stream_bytes(int C) { return (size_t)3 * C * (C / 8) * 48; }
+// w [3C][C] -> chunk-major stream (rows in order: the three chunks are q, k, v), k axis permuted like the MLP's W1
+void lnqkv_pack_stream(const float* w, int C, std::vector<unsigned short>& out) {
+  out.assign(lnqkv_stream_bytes(C) / 2, 0);
+  unsigned short* o = out.data();
+  for (int r = 0; r < 3 * C; ++r)
+    for (int kg = 0; kg < C / 8; ++kg) {
+      for (int e = 0; e < 8; ++e) {
+        const int kp = 8 * kg + e, k = (kp & ~15) + mlp_perm16(kp & 15);
+        mlp_split3(w[(size_t)r * C + k], o + e);
+      }
+      o += 24;
+    }
+}
+
+int launch_swin_lnqkv(const float* x, float* qkv, const int* src_tok, const int* dst_row, const int* pad_rows, int n_pad, const float* ln_g, const float* ln_b,
+                      const void* wstream, const float* bias, int T, int C, hipStream_t s) {
+  if (T <= 0) return 0;
+  if (!lnqkv_supported(C) || !wstream) return NUHTC_E_INVALID;
+  LnQkvParams p{x, qkv, src_tok, dst_row, ln_g, ln_b, reinterpret_cast<const char*>(wstream), bias, T};
+  ProfScope ps("swin_lnqkv", 6.0 * T * C * C, 16.0 * T * C + (double)lnqkv_stream_bytes(C), s);
+  constexpr int NW = 8;
+  auto kern = &swin_lnqkv_kernel<96, NW>;
+  {
+    static std::set<int> done;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return NUHTC_E_HIP;
+    if (!done.count(dev)) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, QkvGeom<96>::LDS_BYTES) != hipSuccess) return NUHTC_E_HIP;
+      done.insert(dev);
+    }
+  }
+  if (n_pad > 0) hipLaunchKernelGGL(qkv_pad_rows_kernel, dim3(cdiv(n_pad, 4)), dim3(256), 0, s, qkv, pad_rows, n_pad, bias, 3 * C);
+  hipLaunchKernelGGL(kern, dim3(cdiv(T, 32 * NW)), dim3(64 * NW), QkvGeom<96>::LDS_BYTES, s, p);
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
 }

@@ -339,8 +339,9 @@ int launch_merge_ln(const float* x, const float* g, const float* b, float* y, in
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256, 3) void window_attn_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ biasT,
-                                                               const float* __restrict__ mask, const int* __restrict__ out_map, float* __restrict__ out, int nPairs,
+__global__ __launch_bounds__(256, 3) void window_attn_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ biasP,
+                                                               const float* __restrict__ maskP, const int* __restrict__ mask_any,
+                                                               const int* __restrict__ out_map, float* __restrict__ out, int nPairs,
                                                                int nWperImg, int C, int nH) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int pair = blockIdx.x * 4 + wave;
@@ -349,8 +350,11 @@ __global__ __launch_bounds__(256, 3) void window_attn_mfma_kernel(const float* _
   const int l32 = lane & 31, half = lane >> 5;
   const long long ld = 3LL * C;
   const float* base = qkv + (long long)win * WS2 * ld + head * HEAD_DIM;
-  const float* bT = biasT + (long long)head * WS2 * WS2;
-  const float* mk = mask ? mask + (long long)(win % nWperImg) * WS2 * WS2 : nullptr;
+  // additive score terms, packed per lane ([ti][half][l32][tj][16], engine.hip pack_attn_terms): 32 contiguous floats per query tile.
+  // Only the windows on the shifted image's last row / column of windows carry a non-zero shift mask.
+  const float* bP = biasP + (long long)head * 4096 + (half * 32 + l32) * 32;                    // + ti * 2048
+  const int wimg = win % nWperImg;
+  const float* mP = (maskP && mask_any[wimg]) ? maskP + (long long)wimg * 4096 + (half * 32 + l32) * 32 : nullptr;
   const float scale = 0.17677669529663687f;   // 32^-0.5
 
   // K fragments of both key tiles: lane (j, half) holds K[tj*32 + j][half*16 .. +16)
@@ -385,21 +389,20 @@ __global__ __launch_bounds__(256, 3) void window_attn_mfma_kernel(const float* _
       for (int q = 0; q < 4; ++q) qf[q] = qp[q];
     }
     float bb[2][16];
+    {
+      const v4f* bp = reinterpret_cast<const v4f*>(bP + ti * 2048);
+      v4f t4[7];
 #pragma unroll
-    for (int tj = 0; tj < 2; ++tj)
+      for (int q = 0; q < 7; ++q) t4[q] = bp[q];          // registers 0..15 of key tile 0, 0..11 of key tile 1 (NR1 = 9 are used)
+      if (mP) {
+        const v4f* mp = reinterpret_cast<const v4f*>(mP + ti * 2048);
 #pragma unroll
-      for (int r = 0; r < (tj ? NR1 : 16); ++r) {
-        const int jc = min(tj * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, WS2 - 1);
-        bb[tj][r] = bT[jc * WS2 + i];
+        for (int q = 0; q < 7; ++q) t4[q] += mp[q];
       }
-    if (mk) {
 #pragma unroll
-      for (int tj = 0; tj < 2; ++tj)
+      for (int q = 0; q < 4; ++q) { bb[0][4 * q] = t4[q].x; bb[0][4 * q + 1] = t4[q].y; bb[0][4 * q + 2] = t4[q].z; bb[0][4 * q + 3] = t4[q].w; }
 #pragma unroll
-        for (int r = 0; r < (tj ? NR1 : 16); ++r) {
-          const int jc = min(tj * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, WS2 - 1);
-          bb[tj][r] += mk[jc * WS2 + i];
-        }
+      for (int q = 0; q < 3; ++q) { bb[1][4 * q] = t4[4 + q].x; bb[1][4 * q + 1] = t4[4 + q].y; bb[1][4 * q + 2] = t4[4 + q].z; bb[1][4 * q + 3] = t4[4 + q].w; }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -460,13 +463,12 @@ __global__ __launch_bounds__(256, 3) void window_attn_mfma_kernel(const float* _
   }
 }
 
-int launch_window_attn(const float* qkv, const float* bias, const float* biasT, const float* mask, const int* out_map, float* out,
+int launch_window_attn(const float* qkv, const float* biasP, const float* maskP, const int* mask_any, const int* out_map, float* out,
                        int nWinTotal, int nWperImg, int C, int nH, hipStream_t s) {
   ProfScope ps("window_attn", 4.0 * 49 * 49 * 32 * nWinTotal * nH, 16.0 * 49 * C * nWinTotal, s);
   int nPairs = nWinTotal * nH;
   if (nPairs <= 0) return 0;
-  if (!biasT) return NUHTC_E_INVALID;
-  (void)bias;
-  hipLaunchKernelGGL(window_attn_mfma_kernel, dim3(cdiv(nPairs, 4)), dim3(256), 0, s, qkv, biasT, mask, out_map, out, nPairs, nWperImg, C, nH);
+  if (!biasP || (maskP && !mask_any)) return NUHTC_E_INVALID;
+  hipLaunchKernelGGL(window_attn_mfma_kernel, dim3(cdiv(nPairs, 4)), dim3(256), 0, s, qkv, biasP, maskP, mask_any, out_map, out, nPairs, nWperImg, C, nH);
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
 }
