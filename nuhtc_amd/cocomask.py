@@ -4,7 +4,8 @@
 pycocotools (requirements.txt: pycocotools==2.0.7) is a third-party dependency that is absent from /root/reference and
 from this image, so this file restates the published algorithm of cocoapi common/maskApi.c (rleEncode, rleDecode,
 rleArea, rleToBbox, rleToString, rleFrString) -- PARITY UNPINNED against the real library; the tests pin it through
-round trips and hand-worked vectors only.
+round trips, hand-worked vectors and an independent scalar restatement of the same C routines (oracle/rle.py,
+tests/test_oracle_outputs.py).
 
 An RLE is {'size': [h, w], 'counts': str}: run lengths over the mask in column-major (Fortran) order, starting with a
 run of zeros (possibly empty)."""

@@ -9,7 +9,8 @@ kept where the contour check passes and the patch centre is not inside a hole), 
 The reference does all of this with OpenCV on an OpenSlide pyramid level; neither library is available here, so the OpenCV
 steps are restated (8-bit RGB->HSV saturation in OpenCV's fixed point, medianBlur with replicated borders, rectangular
 close anchored at size//2, border following for outer contours and holes, shoelace contourArea, boundingRect,
-pointPolygonTest) -- PARITY UNPINNED against cv2; the tests pin behaviour on synthetic slides.  Slides are arrays: the
+pointPolygonTest) -- PARITY UNPINNED against cv2 itself; checked against the independent scalar restatements of the same OpenCV
+routines in oracle/cv_ops.py and the Suzuki-Abe oracle (tests/test_oracle_cv.py), plus behaviour on synthetic slides.  Slides are arrays: the
 segmentation level is a strided view of the level-0 image (`scale` = its downsample factor).
 """
 import numpy as np
@@ -125,7 +126,6 @@ def find_contours_ccomp(binary):
         y0, y1 = max(ys.start - 1, 0), min(ys.stop + 1, fg.shape[0])
         x0, x1 = max(xs.start - 1, 0), min(xs.stop + 1, fg.shape[1])
         hm = bg_lab[y0:y1, x0:x1] == h
-        ring = ndimage.binary_dilation(hm, structure=np.ones((3, 3), bool))
         yy, xx = np.nonzero(hm)
         owner = 0
         for dy, dx in ((0, -1), (-1, 0), (0, 1), (1, 0)):              # a 4-neighbour of the hole is foreground of its parent
@@ -135,7 +135,9 @@ def find_contours_ccomp(binary):
                 break
         if owner == 0:
             continue
-        c = _trace_all(ring) + np.array([x0, y0])
+        # the hole border runs over the foreground pixels around the hole, followed from the hole's side (Suzuki-Abe: start at the
+        # foreground pixel left of the hole's first raster pixel, whose east neighbour is the hole)
+        c = _follow_hole_border(fg, int(yy[0]) + y0, int(xx[0]) + x0 - 1)
         holes_of[owner].append(c)
     out = []
     obj = ndimage.find_objects(lab)
@@ -145,6 +147,43 @@ def find_contours_ccomp(binary):
         c = _trace_all(comp) + np.array([sl[1].start, sl[0].start])
         out.append((c, holes_of[i]))
     return out
+
+
+_DXY = ((1, 0), (1, -1), (0, -1), (-1, -1), (-1, 0), (-1, 1), (0, 1), (1, 1))     # chain codes counter-clockwise from east (dx, dy), y down
+
+
+def _follow_hole_border(fg, y0, x0):
+    """Suzuki-Abe border following (CHAIN_APPROX_NONE) of the hole border that starts at foreground pixel (y0, x0) whose east
+    neighbour belongs to the hole: every foreground pixel 4-adjacent to the hole, in following order, as (n, 2) (x, y).  Unlike
+    the outer trace of the dilated hole, it keeps the foreground pixel inside a concave corner of the hole."""
+    H, W = fg.shape
+
+    def on(y, x):
+        return 0 <= y < H and 0 <= x < W and fg[y, x]
+    s = 0                                      # the east neighbour is the hole: search clockwise from it
+    k = 0
+    while True:
+        s = (s - 1) & 7
+        k += 1
+        if on(y0 + _DXY[s][1], x0 + _DXY[s][0]):
+            break
+        if k == 8:
+            return np.array([[x0, y0]], np.int64)
+    y1, x1 = y0 + _DXY[s][1], x0 + _DXY[s][0]
+    pts = []
+    cy, cx = y0, x0
+    while True:
+        while True:                            # counter-clockwise from the code after the one pointing back
+            s = (s + 1) & 7
+            ny, nx = cy + _DXY[s][1], cx + _DXY[s][0]
+            if on(ny, nx):
+                break
+        pts.append((cx, cy))
+        if (ny, nx) == (y0, x0) and (cy, cx) == (y1, x1):
+            break
+        cy, cx = ny, nx
+        s = (s + 4) & 7
+    return np.array(pts, np.int64)
 
 
 def _trace_all(mask):

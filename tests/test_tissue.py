@@ -39,7 +39,9 @@ def test_primitives_hand_worked():
     # border following with holes: a 6x6 square with a 2x2 hole
     b = np.zeros((10, 10), np.uint8); b[2:8, 2:8] = 255; b[4:6, 4:6] = 0
     (outer, holes), = T.find_contours_ccomp(b)
-    assert T.contour_area(outer) == 25 and len(outer) == 20 and len(holes) == 1 and T.contour_area(holes[0]) == 9
+    # the hole border visits the 8 foreground pixels 4-adjacent to the 2 x 2 hole and cuts its corners diagonally (Suzuki-Abe from the
+    # hole's side; the four pixels diagonal to the hole's corners are not on it): (2 + 1)^2 - 4 * 1/2 = 7, not 9
+    assert T.contour_area(outer) == 25 and len(outer) == 20 and len(holes) == 1 and T.contour_area(holes[0]) == 7 and len(holes[0]) == 8
 
 
 def test_segment_and_tile_synthetic_slide():
