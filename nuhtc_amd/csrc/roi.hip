@@ -284,56 +284,6 @@ __device__ __forceinline__ v2f bin_lds2(const float* tile, const AxisEnt* tx, co
   return acc / (float)(GX * GY);
 }
 
-// RoIs whose footprint does not fit the LDS tiles (large proposals): taken from the fallback list written by
-// roi_classify_kernel.  A 300-px RoI samples its semantic term on a 6x6 grid per 14x14 bin, ~600 dependent gathers per
-// output bin, so one block works on ONE output bin: wave 0 takes the two FPN terms and the first semantic sub-bin, waves
-// 1-3 the other three sub-bins, and the four partial results are combined in the reference's order through LDS.  These
-// blocks are the FIRST FB_SLOTS * 49 blocks of the one roi_feat7 launch: the few long chains of big RoIs start at once and
-// run beside the stream of LDS-path blocks.
-#define FB_SLOTS 256    // fallback RoIs processed concurrently (more are looped over)
-__device__ __forceinline__ void roi_feat7_generic_block(const RoiFeatParams& p, int slot, int bin, float (*part)[64]) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int ph = bin / 7, pw = bin - ph * 7;
-  const int nfb = *p.fb_count;
-  for (int i = slot; i < nfb; i += FB_SLOTS) {
-    const int r = p.fb_list[i];
-    const float* roi = p.rois + (long long)r * 5;
-    const int b = (int)roi[0];
-    const RoiGeom gs = roi_geom(roi, 0.25f, 14, 0);
-    const float* fs = p.sem + (long long)b * p.H0 * p.W0 * 64;
-    // semantic sub-bin of this wave: (2pw + (wave & 1), 2ph + (wave >> 1))
-    const float sub = roi_bin(fs, p.H0, p.W0, gs.x1, gs.y1, gs.bw, gs.bh, gs.gw, gs.gh, 2 * pw + (wave & 1), 2 * ph + (wave >> 1), lane);
-    if (wave) part[wave - 1][lane] = sub;
-    float v = 0.f;
-    if (wave == 0) {
-      float gs2[2];
-#pragma unroll
-      for (int l = 0; l < 2; ++l) {
-        const int Hl = l ? p.H3 : p.H2, Wl = l ? p.W3 : p.W2;
-        const float st = l ? 32.f : 16.f;
-        float cx = floorf((roi[1] + roi[3]) / (2.0f * st)), cy = floorf((roi[2] + roi[4]) / (2.0f * st));
-        cx = fminf(fmaxf(cx, 0.f), (float)(Wl - 1));
-        cy = fminf(fmaxf(cy, 0.f), (float)(Hl - 1));
-        const float* G = l ? p.G3 : p.G2;
-        gs2[l] = G[(((long long)b * Hl + (int)cy) * Wl + (int)cx) * 64 + lane];
-      }
-      const RoiGeom g0 = roi_geom(roi, 0.25f, 7, 2), g1 = roi_geom(roi, 0.125f, 7, 2);
-      const float* f0 = p.x0 + (long long)b * p.H0 * p.W0 * 64;
-      const float* f1 = p.x1 + (long long)b * p.H1 * p.W1 * 64;
-      v += roi_bin(f0, p.H0, p.W0, g0.x1, g0.y1, g0.bw, g0.bh, g0.gw, g0.gh, pw, ph, lane);
-      v += roi_bin(f1, p.H1, p.W1, g1.x1, g1.y1, g1.bw, g1.bh, g1.gw, g1.gh, pw, ph, lane);
-      v += gs2[0];
-      v += gs2[1];
-    }
-    __syncthreads();
-    if (wave == 0) {
-      const float a = sub, bq = part[0][lane], c = part[1][lane], d = part[2][lane];
-      p.out[(long long)r * 49 * 64 + (ph * 7 + pw) * 64 + lane] = v + (((a + bq) + c) + d) * 0.25f;
-    }
-    __syncthreads();
-  }
-}
-
 // RoIs too large for the square LDS tiles but with at most 2x2 semantic samples per 14x14 bin and sides up to SM_MAXSIDE px
 // at network scale: every nucleus-sized box of a 40x slide (40-100 px after the x2 resize).  Their footprint (up to 30x30
 // pixels of 256 bytes per map) fits no LDS tile, and gathering the taps of every sample from L2 moves each pixel 4-16 times.
@@ -516,6 +466,180 @@ __global__ __launch_bounds__(64) void roi_feat7_stream_kernel(RoiFeatParams p) {
   }
 }
 
+// RoIs beyond the stream kernel's limits (sides over SM_MAXSIDE px, or more than 2 x 2 semantic samples per 14 x 14 bin: merged
+// clumps, component proposals up to the whole tile).  Same separable form -- a bin is sum_y sum_x wy[y] wx[x] F[y][x] with merged
+// per-axis weights -- but for footprints of any size: one 4-wave workgroup per RoI, the waves take the footprint rows in turn, a
+// row is contracted along x straight from the map (lane = channel: one coalesced 256-byte pixel per load, J taps per bin column
+// with the merged weights in LDS) and scattered with the row's non-zero y weights (a row touches one or two bin rows); the four
+// partial 7 x 7 x 64 sums meet in LDS.  Every footprint pixel is read once per map instead of once per sample tap: the former
+// one-block-per-bin gathers read a 150-px box's pixels ~16 times and took 21.6 ms per step at 100-200 px boxes.
+#define BG_J 40             // merged taps per bin column: a 7-grid bin of a 1024-px box spans 36.6 stride-4 pixels + 2 (BG_J % 8 == 0)
+#define BG_FH 264           // footprint rows
+struct BigTabs {
+  __attribute__((aligned(16))) float wx[7][BG_J];   // rows 16-byte aligned; entries from J on are zero
+  int xlo[7];
+  int J;                    // taps per bin column actually used
+  float wy[7][BG_FH];
+  int fx0, fy0, fw, fh;
+};
+
+__device__ void bg_accumulate(const float* __restrict__ map, int H, int W, int b, float x1, float y1, float bw, float bh, int Sx, int Sy,
+                              BigTabs* tb, float (&acc)[49]) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // ---- footprint bounds over the valid samples of both axes (threads 0..127: x samples, 128..255: y samples, strided)
+  {
+    const bool is_y = tid >= 128;
+    const int S = is_y ? Sy : Sx;
+    int lo = 1 << 30, hi = -1;
+    for (int sidx = tid & 127; sidx < 7 * S; sidx += 128) {
+      bool v;
+      const AxisEnt e = sm_sample(is_y ? y1 : x1, is_y ? bh : bw, S, sidx, is_y ? H : W, v);
+      if (v) { lo = min(lo, e.lo); hi = max(hi, e.hi); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+    __shared__ int blo[4], bhi[4];
+    if (lane == 0) { blo[wave] = lo; bhi[wave] = hi; }
+    __syncthreads();
+    if (tid == 0) {
+      const int xl = min(blo[0], blo[1]), xh = max(bhi[0], bhi[1]), yl = min(blo[2], blo[3]), yh = max(bhi[2], bhi[3]);
+      const bool empty = xh < 0 || yh < 0;
+      tb->fx0 = empty ? 0 : xl; tb->fy0 = empty ? 0 : yl;
+      tb->fw = empty ? 0 : xh - xl + 1; tb->fh = empty ? 0 : min(yh - yl + 1, BG_FH);
+    }
+    __syncthreads();
+  }
+  const int fx0 = tb->fx0, fy0 = tb->fy0, fw = tb->fw, fh = tb->fh;
+  if (fw == 0 || fh == 0) return;                       // every sample of an axis lies outside the map (block-uniform)
+  // ---- merged per-axis weights
+  if (tid < 7) {
+    int m = 1 << 30, mh = -1;
+    for (int is = 0; is < Sx; ++is) {
+      bool v;
+      const AxisEnt q = sm_sample(x1, bw, Sx, tid * Sx + is, W, v);
+      if (v) { m = min(m, q.lo - fx0); mh = max(mh, q.hi - fx0); }
+    }
+    tb->xlo[tid] = m == (1 << 30) ? 0 : m;
+    tb->wx[tid][0] = (float)(mh < 0 ? 0 : mh - (m == (1 << 30) ? 0 : m) + 1);     // span of this bin, folded into J below
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int J = 1;
+    for (int pw = 0; pw < 7; ++pw) J = max(J, (int)tb->wx[pw][0]);
+    tb->J = min(J, BG_J);
+  }
+  __syncthreads();
+  const int J = tb->J;
+  for (int t = tid; t < 7 * BG_J; t += 256) {
+    const int pw = t / BG_J, j = t - pw * BG_J;
+    float wsum = 0.f;
+    if (j < J) {
+      const int px = fx0 + tb->xlo[pw] + j;
+      for (int is = 0; is < Sx; ++is) {
+        bool v;
+        const AxisEnt q = sm_sample(x1, bw, Sx, pw * Sx + is, W, v);
+        if (v) { if (q.lo == px) wsum += q.h; if (q.hi == px) wsum += q.l; }
+      }
+    }
+    tb->wx[pw][j] = wsum / (float)Sx;
+  }
+  for (int t = tid; t < 7 * fh; t += 256) {
+    const int ph = t / fh, yr = t - ph * fh;
+    float wsum = 0.f;
+    for (int is = 0; is < Sy; ++is) {
+      bool v;
+      const AxisEnt q = sm_sample(y1, bh, Sy, ph * Sy + is, H, v);
+      if (v) { if (q.lo == fy0 + yr) wsum += q.h; if (q.hi == fy0 + yr) wsum += q.l; }
+    }
+    tb->wy[ph][yr] = wsum / (float)Sy;
+  }
+  __syncthreads();
+  // ---- rows of this wave
+  const float* base = map + (((long long)b * H + fy0) * W + fx0) * 64 + lane;
+  for (int yr = wave; yr < fh; yr += 4) {
+    const float* row = base + (long long)yr * W * 64;
+    float T[7];
+#pragma unroll
+    for (int pw = 0; pw < 7; ++pw) {
+      // J taps from pixel xlo[pw] on, eight loads in flight at a time (static byte offsets), their merged weights read four at a
+      // time from LDS.  Taps past the footprint's last pixel carry zero weight: a bin whose taps would run past it (the last
+      // one at most) takes the clamped path so that nothing is read beyond the map
+      const int x0 = tb->xlo[pw];
+      const float* px = row + x0 * 64;
+      const v4f* w4 = reinterpret_cast<const v4f*>(tb->wx[pw]);
+      float t0 = 0.f, t1 = 0.f;
+      if (x0 + ((J + 7) & ~7) <= fw) {
+        for (int j = 0; j < J; j += 8) {
+          float v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = px[(j + u) * 64];
+          const v4f wa = w4[j >> 2], wb = w4[(j >> 2) + 1];
+          t0 = fmaf(wa.x, v[0], t0); t1 = fmaf(wa.y, v[1], t1); t0 = fmaf(wa.z, v[2], t0); t1 = fmaf(wa.w, v[3], t1);
+          t0 = fmaf(wb.x, v[4], t0); t1 = fmaf(wb.y, v[5], t1); t0 = fmaf(wb.z, v[6], t0); t1 = fmaf(wb.w, v[7], t1);
+        }
+      } else {
+        for (int j = 0; j < J; ++j) t0 = fmaf(tb->wx[pw][j], row[min(x0 + j, fw - 1) * 64], t0);
+      }
+      T[pw] = t0 + t1;
+    }
+#pragma unroll
+    for (int ph = 0; ph < 7; ++ph) {
+      const float wyv = tb->wy[ph][yr];
+      if (wyv != 0.f) {                                  // wave-uniform: a row carries weight for one or two bin rows
+#pragma unroll
+        for (int pw = 0; pw < 7; ++pw) acc[ph * 7 + pw] = fmaf(wyv, T[pw], acc[ph * 7 + pw]);
+      }
+    }
+  }
+  __syncthreads();                                       // the tables are rebuilt for the next map
+}
+
+__global__ __launch_bounds__(256) void roi_feat7_big_kernel(RoiFeatParams p) {
+  __shared__ BigTabs tabs;
+  __shared__ float part[3][49 * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nb = p.fb_count[0];
+  for (int job = blockIdx.x; job < nb; job += gridDim.x) {
+    const int r = p.fb_list[job];
+    const float* roi = p.rois + (long long)r * 5;
+    const int b = (int)roi[0];
+    float acc[49];
+#pragma unroll
+    for (int k = 0; k < 49; ++k) acc[k] = 0.f;
+    const RoiGeom g0 = roi_geom(roi, 0.25f, 7, 2), g1 = roi_geom(roi, 0.125f, 7, 2), gs = roi_geom(roi, 0.25f, 14, 0);
+    const bool sem_sep = gs.gw != 1 || gs.gh != 1;       // the semantic 14 x 14 grid takes its own samples
+    for (int m = 0; m < (sem_sep ? 3 : 2); ++m) {
+      const float* map = m == 0 ? (sem_sep ? p.x0 : p.x0sem) : m == 1 ? p.x1 : p.sem;
+      const RoiGeom& g = m == 0 ? g0 : m == 1 ? g1 : gs;
+      const float bmul = m == 2 ? 2.f : 1.f;             // a 7-grid bin is two 14-grid bins: 2 g samples per bin and axis
+      bg_accumulate(map, m == 1 ? p.H1 : p.H0, m == 1 ? p.W1 : p.W0, b, g.x1, g.y1, bmul * g.bw, bmul * g.bh, m == 2 ? 2 * gs.gw : 2,
+                    m == 2 ? 2 * gs.gh : 2, &tabs, acc);
+    }
+    if (wave) {
+#pragma unroll
+      for (int k = 0; k < 49; ++k) part[wave - 1][k * 64 + lane] = acc[k];
+    }
+    __syncthreads();
+    if (wave == 0) {
+      float gsum = 0.f;
+#pragma unroll
+      for (int l = 0; l < 2; ++l) {
+        const int Hl = l ? p.H3 : p.H2, Wl = l ? p.W3 : p.W2;
+        const float st = l ? 32.f : 16.f;
+        float cx = floorf((roi[1] + roi[3]) / (2.0f * st)), cy = floorf((roi[2] + roi[4]) / (2.0f * st));
+        cx = fminf(fmaxf(cx, 0.f), (float)(Wl - 1));
+        cy = fminf(fmaxf(cy, 0.f), (float)(Hl - 1));
+        const float* G = l ? p.G3 : p.G2;
+        gsum += G[(((long long)b * Hl + (int)cy) * Wl + (int)cx) * 64 + lane];
+      }
+      float* out = p.out + (long long)r * 49 * 64;
+#pragma unroll
+      for (int k = 0; k < 49; ++k) out[k * 64 + lane] = ((acc[k] + part[0][k * 64 + lane]) + part[1][k * 64 + lane]) + part[2][k * 64 + lane] + gsum;
+    }
+    __syncthreads();
+  }
+}
+
 // pre-pass: which RoIs fit the LDS tiles (one wave per RoI, the same plan code as the main kernel)
 __global__ __launch_bounds__(256) void roi_classify_kernel(RoiFeatParams p) {
   const int lane = threadIdx.x & 63;
@@ -540,22 +664,15 @@ __global__ __launch_bounds__(256) void roi_classify_kernel(RoiFeatParams p) {
   }
 }
 
-template <int T0, int T1, int FLAG, bool WITH_FALLBACK>
+template <int T0, int T1, int FLAG>
 __global__ __launch_bounds__(256) void roi_feat7_lds_kernel(RoiFeatParams p) {
   __shared__ float tile0[T0 * T0 * 64];
-  __shared__ float tile1[(T1 * T1 * 64 > 3 * 64) ? T1 * T1 * 64 : 3 * 64];
+  __shared__ float tile1[T1 * T1 * 64];
   __shared__ AxisEnt tab[2][2][16];
   // one RoI per block: the 4 waves share the staged footprints and split the 49 bins, so each SIMD holds 4 waves of
   // 4 different RoIs (LDS allows 4 blocks per CU) and the LDS / global latencies of one hide behind the others
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int r = blockIdx.x;
-  if (WITH_FALLBACK) {
-    if (blockIdx.x < FB_SLOTS * 49) {                   // fallback blocks first (see roi_feat7_generic_block)
-      roi_feat7_generic_block(p, blockIdx.x / 49, blockIdx.x % 49, reinterpret_cast<float(*)[64]>(tile1));
-      return;
-    }
-    r = blockIdx.x - FB_SLOTS * 49;
-  }
+  const int r = blockIdx.x;
   if (r >= *p.r_dev || p.fb_flag[r] != FLAG) return;
   const float* roi = p.rois + (long long)r * 5;
   const int b = (int)roi[0];
@@ -701,9 +818,10 @@ int launch_roi_feat(const RoiFeatParams& p, int P, int r_cap, hipStream_t s, hip
     const bool fork = side && ev_fork && ev_join;
     if (fork && (hipEventRecord(ev_fork, s) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess)) return NUHTC_E_HIP;
     hipLaunchKernelGGL(roi_feat7_stream_kernel, dim3(r_cap < 8192 ? r_cap : 8192), dim3(64), 0, fork ? side : s, p);
+    hipLaunchKernelGGL(roi_feat7_big_kernel, dim3(r_cap < 2048 ? r_cap : 2048), dim3(256), 0, fork ? side : s, p);
     if (fork && hipEventRecord(ev_join, side) != hipSuccess) return NUHTC_E_HIP;
-    hipLaunchKernelGGL((roi_feat7_lds_kernel<TS0, TS1, 0, false>), dim3(r_cap), dim3(256), 0, s, p);
-    hipLaunchKernelGGL((roi_feat7_lds_kernel<TP0, TP1, 3, true>), dim3(FB_SLOTS * 49 + r_cap), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((roi_feat7_lds_kernel<TS0, TS1, 0>), dim3(r_cap), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((roi_feat7_lds_kernel<TP0, TP1, 3>), dim3(r_cap), dim3(256), 0, s, p);
     if (fork && hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) return NUHTC_E_HIP;
   } else if (P == 14) hipLaunchKernelGGL(roi_feat14_kernel, dim3(r_cap, 7), dim3(256), 0, s, p);
   else return NUHTC_E_INVALID;
