@@ -11,10 +11,11 @@ struct RoiFeatParams {
   const float* x0sem;   // x0 + sem (P = 7 LDS path: both are sampled at the same points, so one interpolation serves both)
   int H0, W0, H1, W1, H2, W2, H3, W3;
   float* out;           // [R][P*P][64]
-  int* fb_count;        // P=7: [0] big RoIs (one block per bin), [1] mid-size RoIs (gather kernel); the rest fit the LDS tiles
-  int* fb_list;         // [R] big RoIs
+  int* fb_count;        // P=7: [0] big RoIs (row-streaming workgroup each), [1] mid-size RoIs (stream kernel), [2] giant RoIs; the rest fit the LDS tiles
+  int* fb_list;         // [list_cap] big RoIs from the front, giant RoIs from the back
+  int list_cap;
   int* mid_list;        // [R] mid-size RoIs
-  unsigned char* fb_flag; // [R] 0 = LDS path, 1 = gather kernel, 2 = one block per bin
+  unsigned char* fb_flag; // [R] 0 / 3 = LDS tiles (small / large), 1 = stream kernel, 2 = big-box kernel, 4 = giant (sample loop)
 };
 
 struct BboxTailParams {

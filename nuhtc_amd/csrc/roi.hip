@@ -475,18 +475,23 @@ __global__ __launch_bounds__(64) void roi_feat7_stream_kernel(RoiFeatParams p) {
 // one-block-per-bin gathers read a 150-px box's pixels ~16 times and took 21.6 ms per step at 100-200 px boxes.
 #define BG_J 40             // merged taps per bin column: a 7-grid bin of a 1024-px box spans 36.6 stride-4 pixels + 2 (BG_J % 8 == 0)
 #define BG_FH 264           // footprint rows
+#define BG_S 24             // samples per 7-grid bin and axis (2 x the adaptive 14-grid count: boxes up to 12 x 14 x 4 = 672 px); beyond: roi_feat7_giant_kernel
 struct BigTabs {
   __attribute__((aligned(16))) float wx[7][BG_J];   // rows 16-byte aligned; entries from J on are zero
-  int xlo[7];
-  int J;                    // taps per bin column actually used
+  int xlo[7], span[7];
   float wy[7][BG_FH];
   int fx0, fy0, fw, fh;
+  AxisEnt smp[2][7 * BG_S];        // the samples of both axes, computed once per map
+  unsigned char smv[2][7 * BG_S];
+  int blo[4], bhi[4];
 };
 
-__device__ void bg_accumulate(const float* __restrict__ map, int H, int W, int b, float x1, float y1, float bw, float bh, int Sx, int Sy,
+__device__ __forceinline__ void bg_accumulate(const float* __restrict__ map, int H, int W, int b, float x1, float y1, float bw, float bh, int Sx, int Sy,
                               BigTabs* tb, float (&acc)[49]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // ---- footprint bounds over the valid samples of both axes (threads 0..127: x samples, 128..255: y samples, strided)
+  // ---- the samples of both axes, computed once (threads 0..127: x, 128..255: y, strided) and kept in LDS; footprint bounds
+  AxisEnt (&smp)[2][7 * BG_S] = tb->smp;
+  unsigned char (&smv)[2][7 * BG_S] = tb->smv;
   {
     const bool is_y = tid >= 128;
     const int S = is_y ? Sy : Sx;
@@ -494,11 +499,13 @@ __device__ void bg_accumulate(const float* __restrict__ map, int H, int W, int b
     for (int sidx = tid & 127; sidx < 7 * S; sidx += 128) {
       bool v;
       const AxisEnt e = sm_sample(is_y ? y1 : x1, is_y ? bh : bw, S, sidx, is_y ? H : W, v);
+      smp[is_y][sidx] = e;
+      smv[is_y][sidx] = v;
       if (v) { lo = min(lo, e.lo); hi = max(hi, e.hi); }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
-    __shared__ int blo[4], bhi[4];
+    int (&blo)[4] = tb->blo, (&bhi)[4] = tb->bhi;
     if (lane == 0) { blo[wave] = lo; bhi[wave] = hi; }
     __syncthreads();
     if (tid == 0) {
@@ -507,38 +514,36 @@ __device__ void bg_accumulate(const float* __restrict__ map, int H, int W, int b
       tb->fx0 = empty ? 0 : xl; tb->fy0 = empty ? 0 : yl;
       tb->fw = empty ? 0 : xh - xl + 1; tb->fh = empty ? 0 : min(yh - yl + 1, BG_FH);
     }
+    if (tid < 7) {                                      // first pixel and span of each bin column
+      int m = 1 << 30, mh = -1;
+      for (int is = 0; is < Sx; ++is)
+        if (smv[0][tid * Sx + is]) { m = min(m, smp[0][tid * Sx + is].lo); mh = max(mh, smp[0][tid * Sx + is].hi); }
+      tb->xlo[tid] = m == (1 << 30) ? 0 : m;           // (absolute for now)
+      tb->span[tid] = mh < 0 ? 0 : mh - m + 1;
+    }
     __syncthreads();
   }
   const int fx0 = tb->fx0, fy0 = tb->fy0, fw = tb->fw, fh = tb->fh;
-  if (fw == 0 || fh == 0) return;                       // every sample of an axis lies outside the map (block-uniform)
-  // ---- merged per-axis weights
-  if (tid < 7) {
-    int m = 1 << 30, mh = -1;
-    for (int is = 0; is < Sx; ++is) {
-      bool v;
-      const AxisEnt q = sm_sample(x1, bw, Sx, tid * Sx + is, W, v);
-      if (v) { m = min(m, q.lo - fx0); mh = max(mh, q.hi - fx0); }
-    }
-    tb->xlo[tid] = m == (1 << 30) ? 0 : m;
-    tb->wx[tid][0] = (float)(mh < 0 ? 0 : mh - (m == (1 << 30) ? 0 : m) + 1);     // span of this bin, folded into J below
-  }
+  if (fw == 0 || fh == 0) { __syncthreads(); return; }  // every sample of an axis lies outside the map (block-uniform)
+  int J = 1;
+#pragma unroll
+  for (int pw = 0; pw < 7; ++pw) J = max(J, tb->span[pw]);
+  J = min(J, BG_J);
+  // taps are read in groups of 8: a bin column's first pixel is moved left where its padded range would leave the footprint (the
+  // weights below are built from these starts, so they move with it); rows narrower than the padded range take the clamped path
+  const int Jr = (J + 7) & ~7;
+  const bool padded_ok = fw >= Jr;
+  if (padded_ok && tid < 7) tb->xlo[tid] = min(tb->xlo[tid], fx0 + fw - Jr);
   __syncthreads();
-  if (tid == 0) {
-    int J = 1;
-    for (int pw = 0; pw < 7; ++pw) J = max(J, (int)tb->wx[pw][0]);
-    tb->J = min(J, BG_J);
-  }
-  __syncthreads();
-  const int J = tb->J;
+  // ---- merged per-axis weights from the sample table (sums in sample order: deterministic)
   for (int t = tid; t < 7 * BG_J; t += 256) {
     const int pw = t / BG_J, j = t - pw * BG_J;
     float wsum = 0.f;
-    if (j < J) {
-      const int px = fx0 + tb->xlo[pw] + j;
+    if (j < (padded_ok ? Jr : J)) {                   // (a start moved left puts the bin's pixels at taps up to Jr - 1)
+      const int px = tb->xlo[pw] + j;
       for (int is = 0; is < Sx; ++is) {
-        bool v;
-        const AxisEnt q = sm_sample(x1, bw, Sx, pw * Sx + is, W, v);
-        if (v) { if (q.lo == px) wsum += q.h; if (q.hi == px) wsum += q.l; }
+        const AxisEnt q = smp[0][pw * Sx + is];
+        if (smv[0][pw * Sx + is]) { if (q.lo == px) wsum += q.h; if (q.hi == px) wsum += q.l; }
       }
     }
     tb->wx[pw][j] = wsum / (float)Sx;
@@ -547,56 +552,84 @@ __device__ void bg_accumulate(const float* __restrict__ map, int H, int W, int b
     const int ph = t / fh, yr = t - ph * fh;
     float wsum = 0.f;
     for (int is = 0; is < Sy; ++is) {
-      bool v;
-      const AxisEnt q = sm_sample(y1, bh, Sy, ph * Sy + is, H, v);
-      if (v) { if (q.lo == fy0 + yr) wsum += q.h; if (q.hi == fy0 + yr) wsum += q.l; }
+      const AxisEnt q = smp[1][ph * Sy + is];
+      if (smv[1][ph * Sy + is]) { if (q.lo == fy0 + yr) wsum += q.h; if (q.hi == fy0 + yr) wsum += q.l; }
     }
     tb->wy[ph][yr] = wsum / (float)Sy;
   }
   __syncthreads();
+  if (tid < 7) tb->xlo[tid] = max(tb->xlo[tid] - fx0, 0);   // relative to the footprint from here on
+  __syncthreads();
   // ---- rows of this wave
   const float* base = map + (((long long)b * H + fy0) * W + fx0) * 64 + lane;
-  for (int yr = wave; yr < fh; yr += 4) {
-    const float* row = base + (long long)yr * W * 64;
-    float T[7];
-#pragma unroll
-    for (int pw = 0; pw < 7; ++pw) {
-      // J taps from pixel xlo[pw] on, eight loads in flight at a time (static byte offsets), their merged weights read four at a
-      // time from LDS.  Taps past the footprint's last pixel carry zero weight: a bin whose taps would run past it (the last
-      // one at most) takes the clamped path so that nothing is read beyond the map
-      const int x0 = tb->xlo[pw];
-      const float* px = row + x0 * 64;
-      const v4f* w4 = reinterpret_cast<const v4f*>(tb->wx[pw]);
-      float t0 = 0.f, t1 = 0.f;
-      if (x0 + ((J + 7) & ~7) <= fw) {
-        for (int j = 0; j < J; j += 8) {
-          float v[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) v[u] = px[(j + u) * 64];
-          const v4f wa = w4[j >> 2], wb = w4[(j >> 2) + 1];
-          t0 = fmaf(wa.x, v[0], t0); t1 = fmaf(wa.y, v[1], t1); t0 = fmaf(wa.z, v[2], t0); t1 = fmaf(wa.w, v[3], t1);
-          t0 = fmaf(wb.x, v[4], t0); t1 = fmaf(wb.y, v[5], t1); t0 = fmaf(wb.z, v[6], t0); t1 = fmaf(wb.w, v[7], t1);
-        }
-      } else {
-        for (int j = 0; j < J; ++j) t0 = fmaf(tb->wx[pw][j], row[min(x0 + j, fw - 1) * 64], t0);
-      }
-      T[pw] = t0 + t1;
+#define BG_SCATTER()                                                                                              \
+    _Pragma("unroll") for (int ph = 0; ph < 7; ++ph) {                                                            \
+      const float wyv = tb->wy[ph][yr];                                                                           \
+      if (wyv != 0.f) {   /* wave-uniform: a row carries weight for one or two bin rows */                        \
+        _Pragma("unroll") for (int pw = 0; pw < 7; ++pw) acc[ph * 7 + pw] = fmaf(wyv, T[pw], acc[ph * 7 + pw]);  \
+      }                                                                                                           \
     }
+  if (padded_ok && J <= 8) {
+    // the usual case (bins up to 8 pixels wide: boxes up to ~200 px): all 56 taps of a row are requested before the first multiply
+    // (with one bin's loads issued only after the previous bin's sum, a row paid seven memory latencies one after the other)
+    int xo[7];
 #pragma unroll
-    for (int ph = 0; ph < 7; ++ph) {
-      const float wyv = tb->wy[ph][yr];
-      if (wyv != 0.f) {                                  // wave-uniform: a row carries weight for one or two bin rows
+    for (int pw = 0; pw < 7; ++pw) xo[pw] = tb->xlo[pw] * 64;
+    for (int yr = wave; yr < fh; yr += 4) {
+      const float* row = base + (long long)yr * W * 64;
+      float v[7][8];
 #pragma unroll
-        for (int pw = 0; pw < 7; ++pw) acc[ph * 7 + pw] = fmaf(wyv, T[pw], acc[ph * 7 + pw]);
+      for (int pw = 0; pw < 7; ++pw)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[pw][u] = row[xo[pw] + u * 64];
+      float T[7];
+#pragma unroll
+      for (int pw = 0; pw < 7; ++pw) {
+        const v4f wa = reinterpret_cast<const v4f*>(tb->wx[pw])[0], wb = reinterpret_cast<const v4f*>(tb->wx[pw])[1];
+        float t0 = 0.f, t1 = 0.f;
+        t0 = fmaf(wa.x, v[pw][0], t0); t1 = fmaf(wa.y, v[pw][1], t1); t0 = fmaf(wa.z, v[pw][2], t0); t1 = fmaf(wa.w, v[pw][3], t1);
+        t0 = fmaf(wb.x, v[pw][4], t0); t1 = fmaf(wb.y, v[pw][5], t1); t0 = fmaf(wb.z, v[pw][6], t0); t1 = fmaf(wb.w, v[pw][7], t1);
+        T[pw] = t0 + t1;
       }
+      BG_SCATTER()
+    }
+  } else {
+    for (int yr = wave; yr < fh; yr += 4) {
+      const float* row = base + (long long)yr * W * 64;
+      float T[7];
+#pragma unroll
+      for (int pw = 0; pw < 7; ++pw) {
+        const int x0 = tb->xlo[pw];
+        const float* px = row + x0 * 64;
+        const v4f* w4 = reinterpret_cast<const v4f*>(tb->wx[pw]);
+        float t0 = 0.f, t1 = 0.f;
+        if (padded_ok) {
+          for (int j = 0; j < J; j += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = px[(j + u) * 64];
+            const v4f wa = w4[j >> 2], wb = w4[(j >> 2) + 1];
+            t0 = fmaf(wa.x, v[0], t0); t1 = fmaf(wa.y, v[1], t1); t0 = fmaf(wa.z, v[2], t0); t1 = fmaf(wa.w, v[3], t1);
+            t0 = fmaf(wb.x, v[4], t0); t1 = fmaf(wb.y, v[5], t1); t0 = fmaf(wb.z, v[6], t0); t1 = fmaf(wb.w, v[7], t1);
+          }
+        } else {
+          for (int j = 0; j < J; ++j) t0 = fmaf(tb->wx[pw][j], row[min(x0 + j, fw - 1) * 64], t0);
+        }
+        T[pw] = t0 + t1;
+      }
+      BG_SCATTER()
     }
   }
+#undef BG_SCATTER
   __syncthreads();                                       // the tables are rebuilt for the next map
 }
 
-__global__ __launch_bounds__(256) void roi_feat7_big_kernel(RoiFeatParams p) {
-  __shared__ BigTabs tabs;
-  __shared__ float part[3][49 * 64];
+__global__ __launch_bounds__(256, 2) void roi_feat7_big_kernel(RoiFeatParams p) {
+  // the tables of a map and, once the last map is done, the partial sums of one wave share the same LDS (14 KB: the compiler
+  // sizes its register budget by the workgroups the LDS allows)
+  __shared__ __attribute__((aligned(16))) char lds_raw[sizeof(BigTabs) > 49 * 64 * 4 ? sizeof(BigTabs) : 49 * 64 * 4];
+  BigTabs& tabs = *reinterpret_cast<BigTabs*>(lds_raw);
+  float* part = reinterpret_cast<float*>(lds_raw);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nb = p.fb_count[0];
   for (int job = blockIdx.x; job < nb; job += gridDim.x) {
@@ -615,11 +648,19 @@ __global__ __launch_bounds__(256) void roi_feat7_big_kernel(RoiFeatParams p) {
       bg_accumulate(map, m == 1 ? p.H1 : p.H0, m == 1 ? p.W1 : p.W0, b, g.x1, g.y1, bmul * g.bw, bmul * g.bh, m == 2 ? 2 * gs.gw : 2,
                     m == 2 ? 2 * gs.gh : 2, &tabs, acc);
     }
-    if (wave) {
+    // waves 1..3 hand their partial sums to wave 0 one after the other (fixed order: reproducible)
+    for (int w = 1; w < 4; ++w) {
+      if (wave == w) {
 #pragma unroll
-      for (int k = 0; k < 49; ++k) part[wave - 1][k * 64 + lane] = acc[k];
+        for (int k = 0; k < 49; ++k) part[k * 64 + lane] = acc[k];
+      }
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int k = 0; k < 49; ++k) acc[k] += part[k * 64 + lane];
+      }
+      __syncthreads();
     }
-    __syncthreads();
     if (wave == 0) {
       float gsum = 0.f;
 #pragma unroll
@@ -634,9 +675,44 @@ __global__ __launch_bounds__(256) void roi_feat7_big_kernel(RoiFeatParams p) {
       }
       float* out = p.out + (long long)r * 49 * 64;
 #pragma unroll
-      for (int k = 0; k < 49; ++k) out[k * 64 + lane] = ((acc[k] + part[0][k * 64 + lane]) + part[1][k * 64 + lane]) + part[2][k * 64 + lane] + gsum;
+      for (int k = 0; k < 49; ++k) out[k * 64 + lane] = acc[k] + gsum;
     }
-    __syncthreads();
+  }
+}
+
+// Boxes beyond the tables of roi_feat7_big_kernel (more than BG_S samples per bin and axis or BG_FH footprint rows: boxes over
+// ~670 px, which only network inputs above 512 px can hold): mmcv's own sample loop, one workgroup per RoI, a bin per wave in
+// turn.  Slow and general; classified last (roi_classify_kernel, class 4: the tail of fb_list).
+__global__ __launch_bounds__(256) void roi_feat7_giant_kernel(RoiFeatParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ng = p.fb_count[2];
+  for (int job = blockIdx.x; job < ng; job += gridDim.x) {
+    const int r = p.fb_list[p.list_cap - 1 - job];
+    const float* roi = p.rois + (long long)r * 5;
+    const int b = (int)roi[0];
+    const RoiGeom g0 = roi_geom(roi, 0.25f, 7, 2), g1 = roi_geom(roi, 0.125f, 7, 2), gs = roi_geom(roi, 0.25f, 14, 0);
+    const float* f0 = p.x0 + (long long)b * p.H0 * p.W0 * 64;
+    const float* f1 = p.x1 + (long long)b * p.H1 * p.W1 * 64;
+    const float* fs = p.sem + (long long)b * p.H0 * p.W0 * 64;
+    float gsum = 0.f;
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      const int Hl = l ? p.H3 : p.H2, Wl = l ? p.W3 : p.W2;
+      const float st = l ? 32.f : 16.f;
+      float cx = floorf((roi[1] + roi[3]) / (2.0f * st)), cy = floorf((roi[2] + roi[4]) / (2.0f * st));
+      cx = fminf(fmaxf(cx, 0.f), (float)(Wl - 1));
+      cy = fminf(fmaxf(cy, 0.f), (float)(Hl - 1));
+      const float* G = l ? p.G3 : p.G2;
+      gsum += G[(((long long)b * Hl + (int)cy) * Wl + (int)cx) * 64 + lane];
+    }
+    for (int bin = wave; bin < 49; bin += 4) {
+      const int ph = bin / 7, pw = bin - ph * 7;
+      float v = roi_bin(f0, p.H0, p.W0, g0.x1, g0.y1, g0.bw, g0.bh, g0.gw, g0.gh, pw, ph, lane);
+      v += roi_bin(f1, p.H1, p.W1, g1.x1, g1.y1, g1.bw, g1.bh, g1.gw, g1.gh, pw, ph, lane);
+      float sm = 0.f;                                   // adaptive_avg_pool2d 14 -> 7: the four 14-grid bins of this 7-grid bin
+      for (int q = 0; q < 4; ++q) sm += roi_bin(fs, p.H0, p.W0, gs.x1, gs.y1, gs.bw, gs.bh, gs.gw, gs.gh, 2 * pw + (q & 1), 2 * ph + (q >> 1), lane);
+      p.out[(long long)r * 49 * 64 + bin * 64 + lane] = v + sm * 0.25f + gsum;
+    }
   }
 }
 
@@ -657,9 +733,12 @@ __global__ __launch_bounds__(256) void roi_classify_kernel(RoiFeatParams p) {
   // class 0 is split by footprint: 0 = fits the small tiles (8x8 / 5x5 pixels: boxes up to ~24 px, the usual nucleus), 3 = needs
   // the 12x12 / 7x7 tiles; the small variant takes a third of the LDS, so twice as many RoIs are in flight per CU
   if (cls == 0 && !(l0.fw <= TS0 && l0.fh <= TS0 && l1.fw <= TS1 && l1.fh <= TS1)) cls = 3;
+  // class 2 boxes beyond the tables of the big-box kernel (samples per bin, footprint rows, taps per bin column): class 4
+  if (cls == 2 && (2 * gs.gw > BG_S || 2 * gs.gh > BG_S || rhn * 0.25f + 4.f > (float)BG_FH || rwn * 0.25f / 7.f + 3.f > (float)BG_J)) cls = 4;
   if (lane == 0) {
     p.fb_flag[r] = (unsigned char)cls;
     if (cls == 2) p.fb_list[atomicAdd(&p.fb_count[0], 1)] = r;
+    else if (cls == 4) p.fb_list[p.list_cap - 1 - atomicAdd(&p.fb_count[2], 1)] = r;      // from the end of the same list
     else if (cls == 1) p.mid_list[atomicAdd(&p.fb_count[1], 1)] = r;
   }
 }
@@ -813,12 +892,13 @@ int launch_roi_feat(const RoiFeatParams& p, int P, int r_cap, hipStream_t s, hip
   ProfScope ps(P == 7 ? "roi_feat7" : "roi_feat14", 0, 0, s);
   if (r_cap <= 0) return 0;
   if (P == 7) {
-    if (hipMemsetAsync(p.fb_count, 0, 2 * sizeof(int), s) != hipSuccess) return NUHTC_E_HIP;
+    if (hipMemsetAsync(p.fb_count, 0, 4 * sizeof(int), s) != hipSuccess) return NUHTC_E_HIP;
     hipLaunchKernelGGL(roi_classify_kernel, dim3(cdiv(r_cap, 4)), dim3(256), 0, s, p);
     const bool fork = side && ev_fork && ev_join;
     if (fork && (hipEventRecord(ev_fork, s) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess)) return NUHTC_E_HIP;
     hipLaunchKernelGGL(roi_feat7_stream_kernel, dim3(r_cap < 8192 ? r_cap : 8192), dim3(64), 0, fork ? side : s, p);
     hipLaunchKernelGGL(roi_feat7_big_kernel, dim3(r_cap < 2048 ? r_cap : 2048), dim3(256), 0, fork ? side : s, p);
+    hipLaunchKernelGGL(roi_feat7_giant_kernel, dim3(r_cap < 1024 ? r_cap : 1024), dim3(256), 0, fork ? side : s, p);
     if (fork && hipEventRecord(ev_join, side) != hipSuccess) return NUHTC_E_HIP;
     hipLaunchKernelGGL((roi_feat7_lds_kernel<TS0, TS1, 0>), dim3(r_cap), dim3(256), 0, s, p);
     hipLaunchKernelGGL((roi_feat7_lds_kernel<TP0, TP1, 3>), dim3(r_cap), dim3(256), 0, s, p);

@@ -328,3 +328,36 @@ def test_roi_features_all_size_classes(hip_device):
     ms = (mrois[:, 3:] - mrois[:, 1:3]).max(1).values
     print(f'mask RoIs: {D}, max side {float(ms.min()):.0f}..{float(ms.max()):.0f} px, max |err| {float((mgot - mref).abs().max()):.2e}')
     assert float((mgot - mref).abs().max()) <= 2e-4
+
+
+def test_roi_features_giant_boxes_at_1024_px(hip_device):
+    """Boxes beyond the big-box kernel's tables (more than 24 samples per bin and axis: sides over ~670 px, which only a network input
+    above 512 px can hold -- 20x slides, scale_factor 4) take mmcv's own sample loop (roi_feat7_giant_kernel); the big-box kernel right
+    below that limit, with its widest bins.  Engine maps and stage RoIs against the oracle, 2e-4 absolute."""
+    import torch
+    from nuhtc_amd import hip, synth, weights
+    from nuhtc_amd.engine import Engine
+    from oracle import model as O
+    sd = weights.bench_state_dict(3)
+    B, n = 1, 96
+    eng = Engine(sd, device=0, max_batch=B, tile=(256, 256), scale_factor=4.0)
+    eng.enable_token_dump()
+    rng = np.random.default_rng(23)
+    wh = np.concatenate([rng.uniform(120, 660, (n // 2, 2)), rng.uniform(680, 1020, (n // 2, 2))]).astype(np.float32)[None]
+    ctr = rng.uniform(100, 924, (B, n, 2)).astype(np.float32)
+    rois = np.clip(np.concatenate([ctr - wh / 2, ctr + wh / 2], -1), 0, 1024).astype(np.float32)
+    tiles = eng.to_device(synth.nuclei_tiles(B, 256, start=9))
+    eng.infer_fixed_load_async(tiles, torch.from_numpy(rois).to(tiles.device), 8, hip.CH_SWAP)
+    eng.check()
+    counts = eng.buffer('roi_fallback_count').cpu().numpy()
+    assert counts[0] > 10 and counts[2] > 10, counts        # big-box and giant classes are both populated
+    x = [_nchw(eng.buffer(f'x{i}')[:B]) for i in range(4)]
+    sem_feat = _nchw(eng.buffer('sem_feat')[:B])
+    r2 = eng.buffer('rois_stage2')[:n].cpu()
+    with torch.no_grad():
+        ref = O.bbox_feats(x, sem_feat, r2)
+    got = eng.buffer('bbox_feats')[:n].cpu().reshape(n, 7, 7, 64).permute(0, 3, 1, 2)
+    err = (got - ref).abs().reshape(n, -1).max(1).values
+    side = (r2[:, 3:] - r2[:, 1:3]).max(1).values
+    print(f'boxes {float(side.min()):.0f}..{float(side.max()):.0f} px: big {int(counts[0])}, giant {int(counts[2])}, max |err| {float(err.max()):.2e}')
+    assert float(err.max()) <= 2e-4, float(err.max())
