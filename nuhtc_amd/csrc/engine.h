@@ -64,6 +64,8 @@ struct nuhtc_engine {
   int32_t* crop_size = nullptr;    // nuhtc_export_crops scratch [max_batch * max_per_img]
   hipStream_t side = nullptr;       // proposal selection / NMS run here, concurrently with the semantic head on the caller's stream
   hipEvent_t ev_rpn = nullptr, ev_side = nullptr, ev_fpn = nullptr;
+  hipStream_t side2 = nullptr;      // the big-box RoI kernel runs here, beside the stream kernel (side) and the LDS-tile kernels (caller's stream)
+  hipEvent_t ev_side2 = nullptr;
   struct RoiWs* rw = nullptr;
 };
 

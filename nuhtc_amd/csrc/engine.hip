@@ -75,6 +75,8 @@ void nuhtc_destroy(nuhtc_engine* e) {
   hipSetDevice(e->device);
   hipDeviceSynchronize();
   if (e->side) hipStreamDestroy(e->side);
+  if (e->side2) hipStreamDestroy(e->side2);
+  if (e->ev_side2) hipEventDestroy(e->ev_side2);
   if (e->ev_rpn) hipEventDestroy(e->ev_rpn);
   if (e->ev_side) hipEventDestroy(e->ev_side);
   if (e->ev_fpn) hipEventDestroy(e->ev_fpn);
@@ -471,6 +473,8 @@ int nuhtc_finalize(nuhtc_engine* e) {
   HIP_CHECK(e, hipEventCreateWithFlags(&e->ev_rpn, hipEventDisableTiming));
   HIP_CHECK(e, hipEventCreateWithFlags(&e->ev_side, hipEventDisableTiming));
   HIP_CHECK(e, hipEventCreateWithFlags(&e->ev_fpn, hipEventDisableTiming));
+  HIP_CHECK(e, hipStreamCreateWithFlags(&e->side2, hipStreamNonBlocking));
+  HIP_CHECK(e, hipEventCreateWithFlags(&e->ev_side2, hipEventDisableTiming));
   HIP_CHECK(e, hipDeviceSynchronize());
   e->raw.clear();
   e->finalized = true;

@@ -475,9 +475,11 @@ __global__ __launch_bounds__(1024) void nms_prepare_levels_kernel(NmsParams p) {
 // row): the full (cap/64)^2 grid was 374 k one-wave workgroups per launch of which 85 % returned at once, and that many
 // dispatches starved whatever ran beside it on the other stream.  Column areas are staged with the boxes; a column that no
 // row of the tile touches is skipped before the division (inter == 0 gives 0 > thr false whatever the union is).
-__global__ __launch_bounds__(64) void nms_mask_levels_kernel(NmsParams p) {
-  const int b = blockIdx.z;
-  int t = blockIdx.x, rs = 0, rn = 0, nc = 0, g = 0;
+__global__ __launch_bounds__(256) void nms_mask_levels_kernel(NmsParams p) {
+  // four waves per workgroup, each with a tile of its own: a quarter of the dispatches of the one-wave form, whose 72 k workgroups per
+  // launch kept the dispatcher busy enough to slow the semantic branch's kernels on the other stream several-fold while it ran
+  const int b = blockIdx.z, wv4 = threadIdx.x >> 6;
+  int t = blockIdx.x * 4 + wv4, rs = 0, rn = 0, nc = 0, g = 0;
   for (; g < p.n_groups; ++g) {
     rs = p.seg_start[b * p.n_groups + g];
     rn = p.seg_n[b * p.n_groups + g];
@@ -491,10 +493,12 @@ __global__ __launch_bounds__(64) void nms_mask_levels_kernel(NmsParams p) {
   while (t >= nc - r) { t -= nc - r; ++r; }
   const int rb = (rs >> 6) + r, cb = rb + t;               // segments start on multiples of 64
   const int end = rs + rn;                                // one past the group's last row
-  __shared__ float4 cbx[64];
-  __shared__ float car[64];
+  __shared__ float4 cbx4[4][64];
+  __shared__ float car4[4][64];
+  float4* cbx = cbx4[wv4];
+  float* car = car4[wv4];
   const float4* sb = reinterpret_cast<const float4*>(p.sorted_boxes) + (long long)b * p.cap;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const int ncol = min(end - cb * 64, 64);
   if (ncol <= 0) return;
   if (lane < ncol) {
@@ -502,7 +506,8 @@ __global__ __launch_bounds__(64) void nms_mask_levels_kernel(NmsParams p) {
     cbx[lane] = c;
     car[lane] = (c.z - c.x) * (c.w - c.y);
   }
-  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // the wave reads back only what it wrote itself
+  __builtin_amdgcn_wave_barrier();
   const int row = rb * 64 + lane;
   const bool live = row < end;
   const float4 a = sb[live ? row : end - 1];
@@ -617,7 +622,7 @@ int launch_nms_levels(const NmsParams& p, int B, hipStream_t s) {
   size_t lds = (size_t)slot_pow2 * sizeof(u64);
   hipLaunchKernelGGL(nms_prepare_levels_kernel, dim3(B, p.n_groups), dim3(1024), lds, s, p);
   const int slot_chunks = (p.slot + 63) / 64;      // a group holds at most `slot` candidates
-  hipLaunchKernelGGL(nms_mask_levels_kernel, dim3(p.n_groups * (slot_chunks * (slot_chunks + 1) / 2), 1, B), dim3(64), 0, s, p);
+  hipLaunchKernelGGL(nms_mask_levels_kernel, dim3(cdiv(p.n_groups * (slot_chunks * (slot_chunks + 1) / 2), 4), 1, B), dim3(256), 0, s, p);
   hipLaunchKernelGGL(nms_reduce_levels_kernel, dim3(B, p.n_groups), dim3(256), 0, s, p);
   hipLaunchKernelGGL(nms_select_kernel, dim3(B), dim3(1024), 0, s, p);
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
@@ -819,6 +824,60 @@ __global__ void cc_stats_kernel(const int* __restrict__ lab, int* __restrict__ s
   atomicAdd(&s[0], 1);
   atomicMin(&s[1], x); atomicMin(&s[2], y); atomicMax(&s[3], x); atomicMax(&s[4], y);
 }
+// The same statistics with the atomics of a 64-column x CCS_ROWS-row strip collected in LDS first: every row segment's groups go into
+// a small hash table keyed by the root (LDS atomics), and the strip issues one set of 5 global atomics per component it touches --
+// global atomics execute at the memory side at ~50 ns per wave-instruction and CU (MI355X_MICROARCH.md), and a 25-px nucleus crossed
+// by 25 row segments paid 125 of them; per strip it pays 5-10.  Min / max / sum commute: same statistics.
+#define CCS_ROWS 32
+#define CCS_TAB 256
+__global__ __launch_bounds__(256) void cc_stats_strip_kernel(const int* __restrict__ lab, int* __restrict__ stats, int H, int W) {
+  __shared__ int tkey[CCS_TAB];            // root + 1, 0 = empty
+  __shared__ int tval[CCS_TAB][5];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < CCS_TAB; i += 256) { tkey[i] = 0; tval[i][0] = 0; tval[i][1] = 1 << 30; tval[i][2] = 1 << 30; tval[i][3] = -1; tval[i][4] = -1; }
+  __syncthreads();
+  const int x = blockIdx.x * 64 + lane;
+  const long long img = (long long)blockIdx.z * H * W;
+  for (int r = wave; r < CCS_ROWS; r += 4) {
+    const int y = blockIdx.y * CCS_ROWS + r;
+    if (y >= H) break;
+    const int l = lab[img + (long long)y * W + x];
+    unsigned long long todo = __ballot(l >= 0);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int l0 = __shfl(l, leader);
+      const unsigned long long grp = __ballot(l == l0) & todo;
+      if (lane == leader) {
+        const int x1 = x + (63 - __clzll((long long)grp) - leader);
+        int h = (l0 * 0x9E3779B1u) >> 24;             // 8-bit hash of the root
+        int tries = 0;
+        for (; tries < CCS_TAB; ++tries) {
+          const int old = atomicCAS(&tkey[h], 0, l0 + 1);
+          if (old == 0 || old == l0 + 1) break;
+          h = (h + 1) & (CCS_TAB - 1);
+        }
+        if (tries < CCS_TAB) {
+          atomicAdd(&tval[h][0], __popcll(grp));
+          atomicMin(&tval[h][1], x); atomicMin(&tval[h][2], y); atomicMax(&tval[h][3], x1); atomicMax(&tval[h][4], y);
+        } else {                                         // table full (more than 256 components in one strip): straight to memory
+          int* sg = stats + (img + l0) * 5;
+          atomicAdd(&sg[0], __popcll(grp));
+          atomicMin(&sg[1], x); atomicMin(&sg[2], y); atomicMax(&sg[3], x1); atomicMax(&sg[4], y);
+        }
+      }
+      todo &= ~grp;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < CCS_TAB; i += 256) {
+    const int k = tkey[i];
+    if (k) {
+      int* sg = stats + (img + (k - 1)) * 5;
+      atomicAdd(&sg[0], tval[i][0]);
+      atomicMin(&sg[1], tval[i][1]); atomicMin(&sg[2], tval[i][2]); atomicMax(&sg[3], tval[i][3]); atomicMax(&sg[4], tval[i][4]);
+    }
+  }
+}
 __global__ void cc_stats_init_kernel(int* __restrict__ stats, long long total) {
   long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
@@ -895,7 +954,8 @@ int launch_cc_proposals(const CcParams& p, int B, hipStream_t s) {
   hipLaunchKernelGGL(ccl_merge_kernel, dim3(nb), dim3(256), 0, s, Bm, p.labels, 1, H, W, total);
   hipLaunchKernelGGL(ccl_flatten_kernel, dim3(nb), dim3(256), 0, s, p.labels, HW, total);
   hipLaunchKernelGGL(cc_stats_init_kernel, dim3(nb), dim3(256), 0, s, p.stats, total);
-  hipLaunchKernelGGL(cc_stats_kernel, dim3(nb), dim3(256), 0, s, p.labels, p.stats, H, W, total);
+  if ((W & 63) == 0) hipLaunchKernelGGL(cc_stats_strip_kernel, dim3(W / 64, cdiv(H, CCS_ROWS), B), dim3(256), 0, s, p.labels, p.stats, H, W);
+  else hipLaunchKernelGGL(cc_stats_kernel, dim3(nb), dim3(256), 0, s, p.labels, p.stats, H, W, total);
   if (hipMemsetAsync(p.nlist, 0, sizeof(int) * B, s) != hipSuccess) return NUHTC_E_HIP;
   hipLaunchKernelGGL(cc_collect_kernel, dim3(nb), dim3(256), 0, s, p.labels, p.stats, p.list, p.nlist, HW, p.min_area, HW / 4, total);
   hipLaunchKernelGGL(cc_emit_kernel, dim3(B), dim3(1024), 0, s, p.stats, p.list, p.nlist, p.boxes, p.counts, p.overflow, HW, p.cap);

@@ -90,7 +90,7 @@ int launch_build_rois(const float* cc_boxes, const int* cc_counts, int cc_cap, c
 // `side` / `ev_fork` / `ev_join` (optional): the mid-size-RoI gather kernel of the P = 7 path runs on `side` beside the LDS-path
 // kernel and is joined back into `s` before returning
 int launch_roi_feat(const RoiFeatParams& p, int P, int r_cap, hipStream_t s, hipStream_t side = nullptr, hipEvent_t ev_fork = nullptr,
-                    hipEvent_t ev_join = nullptr);
+                    hipEvent_t ev_join = nullptr, hipStream_t side2 = nullptr, hipEvent_t ev_join2 = nullptr);
 int launch_bbox_tail(const BboxTailParams& p, int r_cap, hipStream_t s);
 int launch_det_candidates(const DetCandParams& p, int B, hipStream_t s);
 int launch_det_finish(const DetFinishParams& p, hipStream_t s);

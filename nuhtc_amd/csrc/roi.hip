@@ -468,35 +468,40 @@ __global__ __launch_bounds__(64) void roi_feat7_stream_kernel(RoiFeatParams p) {
 
 // RoIs beyond the stream kernel's limits (sides over SM_MAXSIDE px, or more than 2 x 2 semantic samples per 14 x 14 bin: merged
 // clumps, component proposals up to the whole tile).  Same separable form -- a bin is sum_y sum_x wy[y] wx[x] F[y][x] with merged
-// per-axis weights -- but for footprints of any size: one 4-wave workgroup per RoI, the waves take the footprint rows in turn, a
-// row is contracted along x straight from the map (lane = channel: one coalesced 256-byte pixel per load, J taps per bin column
-// with the merged weights in LDS) and scattered with the row's non-zero y weights (a row touches one or two bin rows); the four
-// partial 7 x 7 x 64 sums meet in LDS.  Every footprint pixel is read once per map instead of once per sample tap: the former
-// one-block-per-bin gathers read a 150-px box's pixels ~16 times and took 21.6 ms per step at 100-200 px boxes.
+// per-axis weights -- for footprints of any size.  One workgroup of 7 x BG_RS waves per RoI: wave (pw, rs) owns bin COLUMN pw and
+// every BG_RS-th footprint row: per row it requests all taps of its column at once (lane = channel: one coalesced 256-byte pixel
+// per load, merged weights from LDS), contracts them to one value and adds it into its 7 bin-row sums with the row's y weights.
+// A wave thus carries 7 accumulators and up to BG_J loads in flight, the workgroup has 14 rows x columns going at once (a whole-tile
+// proposal at the usual load is a latency chain: four waves with all seven columns each took 0.34 ms for one), and every footprint
+// pixel is read once per map instead of once per sample tap (the former one-block-per-bin gathers: 21.6 ms per step at 100-200 px).
 #define BG_J 40             // merged taps per bin column: a 7-grid bin of a 1024-px box spans 36.6 stride-4 pixels + 2 (BG_J % 8 == 0)
 #define BG_FH 264           // footprint rows
 #define BG_S 24             // samples per 7-grid bin and axis (2 x the adaptive 14-grid count: boxes up to 12 x 14 x 4 = 672 px); beyond: roi_feat7_giant_kernel
+#define BG_RS 2             // row splits
+#define BG_NT (7 * BG_RS * 64)
 struct BigTabs {
-  __attribute__((aligned(16))) float wx[7][BG_J];   // rows 16-byte aligned; entries from J on are zero
+  __attribute__((aligned(16))) float wx[7][BG_J];   // rows 16-byte aligned; entries from the padded tap count on are zero
   int xlo[7], span[7];
   float wy[7][BG_FH];
   int fx0, fy0, fw, fh;
   AxisEnt smp[2][7 * BG_S];        // the samples of both axes, computed once per map
   unsigned char smv[2][7 * BG_S];
-  int blo[4], bhi[4];
+  int blo[2], bhi[2];
 };
 
+// one map of one RoI: adds this wave's column of RoIAlign(7x7, Sx x Sy samples per bin) into acc[ph] (lane = channel)
 __device__ __forceinline__ void bg_accumulate(const float* __restrict__ map, int H, int W, int b, float x1, float y1, float bw, float bh, int Sx, int Sy,
-                              BigTabs* tb, float (&acc)[49]) {
+                                              BigTabs* tb, float (&acc)[7]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // ---- the samples of both axes, computed once (threads 0..127: x, 128..255: y, strided) and kept in LDS; footprint bounds
+  const int pw = wave % 7, rs = wave / 7;
   AxisEnt (&smp)[2][7 * BG_S] = tb->smp;
   unsigned char (&smv)[2][7 * BG_S] = tb->smv;
-  {
-    const bool is_y = tid >= 128;
+  // ---- the samples of both axes, computed once (wave 0: x, wave 1: y, strided) and kept in LDS; footprint bounds
+  if (wave < 2) {
+    const bool is_y = wave == 1;
     const int S = is_y ? Sy : Sx;
     int lo = 1 << 30, hi = -1;
-    for (int sidx = tid & 127; sidx < 7 * S; sidx += 128) {
+    for (int sidx = lane; sidx < 7 * S; sidx += 64) {
       bool v;
       const AxisEnt e = sm_sample(is_y ? y1 : x1, is_y ? bh : bw, S, sidx, is_y ? H : W, v);
       smp[is_y][sidx] = e;
@@ -505,29 +510,29 @@ __device__ __forceinline__ void bg_accumulate(const float* __restrict__ map, int
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
-    int (&blo)[4] = tb->blo, (&bhi)[4] = tb->bhi;
-    if (lane == 0) { blo[wave] = lo; bhi[wave] = hi; }
-    __syncthreads();
-    if (tid == 0) {
-      const int xl = min(blo[0], blo[1]), xh = max(bhi[0], bhi[1]), yl = min(blo[2], blo[3]), yh = max(bhi[2], bhi[3]);
-      const bool empty = xh < 0 || yh < 0;
-      tb->fx0 = empty ? 0 : xl; tb->fy0 = empty ? 0 : yl;
-      tb->fw = empty ? 0 : xh - xl + 1; tb->fh = empty ? 0 : min(yh - yl + 1, BG_FH);
-    }
-    if (tid < 7) {                                      // first pixel and span of each bin column
-      int m = 1 << 30, mh = -1;
-      for (int is = 0; is < Sx; ++is)
-        if (smv[0][tid * Sx + is]) { m = min(m, smp[0][tid * Sx + is].lo); mh = max(mh, smp[0][tid * Sx + is].hi); }
-      tb->xlo[tid] = m == (1 << 30) ? 0 : m;           // (absolute for now)
-      tb->span[tid] = mh < 0 ? 0 : mh - m + 1;
-    }
-    __syncthreads();
+    if (lane == 0) { tb->blo[wave] = lo; tb->bhi[wave] = hi; }
   }
+  __syncthreads();
+  if (tid == 0) {
+    const int xl = tb->blo[0], xh = tb->bhi[0], yl = tb->blo[1], yh = tb->bhi[1];
+    const bool empty = xh < 0 || yh < 0;
+    tb->fx0 = empty ? 0 : xl; tb->fy0 = empty ? 0 : yl;
+    tb->fw = empty ? 0 : xh - xl + 1; tb->fh = empty ? 0 : min(yh - yl + 1, BG_FH);
+  }
+  if (tid >= 64 && tid < 71) {                          // first pixel and span of each bin column
+    const int q = tid - 64;
+    int m = 1 << 30, mh = -1;
+    for (int is = 0; is < Sx; ++is)
+      if (smv[0][q * Sx + is]) { m = min(m, smp[0][q * Sx + is].lo); mh = max(mh, smp[0][q * Sx + is].hi); }
+    tb->xlo[q] = m == (1 << 30) ? 0 : m;               // (absolute for now)
+    tb->span[q] = mh < 0 ? 0 : mh - m + 1;
+  }
+  __syncthreads();
   const int fx0 = tb->fx0, fy0 = tb->fy0, fw = tb->fw, fh = tb->fh;
-  if (fw == 0 || fh == 0) { __syncthreads(); return; }  // every sample of an axis lies outside the map (block-uniform)
+  if (fw == 0 || fh == 0) return;                       // every sample of an axis lies outside the map (workgroup-uniform)   // every sample of an axis lies outside the map (block-uniform)
   int J = 1;
 #pragma unroll
-  for (int pw = 0; pw < 7; ++pw) J = max(J, tb->span[pw]);
+  for (int q = 0; q < 7; ++q) J = max(J, tb->span[q]);
   J = min(J, BG_J);
   // taps are read in groups of 8: a bin column's first pixel is moved left where its padded range would leave the footprint (the
   // weights below are built from these starts, so they move with it); rows narrower than the padded range take the clamped path
@@ -536,109 +541,96 @@ __device__ __forceinline__ void bg_accumulate(const float* __restrict__ map, int
   if (padded_ok && tid < 7) tb->xlo[tid] = min(tb->xlo[tid], fx0 + fw - Jr);
   __syncthreads();
   // ---- merged per-axis weights from the sample table (sums in sample order: deterministic)
-  for (int t = tid; t < 7 * BG_J; t += 256) {
-    const int pw = t / BG_J, j = t - pw * BG_J;
+  for (int t = tid; t < 7 * BG_J; t += BG_NT) {
+    const int q = t / BG_J, j = t - q * BG_J;
     float wsum = 0.f;
     if (j < (padded_ok ? Jr : J)) {                   // (a start moved left puts the bin's pixels at taps up to Jr - 1)
-      const int px = tb->xlo[pw] + j;
+      const int px = tb->xlo[q] + j;
       for (int is = 0; is < Sx; ++is) {
-        const AxisEnt q = smp[0][pw * Sx + is];
-        if (smv[0][pw * Sx + is]) { if (q.lo == px) wsum += q.h; if (q.hi == px) wsum += q.l; }
+        const AxisEnt e = smp[0][q * Sx + is];
+        if (smv[0][q * Sx + is]) { if (e.lo == px) wsum += e.h; if (e.hi == px) wsum += e.l; }
       }
     }
-    tb->wx[pw][j] = wsum / (float)Sx;
+    tb->wx[q][j] = wsum / (float)Sx;
   }
-  for (int t = tid; t < 7 * fh; t += 256) {
+  for (int t = tid; t < 7 * fh; t += BG_NT) {
     const int ph = t / fh, yr = t - ph * fh;
     float wsum = 0.f;
     for (int is = 0; is < Sy; ++is) {
-      const AxisEnt q = smp[1][ph * Sy + is];
-      if (smv[1][ph * Sy + is]) { if (q.lo == fy0 + yr) wsum += q.h; if (q.hi == fy0 + yr) wsum += q.l; }
+      const AxisEnt e = smp[1][ph * Sy + is];
+      if (smv[1][ph * Sy + is]) { if (e.lo == fy0 + yr) wsum += e.h; if (e.hi == fy0 + yr) wsum += e.l; }
     }
     tb->wy[ph][yr] = wsum / (float)Sy;
   }
   __syncthreads();
-  if (tid < 7) tb->xlo[tid] = max(tb->xlo[tid] - fx0, 0);   // relative to the footprint from here on
-  __syncthreads();
-  // ---- rows of this wave
-  const float* base = map + (((long long)b * H + fy0) * W + fx0) * 64 + lane;
-#define BG_SCATTER()                                                                                              \
-    _Pragma("unroll") for (int ph = 0; ph < 7; ++ph) {                                                            \
-      const float wyv = tb->wy[ph][yr];                                                                           \
-      if (wyv != 0.f) {   /* wave-uniform: a row carries weight for one or two bin rows */                        \
-        _Pragma("unroll") for (int pw = 0; pw < 7; ++pw) acc[ph * 7 + pw] = fmaf(wyv, T[pw], acc[ph * 7 + pw]);  \
-      }                                                                                                           \
-    }
-  if (padded_ok && J <= 8) {
-    // the usual case (bins up to 8 pixels wide: boxes up to ~200 px): all 56 taps of a row are requested before the first multiply
-    // (with one bin's loads issued only after the previous bin's sum, a row paid seven memory latencies one after the other)
-    int xo[7];
+  // ---- this wave's column, its rows
+  const int x0 = tb->xlo[pw] - fx0;
+  const float* base = map + (((long long)b * H + fy0) * W + fx0 + (padded_ok ? x0 : 0)) * 64 + lane;
+  const v4f* w4 = reinterpret_cast<const v4f*>(tb->wx[pw]);
+  if (padded_ok) {
+    // two rows per step: their taps (up to 2 x 16 per chunk) are all requested before the first multiply, so a step exposes one
+    // memory latency for two rows
+    for (int yr = rs; yr < fh; yr += 2 * BG_RS) {
+      const int yb = yr + BG_RS;
+      const bool hb = yb < fh;                          // wave-uniform
+      const float* rowa = base + (long long)yr * W * 64;
+      const float* rowb = base + (long long)(hb ? yb : yr) * W * 64;
+      float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+      for (int j = 0; j < Jr; j += 16) {
+        float va[16], vb[16];
+        const bool two = j + 8 < Jr;
 #pragma unroll
-    for (int pw = 0; pw < 7; ++pw) xo[pw] = tb->xlo[pw] * 64;
-    for (int yr = wave; yr < fh; yr += 4) {
-      const float* row = base + (long long)yr * W * 64;
-      float v[7][8];
+        for (int u = 0; u < 8; ++u) { va[u] = rowa[(j + u) * 64]; vb[u] = rowb[(j + u) * 64]; }
+        if (two) {
 #pragma unroll
-      for (int pw = 0; pw < 7; ++pw)
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[pw][u] = row[xo[pw] + u * 64];
-      float T[7];
-#pragma unroll
-      for (int pw = 0; pw < 7; ++pw) {
-        const v4f wa = reinterpret_cast<const v4f*>(tb->wx[pw])[0], wb = reinterpret_cast<const v4f*>(tb->wx[pw])[1];
-        float t0 = 0.f, t1 = 0.f;
-        t0 = fmaf(wa.x, v[pw][0], t0); t1 = fmaf(wa.y, v[pw][1], t1); t0 = fmaf(wa.z, v[pw][2], t0); t1 = fmaf(wa.w, v[pw][3], t1);
-        t0 = fmaf(wb.x, v[pw][4], t0); t1 = fmaf(wb.y, v[pw][5], t1); t0 = fmaf(wb.z, v[pw][6], t0); t1 = fmaf(wb.w, v[pw][7], t1);
-        T[pw] = t0 + t1;
+          for (int u = 8; u < 16; ++u) { va[u] = rowa[(j + u) * 64]; vb[u] = rowb[(j + u) * 64]; }
+        }
+        const v4f wa = w4[j >> 2], wb = w4[(j >> 2) + 1];
+        a0 = fmaf(wa.x, va[0], a0); a1 = fmaf(wa.y, va[1], a1); a0 = fmaf(wa.z, va[2], a0); a1 = fmaf(wa.w, va[3], a1);
+        a0 = fmaf(wb.x, va[4], a0); a1 = fmaf(wb.y, va[5], a1); a0 = fmaf(wb.z, va[6], a0); a1 = fmaf(wb.w, va[7], a1);
+        b0 = fmaf(wa.x, vb[0], b0); b1 = fmaf(wa.y, vb[1], b1); b0 = fmaf(wa.z, vb[2], b0); b1 = fmaf(wa.w, vb[3], b1);
+        b0 = fmaf(wb.x, vb[4], b0); b1 = fmaf(wb.y, vb[5], b1); b0 = fmaf(wb.z, vb[6], b0); b1 = fmaf(wb.w, vb[7], b1);
+        if (two) {
+          const v4f wc = w4[(j >> 2) + 2], wd = w4[(j >> 2) + 3];
+          a0 = fmaf(wc.x, va[8], a0); a1 = fmaf(wc.y, va[9], a1); a0 = fmaf(wc.z, va[10], a0); a1 = fmaf(wc.w, va[11], a1);
+          a0 = fmaf(wd.x, va[12], a0); a1 = fmaf(wd.y, va[13], a1); a0 = fmaf(wd.z, va[14], a0); a1 = fmaf(wd.w, va[15], a1);
+          b0 = fmaf(wc.x, vb[8], b0); b1 = fmaf(wc.y, vb[9], b1); b0 = fmaf(wc.z, vb[10], b0); b1 = fmaf(wc.w, vb[11], b1);
+          b0 = fmaf(wd.x, vb[12], b0); b1 = fmaf(wd.y, vb[13], b1); b0 = fmaf(wd.z, vb[14], b0); b1 = fmaf(wd.w, vb[15], b1);
+        }
       }
-      BG_SCATTER()
+      const float ta = a0 + a1, tbv = b0 + b1;
+#pragma unroll
+      for (int ph = 0; ph < 7; ++ph) acc[ph] = fmaf(tb->wy[ph][yr], ta, acc[ph]);
+      if (hb) {
+#pragma unroll
+        for (int ph = 0; ph < 7; ++ph) acc[ph] = fmaf(tb->wy[ph][yb], tbv, acc[ph]);
+      }
     }
   } else {
-    for (int yr = wave; yr < fh; yr += 4) {
+    for (int yr = rs; yr < fh; yr += BG_RS) {
       const float* row = base + (long long)yr * W * 64;
-      float T[7];
+      float t0 = 0.f;
+      for (int j = 0; j < J; ++j) t0 = fmaf(tb->wx[pw][j], row[min(x0 + j, fw - 1) * 64], t0);
 #pragma unroll
-      for (int pw = 0; pw < 7; ++pw) {
-        const int x0 = tb->xlo[pw];
-        const float* px = row + x0 * 64;
-        const v4f* w4 = reinterpret_cast<const v4f*>(tb->wx[pw]);
-        float t0 = 0.f, t1 = 0.f;
-        if (padded_ok) {
-          for (int j = 0; j < J; j += 8) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = px[(j + u) * 64];
-            const v4f wa = w4[j >> 2], wb = w4[(j >> 2) + 1];
-            t0 = fmaf(wa.x, v[0], t0); t1 = fmaf(wa.y, v[1], t1); t0 = fmaf(wa.z, v[2], t0); t1 = fmaf(wa.w, v[3], t1);
-            t0 = fmaf(wb.x, v[4], t0); t1 = fmaf(wb.y, v[5], t1); t0 = fmaf(wb.z, v[6], t0); t1 = fmaf(wb.w, v[7], t1);
-          }
-        } else {
-          for (int j = 0; j < J; ++j) t0 = fmaf(tb->wx[pw][j], row[min(x0 + j, fw - 1) * 64], t0);
-        }
-        T[pw] = t0 + t1;
-      }
-      BG_SCATTER()
+      for (int ph = 0; ph < 7; ++ph) acc[ph] = fmaf(tb->wy[ph][yr], t0, acc[ph]);
     }
   }
-#undef BG_SCATTER
   __syncthreads();                                       // the tables are rebuilt for the next map
 }
 
-__global__ __launch_bounds__(256, 2) void roi_feat7_big_kernel(RoiFeatParams p) {
-  // the tables of a map and, once the last map is done, the partial sums of one wave share the same LDS (14 KB: the compiler
-  // sizes its register budget by the workgroups the LDS allows)
-  __shared__ __attribute__((aligned(16))) char lds_raw[sizeof(BigTabs) > 49 * 64 * 4 ? sizeof(BigTabs) : 49 * 64 * 4];
-  BigTabs& tabs = *reinterpret_cast<BigTabs*>(lds_raw);
-  float* part = reinterpret_cast<float*>(lds_raw);
+__global__ __launch_bounds__(BG_NT) void roi_feat7_big_kernel(RoiFeatParams p) {
+  __shared__ BigTabs tabs;
+  __shared__ float part[BG_RS - 1][7][7][64];             // [row split - 1][pw][ph][channel]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pw = wave % 7, rs = wave / 7;
   const int nb = p.fb_count[0];
   for (int job = blockIdx.x; job < nb; job += gridDim.x) {
     const int r = p.fb_list[job];
     const float* roi = p.rois + (long long)r * 5;
     const int b = (int)roi[0];
-    float acc[49];
+    float acc[7];
 #pragma unroll
-    for (int k = 0; k < 49; ++k) acc[k] = 0.f;
+    for (int k = 0; k < 7; ++k) acc[k] = 0.f;
     const RoiGeom g0 = roi_geom(roi, 0.25f, 7, 2), g1 = roi_geom(roi, 0.125f, 7, 2), gs = roi_geom(roi, 0.25f, 14, 0);
     const bool sem_sep = gs.gw != 1 || gs.gh != 1;       // the semantic 14 x 14 grid takes its own samples
     for (int m = 0; m < (sem_sep ? 3 : 2); ++m) {
@@ -648,20 +640,12 @@ __global__ __launch_bounds__(256, 2) void roi_feat7_big_kernel(RoiFeatParams p) 
       bg_accumulate(map, m == 1 ? p.H1 : p.H0, m == 1 ? p.W1 : p.W0, b, g.x1, g.y1, bmul * g.bw, bmul * g.bh, m == 2 ? 2 * gs.gw : 2,
                     m == 2 ? 2 * gs.gh : 2, &tabs, acc);
     }
-    // waves 1..3 hand their partial sums to wave 0 one after the other (fixed order: reproducible)
-    for (int w = 1; w < 4; ++w) {
-      if (wave == w) {
+    if (rs > 0) {
 #pragma unroll
-        for (int k = 0; k < 49; ++k) part[k * 64 + lane] = acc[k];
-      }
-      __syncthreads();
-      if (wave == 0) {
-#pragma unroll
-        for (int k = 0; k < 49; ++k) acc[k] += part[k * 64 + lane];
-      }
-      __syncthreads();
+      for (int ph = 0; ph < 7; ++ph) part[rs - 1][pw][ph][lane] = acc[ph];
     }
-    if (wave == 0) {
+    __syncthreads();
+    if (rs == 0) {
       float gsum = 0.f;
 #pragma unroll
       for (int l = 0; l < 2; ++l) {
@@ -675,8 +659,14 @@ __global__ __launch_bounds__(256, 2) void roi_feat7_big_kernel(RoiFeatParams p) 
       }
       float* out = p.out + (long long)r * 49 * 64;
 #pragma unroll
-      for (int k = 0; k < 49; ++k) out[k * 64 + lane] = acc[k] + gsum;
+      for (int ph = 0; ph < 7; ++ph) {
+        float v = acc[ph];
+#pragma unroll
+        for (int q = 0; q < BG_RS - 1; ++q) v += part[q][pw][ph][lane];
+        out[(ph * 7 + pw) * 64 + lane] = v + gsum;
+      }
     }
+    __syncthreads();
   }
 }
 
@@ -888,21 +878,31 @@ __global__ __launch_bounds__(256) void roi_feat14_kernel(RoiFeatParams p) {
   }
 }
 
-int launch_roi_feat(const RoiFeatParams& p, int P, int r_cap, hipStream_t s, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join) {
+int launch_roi_feat(const RoiFeatParams& p, int P, int r_cap, hipStream_t s, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, hipStream_t side2,
+                    hipEvent_t ev_join2) {
   ProfScope ps(P == 7 ? "roi_feat7" : "roi_feat14", 0, 0, s);
   if (r_cap <= 0) return 0;
   if (P == 7) {
     if (hipMemsetAsync(p.fb_count, 0, 4 * sizeof(int), s) != hipSuccess) return NUHTC_E_HIP;
     hipLaunchKernelGGL(roi_classify_kernel, dim3(cdiv(r_cap, 4)), dim3(256), 0, s, p);
+    // three size classes side by side: the LDS-tile kernels on the caller's stream, the mid-size stream kernel on `side`, the
+    // big-box kernels on `side2` (at the usual load the latter two hold a few dozen boxes each and are latency chains of ~0.2 ms:
+    // one after the other they outlasted the LDS kernels, which take as long for thousands of nucleus-sized boxes)
     const bool fork = side && ev_fork && ev_join;
+    const bool fork2 = fork && side2 && ev_join2;
     if (fork && (hipEventRecord(ev_fork, s) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess)) return NUHTC_E_HIP;
+    if (fork2 && hipStreamWaitEvent(side2, ev_fork, 0) != hipSuccess) return NUHTC_E_HIP;
     hipLaunchKernelGGL(roi_feat7_stream_kernel, dim3(r_cap < 8192 ? r_cap : 8192), dim3(64), 0, fork ? side : s, p);
-    hipLaunchKernelGGL(roi_feat7_big_kernel, dim3(r_cap < 2048 ? r_cap : 2048), dim3(256), 0, fork ? side : s, p);
-    hipLaunchKernelGGL(roi_feat7_giant_kernel, dim3(r_cap < 1024 ? r_cap : 1024), dim3(256), 0, fork ? side : s, p);
     if (fork && hipEventRecord(ev_join, side) != hipSuccess) return NUHTC_E_HIP;
+    hipStream_t sb = fork2 ? side2 : fork ? side : s;
+    hipLaunchKernelGGL(roi_feat7_big_kernel, dim3(r_cap < 2048 ? r_cap : 2048), dim3(BG_NT), 0, sb, p);
+    hipLaunchKernelGGL(roi_feat7_giant_kernel, dim3(r_cap < 1024 ? r_cap : 1024), dim3(256), 0, sb, p);
+    if (fork2 && hipEventRecord(ev_join2, side2) != hipSuccess) return NUHTC_E_HIP;
+    if (fork && !fork2 && hipEventRecord(ev_join, side) != hipSuccess) return NUHTC_E_HIP;
     hipLaunchKernelGGL((roi_feat7_lds_kernel<TS0, TS1, 0>), dim3(r_cap), dim3(256), 0, s, p);
     hipLaunchKernelGGL((roi_feat7_lds_kernel<TP0, TP1, 3>), dim3(r_cap), dim3(256), 0, s, p);
     if (fork && hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) return NUHTC_E_HIP;
+    if (fork2 && hipStreamWaitEvent(s, ev_join2, 0) != hipSuccess) return NUHTC_E_HIP;
   } else if (P == 14) hipLaunchKernelGGL(roi_feat14_kernel, dim3(r_cap, 7), dim3(256), 0, s, p);
   else return NUHTC_E_INVALID;
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
@@ -1171,7 +1171,9 @@ int launch_paste(const PasteParams& p, int B, hipStream_t s) {
 // ------------------------------------------------------------------------------------------- per-tile filter + mask-NMS
 // tools/infer_wsi.py:486-531: detections are visited in class-major order (np.concatenate of the per-class lists),
 // filtered by margin / min_area, ordered by np.argsort(score)[::-1] and greedily suppressed at mask IoU > thr.
-__global__ __launch_bounds__(256) void tile_post_kernel(TilePostParams p) {
+constexpr int TP_NT = 1024;        // threads of tile_post_kernel (16 waves: the pair tests of a tile run side by side)
+constexpr int TP_BITS = 512;       // candidates up to which the suppression bit matrix fits LDS
+__global__ __launch_bounds__(TP_NT) void tile_post_kernel(TilePostParams p) {
   __shared__ unsigned long long okey[2048];   // sort keys
   __shared__ float4 sbox[2048];               // boxes of the candidates in visiting order (LDS: the pair loop is latency-bound)
   __shared__ int sarea[2048];
@@ -1187,7 +1189,7 @@ __global__ __launch_bounds__(256) void tile_post_kernel(TilePostParams p) {
   const int wpr = p.W >> 5, words = p.H * wpr;
   int npad = 2; while (npad < n) npad <<= 1;
   // class-major position of detection j: (#dets with smaller label) + (#dets with equal label before j)
-  for (int j = tid; j < npad; j += 256) {
+  for (int j = tid; j < npad; j += TP_NT) {
     unsigned long long key = ~0ull;
     if (j < n) {
       int pos = 0;
@@ -1205,7 +1207,7 @@ __global__ __launch_bounds__(256) void tile_post_kernel(TilePostParams p) {
   __syncthreads();
   for (int k = 2; k <= npad; k <<= 1)
     for (int jj = k >> 1; jj > 0; jj >>= 1) {
-      for (int t = tid; t < (npad >> 1); t += 256) {
+      for (int t = tid; t < (npad >> 1); t += TP_NT) {
         int lo = ((t / jj) * (jj << 1)) + (t % jj), hi = lo + jj;
         bool asc = ((lo & k) == 0);
         unsigned long long a = okey[lo], c = okey[hi];
@@ -1213,7 +1215,7 @@ __global__ __launch_bounds__(256) void tile_post_kernel(TilePostParams p) {
       }
       __syncthreads();
     }
-  for (int j = tid; j < n; j += 256) {
+  for (int j = tid; j < n; j += TP_NT) {
     const bool valid = okey[j] != ~0ull;
     const int i = valid ? (int)(okey[j] & 0xFFFF) : 0;
     const float* d = dets + i * 5;
@@ -1225,10 +1227,59 @@ __global__ __launch_bounds__(256) void tile_post_kernel(TilePostParams p) {
   int m = 0;   // candidates that passed the filter sort first
   while (m < n && sidx[m] >= 0) ++m;
   const unsigned* masks = p.masks + (long long)b * K * words;
-  // Greedy suppression: for a kept candidate a, the pairs (a, c > a) are independent of each other, so every wave takes its
-  // own c (popcount of the AND over the rows of a's hull, 64 lanes wide) and there is one barrier per kept candidate
-  // instead of three per overlapping pair.
   const int lane = tid & 63, wave = tid >> 6;
+  constexpr int NWV = TP_NT / 64;
+  if (m <= TP_BITS) {
+    // All pair tests first, side by side: wave w takes the candidates a = w, w + 16, ...; its lanes test the hulls of the later
+    // candidates c (masks live inside their box hulls: no overlap of hulls -> IoU 0) and the few overlapping ones get a wave-wide
+    // popcount of the AND over the rows of a's hull.  supb[a] = the later candidates a would suppress if kept.  The greedy pass
+    // itself is then a walk over that bit matrix by one wave (lane w holds word w of the removed set): same keep set as visiting
+    // the pairs in order, since a test's outcome does not depend on which candidates are still alive.
+    __shared__ unsigned long long supb[TP_BITS][TP_BITS / 64];
+    for (int i = tid; i < m * (TP_BITS / 64); i += TP_NT) supb[i / (TP_BITS / 64)][i % (TP_BITS / 64)] = 0ull;
+    __syncthreads();
+    for (int a = wave; a < m; a += NWV) {
+      const float4 di = sbox[a];
+      const unsigned* mi = masks + (long long)sidx[a] * words;
+      const int y0 = max((int)floorf(di.y) - 1, 0), y1 = min((int)ceilf(di.w) + 1, p.H);   // rows of mask a's hull
+      for (int c0 = a + 1; c0 < m; c0 += 64) {
+        const int c = c0 + lane;
+        bool ov = false;
+        if (c < m) {
+          const float4 dj = sbox[c];
+          ov = fminf(di.z, dj.z) + 2.f > fmaxf(di.x, dj.x) - 2.f && fminf(di.w, dj.w) + 2.f > fmaxf(di.y, dj.y) - 2.f;
+        }
+        unsigned long long todo = __ballot(ov);
+        while (todo) {
+          const int l = __ffsll((long long)todo) - 1;
+          todo &= todo - 1;
+          const int cc = c0 + l;
+          const unsigned* mj = masks + (long long)sidx[cc] * words;
+          int cnt = 0;
+          for (int wv = y0 * wpr + lane; wv < y1 * wpr; wv += 64) cnt += __popc(mi[wv] & mj[wv]);
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+          if (lane == 0) {
+            const int uni = sarea[a] + sarea[cc] - cnt;
+            if (uni > 0 && (double)cnt / (double)uni > p.thr) supb[a][cc >> 6] |= 1ull << (cc & 63);    // (this wave owns row a)
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      unsigned long long removed = 0ull;                 // lane w < 8: word w of the removed set
+      for (int a = 0; a < m; ++a) {
+        const unsigned long long wa = __shfl(removed, a >> 6);
+        if ((wa >> (a & 63)) & 1ull) continue;           // uniform
+        if (lane == 0) keep[sidx[a]] = 1;
+        if (lane < TP_BITS / 64) removed |= supb[a][lane];
+      }
+    }
+    return;
+  }
+  // more candidates than the bit matrix holds: for a kept candidate a, the pairs (a, c > a) are independent of each other, so every wave
+  // takes its own c and there is one barrier per kept candidate
   for (int a = 0; a < m; ++a) {
     if (sup[a]) continue;   // uniform: sup[] only changes between barriers
     const int i = sidx[a];
@@ -1236,10 +1287,9 @@ __global__ __launch_bounds__(256) void tile_post_kernel(TilePostParams p) {
     const float4 di = sbox[a];
     const unsigned* mi = masks + (long long)i * words;
     const int y0 = max((int)floorf(di.y) - 1, 0), y1 = min((int)ceilf(di.w) + 1, p.H);   // rows of mask i's hull
-    for (int c = a + 1 + wave; c < m; c += 4) {
+    for (int c = a + 1 + wave; c < m; c += NWV) {
       if (sup[c]) continue;
       const float4 dj = sbox[c];
-      // masks live inside their box hulls: no overlap of hulls -> IoU 0
       const bool ov = fminf(di.z, dj.z) + 2.f > fmaxf(di.x, dj.x) - 2.f && fminf(di.w, dj.w) + 2.f > fmaxf(di.y, dj.y) - 2.f;
       if (!ov) continue;
       const unsigned* mj = masks + (long long)sidx[c] * words;
@@ -1259,6 +1309,6 @@ __global__ __launch_bounds__(256) void tile_post_kernel(TilePostParams p) {
 int launch_tile_post(const TilePostParams& p, int B, hipStream_t s) {
   ProfScope ps("tile_post", 0, 0, s);
   if (p.max_keep > 2048) return NUHTC_E_INVALID;
-  hipLaunchKernelGGL(tile_post_kernel, dim3(B), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(tile_post_kernel, dim3(B), dim3(TP_NT), 0, s, p);
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
 }

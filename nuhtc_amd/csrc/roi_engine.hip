@@ -304,7 +304,7 @@ int run_roi_path(nuhtc_engine* e, int B, const float* rois_fixed, int n_rois, in
     auto it = e->bufs.find("rois_stage" + std::to_string(k));
     if (it != e->bufs.end() && e->debug_tokens)
       if (hipMemcpyAsync(it->second.ptr, w->rois, (size_t)Rcap * 5 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) FAIL(e, NUHTC_E_HIP, "memcpy failed");
-    RUN(launch_roi_feat(fp, 7, Rcap, s, e->side, e->ev_fpn, e->ev_side));   // (both events are free again after the RPN join)
+    RUN(launch_roi_feat(fp, 7, Rcap, s, e->side, e->ev_fpn, e->ev_side, e->side2, e->ev_side2));   // (both events are free again after the RPN join)
     {
       GemmParams p = gpr(w->feats, e->fc1_w[k], e->fc1_b[k], w->h1, Rcap, 256, 3136);
       p.act = ACT_RELU; p.m_dev = w->roi_total;
