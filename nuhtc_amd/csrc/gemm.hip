@@ -869,7 +869,10 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
     // chip with them; NUHTC_SPLIT_MT=1 / 2 forces one form (dev)
     static const int& force_mt = dev_knob_ref("SPLIT_MT", 0);
     const long long blocks2 = (long long)cdiv(p.M, 256) * (p.N / (32 * nt));
-    const bool mt2 = force_mt ? force_mt == 2 : (!p.m_dev && nt == 3 && blocks2 >= 512);
+    // (round 3, same-box A/B of every 96-column shape left on this kernel -- the M = 262144 stage-1 linears moved to mlp.hip: 128-row
+    // tiles are as fast or faster everywhere, N1152|K384 0.568 vs 0.648 ms, N1536|K384 0.759 vs 0.787, N768|K3072 0.281 vs 0.357; the
+    // 256-row form is kept for launches of at least 2048 such tiles, i.e. M >= 131072 at the path's widths)
+    const bool mt2 = force_mt ? force_mt == 2 : (!p.m_dev && nt == 3 && blocks2 >= 512 && p.M >= 131072);
     if (mt2 && nt == 3) launch_split<2, 3>(q, s);
     else if (nt == 1) launch_split<1, 1>(q, s);
     else if (nt == 2) launch_split<1, 2>(q, s);
