@@ -327,15 +327,17 @@ def main():
     # (tools/dev/round_traffic.sh); the committed summary is used only while it belongs to the GEMM source of this build
     traffic, traffic_note = None, 'no PMC summary for this build (rocprofv3 --pmc passes are run separately: tools/dev/round_traffic.sh)'
     here = os.path.dirname(os.path.abspath(__file__))
-    tf = os.path.join(here, 'profiles', 'r02_traffic.json')
-    if os.path.exists(tf):
-        import hashlib
+    import glob
+    import hashlib
+    sha = hashlib.sha1(open(os.path.join(here, 'nuhtc_amd', 'csrc', 'gemm.hip'), 'rb').read()).hexdigest()
+    for tf in sorted(glob.glob(os.path.join(here, 'profiles', 'r*_traffic.json')), reverse=True):       # newest round first
         tj = json.load(open(tf))
-        sha = hashlib.sha1(open(os.path.join(here, 'nuhtc_amd', 'csrc', 'gemm.hip'), 'rb').read()).hexdigest()
         if tj.get('gemm_hip_sha1') == sha:
-            traffic, traffic_note = tj['hbm_bytes_per_launch'], f"profiles/r02_traffic.json (FETCH_SIZE x2 + WRITE_SIZE passes, gemm.hip {sha[:10]})"
-        else:
-            traffic_note = 'profiles/r02_traffic.json is from another gemm.hip: not reported'
+            traffic = tj['hbm_bytes_per_launch']
+            traffic_note = f"profiles/{os.path.basename(tf)} (FETCH_SIZE x2 + WRITE_SIZE passes, gemm.hip {sha[:10]})"
+            break
+    else:
+        traffic_note = 'no profiles/r*_traffic.json belongs to this gemm.hip: not reported (tools/dev/round_all.sh refreshes it)'
     # per-group fractions: dense groups against the fp32-MFMA roof, gather / scan groups against HBM with their
     # algorithmic bytes; `ms` = sum of launch durations per step (the RPN branch runs beside the semantic branch, so the sum
     # over groups exceeds the step)
