@@ -70,7 +70,7 @@ def cpu_baseline(sd, tiles, eng=None, mode=1, batch=4, timed=3):
     dt = sum(times)
     out = dict(value=n / dt, unit='tiles/s', cores=threads, kind='port',
                sample=f'{timed} timed batches of {batch} synthetic nuclei tiles after 1 warm-up batch of 2 (oracle/model.py, fp32 torch-cpu + C RoIAlign/NMS), '
-                      f'{dt:.1f} s; per batch {[round(batch / t, 3) for t in times]} tiles/s')
+                      f'{dt:.1f} s; per batch {[round(batch / t, 3) for t in times]} tiles/s; bounded deviation from SURVEY 8d (2 warm-up + 10 timed batches of 16 tiles: about 6 minutes of host time)')
     if eng is not None:
         eng.infer_async(eng.to_device(tiles[:n]), mode)
         got = eng.results(n)
