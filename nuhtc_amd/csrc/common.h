@@ -68,6 +68,23 @@ enum AMode { A_PLAIN = 0, A_CONV3 = 1 };
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_COS = 3 /* relu(v*ri[m]*rj[n]-tau)+tau */ };
 enum StoreMode { ST_PLAIN = 0, ST_ROWMAP = 1, ST_DECONV2 = 2 };
 
+// A pointwise (1x1) layer computed in the epilogue of the 3x3 convolution that feeds it (conv.hip): the convolution's output tile
+// never leaves the registers on its way into the second product.
+struct Conv3Fuse {
+  int N2;                 // output channels of the pointwise layer: 32 or 64 (its input is the convolution's 64 channels)
+  const void* w2f;        // device image of its [N2][64] weight from conv3_pack_fuse()
+  const float* bias2;     // [N2] or null
+  float* out2;            // [M][N2]
+  int act2;               // ACT_NONE / ACT_RELU
+  const float* res2;      // optional (N2 == 64): out3 = res2 + out2
+  float* out3;
+  const float* wn1;       // optional 64 -> 1 layer on the convolution's output: outn1[m] = wn1 . conv[m] + *bn1
+  const float* bn1;
+  float* outn1;
+  int store_out;          // the convolution's own output is stored to C (1) or dropped (0)
+};
+int conv3_pack_fuse(const float* w2_host, int N2, void** out_dev);      // caller hipFree()s the image
+
 struct GemmParams {
   const float* A;
   const float* W;      // [N][K] row-major
@@ -96,6 +113,7 @@ struct GemmParams {
   int batch;
   long long sA, sW, sC, sRi, sRj;
   unsigned long long* stamps;   // dev instrumentation (-DNUHTC_GEMM_STAMPS), null otherwise
+  const Conv3Fuse* fuse;        // host-side: pointwise layer fused into an A_CONV3 product (only on the conv.hip path; else NUHTC_E_INVALID)
 };
 int launch_gemm(const GemmParams& p, hipStream_t s);
 // exact three-way bf16 split of a constant weight matrix (host copy given), keyed by its fp32 device pointer: launch_gemm then
@@ -108,6 +126,7 @@ const void* gemm_find_split(const float* w_dev, int N, int K);
 // 3x3 convolution 64 -> 64 with the input halo resident in LDS as bf16 planes (conv.hip); launch_gemm routes A_CONV3 products with a
 // split weight there
 bool conv3_split_supported(const GemmParams& p);
+bool conv3_fuse_available();      // false when the dev knob CONV_HALO routes 3x3 convolutions to the implicit-GEMM path
 int launch_conv3_split(const GemmParams& p, hipStream_t s);
 
 // ----------------------------------------------------------------------------- fused FFN half of a Swin block (mlp.hip)

@@ -16,7 +16,9 @@
 // conflict-free for ds_read_b128 (lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31}); weight image: 400 B per output channel.
 #include <algorithm>
 #include <cstring>
+#include <map>
 #include <mutex>
+#include <vector>
 
 #include "common.h"
 #include "split_math.h"
@@ -29,6 +31,13 @@
 #define CV_WCOL 400                        // bytes per output channel of one tap's weights (8 k-groups x 48 B + 16)
 #define CV_W_BYTES (64 * CV_WCOL)          // 25600
 #define CV_LDS (CV_A_BYTES + 2 * CV_W_BYTES)
+// fused pointwise layer (Conv3Fuse): per-wave exchange slots for the partial sums of the second product, the 64 -> 1 partials,
+// and the three small vectors (conv bias, pointwise bias, 64 -> 1 weight) the epilogue reads
+#define CV_X_OFF CV_LDS
+#define CV_X_SLOT 4096
+#define CV_XN_OFF (CV_X_OFF + 8 * CV_X_SLOT)
+#define CV_K_OFF (CV_XN_OFF + 8 * 256)
+#define CV_LDS_FUSED (CV_K_OFF + 1024)     // 161 280 of the 163 840 bytes of a CU
 
 struct Conv3Params {
   const float* in;        // [nimg][H][W][64]
@@ -39,8 +48,24 @@ struct Conv3Params {
   int nimg, H, W, act;
   int tiles_x, tiles_y;
   unsigned long long* stamps;   // dev instrumentation (-DNUHTC_CONV_STAMPS), null otherwise
+  // fused pointwise layer (template N2 > 0), see Conv3Fuse
+  const char* w2f;        // [2 channel halves][N2 / 32][2 k-steps][3 planes][64 lanes][16 B]
+  const float* bias2;
+  float* out2;
+  const float* res2;
+  float* out3;
+  const float* wn1;
+  const float* bn1;
+  float* outn1;
+  int act2, store_out;
 };
 
+// N2 = 0: the plain convolution.  N2 = 32 / 64: a pointwise layer 64 -> N2 on the (biased, activated) output tile is computed in
+// the epilogue.  A wave holds 32 of the 64 channels of its 32 pixels: with the pointwise weight's k axis permuted on the host
+// (k' = 16 u + 8 half + e  <->  channel 16 u + 8 (e / 4) + 4 half + e % 4, the accumulator layout of the 32x32 MFMA) accumulator
+// registers 8u .. 8u+7 ARE the B operand of k-step u, so each wave multiplies its own channel half (weight fragments held in
+// registers for the workgroup's lifetime) and the two waves of a pixel group add their partial sums through LDS.
+template <int N2>
 __global__ __launch_bounds__(512, 1) void conv3_split_kernel(Conv3Params p) {
   extern __shared__ __attribute__((aligned(256))) char lds[];
   char* Apl = lds;
@@ -102,10 +127,28 @@ __global__ __launch_bounds__(512, 1) void conv3_split_kernel(Conv3Params p) {
   CV_W_LOAD(0)
   // bias of this lane's 16 output channels: loaded once per workgroup (a load in the epilogue would queue behind the next tile's
   // halo loads and expose their HBM latency: vector-memory operations complete in order)
-  v4f bias4[4];
+  v4f bias4[N2 ? 1 : 4];
+  constexpr int OB = N2 / 32;                      // 32-row blocks of the pointwise layer's output
+  u32x4 w2f[OB ? OB : 1][2][3];
+  const int chalf = wave >> 2;
+  if constexpr (N2 == 0) {
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
-    bias4[q] = p.bias ? *reinterpret_cast<const v4f*>(p.bias + 32 * (wave >> 2) + 4 * half + 8 * q) : v4f{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < 4; ++q)
+      bias4[q] = p.bias ? *reinterpret_cast<const v4f*>(p.bias + 32 * (wave >> 2) + 4 * half + 8 * q) : v4f{0.f, 0.f, 0.f, 0.f};
+  } else {
+    float* kst = reinterpret_cast<float*>(lds + CV_K_OFF);      // [0,64) conv bias, [64,128) pointwise bias, [128,192) 64 -> 1 weight, [192] its bias
+    if (tid < 64) kst[tid] = p.bias ? p.bias[tid] : 0.f;
+    else if (tid < 64 + N2) kst[tid] = p.bias2 ? p.bias2[tid - 64] : 0.f;
+    else if (tid >= 128 && tid < 192) kst[tid] = p.wn1 ? p.wn1[tid - 128] : 0.f;
+    else if (tid == 192) kst[tid] = p.bn1 ? *p.bn1 : 0.f;
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          w2f[ob][u][pl] = *reinterpret_cast<const u32x4*>(p.w2f + ((((long long)(chalf * OB + ob) * 2 + u) * 3 + pl) * 64 + lane) * 16);
+  }
 
   // ---- this wave: pixels (row 2 (wave & 3) + (i32 >> 4), column i32 & 15) of the tile x output channels 32 (wave >> 2) ..
   const int prow = 2 * (wave & 3) + (i32 >> 4), pcol = i32 & 15;
@@ -187,15 +230,108 @@ __global__ __launch_bounds__(512, 1) void conv3_split_kernel(Conv3Params p) {
     CSTAMP(sMain)
     // ---- epilogue: register r of lane (pixel, half) is output channel 32 (wave >> 2) + (r & 3) + 8 (r >> 2) + 4 half
     const int y = y0 + prow, x = x0 + pcol;
-    if (y < p.H && x < p.W) {
-      const int cb = 32 * (wave >> 2) + 4 * half;
-      float* o = p.out + (((long long)img * p.H + y) * p.W + x) * 64 + cb;
+    const bool inside = y < p.H && x < p.W;
+    const long long pix = ((long long)img * p.H + y) * p.W + x;
+    if constexpr (N2 == 0) {
+      if (inside) {
+        const int cb = 32 * (wave >> 2) + 4 * half;
+        float* o = p.out + pix * 64 + cb;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v4f v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+          v += bias4[q];
+          if (p.act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          *reinterpret_cast<v4f*>(o + 8 * q) = v;
+        }
+      }
+    } else {
+      const float* kst = reinterpret_cast<const float*>(lds + CV_K_OFF);
+      const int cb = 32 * chalf + 4 * half;
+      u32x4 vp[2][3];                    // the output tile as the B operand of the second product: k-step u = registers 8u .. 8u+7
+      float n1 = 0.f;
+      // the residual of the second output is requested before this tile's first store: a load's data is waited for together with
+      // every vector-memory operation issued before it, and stores under load take microseconds to be acknowledged
+      v4f res[N2 == 64 ? 4 : 1];
+      if constexpr (N2 == 64) {
+        if (p.out3 && inside) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) res[q] = *reinterpret_cast<const v4f*>(p.res2 + pix * 64 + 32 * chalf + 4 * half + 8 * q);
+        }
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         v4f v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-        v += bias4[q];
+        v += *reinterpret_cast<const v4f*>(kst + cb + 8 * q);
         if (p.act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        *reinterpret_cast<v4f*>(o + 8 * q) = v;
+        if (p.store_out && inside) *reinterpret_cast<v4f*>(p.out + pix * 64 + cb + 8 * q) = v;
+        if (p.outn1) {
+          const v4f wv = *reinterpret_cast<const v4f*>(kst + 128 + cb + 8 * q);
+          n1 = fmaf(v.x, wv.x, n1); n1 = fmaf(v.y, wv.y, n1); n1 = fmaf(v.z, wv.z, n1); n1 = fmaf(v.w, wv.w, n1);
+        }
+        const int u = q >> 1, d0 = 2 * (q & 1);
+        NUHTC_SPLIT3_INTO(vp[u], d0, v.x, v.y)
+        NUHTC_SPLIT3_INTO(vp[u], d0 + 1, v.z, v.w)
+      }
+      f32x16 acc2[OB];
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[ob][r] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) acc2[ob] = mfma_split6_wa(w2f[ob][u], vp[u], acc2[ob]);
+      }
+      // the other channel half's partial sums: N2 = 64: this wave keeps output block `chalf` and hands over the other one;
+      // N2 = 32: it keeps registers 8 chalf .. 8 chalf + 7 of the one block and hands over the other eight
+      char* xs = lds + CV_X_OFF + wave * CV_X_SLOT + lane * 16;
+      const char* xr = lds + CV_X_OFF + (wave ^ 4) * CV_X_SLOT + lane * 16;
+      if constexpr (N2 == 64) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const v4f a0 = {acc2[0][4 * q], acc2[0][4 * q + 1], acc2[0][4 * q + 2], acc2[0][4 * q + 3]};
+          const v4f a1 = {acc2[1][4 * q], acc2[1][4 * q + 1], acc2[1][4 * q + 2], acc2[1][4 * q + 3]};
+          *reinterpret_cast<v4f*>(xs + q * 1024) = chalf ? a0 : a1;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const v4f a0 = {acc2[0][4 * q], acc2[0][4 * q + 1], acc2[0][4 * q + 2], acc2[0][4 * q + 3]};
+          const v4f a1 = {acc2[0][8 + 4 * q], acc2[0][8 + 4 * q + 1], acc2[0][8 + 4 * q + 2], acc2[0][8 + 4 * q + 3]};
+          *reinterpret_cast<v4f*>(xs + q * 1024) = chalf ? a0 : a1;
+        }
+      }
+      float* xn = reinterpret_cast<float*>(lds + CV_XN_OFF);
+      if (p.outn1) {
+        n1 += __shfl_xor(n1, 32);
+        xn[wave * 64 + lane] = n1;
+      }
+      CV_RAW_BARRIER()
+      if (p.outn1 && chalf == 0 && half == 0 && inside) p.outn1[pix] = (n1 + xn[(wave ^ 4) * 64 + lane]) + kst[192];
+      if constexpr (N2 == 64) {
+        const int c2 = 32 * chalf + 4 * half;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const v4f mine = chalf ? v4f{acc2[1][4 * q], acc2[1][4 * q + 1], acc2[1][4 * q + 2], acc2[1][4 * q + 3]}
+                                 : v4f{acc2[0][4 * q], acc2[0][4 * q + 1], acc2[0][4 * q + 2], acc2[0][4 * q + 3]};
+          const v4f other = *reinterpret_cast<const v4f*>(xr + q * 1024);
+          // channel half 0's partial first, whichever wave does the addition
+          v4f v = (chalf ? other + mine : mine + other) + *reinterpret_cast<const v4f*>(kst + 64 + c2 + 8 * q);
+          if (p.act2 == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          if (inside) {
+            *reinterpret_cast<v4f*>(p.out2 + pix * 64 + c2 + 8 * q) = v;
+            if (p.out3) *reinterpret_cast<v4f*>(p.out3 + pix * 64 + c2 + 8 * q) = res[q] + v;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const v4f mine = chalf ? v4f{acc2[0][8 + 4 * q], acc2[0][8 + 4 * q + 1], acc2[0][8 + 4 * q + 2], acc2[0][8 + 4 * q + 3]}
+                                 : v4f{acc2[0][4 * q], acc2[0][4 * q + 1], acc2[0][4 * q + 2], acc2[0][4 * q + 3]};
+          const v4f other = *reinterpret_cast<const v4f*>(xr + q * 1024);
+          const int c2 = 16 * chalf + 8 * q + 4 * half;          // registers 8 chalf + 4 q .. + 3  ->  channels 8 (2 chalf + q) + 4 half ..
+          v4f v = (chalf ? other + mine : mine + other) + *reinterpret_cast<const v4f*>(kst + 64 + c2);
+          if (p.act2 == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          if (inside) *reinterpret_cast<v4f*>(p.out2 + pix * 32 + c2) = v;
+        }
       }
     }
     CV_W_LOAD(0)
@@ -219,9 +355,58 @@ __global__ __launch_bounds__(512, 1) void conv3_split_kernel(Conv3Params p) {
 #undef CV_HALO_LOAD
 }
 
-bool conv3_split_supported(const GemmParams& p) {
+bool conv3_split_supported(const GemmParams& p) {      // (with p.fuse the pointwise layer rides in the epilogue; checked at launch)
   return p.amode == A_CONV3 && p.Wsplit && p.cC == 64 && p.N == 64 && p.K == 576 && p.lda == 576 && p.ldc == 64 && !p.res && !p.up && p.store == ST_PLAIN &&
          (p.act == ACT_NONE || p.act == ACT_RELU) && p.alpha == 1.f && p.batch <= 1 && p.M % (p.cH * p.cW) == 0 && (!p.m_dev || p.m_mul == p.cH * p.cW);
+}
+
+// [N2][64] fp32 -> the fragment image the fused epilogue holds in registers (see conv3_split_kernel<N2>)
+static inline unsigned short cv_bf16_rn(float f) {
+  unsigned u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+static inline float cv_bf16_f(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
+int conv3_pack_fuse(const float* w2, int N2, void** out_dev) {
+  if (N2 != 32 && N2 != 64) return NUHTC_E_INVALID;
+  const int OB = N2 / 32;
+  std::vector<unsigned short> img((size_t)2 * OB * 2 * 3 * 64 * 8);
+  for (int ch = 0; ch < 2; ++ch)
+    for (int ob = 0; ob < OB; ++ob)
+      for (int u = 0; u < 2; ++u)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int e = 0; e < 8; ++e) {
+            const int i32 = lane & 31, h = lane >> 5;
+            const int k = 32 * ch + 16 * u + 8 * (e >> 2) + 4 * h + (e & 3);
+            const float w = w2[(size_t)(32 * ob + i32) * 64 + k];
+            const unsigned short b1 = cv_bf16_rn(w);
+            const float r1 = w - cv_bf16_f(b1);
+            const unsigned short b2 = cv_bf16_rn(r1);
+            const unsigned short b3 = cv_bf16_rn(r1 - cv_bf16_f(b2));
+            const size_t base = ((((size_t)(ch * OB + ob) * 2 + u) * 3) * 64 + lane) * 8 + e;
+            img[base] = b1; img[base + 64 * 8] = b2; img[base + 2 * 64 * 8] = b3;
+          }
+  void* d = nullptr;
+  if (hipMalloc(&d, img.size() * 2) != hipSuccess) return NUHTC_E_HIP;
+  if (hipMemcpy(d, img.data(), img.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { hipFree(d); return NUHTC_E_HIP; }
+  *out_dev = d;
+  return 0;
+}
+
+template <int N2>
+static int conv3_raise_lds() {       // more than the default 64 KB of dynamic LDS: raised once per device and instantiation
+  static std::map<int, bool> done;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return NUHTC_E_HIP;
+  if (!done[dev]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_split_kernel<N2>), hipFuncAttributeMaxDynamicSharedMemorySize, N2 ? CV_LDS_FUSED : CV_LDS) != hipSuccess)
+      return NUHTC_E_HIP;
+    done[dev] = true;
+  }
+  return 0;
 }
 
 int launch_conv3_split(const GemmParams& g, hipStream_t s) {
@@ -232,16 +417,18 @@ int launch_conv3_split(const GemmParams& g, hipStream_t s) {
   p.tiles_x = cdiv(g.cW, CV_TW); p.tiles_y = cdiv(g.cH, CV_TH);
   const int ntile = p.nimg * p.tiles_x * p.tiles_y;
   if (ntile <= 0) return 0;
+  int n2 = 0;
+  if (const Conv3Fuse* f = g.fuse) {
+    if ((f->N2 != 32 && f->N2 != 64) || !f->w2f || !f->out2 || (f->out3 && (!f->res2 || f->N2 != 64)) || (f->outn1 && !f->wn1) ||
+        (f->act2 != ACT_NONE && f->act2 != ACT_RELU) || (f->store_out && !g.C))
+      return NUHTC_E_INVALID;
+    n2 = f->N2;
+    p.w2f = reinterpret_cast<const char*>(f->w2f); p.bias2 = f->bias2; p.out2 = f->out2; p.res2 = f->res2; p.out3 = f->out3;
+    p.wn1 = f->wn1; p.bn1 = f->bn1; p.outn1 = f->outn1; p.act2 = f->act2; p.store_out = f->store_out;
+  }
   {
-    static std::map<int, bool> done;       // more than the default 64 KB of dynamic LDS: raised once per device
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lock(mu);
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return NUHTC_E_HIP;
-    if (!done[dev]) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CV_LDS) != hipSuccess) return NUHTC_E_HIP;
-      done[dev] = true;
-    }
+    const int rc = n2 == 64 ? conv3_raise_lds<64>() : n2 == 32 ? conv3_raise_lds<32>() : conv3_raise_lds<0>();
+    if (rc) return rc;
   }
   int ncu = 256;
   {
@@ -263,7 +450,9 @@ int launch_conv3_split(const GemmParams& g, hipStream_t s) {
   if (!stamp_buf && hipMalloc(&stamp_buf, 8ull * 8 * 8 * 512) != hipSuccess) return NUHTC_E_HIP;
   p.stamps = stamp_buf;
 #endif
-  hipLaunchKernelGGL(conv3_split_kernel, dim3(grid), dim3(512), CV_LDS, s, p);
+  if (n2 == 64) hipLaunchKernelGGL(conv3_split_kernel<64>, dim3(grid), dim3(512), CV_LDS_FUSED, s, p);
+  else if (n2 == 32) hipLaunchKernelGGL(conv3_split_kernel<32>, dim3(grid), dim3(512), CV_LDS_FUSED, s, p);
+  else hipLaunchKernelGGL(conv3_split_kernel<0>, dim3(grid), dim3(512), CV_LDS, s, p);
 #ifdef NUHTC_CONV_STAMPS
   {
     static int cnt = 0, dump_at = -1;   // launch NUHTC_STAMP_AT of the process is dumped to /tmp/conv_stamps.txt

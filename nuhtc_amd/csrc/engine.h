@@ -47,6 +47,7 @@ struct nuhtc_engine {
   // neck / dense heads
   float *lat_w[4], *lat_b[4], *fpn_w[4], *fpn_b[4];
   float *rpn_w, *rpn_b, *rpn_hw, *rpn_hb;
+  void *rpn_hf, *sem_lf[4], *sem_ef;   // pointwise layers as conv3_pack_fuse images (split pipe): computed in the epilogue of the 3x3 convolution before them
   float *sem_lw[4], *sem_lb[4], *sem_cw[4], *sem_cb[4], *sem_ew, *sem_eb, *sem_gw, *sem_gb;
   // roi heads
   float *fc1_w[3], *fc1_b[3], *fc2_w[3], *fc2_b[3], *head_w[3], *head_b[3];   // head_w: [16][256] rows 0..nc+1 normed cls, then 4 reg

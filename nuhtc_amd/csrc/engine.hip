@@ -167,6 +167,16 @@ int upload_gemm_weight(nuhtc_engine* e, float** dst, const std::vector<float>& v
   return 0;
 }
 
+static int upload_fuse(nuhtc_engine* e, void** dst, const std::vector<float>& w, int N2) {
+  *dst = nullptr;
+  if (e->cfg.matrix_pipe != NUHTC_PIPE_BF16_SPLIT) return 0;
+  if (w.size() != (size_t)N2 * 64) FAIL(e, NUHTC_E_INVALID, "upload_fuse: shape mismatch");
+  const int rc = conv3_pack_fuse(w.data(), N2, dst);
+  if (rc) FAIL(e, rc, "conv3_pack_fuse failed");
+  e->allocs.push_back(*dst);
+  return 0;
+}
+
 static int upload_i(nuhtc_engine* e, int** dst, const std::vector<int>& v) {
   int rc = dev_alloc(e, (void**)dst, v.size() * sizeof(int));
   if (rc) return rc;
@@ -409,7 +419,7 @@ int nuhtc_finalize(nuhtc_engine* e) {
     for (int n = 0; n < 3; ++n) { b[n] = kb->data[n]; for (int k = 0; k < 64; ++k) w[n * 64 + k] = kw->data[n * 64 + k]; }
     for (int n = 0; n < 12; ++n) { b[3 + n] = rb->data[n]; for (int k = 0; k < 64; ++k) w[(3 + n) * 64 + k] = rw->data[n * 64 + k]; }
     if ((rc = upload_gemm_weight(e, &e->rpn_w, pack_conv3(*cw, 64, 64), 64, 576)) || (rc = upload(e, &e->rpn_b, cb->data)) ||
-        (rc = upload_gemm_weight(e, &e->rpn_hw, w, 32, 64)) || (rc = upload(e, &e->rpn_hb, b)))
+        (rc = upload_gemm_weight(e, &e->rpn_hw, w, 32, 64)) || (rc = upload(e, &e->rpn_hb, b)) || (rc = upload_fuse(e, &e->rpn_hf, w, 32)))
       return rc;
   }
   // ---- semantic head
@@ -420,13 +430,13 @@ int nuhtc_finalize(nuhtc_engine* e) {
       RAW(lb, p + "lateral_convs." + std::to_string(i) + ".conv.bias", 64);
       RAW(cw, p + "convs." + std::to_string(i) + ".conv.weight", 64, 64, 3, 3);
       RAW(cb, p + "convs." + std::to_string(i) + ".conv.bias", 64);
-      if ((rc = upload_gemm_weight(e, &e->sem_lw[i], lw->data, 64, 64)) || (rc = upload(e, &e->sem_lb[i], lb->data)) ||
+      if ((rc = upload_gemm_weight(e, &e->sem_lw[i], lw->data, 64, 64)) || (rc = upload(e, &e->sem_lb[i], lb->data)) || (rc = upload_fuse(e, &e->sem_lf[i], lw->data, 64)) ||
           (rc = upload_gemm_weight(e, &e->sem_cw[i], pack_conv3(*cw, 64, 64), 64, 576)) || (rc = upload(e, &e->sem_cb[i], cb->data)))
         return rc;
     }
     RAW(ew, p + "conv_embedding.conv.weight", 64, 64, 1, 1); RAW(eb, p + "conv_embedding.conv.bias", 64);
     RAW(gw, p + "conv_logits.weight", 1, 64, 1, 1); RAW(gb, p + "conv_logits.bias", 1);
-    if ((rc = upload_gemm_weight(e, &e->sem_ew, ew->data, 64, 64)) || (rc = upload(e, &e->sem_eb, eb->data)) || (rc = upload(e, &e->sem_gw, gw->data)) ||
+    if ((rc = upload_gemm_weight(e, &e->sem_ew, ew->data, 64, 64)) || (rc = upload(e, &e->sem_eb, eb->data)) || (rc = upload_fuse(e, &e->sem_ef, ew->data, 64)) || (rc = upload(e, &e->sem_gw, gw->data)) ||
         (rc = upload(e, &e->sem_gb, gb->data)))
       return rc;
   }
@@ -496,10 +506,16 @@ static GemmParams gp(const float* A, const float* W, const float* bias, float* C
   } while (0)
 
 static int conv3x3(nuhtc_engine* e, const float* in, const float* w, const float* b, float* out, int nimg, int H, int W, int act,
-                   const int* m_dev, int m_mul, hipStream_t s) {
+                   const int* m_dev, int m_mul, hipStream_t s, const Conv3Fuse* fuse = nullptr) {
   GemmParams p = gp(in, w, b, out, nimg * H * W, 64, 576);
-  p.amode = A_CONV3; p.cH = H; p.cW = W; p.cC = 64; p.act = act; p.m_dev = m_dev; p.m_mul = m_mul;
+  p.amode = A_CONV3; p.cH = H; p.cW = W; p.cC = 64; p.act = act; p.m_dev = m_dev; p.m_mul = m_mul; p.fuse = fuse;
   return launch_gemm(p, s);
+}
+static Conv3Fuse pointwise(int N2, const void* w2f, const float* bias2, float* out2, int act2, int store_out) {
+  Conv3Fuse f;
+  memset(&f, 0, sizeof(f));
+  f.N2 = N2; f.w2f = w2f; f.bias2 = bias2; f.out2 = out2; f.act2 = act2; f.store_out = store_out;
+  return f;
 }
 
 int run_backbone(nuhtc_engine* e, int B, hipStream_t s) {
@@ -575,9 +591,18 @@ int run_neck_heads(nuhtc_engine* e, int B, hipStream_t s) {
     if (i < 3) { p.up = e->lat[i + 1]; p.upH = g.H; p.upW = g.W; }
     RUN(launch_gemm(p, s));
   }
+  // Pointwise layers that follow a 3x3 convolution are computed in that convolution's epilogue on the split pipe (conv.hip,
+  // Conv3Fuse): the semantic head's lateral 1x1 rides on the FPN output conv of its level, the RPN's cls + reg layer on the RPN
+  // conv (whose output is then never stored), conv_logits + conv_embedding (+ x0 + sem) on the semantic head's last conv.
+  const bool fuse = e->rpn_hf && conv3_fuse_available();
   for (int i = 0; i < 4; ++i) {
     const StageGeom& g = e->st[i];
-    RUN(conv3x3(e, e->lat[i], e->fpn_w[i], e->fpn_b[i], e->x[i], B, g.H, g.W, ACT_NONE, nullptr, 1, s));
+    if (fuse) {
+      const Conv3Fuse f = pointwise(64, e->sem_lf[i], e->sem_lb[i], e->semg[i], ACT_NONE, 1);
+      RUN(conv3x3(e, e->lat[i], e->fpn_w[i], e->fpn_b[i], e->x[i], B, g.H, g.W, ACT_NONE, nullptr, 1, s, &f));
+    } else {
+      RUN(conv3x3(e, e->lat[i], e->fpn_w[i], e->fpn_b[i], e->x[i], B, g.H, g.W, ACT_NONE, nullptr, 1, s));
+    }
   }
   // RPN head (mmdet/models/dense_heads/rpn_head.py:62-68).  The RPN branch (conv + 1x1 heads here, proposal selection and
   // NMS in run_roi_path) and the semantic branch below both depend only on the FPN maps: the RPN branch runs on the side
@@ -587,20 +612,34 @@ int run_neck_heads(nuhtc_engine* e, int B, hipStream_t s) {
     FAIL(e, NUHTC_E_HIP, "side-stream fork failed");
   for (int i = 0; i < 4; ++i) {
     const StageGeom& g = e->st[i];
-    RUN(conv3x3(e, e->x[i], e->rpn_w, e->rpn_b, e->tmpR, B, g.H, g.W, ACT_RELU, nullptr, 1, s2));
-    RUN(launch_gemm(gp(e->tmpR, e->rpn_hw, e->rpn_hb, e->rpn[i], B * g.H * g.W, 32, 64), s2));
+    if (fuse) {
+      const Conv3Fuse f = pointwise(32, e->rpn_hf, e->rpn_hb, e->rpn[i], ACT_NONE, 0);
+      RUN(conv3x3(e, e->x[i], e->rpn_w, e->rpn_b, e->tmpR, B, g.H, g.W, ACT_RELU, nullptr, 1, s2, &f));
+    } else {
+      RUN(conv3x3(e, e->x[i], e->rpn_w, e->rpn_b, e->tmpR, B, g.H, g.W, ACT_RELU, nullptr, 1, s2));
+      RUN(launch_gemm(gp(e->tmpR, e->rpn_hw, e->rpn_hb, e->rpn[i], B * g.H * g.W, 32, 64), s2));
+    }
   }
   if (hipEventRecord(e->ev_rpn, s2) != hipSuccess) FAIL(e, NUHTC_E_HIP, "hipEventRecord failed");   // RPN maps ready (side stream)
   // FusedSemanticHead (fused_semantic_head.py:97-111)
-  for (int i = 0; i < 4; ++i) {
-    const StageGeom& g = e->st[i];
-    RUN(launch_gemm(gp(e->x[i], e->sem_lw[i], e->sem_lb[i], e->semg[i], B * g.H * g.W, 64, 64), s));
-  }
+  if (!fuse)
+    for (int i = 0; i < 4; ++i) {
+      const StageGeom& g = e->st[i];
+      RUN(launch_gemm(gp(e->x[i], e->sem_lw[i], e->sem_lb[i], e->semg[i], B * g.H * g.W, 64, 64), s));
+    }
   const StageGeom& g0 = e->st[0];
   RUN(launch_sem_fuse(e->semg[0], e->semg[1], e->semg[2], e->semg[3], e->tmpA, B, g0.H, g0.W, s));
   float* a = e->tmpA;
   float* b = e->tmpB;
   for (int j = 0; j < 4; ++j) {
+    if (fuse && j == 3) {
+      // conv_logits (64 -> 1), conv_embedding (+ ReLU) and x0 + sem for the 7x7 RoI features, all from the tile in registers
+      Conv3Fuse f = pointwise(64, e->sem_ef, e->sem_eb, e->sem_feat, ACT_RELU, 0);
+      f.res2 = e->x[0]; f.out3 = e->x0sem;
+      f.wn1 = e->sem_gw; f.bn1 = e->sem_gb; f.outn1 = e->sem_pred;
+      RUN(conv3x3(e, a, e->sem_cw[j], e->sem_cb[j], b, B, g0.H, g0.W, ACT_RELU, nullptr, 1, s, &f));
+      return 0;
+    }
     RUN(conv3x3(e, a, e->sem_cw[j], e->sem_cb[j], b, B, g0.H, g0.W, ACT_RELU, nullptr, 1, s));
     std::swap(a, b);
   }

@@ -800,6 +800,12 @@ static void launch_split(const GemmParams& q, hipStream_t s) {
   else hipLaunchKernelGGL((gemm_split_kernel<MT, NT, A_PLAIN>), grid, dim3(256), 0, s, q);
 }
 
+bool conv3_fuse_available() {
+  static const int& conv_halo = dev_knob_ref("CONV_HALO", 1);
+  static const int& conv_fuse = dev_knob_ref("CONV_FUSE", 1);
+  return conv_halo && conv_fuse;
+}
+
 int launch_gemm(const GemmParams& p, hipStream_t s) {
   if (p.M <= 0) return 0;
   if (p.K % 32 != 0 || p.N % 32 != 0) return NUHTC_E_INVALID;
@@ -841,20 +847,24 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
   }
   static const int& conv_halo = dev_knob_ref("CONV_HALO", 1);
   const bool halo = conv_halo && conv3_split_supported(q);      // 3x3 convolutions: halo tile in LDS, split once (conv.hip)
+  if (p.fuse && !halo) return NUHTC_E_INVALID;                  // a fused pointwise layer exists on that path only (the caller checks conv3_fuse_available)
   const double nb = p.batch > 0 ? p.batch : 1;
   const char* tag = "gemm";
   if (prof_enabled()) {   // per-shape tags, e.g. "gemm_kernel<3>|N288|K96" (strings live for the process lifetime)
     static std::map<long long, std::string> names;
-    long long key = ((long long)nt << 40) | ((long long)p.N << 20) | p.K | ((long long)(p.amode == A_CONV3) << 44) | ((long long)halo << 45);
+    long long key = ((long long)nt << 40) | ((long long)p.N << 20) | p.K | ((long long)(p.amode == A_CONV3) << 44) | ((long long)halo << 45) | ((long long)(p.fuse ? p.fuse->N2 / 32 : 0) << 46);
     auto it = names.find(key);
     if (it == names.end())
-      it = names.emplace(key, "gemm_kernel<" + std::to_string(nt) + ">|N" + std::to_string(p.N) + "|K" + std::to_string(p.K) + (p.amode == A_CONV3 ? (halo ? "|conv3halo" : "|conv3") : "")).first;
+      it = names.emplace(key, "gemm_kernel<" + std::to_string(nt) + ">|N" + std::to_string(p.N) + "|K" + std::to_string(p.K) + (p.amode == A_CONV3 ? (halo ? "|conv3halo" : "|conv3") : "") + (p.fuse ? "+pw" + std::to_string(p.fuse->N2) : "")).first;
     tag = it->second.c_str();
   }
   // algorithmic work of the launch (a device-side row count is applied when the records are read)
   // bytes: A, W, C once each, plus the row term the epilogue adds (residual: M x N; FPN parent at half resolution: M x N / 4)
   const double row_term = p.res ? (double)p.M * p.N : p.up ? 0.25 * p.M * p.N : 0.0;
-  ProfScope ps(tag, 2.0 * p.M * p.N * p.K * nb, 4.0 * nb * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N + row_term), s);
+  // a fused pointwise layer adds its own product and outputs, and takes away the convolution's output when that is not stored
+  const double fuse_flop = p.fuse ? 2.0 * p.M * 64 * (p.fuse->N2 + (p.fuse->outn1 ? 1 : 0)) : 0.0;
+  const double fuse_bytes = p.fuse ? 4.0 * p.M * (p.fuse->N2 * (p.fuse->out3 ? 3.0 : 1.0) + (p.fuse->outn1 ? 1 : 0) - (p.fuse->store_out ? 0 : p.N)) : 0.0;
+  ProfScope ps(tag, 2.0 * p.M * p.N * p.K * nb + fuse_flop, 4.0 * nb * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N + row_term) + fuse_bytes, s);
   ps.device_rows(p.m_dev, p.m_mul, p.M);
 #ifdef NUHTC_GEMM_STAMPS
   static unsigned long long* stamp_buf = nullptr;

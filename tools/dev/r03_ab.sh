@@ -2,7 +2,7 @@
 # quick A/B: env settings given as arguments "NAME=VAL,NAME2=VAL2" ... one bench per argument (dev build)
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/ab
-B="python bench.py --no-cpu-baseline --no-fp32-pipe --no-roi-load --steps 40 --gemm-shapes"
+B="python bench.py --no-cpu-baseline --no-fp32-pipe --no-roi-load --steps ${AB_STEPS:-40} --gemm-shapes"
 i=0
 for cfg in "$@"; do
   i=$((i+1))
