@@ -11,10 +11,13 @@ struct RoiFeatParams {
   const float* x0sem;   // x0 + sem (P = 7 LDS path: both are sampled at the same points, so one interpolation serves both)
   int H0, W0, H1, W1, H2, W2, H3, W3;
   float* out;           // [R][P*P][64]
-  int* fb_count;        // P=7: [0] big RoIs (row-streaming workgroup each), [1] mid-size RoIs (stream kernel), [2] giant RoIs; the rest fit the LDS tiles
+  int* fb_count;        // [8] P=7: [0] big RoIs (row-streaming workgroup each), [1] mid-size RoIs (stream kernel), [2] giant RoIs (the rest fit the LDS tiles); [3], [4] job counters of the stream / big-box kernels
   int* fb_list;         // [list_cap] big RoIs from the front, giant RoIs from the back
   int list_cap;
   int* mid_list;        // [R] mid-size RoIs
+  float* big_part;      // optional [big_split_max][3 maps][49][64]: per-map partial features of the big boxes while they are few (one workgroup per map)
+  int big_split_max;
+  int stream_few;       // short mid-size lists go to roi_feat7_stream_few_kernel (several loading waves per RoI, same sums)
   unsigned char* fb_flag; // [R] 0 / 3 = LDS tiles (small / large), 1 = stream kernel, 2 = big-box kernel, 4 = giant (sample loop)
 };
 

@@ -298,6 +298,8 @@ __device__ __forceinline__ v2f bin_lds2(const float* tile, const AxisEnt* tx, co
 #define SM_ROWPX 36         // LDS ring slot: 32 footprint pixels + room for the padded taps of the last bin
 #define SM_J 5              // merged taps per bin and axis: samples of a bin lie within bw * (S-1)/S <= 3 px, so they touch <= 5 pixels
 #define SM_FH 32            // rows of the dense y-weight table
+#define SMF_W 4             // roi_feat7_stream_few_kernel: waves per RoI
+#define SMF_MAX 1024        // mid-size RoIs per launch up to which that form runs instead of roi_feat7_stream_kernel
 
 struct StreamTabs {
   float wx[7][SM_J];        // merged x weights of bin pw, tap j = pixel xlo[pw] + j
@@ -421,13 +423,19 @@ __global__ __launch_bounds__(64) void roi_feat7_stream_kernel(RoiFeatParams p) {
   __shared__ StreamTabs tabs;
   const int lane = threadIdx.x;
   const int nm = p.fb_count[1];
-  if ((int)blockIdx.x >= nm) return;                    // (most launches of the usual small-RoI load have no mid-size RoI at all)
+  if ((int)blockIdx.x >= nm || (p.stream_few && nm <= SMF_MAX)) return;     // (short lists: roi_feat7_stream_few_kernel)
   // ring pixels beyond a footprint's width are read with zero weights: clear the ring once so they never hold NaN bits
   // (afterwards they hold stale map values, which are finite)
   for (int t = lane; t < 2 * SM_ROWPX * 64; t += 64) ring[t] = 0.f;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
-  for (int job = blockIdx.x; job < nm; job += gridDim.x) {
+  // jobs are fetched from a counter (fb_count[3], zeroed with the other counts): the grid is only as large as what is resident at
+  // once, and RoIs differ fourfold in footprint rows
+  for (;;) {
+    int job = 0;
+    if (lane == 0) job = atomicAdd(&p.fb_count[3], 1);
+    job = __shfl(job, 0);
+    if (job >= nm) break;
     const int r = p.mid_list[job];
     const float* roi = p.rois + (long long)r * 5;
     const int b = (int)roi[0];
@@ -466,6 +474,173 @@ __global__ __launch_bounds__(64) void roi_feat7_stream_kernel(RoiFeatParams p) {
   }
 }
 
+// ---- the same kernel for a SHORT list of mid-size RoIs (the usual load has a few dozen of them per batch).  One wave per RoI makes
+// a RoI a chain of one memory latency per footprint row (~0.2 ms for ~100 rows over its maps): while the whole list fits the chip
+// at once, a RoI gets a workgroup of SMF_W waves that all LOAD rows -- SMF_W rows per step into one half of a ring of 2 x SMF_W row
+// slots, one barrier per step -- and wave 0 alone contracts them, in row order with the arithmetic of sm_accumulate: the features
+// are bit-identical to the one-wave kernel's, so a RoI's result does not depend on how many others the batch holds.
+struct StreamFewShared {
+  StreamTabs tabs;
+  int fx0, fy0, fw, fh;
+};
+
+__device__ __forceinline__ void smf_accumulate(const float* __restrict__ map, int H, int W, int b, float x1, float y1, float bw, float bh,
+                                               int Sx, int Sy, StreamFewShared* sh, float* ring, float (&acc)[49], int lane, int wave) {
+  StreamTabs* tb = &sh->tabs;
+  if (wave == 0) {
+    // ---- footprint bounds and merged weights: the statements of sm_accumulate
+    const bool is_y = lane >= 32;
+    const int idx = lane & 31;
+    const int S = is_y ? Sy : Sx;
+    bool valid = false;
+    AxisEnt e{0, 0, 0.f, 0.f};
+    if (idx < 7 * S) e = sm_sample(is_y ? y1 : x1, is_y ? bh : bw, S, idx, is_y ? H : W, valid);
+    const int lo = half_min(valid ? e.lo : (1 << 30)), hi = half_max(valid ? e.hi : -1);
+    const int fx0 = __shfl(lo, 0), fx1 = __shfl(hi, 0), fy0 = __shfl(lo, 32), fy1 = __shfl(hi, 32);
+    const bool none = fx1 < 0 || fy1 < 0;
+    const int fw = none ? 0 : fx1 - fx0 + 1, fh = none ? 0 : min(fy1 - fy0 + 1, SM_FH);
+    if (lane == 0) { sh->fx0 = fx0; sh->fy0 = fy0; sh->fw = fw; sh->fh = fh; }
+    if (!none) {
+      if (lane < 7) {
+        int m = 1 << 30;
+        for (int is = 0; is < Sx; ++is) {
+          bool v;
+          const AxisEnt q = sm_sample(x1, bw, Sx, lane * Sx + is, W, v);
+          if (v) m = min(m, q.lo - fx0);
+        }
+        tb->xlo[lane] = m == (1 << 30) ? 0 : m;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      if (lane < 7 * SM_J) {
+        const int pw = lane / SM_J, j = lane - pw * SM_J;
+        const int px = fx0 + tb->xlo[pw] + j;
+        float wsum = 0.f;
+        for (int is = 0; is < Sx; ++is) {
+          bool v;
+          const AxisEnt q = sm_sample(x1, bw, Sx, pw * Sx + is, W, v);
+          if (v) { if (q.lo == px) wsum += q.h; if (q.hi == px) wsum += q.l; }
+        }
+        tb->wx[pw][j] = wsum / (float)Sx;
+      }
+      for (int t = lane; t < 7 * SM_FH; t += 64) {
+        const int ph = t / SM_FH, yr = t - ph * SM_FH;
+        float wsum = 0.f;
+        for (int is = 0; is < Sy; ++is) {
+          bool v;
+          const AxisEnt q = sm_sample(y1, bh, Sy, ph * Sy + is, H, v);
+          if (v) { if (q.lo == fy0 + yr) wsum += q.h; if (q.hi == fy0 + yr) wsum += q.l; }
+        }
+        tb->wy[ph][yr] = wsum / (float)Sy;
+      }
+    }
+  }
+  __syncthreads();
+  const int fx0 = sh->fx0, fy0 = sh->fy0, fw = sh->fw, fh = sh->fh;
+  if (fh == 0) { __syncthreads(); return; }             // every sample of an axis lies outside the map (workgroup-uniform)
+  float wxr[7][SM_J];
+  int xbase[7];
+  if (wave == 0) {
+#pragma unroll
+    for (int pw = 0; pw < 7; ++pw) {
+      xbase[pw] = tb->xlo[pw] * 64 + lane;
+#pragma unroll
+      for (int j = 0; j < SM_J; ++j) wxr[pw][j] = tb->wx[pw][j];
+    }
+  }
+  const float* base = map + (((long long)b * H + fy0) * W + fx0) * 64;
+  const int sub = lane >> 4, c4 = (lane & 15) * 4;
+  const int n4 = (fw + 3) >> 2;
+  v4f stg[8];
+  auto load_row = [&](int yr) {
+    const float* src = base + (long long)yr * W * 64;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      int px = 4 * q + sub;
+      px = px < fw ? px : fw - 1;
+      if (q < n4) stg[q] = *reinterpret_cast<const v4f*>(src + px * 64 + c4);
+    }
+  };
+  auto store_row = [&](int yr) {                        // ring slot of row yr: half (yr / SMF_W) & 1, slot yr % SMF_W
+    float* dst = ring + (((yr / SMF_W) & 1) * SMF_W + (yr % SMF_W)) * (SM_ROWPX * 64);
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (q < n4) *reinterpret_cast<v4f*>(dst + (4 * q + sub) * 64 + c4) = stg[q];
+  };
+  if (wave < fh) { load_row(wave); store_row(wave); }
+  __syncthreads();
+  for (int y0 = 0; y0 < fh; y0 += SMF_W) {
+    const int ynext = y0 + SMF_W + wave;
+    if (ynext < fh) load_row(ynext);                    // stays in flight while this step's rows are contracted
+    if (wave == 0) {
+      for (int yr = y0; yr < min(y0 + SMF_W, fh); ++yr) {
+        const float* row = ring + (((yr / SMF_W) & 1) * SMF_W + (yr % SMF_W)) * (SM_ROWPX * 64);
+        float T[7];
+#pragma unroll
+        for (int pw = 0; pw < 7; ++pw) {
+          float t = 0.f;
+#pragma unroll
+          for (int j = 0; j < SM_J; ++j) t = fmaf(wxr[pw][j], row[xbase[pw] + j * 64], t);
+          T[pw] = t;
+        }
+#pragma unroll
+        for (int ph = 0; ph < 7; ++ph) {
+          const float wyv = tb->wy[ph][yr];
+#pragma unroll
+          for (int pw = 0; pw < 7; ++pw) acc[ph * 7 + pw] = fmaf(wyv, T[pw], acc[ph * 7 + pw]);
+        }
+      }
+    }
+    if (ynext < fh) store_row(ynext);                   // the other half: its readers finished before the previous barrier
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(64 * SMF_W) void roi_feat7_stream_few_kernel(RoiFeatParams p) {
+  __shared__ __attribute__((aligned(16))) float ring[2 * SMF_W * SM_ROWPX * 64];
+  __shared__ StreamFewShared sh;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nm = p.fb_count[1];
+  if (nm > SMF_MAX || (int)blockIdx.x >= nm) return;
+  for (int t = threadIdx.x; t < 2 * SMF_W * SM_ROWPX * 64; t += 64 * SMF_W) ring[t] = 0.f;     // (see roi_feat7_stream_kernel)
+  __syncthreads();
+  for (int job = blockIdx.x; job < nm; job += gridDim.x) {
+    const int r = p.mid_list[job];
+    const float* roi = p.rois + (long long)r * 5;
+    const int b = (int)roi[0];
+    float acc[49];
+#pragma unroll
+    for (int k = 0; k < 49; ++k) acc[k] = 0.f;
+    const RoiGeom g0 = roi_geom(roi, 0.25f, 7, 2), g1 = roi_geom(roi, 0.125f, 7, 2), gs = roi_geom(roi, 0.25f, 14, 0);
+    const bool sem2 = gs.gw == 2 || gs.gh == 2;
+    for (int m = 0; m < (sem2 ? 3 : 2); ++m) {
+      const float* map = m == 0 ? (sem2 ? p.x0 : p.x0sem) : m == 1 ? p.x1 : p.sem;
+      const RoiGeom& g = m == 0 ? g0 : m == 1 ? g1 : gs;
+      const float bmul = m == 2 ? 2.f : 1.f;
+      smf_accumulate(map, m == 1 ? p.H1 : p.H0, m == 1 ? p.W1 : p.W0, b, g.x1, g.y1, bmul * g.bw, bmul * g.bh, m == 2 ? 2 * gs.gw : 2,
+                     m == 2 ? 2 * gs.gh : 2, &sh, ring, acc, lane, wave);
+    }
+    if (wave == 0) {
+      float gsum = 0.f;
+#pragma unroll
+      for (int l = 0; l < 2; ++l) {
+        const int Hl = l ? p.H3 : p.H2, Wl = l ? p.W3 : p.W2;
+        const float st = l ? 32.f : 16.f;
+        float cx = floorf((roi[1] + roi[3]) / (2.0f * st)), cy = floorf((roi[2] + roi[4]) / (2.0f * st));
+        cx = fminf(fmaxf(cx, 0.f), (float)(Wl - 1));
+        cy = fminf(fmaxf(cy, 0.f), (float)(Hl - 1));
+        const float* G = l ? p.G3 : p.G2;
+        gsum += G[(((long long)b * Hl + (int)cy) * Wl + (int)cx) * 64 + lane];
+      }
+#pragma unroll
+      for (int k = 0; k < 49; ++k) acc[k] += gsum;
+      float* out = p.out + (long long)r * 49 * 64;
+#pragma unroll
+      for (int k = 0; k < 49; ++k) out[k * 64 + lane] = acc[k];
+    }
+  }
+}
+
 // RoIs beyond the stream kernel's limits (sides over SM_MAXSIDE px, or more than 2 x 2 semantic samples per 14 x 14 bin: merged
 // clumps, component proposals up to the whole tile).  Same separable form -- a bin is sum_y sum_x wy[y] wx[x] F[y][x] with merged
 // per-axis weights -- for footprints of any size.  One workgroup of 7 x BG_RS waves per RoI: wave (pw, rs) owns bin COLUMN pw and
@@ -478,6 +653,7 @@ __global__ __launch_bounds__(64) void roi_feat7_stream_kernel(RoiFeatParams p) {
 #define BG_FH 264           // footprint rows
 #define BG_S 24             // samples per 7-grid bin and axis (2 x the adaptive 14-grid count: boxes up to 12 x 14 x 4 = 672 px); beyond: roi_feat7_giant_kernel
 #define BG_RS 2             // row splits
+#define BG_RPS 2            // rows per step and wave
 #define BG_NT (7 * BG_RS * 64)
 struct BigTabs {
   __attribute__((aligned(16))) float wx[7][BG_J];   // rows 16-byte aligned; entries from the padded tap count on are zero
@@ -568,42 +744,57 @@ __device__ __forceinline__ void bg_accumulate(const float* __restrict__ map, int
   const float* base = map + (((long long)b * H + fy0) * W + fx0 + (padded_ok ? x0 : 0)) * 64 + lane;
   const v4f* w4 = reinterpret_cast<const v4f*>(tb->wx[pw]);
   if (padded_ok) {
-    // two rows per step: their taps (up to 2 x 16 per chunk) are all requested before the first multiply, so a step exposes one
-    // memory latency for two rows
-    for (int yr = rs; yr < fh; yr += 2 * BG_RS) {
-      const int yb = yr + BG_RS;
-      const bool hb = yb < fh;                          // wave-uniform
-      const float* rowa = base + (long long)yr * W * 64;
-      const float* rowb = base + (long long)(hb ? yb : yr) * W * 64;
-      float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+    // BG_RPS rows per step: their taps (BG_RPS x 16 per chunk) are all requested before the first multiply, so a step exposes one
+    // memory latency for BG_RPS rows (a box is a latency chain: with two rows per step a whole-tile box took 0.2 ms)
+    for (int yr = rs; yr < fh; yr += BG_RPS * BG_RS) {
+      const float* rowp[BG_RPS];
+      bool have[BG_RPS];                                  // wave-uniform
+#pragma unroll
+      for (int k = 0; k < BG_RPS; ++k) {
+        const int y = yr + k * BG_RS;
+        have[k] = y < fh;
+        rowp[k] = base + (long long)(have[k] ? y : yr) * W * 64;
+      }
+      float t0[BG_RPS], t1[BG_RPS];
+#pragma unroll
+      for (int k = 0; k < BG_RPS; ++k) { t0[k] = 0.f; t1[k] = 0.f; }
       for (int j = 0; j < Jr; j += 16) {
-        float va[16], vb[16];
+        float v[BG_RPS][16];
         const bool two = j + 8 < Jr;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { va[u] = rowa[(j + u) * 64]; vb[u] = rowb[(j + u) * 64]; }
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int k = 0; k < BG_RPS; ++k) v[k][u] = rowp[k][(j + u) * 64];
         if (two) {
 #pragma unroll
-          for (int u = 8; u < 16; ++u) { va[u] = rowa[(j + u) * 64]; vb[u] = rowb[(j + u) * 64]; }
+          for (int u = 8; u < 16; ++u)
+#pragma unroll
+            for (int k = 0; k < BG_RPS; ++k) v[k][u] = rowp[k][(j + u) * 64];
         }
         const v4f wa = w4[j >> 2], wb = w4[(j >> 2) + 1];
-        a0 = fmaf(wa.x, va[0], a0); a1 = fmaf(wa.y, va[1], a1); a0 = fmaf(wa.z, va[2], a0); a1 = fmaf(wa.w, va[3], a1);
-        a0 = fmaf(wb.x, va[4], a0); a1 = fmaf(wb.y, va[5], a1); a0 = fmaf(wb.z, va[6], a0); a1 = fmaf(wb.w, va[7], a1);
-        b0 = fmaf(wa.x, vb[0], b0); b1 = fmaf(wa.y, vb[1], b1); b0 = fmaf(wa.z, vb[2], b0); b1 = fmaf(wa.w, vb[3], b1);
-        b0 = fmaf(wb.x, vb[4], b0); b1 = fmaf(wb.y, vb[5], b1); b0 = fmaf(wb.z, vb[6], b0); b1 = fmaf(wb.w, vb[7], b1);
+#pragma unroll
+        for (int k = 0; k < BG_RPS; ++k) {
+          t0[k] = fmaf(wa.x, v[k][0], t0[k]); t1[k] = fmaf(wa.y, v[k][1], t1[k]); t0[k] = fmaf(wa.z, v[k][2], t0[k]); t1[k] = fmaf(wa.w, v[k][3], t1[k]);
+          t0[k] = fmaf(wb.x, v[k][4], t0[k]); t1[k] = fmaf(wb.y, v[k][5], t1[k]); t0[k] = fmaf(wb.z, v[k][6], t0[k]); t1[k] = fmaf(wb.w, v[k][7], t1[k]);
+        }
         if (two) {
           const v4f wc = w4[(j >> 2) + 2], wd = w4[(j >> 2) + 3];
-          a0 = fmaf(wc.x, va[8], a0); a1 = fmaf(wc.y, va[9], a1); a0 = fmaf(wc.z, va[10], a0); a1 = fmaf(wc.w, va[11], a1);
-          a0 = fmaf(wd.x, va[12], a0); a1 = fmaf(wd.y, va[13], a1); a0 = fmaf(wd.z, va[14], a0); a1 = fmaf(wd.w, va[15], a1);
-          b0 = fmaf(wc.x, vb[8], b0); b1 = fmaf(wc.y, vb[9], b1); b0 = fmaf(wc.z, vb[10], b0); b1 = fmaf(wc.w, vb[11], b1);
-          b0 = fmaf(wd.x, vb[12], b0); b1 = fmaf(wd.y, vb[13], b1); b0 = fmaf(wd.z, vb[14], b0); b1 = fmaf(wd.w, vb[15], b1);
+#pragma unroll
+          for (int k = 0; k < BG_RPS; ++k) {
+            t0[k] = fmaf(wc.x, v[k][8], t0[k]); t1[k] = fmaf(wc.y, v[k][9], t1[k]); t0[k] = fmaf(wc.z, v[k][10], t0[k]); t1[k] = fmaf(wc.w, v[k][11], t1[k]);
+            t0[k] = fmaf(wd.x, v[k][12], t0[k]); t1[k] = fmaf(wd.y, v[k][13], t1[k]); t0[k] = fmaf(wd.z, v[k][14], t0[k]); t1[k] = fmaf(wd.w, v[k][15], t1[k]);
+          }
         }
       }
-      const float ta = a0 + a1, tbv = b0 + b1;
+      // rows enter the bin sums in ascending order (the order of the two-rows-per-step form: results are unchanged)
 #pragma unroll
-      for (int ph = 0; ph < 7; ++ph) acc[ph] = fmaf(tb->wy[ph][yr], ta, acc[ph]);
-      if (hb) {
+      for (int k = 0; k < BG_RPS; ++k) {
+        if (have[k]) {
+          const float t = t0[k] + t1[k];
+          const int y = yr + k * BG_RS;
 #pragma unroll
-        for (int ph = 0; ph < 7; ++ph) acc[ph] = fmaf(tb->wy[ph][yb], tbv, acc[ph]);
+          for (int ph = 0; ph < 7; ++ph) acc[ph] = fmaf(tb->wy[ph][y], t, acc[ph]);
+        }
       }
     }
   } else {
@@ -621,30 +812,65 @@ __device__ __forceinline__ void bg_accumulate(const float* __restrict__ map, int
 __global__ __launch_bounds__(BG_NT) void roi_feat7_big_kernel(RoiFeatParams p) {
   __shared__ BigTabs tabs;
   __shared__ float part[BG_RS - 1][7][7][64];             // [row split - 1][pw][ph][channel]
+  __shared__ float totl[7][7][64];                        // [pw][ph][channel]: sum over the maps (row split 0's waves, one slot per thread)
+  __shared__ int s_job;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int pw = wave % 7, rs = wave / 7;
   const int nb = p.fb_count[0];
-  for (int job = blockIdx.x; job < nb; job += gridDim.x) {
-    const int r = p.fb_list[job];
+  // A box is a latency chain (tables, then footprint rows in steps of one memory latency).  While the big boxes are few -- the usual
+  // load: a few dozen component proposals per batch -- each of a box's maps goes to a workgroup of its own and
+  // roi_feat7_big_combine_kernel adds the maps' partial results in map order (a kernel boundary: an in-kernel hand-over needs an
+  // agent-scope release per workgroup, which writes back the whole L2 under the LDS-tile kernel's output stream -- measured slower
+  // than no split).  The sums are formed in the same order in both modes (rows of a map, row splits, maps, attention term), so a
+  // box's features do not depend on how many other big boxes the batch holds.
+  const bool split = p.big_part && nb <= p.big_split_max;
+  const int njobs = split ? 3 * nb : nb;
+  for (;;) {                                              // jobs from a counter (fb_count[4]): boxes differ widely in rows
+    if (threadIdx.x == 0) s_job = atomicAdd(&p.fb_count[4], 1);
+    __syncthreads();
+    const int job = s_job;
+    __syncthreads();
+    if (job >= njobs) break;
+    const int bi = split ? job / 3 : job, only = split ? job - 3 * bi : -1;
+    const int r = p.fb_list[bi];
     const float* roi = p.rois + (long long)r * 5;
     const int b = (int)roi[0];
-    float acc[7];
+    bool sem_sep;                                         // the semantic 14 x 14 grid takes its own samples
+    { const RoiGeom gs = roi_geom(roi, 0.25f, 14, 0); sem_sep = gs.gw != 1 || gs.gh != 1; }
+    const int nmaps = sem_sep ? 3 : 2;
+    if (only >= nmaps) continue;                          // (workgroup-uniform)
+    if (rs == 0) {
 #pragma unroll
-    for (int k = 0; k < 7; ++k) acc[k] = 0.f;
-    const RoiGeom g0 = roi_geom(roi, 0.25f, 7, 2), g1 = roi_geom(roi, 0.125f, 7, 2), gs = roi_geom(roi, 0.25f, 14, 0);
-    const bool sem_sep = gs.gw != 1 || gs.gh != 1;       // the semantic 14 x 14 grid takes its own samples
-    for (int m = 0; m < (sem_sep ? 3 : 2); ++m) {
+      for (int ph = 0; ph < 7; ++ph) totl[pw][ph][lane] = 0.f;
+    }
+    for (int m = 0; m < nmaps; ++m) {
+      if (only >= 0 && m != only) continue;
+      float acc[7];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) acc[k] = 0.f;
       const float* map = m == 0 ? (sem_sep ? p.x0 : p.x0sem) : m == 1 ? p.x1 : p.sem;
-      const RoiGeom& g = m == 0 ? g0 : m == 1 ? g1 : gs;
+      const RoiGeom g = m == 0 ? roi_geom(roi, 0.25f, 7, 2) : m == 1 ? roi_geom(roi, 0.125f, 7, 2) : roi_geom(roi, 0.25f, 14, 0);
       const float bmul = m == 2 ? 2.f : 1.f;             // a 7-grid bin is two 14-grid bins: 2 g samples per bin and axis
-      bg_accumulate(map, m == 1 ? p.H1 : p.H0, m == 1 ? p.W1 : p.W0, b, g.x1, g.y1, bmul * g.bw, bmul * g.bh, m == 2 ? 2 * gs.gw : 2,
-                    m == 2 ? 2 * gs.gh : 2, &tabs, acc);
-    }
-    if (rs > 0) {
+      bg_accumulate(map, m == 1 ? p.H1 : p.H0, m == 1 ? p.W1 : p.W0, b, g.x1, g.y1, bmul * g.bw, bmul * g.bh, m == 2 ? 2 * g.gw : 2,
+                    m == 2 ? 2 * g.gh : 2, &tabs, acc);
+      if (rs > 0) {
 #pragma unroll
-      for (int ph = 0; ph < 7; ++ph) part[rs - 1][pw][ph][lane] = acc[ph];
+        for (int ph = 0; ph < 7; ++ph) part[rs - 1][pw][ph][lane] = acc[ph];
+      }
+      __syncthreads();
+      if (rs == 0) {
+#pragma unroll
+        for (int ph = 0; ph < 7; ++ph) {
+          float v = acc[ph];
+#pragma unroll
+          for (int q = 0; q < BG_RS - 1; ++q) v += part[q][pw][ph][lane];
+          if (split) p.big_part[(((long long)bi * 3 + m) * 49 + ph * 7 + pw) * 64 + lane] = v;
+          else totl[pw][ph][lane] += v;
+        }
+      }
+      // (the next map's bg_accumulate passes several barriers before a wave writes `part` again)
     }
-    __syncthreads();
+    if (split) continue;                                  // roi_feat7_big_combine_kernel adds the maps (workgroup-uniform)
     if (rs == 0) {
       float gsum = 0.f;
 #pragma unroll
@@ -659,14 +885,41 @@ __global__ __launch_bounds__(BG_NT) void roi_feat7_big_kernel(RoiFeatParams p) {
       }
       float* out = p.out + (long long)r * 49 * 64;
 #pragma unroll
-      for (int ph = 0; ph < 7; ++ph) {
-        float v = acc[ph];
-#pragma unroll
-        for (int q = 0; q < BG_RS - 1; ++q) v += part[q][pw][ph][lane];
-        out[(ph * 7 + pw) * 64 + lane] = v + gsum;
-      }
+      for (int ph = 0; ph < 7; ++ph) out[(ph * 7 + pw) * 64 + lane] = totl[pw][ph][lane] + gsum;
     }
     __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(448) void roi_feat7_big_combine_kernel(RoiFeatParams p) {
+  const int nb = p.fb_count[0];
+  if (!(p.big_part && nb <= p.big_split_max)) return;
+  const int lane = threadIdx.x & 63, pw = threadIdx.x >> 6;
+  for (int bi = blockIdx.x; bi < nb; bi += gridDim.x) {
+    const int r = p.fb_list[bi];
+    const float* roi = p.rois + (long long)r * 5;
+    const int b = (int)roi[0];
+    bool sem_sep;
+    { const RoiGeom gs = roi_geom(roi, 0.25f, 14, 0); sem_sep = gs.gw != 1 || gs.gh != 1; }
+    const int nmaps = sem_sep ? 3 : 2;
+    float gsum = 0.f;
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      const int Hl = l ? p.H3 : p.H2, Wl = l ? p.W3 : p.W2;
+      const float st = l ? 32.f : 16.f;
+      float cx = floorf((roi[1] + roi[3]) / (2.0f * st)), cy = floorf((roi[2] + roi[4]) / (2.0f * st));
+      cx = fminf(fmaxf(cx, 0.f), (float)(Wl - 1));
+      cy = fminf(fmaxf(cy, 0.f), (float)(Hl - 1));
+      const float* G = l ? p.G3 : p.G2;
+      gsum += G[(((long long)b * Hl + (int)cy) * Wl + (int)cx) * 64 + lane];
+    }
+    float* out = p.out + (long long)r * 49 * 64;
+#pragma unroll
+    for (int ph = 0; ph < 7; ++ph) {
+      float t = 0.f;
+      for (int m = 0; m < nmaps; ++m) t += p.big_part[(((long long)bi * 3 + m) * 49 + ph * 7 + pw) * 64 + lane];
+      out[(ph * 7 + pw) * 64 + lane] = t + gsum;
+    }
   }
 }
 
@@ -883,7 +1136,7 @@ int launch_roi_feat(const RoiFeatParams& p, int P, int r_cap, hipStream_t s, hip
   ProfScope ps(P == 7 ? "roi_feat7" : "roi_feat14", 0, 0, s);
   if (r_cap <= 0) return 0;
   if (P == 7) {
-    if (hipMemsetAsync(p.fb_count, 0, 4 * sizeof(int), s) != hipSuccess) return NUHTC_E_HIP;
+    if (hipMemsetAsync(p.fb_count, 0, 8 * sizeof(int), s) != hipSuccess) return NUHTC_E_HIP;      // three list lengths, two job counters
     hipLaunchKernelGGL(roi_classify_kernel, dim3(cdiv(r_cap, 4)), dim3(256), 0, s, p);
     // three size classes side by side: the LDS-tile kernels on the caller's stream, the mid-size stream kernel on `side`, the
     // big-box kernels on `side2` (at the usual load the latter two hold a few dozen boxes each and are latency chains of ~0.2 ms:
@@ -892,11 +1145,17 @@ int launch_roi_feat(const RoiFeatParams& p, int P, int r_cap, hipStream_t s, hip
     const bool fork2 = fork && side2 && ev_join2;
     if (fork && (hipEventRecord(ev_fork, s) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess)) return NUHTC_E_HIP;
     if (fork2 && hipStreamWaitEvent(side2, ev_fork, 0) != hipSuccess) return NUHTC_E_HIP;
-    hipLaunchKernelGGL(roi_feat7_stream_kernel, dim3(r_cap < 8192 ? r_cap : 8192), dim3(64), 0, fork ? side : s, p);
+    // Grids are sized to what is resident at once (the kernels walk their lists with a grid stride): the lists are short at the
+    // usual load, and every workgroup of a larger grid still has to be placed on a chip the LDS-tile kernel keeps full before it can
+    // find its list empty and leave.  (Even so the side kernels' workgroups are placed mostly as the LDS-tile kernel drains: a
+    // higher stream priority for them costs the batches in flight 12 %, launching the short LDS-tile variant first changes nothing.)
+    if (p.stream_few) hipLaunchKernelGGL(roi_feat7_stream_few_kernel, dim3(r_cap < 512 ? r_cap : 512), dim3(64 * SMF_W), 0, fork ? side : s, p);
+    hipLaunchKernelGGL(roi_feat7_stream_kernel, dim3(r_cap < 2048 ? r_cap : 2048), dim3(64), 0, fork ? side : s, p);
     if (fork && hipEventRecord(ev_join, side) != hipSuccess) return NUHTC_E_HIP;
     hipStream_t sb = fork2 ? side2 : fork ? side : s;
-    hipLaunchKernelGGL(roi_feat7_big_kernel, dim3(r_cap < 2048 ? r_cap : 2048), dim3(BG_NT), 0, sb, p);
-    hipLaunchKernelGGL(roi_feat7_giant_kernel, dim3(r_cap < 1024 ? r_cap : 1024), dim3(256), 0, sb, p);
+    hipLaunchKernelGGL(roi_feat7_big_kernel, dim3(std::min(512, 3 * r_cap)), dim3(BG_NT), 0, sb, p);
+    if (p.big_part) hipLaunchKernelGGL(roi_feat7_big_combine_kernel, dim3(std::min(128, r_cap)), dim3(448), 0, sb, p);
+    hipLaunchKernelGGL(roi_feat7_giant_kernel, dim3(r_cap < 256 ? r_cap : 256), dim3(256), 0, sb, p);
     if (fork2 && hipEventRecord(ev_join2, side2) != hipSuccess) return NUHTC_E_HIP;
     if (fork && !fork2 && hipEventRecord(ev_join, side) != hipSuccess) return NUHTC_E_HIP;
     hipLaunchKernelGGL((roi_feat7_lds_kernel<TS0, TS1, 0>), dim3(r_cap), dim3(256), 0, s, p);

@@ -8,6 +8,7 @@
 #include "proposals.h"
 #include "roi.h"
 
+#define BIG_SPLIT_MAX 512      // big boxes per batch up to which each of a box's maps gets a workgroup of its own (roi_feat7_big_kernel)
 struct RoiWs {
   // RPN proposals
   float *cand_boxes, *cand_scores;
@@ -31,6 +32,7 @@ struct RoiWs {
   float *G2, *G3, *ap_inv, *ap_S, *ap_Ft;
   float *feats, *h1, *h2;
   int *fb_count, *fb_list, *mid_list;
+  float* big_part;      // per-map partial features of the big boxes while they are few (roi_feat7_big_kernel)
   unsigned char* fb_flag;
   float *cls[3], *reg[3];
   int total_cap;
@@ -194,8 +196,9 @@ int alloc_roi_workspace(nuhtc_engine* e) {
       (rc = wsa(e, &w->ap_inv, nullptr, {B, e->st[2].H * e->st[2].W}, 0)) ||
       (rc = wsa(e, &w->ap_S, nullptr, {B, (int64_t)e->st[2].H * e->st[2].W, (int64_t)e->st[2].H * e->st[2].W}, 0)) ||
       (rc = wsa(e, &w->ap_Ft, nullptr, {B, 64, e->st[2].H * e->st[2].W}, 0)) ||
-      (rc = wsa(e, &w->fb_count, "roi_fallback_count", {4}, 1)) || (rc = wsa(e, &w->mid_list, nullptr, {T}, 1)) || (rc = wsa(e, &w->fb_list, nullptr, {T}, 1)) || (rc = wsa(e, &w->fb_flag, nullptr, {T}, 2)))
+      (rc = wsa(e, &w->fb_count, "roi_fallback_count", {8}, 1)) || (rc = wsa(e, &w->mid_list, nullptr, {T}, 1)) || (rc = wsa(e, &w->fb_list, nullptr, {T}, 1)) || (rc = wsa(e, &w->fb_flag, nullptr, {T}, 2)))
     return rc;
+  if ((rc = wsa(e, &w->big_part, nullptr, {BIG_SPLIT_MAX, 3, 49, 64}, 0))) return rc;
   for (int k = 0; k < 3; ++k) {
     std::string n = std::to_string(k);
     if ((rc = wsa(e, &w->cls[k], ("cls" + n).c_str(), {T, 16}, 0)) || (rc = wsa(e, &w->reg[k], ("reg" + n).c_str(), {T, 4}, 0))) return rc;
@@ -299,6 +302,10 @@ int run_roi_path(nuhtc_engine* e, int B, const float* rois_fixed, int n_rois, in
   fp.rois = w->rois; fp.r_dev = w->roi_total; fp.x0 = e->x[0]; fp.x1 = e->x[1]; fp.G2 = w->G2; fp.G3 = w->G3; fp.sem = e->sem_feat; fp.x0sem = e->x0sem;
   fp.H0 = e->st[0].H; fp.W0 = e->st[0].W; fp.H1 = e->st[1].H; fp.W1 = e->st[1].W; fp.H2 = e->st[2].H; fp.W2 = e->st[2].W; fp.H3 = e->st[3].H; fp.W3 = e->st[3].W;
   fp.out = w->feats; fp.fb_count = w->fb_count; fp.fb_list = w->fb_list; fp.list_cap = w->total_cap; fp.mid_list = w->mid_list; fp.fb_flag = w->fb_flag;
+  static const int& stream_few = dev_knob_ref("STREAM_FEW", 1);
+  fp.stream_few = stream_few;
+  static const int& big_split = dev_knob_ref("BIG_SPLIT", 1);
+  fp.big_part = big_split ? w->big_part : nullptr; fp.big_split_max = BIG_SPLIT_MAX;
   // ---- 3-stage cascade (htc_roi_head_cus.py:2255-2280)
   for (int k = 0; k < 3; ++k) {
     auto it = e->bufs.find("rois_stage" + std::to_string(k));

@@ -15,7 +15,7 @@ try:
     k = d['kernel_ms_per_step']
     print(sys.argv[1], '| value %.0f seq %.0f (%.2f ms) clock %.2f' % (d['value'], d['sequential']['value'], d['sequential']['ms_per_step'], d['roofline']['shader_clock_ghz_under_step']),
           {a: k.get(a) for a in ('gemm_kernel<3>', 'gemm_kernel<2>', 'gemm_kernel<1>', 'swin_mlp', 'window_attn', 'layernorm')})
-    print('   ', {a: b['ms_per_step'] for a, b in d['gemm_shapes'].items() if 'conv3' in a or 'K96' in a})
+    print('   ', {a: b['ms_per_step'] for a, b in d['gemm_shapes'].items() if 'conv3' in a or 'K96' in a or 'N256' in a or 'N1024' in a})
 except Exception as e:
     print(sys.argv[1], 'failed', e)
 P
