@@ -63,6 +63,7 @@ struct nuhtc_engine {
   int* overflow = nullptr;  // dev int[4]
   int32_t* export_pos = nullptr;   // nuhtc_export_kept scratch [max_batch * max_per_img]
   int32_t* crop_size = nullptr;    // nuhtc_export_crops scratch [max_batch * max_per_img]
+  hipStream_t own = nullptr;        // a stream for the caller to run this engine on (nuhtc_stream): created right before the two side streams
   hipStream_t side = nullptr;       // proposal selection / NMS run here, concurrently with the semantic head on the caller's stream
   hipEvent_t ev_rpn = nullptr, ev_side = nullptr, ev_fpn = nullptr;
   hipStream_t side2 = nullptr;      // the big-box RoI kernel runs here, beside the stream kernel (side) and the LDS-tile kernels (caller's stream)

@@ -3,6 +3,7 @@
 // nuhtc/models/htc_roi_head_cus.py:2184-2372).  Host code only enqueues kernels; there is no CPU fallback.
 #include <cmath>
 #include <cstring>
+#include <mutex>
 
 #include "common.h"
 #include "engine.h"
@@ -70,12 +71,26 @@ int nuhtc_create(const nuhtc_config* cfg, int device, nuhtc_engine** out) {
   return 0;
 }
 
+// The three streams of an engine (the one handed out by nuhtc_stream + two side streams) live for the whole process: a closed
+// engine returns them to a per-device pool and the next engine takes them over.  The stream handed out may be in use by the
+// caller's allocator after the engine is gone (PyTorch's caching allocator records events on the stream a block was allocated
+// on when the block is freed: a destroyed stream there is a segmentation fault), and a pooled triple keeps the placement it was
+// created with (see nuhtc_finalize).
+struct StreamTriple { hipStream_t own, side, side2; };
+static std::mutex g_stream_mu;
+static std::map<int, std::vector<StreamTriple>> g_stream_pool;
+
 void nuhtc_destroy(nuhtc_engine* e) {
   if (!e) return;
   hipSetDevice(e->device);
   hipDeviceSynchronize();
-  if (e->side) hipStreamDestroy(e->side);
-  if (e->side2) hipStreamDestroy(e->side2);
+  if (e->own && e->side && e->side2) {
+    std::lock_guard<std::mutex> lock(g_stream_mu);
+    g_stream_pool[e->device].push_back(StreamTriple{e->own, e->side, e->side2});
+  } else {
+    if (e->side) hipStreamDestroy(e->side);
+    if (e->side2) hipStreamDestroy(e->side2);
+  }
   if (e->ev_side2) hipEventDestroy(e->ev_side2);
   if (e->ev_rpn) hipEventDestroy(e->ev_rpn);
   if (e->ev_side) hipEventDestroy(e->ev_side);
@@ -84,6 +99,8 @@ void nuhtc_destroy(nuhtc_engine* e) {
   for (void* p : e->allocs) hipFree(p);
   delete e;
 }
+
+void* nuhtc_stream(nuhtc_engine* e) { return e ? (void*)e->own : nullptr; }
 
 // Names and shapes of the state_dict entries the path reads (the same table as nuhtc_amd/weights.py:schema).
 static std::map<std::string, std::vector<int64_t>> weight_schema(int nc) {
@@ -476,14 +493,27 @@ int nuhtc_finalize(nuhtc_engine* e) {
     // kernel of the component-proposal chain takes 200 us beside nms_mask_levels_kernel).  Running the branch at the lowest
     // stream priority (NUHTC_SIDE_PRIO=1, dev) frees the main stream but stretches the RPN chain by the same amount, and the
     // join then waits for it: measured 11.48-11.52 against 11.41-11.46 ms per step, so the default stays equal priority.
-    int least = 0, greatest = 0;
-    HIP_CHECK(e, hipDeviceGetStreamPriorityRange(&least, &greatest));
-    HIP_CHECK(e, hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, dev_knob("SIDE_PRIO", 0) ? least : 0));
+    // The stream handed out by nuhtc_stream() and the two side streams are created back to back: the runtime deals its hardware
+    // queues to streams in creation order and the queues go round the command processor's four pipes, so the three end up on
+    // three different pipes whatever GPU_MAX_HW_QUEUES is.  (Two queues of one pipe that wait on each other's events stall each
+    // other: with 8-24 queues an engine whose side stream shared the pipe of the caller's stream ran 30 % slower.)
+    bool pooled = false;
+    {
+      std::lock_guard<std::mutex> lock(g_stream_mu);
+      auto& pool = g_stream_pool[e->device];
+      if (!pool.empty()) { e->own = pool.back().own; e->side = pool.back().side; e->side2 = pool.back().side2; pool.pop_back(); pooled = true; }
+    }
+    if (!pooled) {
+      HIP_CHECK(e, hipStreamCreateWithFlags(&e->own, hipStreamNonBlocking));
+      int least = 0, greatest = 0;
+      HIP_CHECK(e, hipDeviceGetStreamPriorityRange(&least, &greatest));
+      HIP_CHECK(e, hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, dev_knob("SIDE_PRIO", 0) ? least : 0));
+      HIP_CHECK(e, hipStreamCreateWithFlags(&e->side2, hipStreamNonBlocking));
+    }
   }
   HIP_CHECK(e, hipEventCreateWithFlags(&e->ev_rpn, hipEventDisableTiming));
   HIP_CHECK(e, hipEventCreateWithFlags(&e->ev_side, hipEventDisableTiming));
   HIP_CHECK(e, hipEventCreateWithFlags(&e->ev_fpn, hipEventDisableTiming));
-  HIP_CHECK(e, hipStreamCreateWithFlags(&e->side2, hipStreamNonBlocking));
   HIP_CHECK(e, hipEventCreateWithFlags(&e->ev_side2, hipEventDisableTiming));
   HIP_CHECK(e, hipDeviceSynchronize());
   e->raw.clear();

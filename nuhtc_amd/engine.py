@@ -72,6 +72,8 @@ class Engine:
             shape = (ctypes.c_int64 * a.ndim)(*a.shape)
             self._check(self.lib.nuhtc_load_weight(self.h, name.encode(), a.ctypes.data_as(ctypes.c_void_p), shape, a.ndim))
         self._check(self.lib.nuhtc_finalize(self.h))
+        # a stream of the engine's own (nuhtc_stream): EnginePipeline runs the engine on it; any other stream works as well
+        self.stream = torch.cuda.ExternalStream(self.lib.nuhtc_stream(self.h), device=self.device)
         B, K = cfg.max_batch, cfg.max_per_img
         with torch.cuda.device(self.device):
             self.boxes = torch.zeros(B, K, 5, dtype=torch.float32, device=self.device)

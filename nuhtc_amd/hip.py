@@ -39,7 +39,7 @@ class Dets(ctypes.Structure):
 EXPORTS = ['nuhtc_default_config', 'nuhtc_create', 'nuhtc_destroy', 'nuhtc_last_error', 'nuhtc_load_weight',
            'nuhtc_finalize', 'nuhtc_infer', 'nuhtc_infer_fixed_load', 'nuhtc_check', 'nuhtc_get_buffer',
            'nuhtc_op_gemm', 'nuhtc_op_gemm_split', 'nuhtc_op_roi_align', 'nuhtc_op_nms', 'nuhtc_profile_enable', 'nuhtc_profile_read', 'nuhtc_dev_knob', 'nuhtc_export_crops',
-           'nuhtc_mask_contours', 'nuhtc_merge_overlap', 'nuhtc_export_kept', 'nuhtc_clock_probe', 'nuhtc_op_swin_mlp']
+           'nuhtc_mask_contours', 'nuhtc_merge_overlap', 'nuhtc_export_kept', 'nuhtc_clock_probe', 'nuhtc_op_swin_mlp', 'nuhtc_stream']
 
 _lib = None
 
@@ -79,14 +79,16 @@ def load():
     lib.nuhtc_profile_enable.argtypes = [ci]
     lib.nuhtc_clock_probe.argtypes = [ci, ctypes.c_uint64, vp, vp]
     lib.nuhtc_dev_knob.argtypes = [ctypes.c_char_p, ci]
+    lib.nuhtc_stream.argtypes = [vp]
     lib.nuhtc_profile_read.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if fn.restype is ctypes.c_int or name not in ('nuhtc_default_config', 'nuhtc_destroy', 'nuhtc_last_error'):
+        if fn.restype is ctypes.c_int or name not in ('nuhtc_default_config', 'nuhtc_destroy', 'nuhtc_last_error', 'nuhtc_stream'):
             fn.restype = ci
     lib.nuhtc_last_error.restype = ctypes.c_char_p
     lib.nuhtc_default_config.restype = None
     lib.nuhtc_destroy.restype = None
+    lib.nuhtc_stream.restype = ctypes.c_void_p
     _lib = lib
     return lib
 

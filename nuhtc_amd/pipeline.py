@@ -22,8 +22,9 @@ class EnginePipeline:
     def __init__(self, state_dict, device=0, depth=4, **engine_kw):
         self.engines = [Engine(state_dict, device=device, **engine_kw) for _ in range(depth)]
         self.device = self.engines[0].device
-        with torch.cuda.device(self.device):
-            self.streams = [torch.cuda.Stream(device=self.device) for _ in range(depth)]
+        # every engine runs on the stream it created next to its side streams (nuhtc_stream: three different pipes of the command
+        # processor by construction, include/nuhtc_hip.h)
+        self.streams = [e.stream for e in self.engines]
         self.pending = collections.deque()      # (slot, B, event, user tag)
         self.next = 0
 

@@ -369,3 +369,39 @@ def test_batch_64_slide_equals_batch_8(hip_device, tmp_path):
         outs[bs] = {f: open(tmp_path / f'b{bs}/nuclei/slide' / f, 'rb').read() for f in ('slide.geojson', 'slide_merged.geojson')}
     assert len(outs[64]['slide.geojson']) > 100000
     assert outs[64] == outs[8]
+
+
+@pytest.mark.gpu
+def test_engine_stream_outlives_the_engine_and_gives_the_same_results(hip_device):
+    """nuhtc_stream(): an engine run on the stream it owns gives the results of the default stream; the stream stays usable after
+    the engine is closed (PyTorch's allocator touches the stream a block was allocated on when the block is freed) and the next
+    engine of the device takes the pooled streams over."""
+    import gc
+    import torch
+    from nuhtc_amd import hip, synth, weights
+    from nuhtc_amd.engine import Engine
+    sd = weights.bench_state_dict()
+    tiles_np = synth.nuclei_tiles(2, 256, start=5)
+    a = Engine(sd, device=0, max_batch=2, tile=(256, 256))
+    tiles = a.to_device(tiles_np)
+    a.infer_async(tiles, hip.CH_SWAP); a.check()
+    ref = (a.counts.clone(), a.boxes.clone(), a.labels.clone())
+    st = a.stream
+    assert st.cuda_stream != 0 and st.cuda_stream != torch.cuda.current_stream().cuda_stream
+    with torch.cuda.stream(st):
+        t2 = a.to_device(tiles_np)                   # a block allocated on the engine's stream
+        a.infer_async(t2, hip.CH_SWAP)
+    st.synchronize(); a.check()
+    assert torch.equal(a.counts, ref[0]) and torch.equal(a.boxes, ref[1]) and torch.equal(a.labels, ref[2])
+    handle = st.cuda_stream
+    a.close()
+    del t2; gc.collect(); torch.cuda.empty_cache(); torch.cuda.synchronize()      # segfaulted when nuhtc_destroy destroyed the stream
+    with torch.cuda.stream(st):
+        assert float(torch.ones(8, device='cuda').sum()) == 8.0
+    b = Engine(sd, device=0, max_batch=2, tile=(256, 256))
+    assert b.stream.cuda_stream == handle                                           # the pooled triple
+    with torch.cuda.stream(b.stream):
+        b.infer_async(b.to_device(tiles_np), hip.CH_SWAP)
+    b.stream.synchronize(); b.check()
+    assert torch.equal(b.counts, ref[0]) and torch.equal(b.boxes, ref[1])
+    b.close()

@@ -6,11 +6,13 @@ from nuhtc_amd import hip, synth, weights
 from nuhtc_amd.engine import Engine
 sd = weights.bench_state_dict()
 tiles = None
+OWN = os.environ.get('OWN', '1') == '1'      # run every engine on its own stream (nuhtc_stream) or all on the default stream
 def rate(e, n=20):
-    for _ in range(4): e.infer_async(tiles, hip.CH_SWAP)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(n): e.infer_async(tiles, hip.CH_SWAP)
-    torch.cuda.synchronize(); return 16 * n / (time.perf_counter() - t0)
+    with torch.cuda.stream(e.stream if OWN else torch.cuda.current_stream()):
+        for _ in range(4): e.infer_async(tiles, hip.CH_SWAP)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(n): e.infer_async(tiles, hip.CH_SWAP)
+        torch.cuda.synchronize(); return 16 * n / (time.perf_counter() - t0)
 engines = []
 out = []
 for i in range(int(os.environ.get('NENG', '10'))):
