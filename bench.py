@@ -242,30 +242,39 @@ def main():
     # `--in-flight 0 / 1` times one batch at a time instead (the profiling passes: per-kernel durations need that); the
     # one-batch-at-a-time rate of the same K steps is always measured right after and reported as `sequential`.
     depth = max(1, args.in_flight)
-    engs = [eng] + [Engine(sd, device=local_rank, max_batch=args.batch, tile=(256, 256), matrix_pipe=pipe) for _ in range(depth - 1)]
-    streams = [e.stream for e in engs]     # (streams[0] is the current stream)
+    # engines that run beside each other use the throughput tile policy (what nuhtc_amd.pipeline.EnginePipeline sets); `eng`, the
+    # engine of `sequential` and of every per-kernel figure, keeps the default (latency) policy
+    if depth > 1:
+        engs = [Engine(sd, device=local_rank, max_batch=args.batch, tile=(256, 256), matrix_pipe=pipe, tile_policy=hip.TILES_THROUGHPUT) for _ in range(depth)]
+    else:
+        engs = [eng]
+    streams = [e.stream for e in engs]
 
     def run(k):
         for i in range(k):
             with torch.cuda.stream(streams[i % depth]):
                 step_fn(engs[i % depth])
-    for st in streams[1:]:
-        st.wait_stream(torch.cuda.current_stream())
-    for e in engs[1:]:          # untimed: first-call allocations of the other engines (engine 0 went through the settle phase)
-        step_fn(e)
+    for st in streams:
+        if st != torch.cuda.current_stream():
+            st.wait_stream(torch.cuda.current_stream())
+    for e in engs:              # untimed: first-call allocations of these engines
+        if e is not eng:
+            step_fn(e)
     torch.cuda.synchronize()
     run(args.warmup)
     last = engs[(args.steps - 1) % depth]          # the engine that will run step K
-    for st in streams[1:]:
-        torch.cuda.current_stream().wait_stream(st)
+    for st in streams:
+        if st != torch.cuda.current_stream():
+            torch.cuda.current_stream().wait_stream(st)
     exchange(last)      # untimed: the first call allocates the pinned export buffers and loads lazily-built device code
     for e in engs:
         e.check()
     sync_all()
     t0 = time.perf_counter()
     run(args.steps)
-    for st in streams[1:]:
-        torch.cuda.current_stream().wait_stream(st)
+    for st in streams:
+        if st != torch.cuda.current_stream():
+            torch.cuda.current_stream().wait_stream(st)
     gathered = exchange(last)            # once, inside the timed region: the records of step K
     ranks_seen = sorted(int(g[-1][0]) for g in gathered)
     gathered_records = int(sum(g[0].shape[0] for g in gathered))
@@ -282,9 +291,9 @@ def main():
     # the same K steps one batch at a time (what the per-kernel numbers below belong to)
     sequential = None
     if depth > 1:
-        for e in engs[1:]:
+        for e in engs:
             e.close()
-        engs = engs[:1]
+        engs = [eng]
         sync_all()
         t0 = time.perf_counter()
         for _ in range(args.steps):

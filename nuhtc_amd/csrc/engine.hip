@@ -32,6 +32,7 @@ void nuhtc_default_config(nuhtc_config* c) {
   memcpy(c->stage_stds, st, sizeof(st));
   c->margin = 2; c->min_area = 10; c->mask_nms_thr = 0.05f;
   c->matrix_pipe = NUHTC_PIPE_BF16_SPLIT;
+  c->tile_policy = NUHTC_TILES_LATENCY;
 }
 
 const char* nuhtc_last_error(const nuhtc_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
@@ -58,6 +59,7 @@ int nuhtc_create(const nuhtc_config* cfg, int device, nuhtc_engine** out) {
   if (cfg->rpn_nms_pre < 1 || cfg->rpn_nms_pre > 4096 || cfg->rpn_max_per_img < 1 || cfg->rpn_max_per_img > 4096) { g_create_error = "rpn_nms_pre / rpn_max_per_img out of range (<=4096)"; return NUHTC_E_INVALID; }
   if (cfg->max_per_img < 1 || cfg->max_per_img > 2048) { g_create_error = "max_per_img out of range"; return NUHTC_E_INVALID; }
   if (cfg->max_cc_proposals < 0 || cfg->max_cc_proposals > 4096) { g_create_error = "max_cc_proposals out of range"; return NUHTC_E_INVALID; }
+  if (cfg->tile_policy != NUHTC_TILES_LATENCY && cfg->tile_policy != NUHTC_TILES_THROUGHPUT) { g_create_error = "tile_policy must be NUHTC_TILES_LATENCY or NUHTC_TILES_THROUGHPUT"; return NUHTC_E_INVALID; }
   if (cfg->matrix_pipe != NUHTC_PIPE_BF16_SPLIT && cfg->matrix_pipe != NUHTC_PIPE_FP32) { g_create_error = "matrix_pipe must be NUHTC_PIPE_BF16_SPLIT or NUHTC_PIPE_FP32"; return NUHTC_E_INVALID; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { g_create_error = "no such HIP device"; return NUHTC_E_HIP; }
@@ -550,6 +552,8 @@ static Conv3Fuse pointwise(int N2, const void* w2f, const float* bias2, float* o
 
 int run_backbone(nuhtc_engine* e, int B, hipStream_t s) {
   const int Hn = e->Hn, Wn = e->Wn;
+  // the Swin linears take the block-tile form of the engine's tile policy (nuhtc_config.tile_policy, gemm.hip)
+  auto linear = [&](GemmParams p) { p.throughput = e->cfg.tile_policy == NUHTC_TILES_THROUGHPUT; return launch_gemm(p, s); };
   RUN(launch_patch_embed(e->img, e->pe_w, e->pe_b, e->pe_g, e->pe_beta, e->tokA, B, Hn, Wn, s));
   float* x = e->tokA;
   float* xalt = e->tokB;
@@ -572,14 +576,14 @@ int run_backbone(nuhtc_engine* e, int B, hipStream_t s) {
       {
         GemmParams p = gp(e->xw, w.qkv_w, w.qkv_b, e->qkv, T, 3 * C, C);
         p.store = ST_ROWMAP; p.row_map = g.vrow[sh];
-        RUN(launch_gemm(p, s));
+        RUN(linear(p));
       }
       }
       RUN(launch_window_attn(e->qkv, w.relbT, sh ? g.mask : nullptr, sh ? g.mask_any : nullptr, g.cidx[sh], e->att, B * g.nW, g.nW, C, g.nH, s));
       {
         GemmParams p = gp(e->att, w.proj_w, w.proj_b, x, T, C, C);
         p.store = ST_ROWMAP; p.row_map = g.ctok[sh]; p.res = x; p.ldr = C;
-        RUN(launch_gemm(p, s));
+        RUN(linear(p));
       }
       // x += W2·gelu(W1·LN2(x))      (swin.py:365-367, mmcv FFN)
       static const int& fused_mlp = dev_knob_ref("FUSED_MLP", 1);
@@ -590,12 +594,12 @@ int run_backbone(nuhtc_engine* e, int B, hipStream_t s) {
       {
         GemmParams p = gp(e->xw, w.f1_w, w.f1_b, e->hid, T, 4 * C, C);
         p.act = ACT_GELU;
-        RUN(launch_gemm(p, s));
+        RUN(linear(p));
       }
       {
         GemmParams p = gp(e->hid, w.f2_w, w.f2_b, x, T, C, 4 * C);
         p.res = x; p.ldr = C;
-        RUN(launch_gemm(p, s));
+        RUN(linear(p));
       }
       }
       if (e->debug_tokens) {
@@ -606,7 +610,7 @@ int run_backbone(nuhtc_engine* e, int B, hipStream_t s) {
     RUN(launch_layernorm(x, nullptr, e->on_g[st], e->on_b[st], e->c[st], T, C, s));   // swin.py:756-762 (tokens == NHWC)
     if (st < 3) {
       RUN(launch_merge_ln(x, e->mg_g[st], e->mg_b[st], e->xw, B, g.H, g.W, C, s));
-      RUN(launch_gemm(gp(e->xw, e->mg_w[st], nullptr, xalt, T / 4, 2 * C, 4 * C), s));
+      RUN(linear(gp(e->xw, e->mg_w[st], nullptr, xalt, T / 4, 2 * C, 4 * C)));
       std::swap(x, xalt);
     }
   }

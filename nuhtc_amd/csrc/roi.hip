@@ -1153,9 +1153,9 @@ int launch_roi_feat(const RoiFeatParams& p, int P, int r_cap, hipStream_t s, hip
     hipLaunchKernelGGL(roi_feat7_stream_kernel, dim3(r_cap < 2048 ? r_cap : 2048), dim3(64), 0, fork ? side : s, p);
     if (fork && hipEventRecord(ev_join, side) != hipSuccess) return NUHTC_E_HIP;
     hipStream_t sb = fork2 ? side2 : fork ? side : s;
+    hipLaunchKernelGGL(roi_feat7_giant_kernel, dim3(r_cap < 256 ? r_cap : 256), dim3(256), 0, sb, p);      // (usually empty: first, so the chain the join waits for ends with the combine)
     hipLaunchKernelGGL(roi_feat7_big_kernel, dim3(std::min(512, 3 * r_cap)), dim3(BG_NT), 0, sb, p);
     if (p.big_part) hipLaunchKernelGGL(roi_feat7_big_combine_kernel, dim3(std::min(128, r_cap)), dim3(448), 0, sb, p);
-    hipLaunchKernelGGL(roi_feat7_giant_kernel, dim3(r_cap < 256 ? r_cap : 256), dim3(256), 0, sb, p);
     if (fork2 && hipEventRecord(ev_join2, side2) != hipSuccess) return NUHTC_E_HIP;
     if (fork && !fork2 && hipEventRecord(ev_join, side) != hipSuccess) return NUHTC_E_HIP;
     hipLaunchKernelGGL((roi_feat7_lds_kernel<TS0, TS1, 0>), dim3(r_cap), dim3(256), 0, s, p);
