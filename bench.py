@@ -26,12 +26,9 @@ import os
 import sys
 import time
 
-# Hardware queues of the HIP runtime (default 4): every engine runs on three streams (its own + two side streams) and four engines
-# are in flight, so with the default the twelve streams share four queues and unrelated batches wait on each other: 16 queues
-# measured +3 % on `value`.  Must be set before the runtime initialises; an exported GPU_MAX_HW_QUEUES wins.  (More queues than 4
-# put several queues on one pipe of the command processor: engines are therefore run on the stream they create next to their side
-# streams, nuhtc_stream(), which keeps an engine's three streams on three pipes.)
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
+# (GPU_MAX_HW_QUEUES is left at the HIP runtime's default of 4: the four engines in flight run the throughput schedule, one stream
+# each, and four streams on four queues -- one per pipe of the command processor -- measured 1895-1905 tiles/s against 1820-1837
+# with 8 or 16 queues.  `config.hw_queues` records an exported value.)
 
 import numpy as np
 import torch
@@ -242,10 +239,10 @@ def main():
     # `--in-flight 0 / 1` times one batch at a time instead (the profiling passes: per-kernel durations need that); the
     # one-batch-at-a-time rate of the same K steps is always measured right after and reported as `sequential`.
     depth = max(1, args.in_flight)
-    # engines that run beside each other use the throughput tile policy (what nuhtc_amd.pipeline.EnginePipeline sets); `eng`, the
-    # engine of `sequential` and of every per-kernel figure, keeps the default (latency) policy
+    # engines that run beside each other use the throughput schedule (what nuhtc_amd.pipeline.EnginePipeline sets); `eng`, the
+    # engine of `sequential` and of every per-kernel figure, keeps the default (latency) schedule
     if depth > 1:
-        engs = [Engine(sd, device=local_rank, max_batch=args.batch, tile=(256, 256), matrix_pipe=pipe, tile_policy=hip.TILES_THROUGHPUT) for _ in range(depth)]
+        engs = [Engine(sd, device=local_rank, max_batch=args.batch, tile=(256, 256), matrix_pipe=pipe, schedule=hip.SCHED_THROUGHPUT) for _ in range(depth)]
     else:
         engs = [eng]
     streams = [e.stream for e in engs]
@@ -477,7 +474,7 @@ def main():
                                    'incl. proposals, cascade, masks, per-tile mask-NMS' + (' [fixed load: 1064 RoIs, 64 detections per tile]' if args.fixed_load else ''), 'batch_per_gpu': B,
                        'weights': 'seeded synthetic (weights.bench_state_dict); pannuke.pth not distributed',
                        'tiles': 'synthetic nuclei tiles (nuhtc_amd.synth), resident in HBM',
-                       'batches_in_flight': depth, 'hw_queues': os.environ.get('GPU_MAX_HW_QUEUES'),
+                       'batches_in_flight': depth, 'hw_queues': os.environ.get('GPU_MAX_HW_QUEUES', 'runtime default (4)'),
                        'mean_rois_per_tile': float(roi_counts.mean()), 'mean_dets_per_tile': float(counts.mean())},
             'roofline': {'bound': 'mfma', 'kernel': DOMINANT + (' (Swin-T linears: gemm_split_kernel<3,0>, 6 x v_mfma_f32_32x32x16_bf16 per 32x32x16 fp32 product)' if args.pipe == 'split'
                                                                 else ' (Swin-T linears, fp32 v_mfma_f32_32x32x2_f32)'), 'achieved': achieved,

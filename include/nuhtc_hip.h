@@ -58,12 +58,16 @@ enum { NUHTC_CH_AS_IS = 0, NUHTC_CH_SWAP = 1 };
  *   NUHTC_PIPE_FP32: v_mfma_f32_32x32x2_f32, bitwise an fp32 fma chain (1/16 of the bf16 MFMA rate on gfx950). */
 enum { NUHTC_PIPE_BF16_SPLIT = 0, NUHTC_PIPE_FP32 = 1 };
 
-/* Block tiles of the Swin linears (same arithmetic, same results bit for bit: the k order of a dot product does not depend on the tile).
- *   NUHTC_TILES_LATENCY (default): 128-row tiles, the launch fills the chip soonest -- fastest for one batch at a time.
- *   NUHTC_TILES_THROUGHPUT: 256-row tiles (two row tiles per wave: fewer LDS bytes and operand splits per MFMA) -- for engines
- *       that run beside others (nuhtc_amd.pipeline.EnginePipeline sets it): the under-filled tail of a launch is then filled by
- *       another batch's kernels.  Measured +1.5 % with four batches in flight, -3 % for a batch alone. */
-enum { NUHTC_TILES_LATENCY = 0, NUHTC_TILES_THROUGHPUT = 1 };
+/* What an engine's launch schedule is tuned for (same arithmetic, same results bit for bit):
+ *   NUHTC_SCHED_LATENCY (default): one batch at a time as fast as possible -- 128-row block tiles for the Swin linears (the launch
+ *       fills the chip soonest), the RPN branch and the big / mid-size RoI classes on the engine's two side streams beside the
+ *       caller's stream.
+ *   NUHTC_SCHED_THROUGHPUT: for engines that run beside others (nuhtc_amd.pipeline.EnginePipeline sets it) -- 256-row block
+ *       tiles (fewer LDS bytes and operand splits per MFMA; another batch's kernels fill the under-filled tail of a launch) and
+ *       every kernel of the batch on the caller's stream (the other batches are the concurrency; forks and joins inside a batch
+ *       only add cross-stream waits and kernels that compete with their own batch).  Measured with four batches in flight:
+ *       +1.5 % for the tiles, +4 % for the single stream; a batch alone is 3-5 % slower this way. */
+enum { NUHTC_SCHED_LATENCY = 0, NUHTC_SCHED_THROUGHPUT = 1 };
 
 typedef struct nuhtc_engine nuhtc_engine;
 
@@ -101,7 +105,7 @@ typedef struct nuhtc_config {
   int32_t min_area;          /* 10   */
   float   mask_nms_thr;      /* 0.05 */
   int32_t matrix_pipe;       /* NUHTC_PIPE_BF16_SPLIT (default) or NUHTC_PIPE_FP32 */
-  int32_t tile_policy;       /* NUHTC_TILES_LATENCY (default) or NUHTC_TILES_THROUGHPUT: block tiles of the Swin linears (v5) */
+  int32_t schedule;          /* NUHTC_SCHED_LATENCY (default) or NUHTC_SCHED_THROUGHPUT (v5) */
 } nuhtc_config;
 
 /* Fills `cfg` with the PanNuke defaults listed above. */

@@ -32,7 +32,7 @@ void nuhtc_default_config(nuhtc_config* c) {
   memcpy(c->stage_stds, st, sizeof(st));
   c->margin = 2; c->min_area = 10; c->mask_nms_thr = 0.05f;
   c->matrix_pipe = NUHTC_PIPE_BF16_SPLIT;
-  c->tile_policy = NUHTC_TILES_LATENCY;
+  c->schedule = NUHTC_SCHED_LATENCY;
 }
 
 const char* nuhtc_last_error(const nuhtc_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
@@ -59,7 +59,7 @@ int nuhtc_create(const nuhtc_config* cfg, int device, nuhtc_engine** out) {
   if (cfg->rpn_nms_pre < 1 || cfg->rpn_nms_pre > 4096 || cfg->rpn_max_per_img < 1 || cfg->rpn_max_per_img > 4096) { g_create_error = "rpn_nms_pre / rpn_max_per_img out of range (<=4096)"; return NUHTC_E_INVALID; }
   if (cfg->max_per_img < 1 || cfg->max_per_img > 2048) { g_create_error = "max_per_img out of range"; return NUHTC_E_INVALID; }
   if (cfg->max_cc_proposals < 0 || cfg->max_cc_proposals > 4096) { g_create_error = "max_cc_proposals out of range"; return NUHTC_E_INVALID; }
-  if (cfg->tile_policy != NUHTC_TILES_LATENCY && cfg->tile_policy != NUHTC_TILES_THROUGHPUT) { g_create_error = "tile_policy must be NUHTC_TILES_LATENCY or NUHTC_TILES_THROUGHPUT"; return NUHTC_E_INVALID; }
+  if (cfg->schedule != NUHTC_SCHED_LATENCY && cfg->schedule != NUHTC_SCHED_THROUGHPUT) { g_create_error = "schedule must be NUHTC_SCHED_LATENCY or NUHTC_SCHED_THROUGHPUT"; return NUHTC_E_INVALID; }
   if (cfg->matrix_pipe != NUHTC_PIPE_BF16_SPLIT && cfg->matrix_pipe != NUHTC_PIPE_FP32) { g_create_error = "matrix_pipe must be NUHTC_PIPE_BF16_SPLIT or NUHTC_PIPE_FP32"; return NUHTC_E_INVALID; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { g_create_error = "no such HIP device"; return NUHTC_E_HIP; }
@@ -552,8 +552,8 @@ static Conv3Fuse pointwise(int N2, const void* w2f, const float* bias2, float* o
 
 int run_backbone(nuhtc_engine* e, int B, hipStream_t s) {
   const int Hn = e->Hn, Wn = e->Wn;
-  // the Swin linears take the block-tile form of the engine's tile policy (nuhtc_config.tile_policy, gemm.hip)
-  auto linear = [&](GemmParams p) { p.throughput = e->cfg.tile_policy == NUHTC_TILES_THROUGHPUT; return launch_gemm(p, s); };
+  // the Swin linears take the block-tile form of the engine's schedule (nuhtc_config.schedule, gemm.hip)
+  auto linear = [&](GemmParams p) { p.throughput = e->cfg.schedule == NUHTC_SCHED_THROUGHPUT; return launch_gemm(p, s); };
   RUN(launch_patch_embed(e->img, e->pe_w, e->pe_b, e->pe_g, e->pe_beta, e->tokA, B, Hn, Wn, s));
   float* x = e->tokA;
   float* xalt = e->tokB;
@@ -641,8 +641,9 @@ int run_neck_heads(nuhtc_engine* e, int B, hipStream_t s) {
   // RPN head (mmdet/models/dense_heads/rpn_head.py:62-68).  The RPN branch (conv + 1x1 heads here, proposal selection and
   // NMS in run_roi_path) and the semantic branch below both depend only on the FPN maps: the RPN branch runs on the side
   // stream from here on, so the tails of either branch's launches are filled by the other's blocks; joined before build_rois.
-  hipStream_t s2 = e->side;
-  if (hipEventRecord(e->ev_fpn, s) != hipSuccess || hipStreamWaitEvent(s2, e->ev_fpn, 0) != hipSuccess)
+  // (throughput schedule: the branch stays on the caller's stream, the fork below is then a no-op between a stream and itself)
+  hipStream_t s2 = e->cfg.schedule == NUHTC_SCHED_THROUGHPUT ? s : e->side;
+  if (s2 != s && (hipEventRecord(e->ev_fpn, s) != hipSuccess || hipStreamWaitEvent(s2, e->ev_fpn, 0) != hipSuccess))
     FAIL(e, NUHTC_E_HIP, "side-stream fork failed");
   for (int i = 0; i < 4; ++i) {
     const StageGeom& g = e->st[i];
@@ -654,7 +655,7 @@ int run_neck_heads(nuhtc_engine* e, int B, hipStream_t s) {
       RUN(launch_gemm(gp(e->tmpR, e->rpn_hw, e->rpn_hb, e->rpn[i], B * g.H * g.W, 32, 64), s2));
     }
   }
-  if (hipEventRecord(e->ev_rpn, s2) != hipSuccess) FAIL(e, NUHTC_E_HIP, "hipEventRecord failed");   // RPN maps ready (side stream)
+  if (s2 != s && hipEventRecord(e->ev_rpn, s2) != hipSuccess) FAIL(e, NUHTC_E_HIP, "hipEventRecord failed");   // RPN maps ready (side stream)
   // FusedSemanticHead (fused_semantic_head.py:97-111)
   if (!fuse)
     for (int i = 0; i < 4; ++i) {

@@ -882,7 +882,7 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
     // (round 3, same-box A/B of every 96-column shape left on this kernel -- the M = 262144 stage-1 linears moved to mlp.hip: 128-row
     // tiles are as fast or faster everywhere, N1152|K384 0.568 vs 0.648 ms, N1536|K384 0.759 vs 0.787, N768|K3072 0.281 vs 0.357; the
     // 256-row form is kept for launches of at least 2048 such tiles, i.e. M >= 131072 at the path's widths)
-    // (nuhtc_config.tile_policy = NUHTC_TILES_THROUGHPUT: with other batches in flight the under-filled tail of a launch is
+    // (nuhtc_config.schedule = NUHTC_SCHED_THROUGHPUT: with other batches in flight the under-filled tail of a launch is
     // filled by their kernels and the 256-row tile's lower LDS traffic per MFMA wins: +1.5 % on four batches in flight, -3 % alone)
     const bool mt2 = force_mt ? force_mt == 2 : (!p.m_dev && nt == 3 && (p.throughput || (blocks2 >= 512 && p.M >= 131072)));
     if (mt2 && nt == 3) launch_split<2, 3>(q, s);

@@ -250,8 +250,8 @@ int run_roi_path(nuhtc_engine* e, int B, const float* rois_fixed, int n_rois, in
     sp.img_h = e->Hv; sp.img_w = e->Wv; sp.min_size = c.rpn_min_bbox_size;      // max_shape = img_shape (rpn_head.py:141,219)
     // RPN selection + NMS depend only on the RPN maps: they run on the side stream, overlapping the semantic head /
     // connected-component kernels the caller's stream is still working through (fork at ev_rpn, join before build_rois)
-    hipStream_t s2 = e->side;
-    if (hipStreamWaitEvent(s2, e->ev_rpn, 0) != hipSuccess) FAIL(e, NUHTC_E_HIP, "hipStreamWaitEvent failed");
+    hipStream_t s2 = e->cfg.schedule == NUHTC_SCHED_THROUGHPUT ? s : e->side;
+    if (s2 != s && hipStreamWaitEvent(s2, e->ev_rpn, 0) != hipSuccess) FAIL(e, NUHTC_E_HIP, "hipStreamWaitEvent failed");
     RUN(launch_rpn_select(lv, sp, B, s2));
     NmsParams np;
     memset(&np, 0, sizeof(np));
@@ -261,7 +261,7 @@ int run_roi_path(nuhtc_engine* e, int B, const float* rois_fixed, int n_rois, in
     np.out_dets = w->rpn_dets; np.out_src = w->rpn_src; np.out_counts = w->rpn_counts;
     np.seg_start = w->nms_seg_start; np.seg_n = w->nms_seg_n; np.sorted_pos = w->nms_pos; np.keepbits = w->nms_keepbits;
     RUN(launch_nms_levels(np, B, s2));
-    if (hipEventRecord(e->ev_side, s2) != hipSuccess) FAIL(e, NUHTC_E_HIP, "hipEventRecord failed");
+    if (s2 != s && hipEventRecord(e->ev_side, s2) != hipSuccess) FAIL(e, NUHTC_E_HIP, "hipEventRecord failed");
     // ---- connected-component ("watershed") proposals (htc_roi_head_cus.py:283-342)
     if (c.watershed_proposal && c.max_cc_proposals > 0) {
       CcParams cp;
@@ -293,7 +293,7 @@ int run_roi_path(nuhtc_engine* e, int B, const float* rois_fixed, int n_rois, in
     }
   }
   // join: the side stream carries the RPN branch (convs + heads from run_neck_heads, selection + NMS above)
-  if (hipStreamWaitEvent(s, fixed ? e->ev_rpn : e->ev_side, 0) != hipSuccess) FAIL(e, NUHTC_E_HIP, "hipStreamWaitEvent failed");
+  if (e->cfg.schedule != NUHTC_SCHED_THROUGHPUT && hipStreamWaitEvent(s, fixed ? e->ev_rpn : e->ev_side, 0) != hipSuccess) FAIL(e, NUHTC_E_HIP, "hipStreamWaitEvent failed");
   RUN(launch_build_rois(use_cc ? w->cc_boxes : nullptr, w->cc_counts, std::max(c.max_cc_proposals, 1), w->rpn_dets, w->rpn_counts, c.rpn_max_per_img,
                         rois_fixed, n_rois, w->rois, w->roi_off, w->roi_cnt, w->roi_total, B, s));
   const int Rcap = fixed ? B * n_rois : B * e->roi_cap;
@@ -311,7 +311,7 @@ int run_roi_path(nuhtc_engine* e, int B, const float* rois_fixed, int n_rois, in
     auto it = e->bufs.find("rois_stage" + std::to_string(k));
     if (it != e->bufs.end() && e->debug_tokens)
       if (hipMemcpyAsync(it->second.ptr, w->rois, (size_t)Rcap * 5 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) FAIL(e, NUHTC_E_HIP, "memcpy failed");
-    RUN(launch_roi_feat(fp, 7, Rcap, s, e->side, e->ev_fpn, e->ev_side, e->side2, e->ev_side2));   // (both events are free again after the RPN join)
+    RUN(launch_roi_feat(fp, 7, Rcap, s, e->cfg.schedule == NUHTC_SCHED_THROUGHPUT ? nullptr : e->side, e->ev_fpn, e->ev_side, e->side2, e->ev_side2));   // (both events are free again after the RPN join)
     {
       GemmParams p = gpr(w->feats, e->fc1_w[k], e->fc1_b[k], w->h1, Rcap, 256, 3136);
       p.act = ACT_RELU; p.m_dev = w->roi_total;

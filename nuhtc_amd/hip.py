@@ -13,7 +13,7 @@ OK, E_INVALID, E_HIP, E_STATE, E_CAPACITY, E_NOTFOUND = 0, -1, -2, -3, -4, -5
 CH_AS_IS, CH_SWAP = 0, 1
 OVERLAP_MASK, OVERLAP_POLYGON = 0, 1
 PIPE_BF16_SPLIT, PIPE_FP32 = 0, 1
-TILES_LATENCY, TILES_THROUGHPUT = 0, 1
+SCHED_LATENCY, SCHED_THROUGHPUT = 0, 1
 
 
 class Config(ctypes.Structure):
@@ -28,7 +28,7 @@ class Config(ctypes.Structure):
         ('watershed_proposal', ctypes.c_int32), ('max_cc_proposals', ctypes.c_int32),
         ('stage_stds', (ctypes.c_float * 4) * 3),
         ('margin', ctypes.c_int32), ('min_area', ctypes.c_int32), ('mask_nms_thr', ctypes.c_float),
-        ('matrix_pipe', ctypes.c_int32), ('tile_policy', ctypes.c_int32),
+        ('matrix_pipe', ctypes.c_int32), ('schedule', ctypes.c_int32),
     ]
 
 

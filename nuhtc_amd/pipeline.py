@@ -20,9 +20,9 @@ from .engine import Engine
 
 class EnginePipeline:
     def __init__(self, state_dict, device=0, depth=4, **engine_kw):
-        if depth > 1:           # engines that run beside each other take the block tiles that do most work per LDS byte (include/nuhtc_hip.h)
+        if depth > 1:           # engines that run beside each other: throughput schedule (include/nuhtc_hip.h)
             from . import hip
-            engine_kw.setdefault('tile_policy', hip.TILES_THROUGHPUT)
+            engine_kw.setdefault('schedule', hip.SCHED_THROUGHPUT)
         self.engines = [Engine(state_dict, device=device, **engine_kw) for _ in range(depth)]
         self.device = self.engines[0].device
         # every engine runs on the stream it created next to its side streams (nuhtc_stream: three different pipes of the command

@@ -408,17 +408,17 @@ def test_engine_stream_outlives_the_engine_and_gives_the_same_results(hip_device
 
 
 @pytest.mark.gpu
-def test_tile_policy_throughput_is_bit_identical(hip_device):
-    """nuhtc_config.tile_policy only changes the block tiles of the Swin linears (256-row instead of 128-row): every output of the
-    path must be the same bit for bit; an unknown policy is refused at nuhtc_create."""
+def test_throughput_schedule_is_bit_identical(hip_device):
+    """nuhtc_config.schedule = NUHTC_SCHED_THROUGHPUT changes the block tiles of the Swin linears (256-row instead of 128-row) and keeps
+    every kernel on the caller's stream: every output of the path must be the same bit for bit; an unknown value is refused."""
     import torch
     from nuhtc_amd import hip, synth, weights
     from nuhtc_amd.engine import Engine, HipError
     sd = weights.bench_state_dict()
     tiles_np = synth.nuclei_tiles(3, 256, start=11)
     a = Engine(sd, device=0, max_batch=3, tile=(256, 256))
-    b = Engine(sd, device=0, max_batch=3, tile=(256, 256), tile_policy=hip.TILES_THROUGHPUT)
-    assert a.cfg.tile_policy == hip.TILES_LATENCY and b.cfg.tile_policy == hip.TILES_THROUGHPUT
+    b = Engine(sd, device=0, max_batch=3, tile=(256, 256), schedule=hip.SCHED_THROUGHPUT)
+    assert a.cfg.schedule == hip.SCHED_LATENCY and b.cfg.schedule == hip.SCHED_THROUGHPUT
     for e in (a, b):
         e.infer_async(e.to_device(tiles_np), hip.CH_SWAP); e.check()
     assert int(a.counts.sum()) > 20
@@ -428,4 +428,4 @@ def test_tile_policy_throughput_is_bit_identical(hip_device):
         assert torch.equal(getattr(a, f), getattr(b, f)), f
     a.close(); b.close()
     with pytest.raises(HipError):
-        Engine(sd, device=0, max_batch=1, tile=(256, 256), tile_policy=7)
+        Engine(sd, device=0, max_batch=1, tile=(256, 256), schedule=7)

@@ -14,10 +14,6 @@ import os
 import sys
 import time
 
-# 16 hardware queues instead of the HIP runtime's 4 (read when the runtime initialises; an exported value wins): the slide loop
-# keeps four engines x three streams busy (nuhtc_amd.pipeline; bench.py measured +3-5 % with one queue per stream)
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
-
 import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
