@@ -474,7 +474,7 @@ def main():
                                    'incl. proposals, cascade, masks, per-tile mask-NMS' + (' [fixed load: 1064 RoIs, 64 detections per tile]' if args.fixed_load else ''), 'batch_per_gpu': B,
                        'weights': 'seeded synthetic (weights.bench_state_dict); pannuke.pth not distributed',
                        'tiles': 'synthetic nuclei tiles (nuhtc_amd.synth), resident in HBM',
-                       'batches_in_flight': depth, 'hw_queues': os.environ.get('GPU_MAX_HW_QUEUES', 'runtime default (4)'),
+                       'batches_in_flight': depth, 'schedule': 'NUHTC_SCHED_THROUGHPUT for the engines in flight (one stream, 256-row tiles); NUHTC_SCHED_LATENCY for `sequential` and the per-kernel figures' if depth > 1 else 'NUHTC_SCHED_LATENCY', 'hw_queues': os.environ.get('GPU_MAX_HW_QUEUES', 'runtime default (4)'),
                        'mean_rois_per_tile': float(roi_counts.mean()), 'mean_dets_per_tile': float(counts.mean())},
             'roofline': {'bound': 'mfma', 'kernel': DOMINANT + (' (Swin-T linears: gemm_split_kernel<3,0>, 6 x v_mfma_f32_32x32x16_bf16 per 32x32x16 fp32 product)' if args.pipe == 'split'
                                                                 else ' (Swin-T linears, fp32 v_mfma_f32_32x32x2_f32)'), 'achieved': achieved,
