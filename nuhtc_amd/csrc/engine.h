@@ -61,6 +61,7 @@ struct nuhtc_engine {
   int roi_cap = 0;          // rois per tile: max_cc_proposals + rpn_max_per_img
   int cand_cap = 0;         // rpn candidates per tile (<= 4 * nms_pre), det candidates per tile
   int* overflow = nullptr;  // dev int[4]
+  int* overflow_host = nullptr;   // pinned int[4]: nuhtc_check copies the flags on the caller's stream (a synchronous hipMemcpy goes through the null stream and waited ~6 ms per call in a loop that keeps four batches in flight)
   int32_t* export_pos = nullptr;   // nuhtc_export_kept scratch [max_batch * max_per_img]
   int32_t* crop_size = nullptr;    // nuhtc_export_crops scratch [max_batch * max_per_img]
   hipStream_t own = nullptr;        // a stream for the caller to run this engine on (nuhtc_stream): created right before the two side streams

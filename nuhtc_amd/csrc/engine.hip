@@ -97,6 +97,7 @@ void nuhtc_destroy(nuhtc_engine* e) {
   if (e->ev_rpn) hipEventDestroy(e->ev_rpn);
   if (e->ev_side) hipEventDestroy(e->ev_side);
   if (e->ev_fpn) hipEventDestroy(e->ev_fpn);
+  if (e->overflow_host) hipHostFree(e->overflow_host);
   for (const float* w : e->split_weights) gemm_unregister_split(w);
   for (void* p : e->allocs) hipFree(p);
   delete e;
@@ -782,12 +783,10 @@ int nuhtc_export_crops(nuhtc_engine* e, const uint32_t* words_dev, const int32_t
 int nuhtc_check(nuhtc_engine* e, void* stream) {
   if (!e) return NUHTC_E_INVALID;
   HIP_CHECK(e, hipSetDevice(e->device));
+  if (e->overflow && !e->overflow_host) HIP_CHECK(e, hipHostMalloc((void**)&e->overflow_host, 4 * sizeof(int), hipHostMallocDefault));
+  if (e->overflow) HIP_CHECK(e, hipMemcpyAsync(e->overflow_host, e->overflow, 4 * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIP_CHECK(e, hipStreamSynchronize((hipStream_t)stream));
-  if (e->overflow) {
-    int h[4] = {0, 0, 0, 0};
-    HIP_CHECK(e, hipMemcpy(h, e->overflow, sizeof(h), hipMemcpyDeviceToHost));
-    if (h[0]) FAIL(e, NUHTC_E_CAPACITY, "connected-component proposals exceeded max_cc_proposals on at least one tile");
-  }
+  if (e->overflow && e->overflow_host[0]) FAIL(e, NUHTC_E_CAPACITY, "connected-component proposals exceeded max_cc_proposals on at least one tile");
   return 0;
 }
 

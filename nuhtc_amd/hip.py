@@ -125,13 +125,16 @@ def profile_read():
 
 
 class ClockProbe:
-    """Shader clock held while other kernels run: start() enqueues the one-wave probe on a stream of its own for `ms` milliseconds,
-    ghz() waits for it and returns cycles / reference ticks x 0.1 GHz."""
+    """Shader clock held while other kernels run: start() enqueues the one-wave probe for `ms` milliseconds, ghz() waits for it and
+    returns cycles / reference ticks x 0.1 GHz.  The probe goes to the device's NULL stream: an engine's three streams take three
+    of the runtime's four hardware queues, and a probe on a stream that shares a queue with the engine would run alone, ahead of
+    the steps it is meant to run beside (it then reports the idle clock).  The engine's streams are non-blocking: the null stream
+    does not synchronise with them."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, stream=None):
         import torch
         self.device = device
-        self.stream = torch.cuda.Stream(device=device)
+        self.stream = stream if stream is not None else torch.cuda.default_stream(device)
         self.out = torch.zeros(2, dtype=torch.int64, device=torch.device('cuda', device))
 
     def start(self, ms):

@@ -9,6 +9,12 @@ that copy blocks the submitting thread for ≈ 4 ms per batch, but staging throu
 the kernels: 1431 -> 688 tiles/s; a staging buffer of ordinary memory page-locked with hipHostRegister: 613; the pageable copy on
 an idle per-slot copy stream: 1223), so the plain copy on the slot's stream stays.
 
+Round 3: the engines of a pipeline run the throughput schedule (include/nuhtc_hip.h: one stream per engine, 256-row tiles), and the
+default depth is six: the loop's host waits for the oldest batch before it reuses that slot, so with `depth` slots only depth - 1
+batches are on the GPU while it unpacks and resubmits.  Full path from host tiles (tools/dev/pipe_rate.py): 1.49k tiles/s with four
+slots on the runtime's four hardware queues, 1.71k with six, 1.83k with six and GPU_MAX_HW_QUEUES=16 (the slide tools set it);
+bench.py's loop never waits on the host and peaks at four slots on four queues (1.90k).
+
 The reference has no counterpart (its DataLoader overlaps only the CPU tile reads with the GPU, tools/infer_wsi.py:466-476)."""
 import collections
 
@@ -19,7 +25,7 @@ from .engine import Engine
 
 
 class EnginePipeline:
-    def __init__(self, state_dict, device=0, depth=4, **engine_kw):
+    def __init__(self, state_dict, device=0, depth=6, **engine_kw):
         if depth > 1:           # engines that run beside each other: throughput schedule (include/nuhtc_hip.h)
             from . import hip
             engine_kw.setdefault('schedule', hip.SCHED_THROUGHPUT)
@@ -69,7 +75,8 @@ class EnginePipeline:
         `stream` (torch.cuda.stream(stream)) before submitting to that slot again."""
         slot, B, ev, tag, _ = self.pending.popleft()
         ev.synchronize()
-        self.engines[slot].check()
+        with torch.cuda.stream(self.streams[slot]):      # (the flags are read on the slot's own, by now idle, stream)
+            self.engines[slot].check()
         return self.engines[slot], B, self.streams[slot], tag
 
     def drain(self):

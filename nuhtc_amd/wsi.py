@@ -203,7 +203,7 @@ def _unpack(eng, B, i0, coords, P, rec, exported=False):
         rec['ring'].append(np.concatenate([c, c[:1]], 0) + np.array([ox, oy], np.int64))   # mask2inst + contour_map
 
 
-def infer_tiles(model, tiles, coords, batch_size=16, depth=4):
+def infer_tiles(model, tiles, coords, batch_size=16, depth=6):
     """Run the engine over `tiles` (N,P,P,3) and return per-detection records that survive the per-tile margin /
     min-area filter + mask-NMS (computed on the GPU, tools/infer_wsi.py:510-531), in slide coordinates.  `depth` batches
     are kept in flight (nuhtc_amd.pipeline): the host unpacks batch i while the GPU runs batch i+1.

@@ -422,8 +422,10 @@ def test_throughput_schedule_is_bit_identical(hip_device):
     for e in (a, b):
         e.infer_async(e.to_device(tiles_np), hip.CH_SWAP); e.check()
     assert int(a.counts.sum()) > 20
-    for name in ('c0', 'c3', 'x0', 'sem_feat', 'rois'):
+    for name in ('c0', 'c3', 'x0', 'sem_feat', 'sem_pred', 'roi_counts'):
         assert torch.equal(a.buffer(name), b.buffer(name)), name
+    n = int(a.buffer('roi_total').item())                    # (rows past the total are workspace)
+    assert n == int(b.buffer('roi_total').item()) and torch.equal(a.buffer('rois')[:n], b.buffer('rois')[:n])
     for f in ('counts', 'boxes', 'labels', 'masks', 'keep'):
         assert torch.equal(getattr(a, f), getattr(b, f)), f
     a.close(); b.close()

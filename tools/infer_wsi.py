@@ -22,6 +22,9 @@ import json
 import os
 import sys
 
+# 16 hardware queues instead of the HIP runtime's 4 (read when the runtime initialises; an exported value wins): see tools/bench_wsi.py
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
+
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
