@@ -163,8 +163,9 @@ int nuhtc_mask_contours(nuhtc_engine* e, const nuhtc_dets* dets, int B, int cap,
 /* Compacts the kept detections of a finished nuhtc_infer (slots r < counts[b] with keep set), in (tile, slot) order, into
  * dense device buffers of capacity `cap` rows, so that a slide loop fetches a batch's results with a few fixed-size
  * asynchronous copies instead of one copy per detection (the fields tools/infer_wsi.py:486-539 reads out of `result`):
- * n_dev [1] = number of kept detections (may exceed cap: then only the first cap rows were written and the caller falls
- * back to reading the detection buffers directly); idx_dev [cap] = b * max_per_img + r; boxes_dev [cap][5]; labels_dev
+ * n_dev [2]: [0] = number of kept detections (may exceed cap: then only the first cap rows were written and the caller falls
+ * back to reading the detection buffers directly), [1] = the capacity flag of that inference (non-zero: nuhtc_check would return
+ * NUHTC_E_CAPACITY; v5); idx_dev [cap] = b * max_per_img + r; boxes_dev [cap][5]; labels_dev
  * [cap]; cn_dev [cap] / xy_dev [cap][contour_cap][2] = contour length / vertices from nuhtc_mask_contours (contour_n /
  * contour_xy may be NULL: cn = 0, no vertices); words_dev [cap][tile_h * tile_w / 32] = the bit-packed masks.
  * Enqueues on `stream`; does not synchronise. */

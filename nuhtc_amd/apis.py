@@ -51,7 +51,7 @@ class Detector:
                           max_cc_proposals=self.max_cc_proposals, **opts)
         return self._cached(key, make)
 
-    def pipeline(self, tile_hw, depth=6):
+    def pipeline(self, tile_hw, depth=4):
         """`depth` engines on their own streams for the streaming (WSI) path: nuhtc_amd.pipeline.EnginePipeline."""
         from .pipeline import EnginePipeline
         key = (int(tile_hw[0]), int(tile_hw[1]), int(depth))

@@ -759,6 +759,10 @@ int nuhtc_export_kept(nuhtc_engine* e, const nuhtc_dets* dets, int B, const int3
                  e->cfg.tile_h * (e->cfg.tile_w / 32), contour_cap, cap, n_dev, idx_dev, boxes_dev, labels_dev, cn_dev, xy_dev, words_dev};
   int rc = launch_export_kept(p, e->export_pos, (hipStream_t)stream);
   if (rc) FAIL(e, rc, "export launch failed");
+  // n_dev[1]: the capacity flag nuhtc_check reports, so that a caller that fetches results through this export needs no second
+  // round trip (and may have the engine's next batch enqueued already, which resets the flag)
+  if (e->overflow) HIP_CHECK(e, hipMemcpyAsync(n_dev + 1, e->overflow, sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  else HIP_CHECK(e, hipMemsetAsync(n_dev + 1, 0, sizeof(int32_t), (hipStream_t)stream));
   return 0;
 }
 

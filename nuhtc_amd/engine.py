@@ -188,7 +188,7 @@ class Engine:
         ex = getattr(self, '_ex', None)
         if ex is None or ex['cap'] != cap or ex['ccap'] != contour_cap or ex['pool'] != pool:
             dev = lambda *shape, dtype: torch.zeros(*shape, dtype=dtype, device=self.device)
-            names = dict(nk=((1,), torch.int32), idx=((cap,), torch.int64), boxes=((cap, 5), torch.float32), labels=((cap,), torch.int32),
+            names = dict(nk=((2,), torch.int32), idx=((cap,), torch.int64), boxes=((cap, 5), torch.float32), labels=((cap,), torch.int32),
                          cn=((cap,), torch.int32), crop_box=((cap, 4), torch.int32), crop_area=((cap,), torch.int32),
                          crop_off=((cap + 1,), torch.int32), crop_words=((pool,), torch.int32), xy=((cap, contour_cap, 2), torch.int16))
             # every field is a view into ONE device buffer and ONE pinned host buffer: a batch's results leave the device in a single
@@ -198,10 +198,12 @@ class Engine:
                 offs[k] = total
                 total += (int(np.prod(sh)) * torch.empty(0, dtype=dt).element_size() + 255) // 256 * 256
             blob_dev = torch.zeros(total, dtype=torch.uint8, device=self.device)
-            blob_host = torch.zeros(total, dtype=torch.uint8).pin_memory()
+            # two pinned host buffers, used in turn: the views export_read() hands out stay intact while the NEXT batch of this
+            # engine is enqueued and runs (the slide loop resubmits a slot before it unpacks what the slot just delivered)
+            blob_hosts = [torch.zeros(total, dtype=torch.uint8).pin_memory() for _ in range(2)]
             view = lambda blob, k: blob[offs[k]:offs[k] + int(np.prod(names[k][0])) * torch.empty(0, dtype=names[k][1]).element_size()].view(names[k][1]).view(*names[k][0])
-            ex = self._ex = dict(cap=cap, ccap=contour_cap, pool=pool, blob_dev=blob_dev, blob_host=blob_host,
-                                 host={k: view(blob_host, k) for k in names}, dev={k: view(blob_dev, k) for k in names})
+            ex = self._ex = dict(cap=cap, ccap=contour_cap, pool=pool, blob_dev=blob_dev, blob_hosts=blob_hosts, turn=0,
+                                 hosts=[{k: view(b, k) for k in names} for b in blob_hosts], dev={k: view(blob_dev, k) for k in names})
             ex['dev']['words'] = dev(cap, W, dtype=torch.int32)          # full masks of the kept detections: device only
         self.contours_async(B, contour_cap)
         d = ex['dev']
@@ -212,15 +214,22 @@ class Engine:
                                                self._stream()))
         self._check(self.lib.nuhtc_export_crops(self.h, vp(d['words']), vp(d['nk']), cap, vp(d['crop_box']), vp(d['crop_area']), vp(d['crop_off']),
                                                 vp(d['crop_words']), pool, self._stream()))
-        ex['blob_host'].copy_(ex['blob_dev'], non_blocking=True)
+        ex['turn'] ^= 1
+        ex['host'] = ex['hosts'][ex['turn']]
+        ex['blob_hosts'][ex['turn']].copy_(ex['blob_dev'], non_blocking=True)
         ex['B'] = B
+        return ex['turn']
 
-    def export_read(self):
+    def export_read(self, turn=None):
         """-> dict of numpy views (n kept detections: tile index in the batch, slot, box+score, label, contour length
         (<= 0: traced by the host mirror), contour vertices, bit-packed mask words) of the pinned buffers export_async
         filled, or None when the batch held more kept detections than the buffers (use the synchronous path then).
-        The views are valid until the next export_async of this engine."""
-        ex = self._ex['host']
+        The views stay valid through the next export_async of this engine (two host buffers used in turn), not the one after;
+        `turn` selects the buffer of an earlier export_async (its return value) when the next batch has been enqueued already.
+        Raises on the capacity flag of that inference (what check() reports)."""
+        ex = self._ex['hosts'][self._ex['turn'] if turn is None else turn]
+        if int(ex['nk'][1]):
+            raise HipError('connected-component proposals exceeded max_cc_proposals on at least one tile (NUHTC_E_CAPACITY)')
         n = int(ex['nk'][0])
         if n > self._ex['cap']:
             return None

@@ -9,11 +9,12 @@ that copy blocks the submitting thread for ≈ 4 ms per batch, but staging throu
 the kernels: 1431 -> 688 tiles/s; a staging buffer of ordinary memory page-locked with hipHostRegister: 613; the pageable copy on
 an idle per-slot copy stream: 1223), so the plain copy on the slot's stream stays.
 
-Round 3: the engines of a pipeline run the throughput schedule (include/nuhtc_hip.h: one stream per engine, 256-row tiles), and the
-default depth is six: the loop's host waits for the oldest batch before it reuses that slot, so with `depth` slots only depth - 1
-batches are on the GPU while it unpacks and resubmits.  Full path from host tiles (tools/dev/pipe_rate.py): 1.49k tiles/s with four
-slots on the runtime's four hardware queues, 1.71k with six, 1.83k with six and GPU_MAX_HW_QUEUES=16 (the slide tools set it);
-bench.py's loop never waits on the host and peaks at four slots on four queues (1.90k).
+Round 3: the engines of a pipeline run the throughput schedule (include/nuhtc_hip.h: one stream per engine, 256-row tiles), and a
+slot holds up to two exported batches (see EnginePipeline.per_slot): with one batch per slot the batches in flight finish together
+and the GPU idles while the host refills the slots.  Slide level from host tiles (tools/bench_wsi.py, 10 000 tiles): 1.49k tiles/s at
+the start of the round, 1.80k now with four engines and GPU_MAX_HW_QUEUES=16 (the slide tools set it; 1.57k on the runtime's four
+queues, where the caller's stream shares a queue with an engine; 1.73k with three engines on four queues); bench.py's loop never
+waits on the host and runs four engines on four queues at 1.90k.
 
 The reference has no counterpart (its DataLoader overlaps only the CPU tile reads with the GPU, tools/infer_wsi.py:466-476)."""
 import collections
@@ -25,7 +26,7 @@ from .engine import Engine
 
 
 class EnginePipeline:
-    def __init__(self, state_dict, device=0, depth=6, **engine_kw):
+    def __init__(self, state_dict, device=0, depth=4, per_slot=2, **engine_kw):
         if depth > 1:           # engines that run beside each other: throughput schedule (include/nuhtc_hip.h)
             from . import hip
             engine_kw.setdefault('schedule', hip.SCHED_THROUGHPUT)
@@ -34,37 +35,58 @@ class EnginePipeline:
         # every engine runs on the stream it created next to its side streams (nuhtc_stream: three different pipes of the command
         # processor by construction, include/nuhtc_hip.h)
         self.streams = [e.stream for e in self.engines]
-        self.pending = collections.deque()      # (slot, B, event, user tag)
+        self.pending = collections.deque()      # (slot, B, event, user tag, keep-alive, export turn)
         self.next = 0
+        # Batches submitted with export=True leave the device through the engine's two host buffers, used in turn: a slot may hold
+        # `per_slot` = 2 such batches, the second queued behind the first on the slot's stream.  The streams then never run dry while
+        # the host waits for, unpacks and resubmits a batch -- with one batch per slot the batches in flight finish together and the
+        # GPU idles until the host has refilled the slots (1.51k tiles/s against 1.9k for the same four engines fed without pause).
+        # Batches whose results are read from the engine's own tensors (export=False) stay one per slot.
+        self.per_slot = max(1, min(2, int(per_slot)))
 
     @property
     def depth(self):
         return len(self.engines)
 
+    def _held(self, slot):
+        return [p for p in self.pending if p[0] == slot]
+
     def submit(self, tiles, channel_mode, tag=None, export=False):
         """Enqueue one batch (host ndarray / tensor, or device tensor) on the next slot; returns the slot's engine.
-        Blocks only when that slot still holds an uncollected batch.  export=True also enqueues Engine.export_async."""
+        Raises when that slot cannot take another batch (collect() first: see full()).  export=True also enqueues
+        Engine.export_async."""
         slot = self.next
-        if any(p[0] == slot for p in self.pending):
+        held = self._held(slot)
+        if held and (not export or len(held) >= self.per_slot or any(p[5] is None for p in held)):
             raise RuntimeError('pipeline slot still holds an uncollected batch: call collect() first')
         self.next = (slot + 1) % self.depth
         eng, st = self.engines[slot], self.streams[slot]
-        st.wait_stream(torch.cuda.current_stream(self.device))
+        # A device batch was produced on the caller's stream: order the slot's stream behind it.  Host batches need no such wait, and
+        # it is not free: the event is recorded on the caller's stream, which with the runtime's four hardware queues shares a queue
+        # with one of the engines -- the marker then sits behind that engine's queued batches and the new batch waits for them
+        # (the slide loop ran at 1.51k instead of 1.8k tiles/s).
+        if isinstance(tiles, torch.Tensor) and tiles.is_cuda:
+            st.wait_stream(torch.cuda.current_stream(self.device))
         # the host source of an asynchronous H2D copy must outlive the copy: keep it (and the device batch) referenced
         # until the batch is collected, callers may hand in temporaries
         src = torch.from_numpy(np.ascontiguousarray(tiles)) if isinstance(tiles, np.ndarray) else tiles
+        turn = None
         with torch.cuda.stream(st):
             dev = eng.to_device(src)
             B = eng.infer_async(dev, channel_mode)
             if export:                      # contours + gather of the kept detections into pinned host buffers, still asynchronous
-                eng.export_async(B)
+                turn = eng.export_async(B)
             ev = torch.cuda.Event()
             ev.record(st)
-        self.pending.append((slot, B, ev, tag, (dev, src)))
+        self.pending.append((slot, B, ev, tag, (dev, src), turn))
         return eng
 
-    def full(self):
-        return len(self.pending) >= self.depth
+    def full(self, export=False):
+        """No slot free for the next submit() (of that kind)."""
+        held = self._held(self.next)
+        if not held:
+            return False
+        return not export or len(held) >= self.per_slot or any(p[5] is None for p in held)
 
     def close(self):
         for e in self.engines:
@@ -72,11 +94,14 @@ class EnginePipeline:
 
     def collect(self):
         """Oldest submitted batch: waits for it and returns (engine, B, stream, tag); read the engine's output tensors on
-        `stream` (torch.cuda.stream(stream)) before submitting to that slot again."""
-        slot, B, ev, tag, _ = self.pending.popleft()
+        `stream` (torch.cuda.stream(stream)) before submitting to that slot again -- or, for a batch submitted with export=True,
+        read `engine.export_read(pipeline.last_turn)`: the engine's own tensors may belong to the slot's next batch by then."""
+        slot, B, ev, tag, _, turn = self.pending.popleft()
         ev.synchronize()
-        with torch.cuda.stream(self.streams[slot]):      # (the flags are read on the slot's own, by now idle, stream)
-            self.engines[slot].check()
+        self.last_turn = turn
+        if turn is None:
+            with torch.cuda.stream(self.streams[slot]):      # (the flags are read on the slot's own, by now idle, stream)
+                self.engines[slot].check()
         return self.engines[slot], B, self.streams[slot], tag
 
     def drain(self):

@@ -203,40 +203,48 @@ def _unpack(eng, B, i0, coords, P, rec, exported=False):
         rec['ring'].append(np.concatenate([c, c[:1]], 0) + np.array([ox, oy], np.int64))   # mask2inst + contour_map
 
 
-def infer_tiles(model, tiles, coords, batch_size=16, depth=6):
+def infer_tiles(model, tiles, coords, batch_size=16, depth=4):
     """Run the engine over `tiles` (N,P,P,3) and return per-detection records that survive the per-tile margin /
-    min-area filter + mask-NMS (computed on the GPU, tools/infer_wsi.py:510-531), in slide coordinates.  `depth` batches
-    are kept in flight (nuhtc_amd.pipeline): the host unpacks batch i while the GPU runs batch i+1.
+    min-area filter + mask-NMS (computed on the GPU, tools/infer_wsi.py:510-531), in slide coordinates.  `depth` engines
+    are kept busy with up to two batches each (nuhtc_amd.pipeline): the host unpacks batch i while the GPU runs the next ones.
 
     Returns dict(tile, box (n,4) float64 slide px, score, label, mask (list of (bool crop, x0, y0)), ring (closed
     (n+1,2) int64 contour in slide px, traced on the GPU: nuhtc_mask_contours))."""
     import torch
     P = tiles.shape[1]
-    parts = []
+    parts = {}                 # first tile of the batch -> the batch's records (array form), joined in batch order at the end
+    redo = []
     pipe = model.pipeline(tiles.shape[1:3], depth)
 
     def finish():
         eng, B, stream, i0 = pipe.collect()
-        with torch.cuda.stream(stream):
-            g = eng.export_read()
-            if g is not None:
-                if g['n']:
-                    _unpack_packed(eng, g, i0, coords, parts)      # device crops: whole-batch array operations
-            else:
-                # this batch alone held more kept detections than the export buffers: its records come through the per-detection
-                # path and join the others as one more part (later batches keep the packed path)
-                one = dict(tile=[], box=[], score=[], label=[], mask=[], ring=[])
-                _unpack(eng, B, i0, coords, P, one, exported=False)
-                if one['tile']:
-                    parts.append(_part_from_lists(one))
+        g = eng.export_read(pipe.last_turn)
+        if g is not None and g['crop_total'] <= g['pool']:
+            if g['n']:
+                one = []
+                _unpack_packed(eng, g, i0, coords, one)            # device crops: whole-batch array operations
+                if one:
+                    parts[i0] = one[0]
+        else:
+            # this batch alone held more kept detections (or mask-crop words) than the export buffers: its records have to come from
+            # the engine's own tensors, which may belong to the slot's next batch by now -- it is run again, alone, at the end
+            redo.append(i0)
 
     for i in range(0, len(tiles), batch_size):
-        if pipe.full():
+        if pipe.full(export=True):
             finish()
         pipe.submit(tiles[i:i + batch_size], hip.CH_SWAP, tag=i, export=True)
     while pipe.pending:
         finish()
-    return _records_from_parts(parts)
+    for i0 in redo:            # the per-detection path (later batches kept the packed path)
+        eng = pipe.submit(tiles[i0:i0 + batch_size], hip.CH_SWAP, tag=i0, export=False)
+        eng, B, stream, _ = pipe.collect()
+        with torch.cuda.stream(stream):
+            one = dict(tile=[], box=[], score=[], label=[], mask=[], ring=[])
+            _unpack(eng, B, i0, coords, P, one, exported=False)
+            if one['tile']:
+                parts[i0] = _part_from_lists(one)
+    return _records_from_parts([parts[k] for k in sorted(parts)])
 
 
 def _part_from_lists(rec):

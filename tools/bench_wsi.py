@@ -15,8 +15,8 @@ import sys
 import time
 
 # 16 hardware queues instead of the HIP runtime's 4 (read when the runtime initialises; an exported value wins): the slide loop keeps
-# six one-stream engines in flight (nuhtc_amd.pipeline), and its host waits for every batch's results -- 1.49k tiles/s with four
-# engines on the default queues, 1.71k with six, 1.83k with six on 16 queues (tools/dev/pipe_rate.py)
+# four one-stream engines busy (nuhtc_amd.pipeline) and also uses the caller's stream -- with four queues that stream shares a
+# queue with an engine: 1.57k tiles/s slide-level against 1.80k with 16 queues (three engines on four queues: 1.73k)
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
 
 import numpy as np
@@ -28,7 +28,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--grid', type=int, default=100, help='tiles per side (default 100 -> 10 000 tiles)')
     ap.add_argument('--batch_size', type=int, default=16)
-    ap.add_argument('--depth', type=int, default=6, help='batches in flight per GPU')
+    ap.add_argument('--depth', type=int, default=4, help='engines (slots) per GPU; each holds up to two batches')
     ap.add_argument('--overlap_threshold', type=float, default=0.05)
     ap.add_argument('--workers', type=int, default=16, help='host processes rendering the synthetic canvas')
     ap.add_argument('--config', default=os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'configs/nuhtc/htc_lite_swin_pannuke_infer.py'))
