@@ -361,3 +361,50 @@ def test_roi_features_giant_boxes_at_1024_px(hip_device):
     side = (r2[:, 3:] - r2[:, 1:3]).max(1).values
     print(f'boxes {float(side.min()):.0f}..{float(side.max()):.0f} px: big {int(counts[0])}, giant {int(counts[2])}, max |err| {float(err.max()):.2e}')
     assert float(err.max()) <= 2e-4, float(err.max())
+
+
+@pytest.mark.gpu
+def test_roi_features_long_lists_and_batch_independence(hip_device):
+    """The mid-size and big-box RoI kernels have a short-list and a long-list form (roi.hip: roi_feat7_stream_few_kernel / one
+    workgroup per map below 1024 / 512 boxes per batch, roi_feat7_stream_kernel / one workgroup per box above).  Here the lists are
+    long -- 1400 RoIs of 44-300 px per tile -- and checked against the oracle on a sample; then the first 150 RoIs of every tile are
+    run alone (short lists): their features must be the same BIT FOR BIT, a box's result may not depend on what else the batch holds."""
+    import torch
+    from nuhtc_amd import hip, synth, weights
+    from nuhtc_amd.engine import Engine
+    from oracle import model as O
+    sd = weights.bench_state_dict(3)
+    B, n, m = 2, 1400, 150
+    eng = Engine(sd, device=0, max_batch=B, tile=(256, 256))
+    eng.enable_token_dump()
+    rng = np.random.default_rng(23)
+    wh = np.concatenate([rng.uniform(44, 112, (n // 2, 2)), rng.uniform(112, 300, (n // 2, 2))])
+    wh = np.stack([rng.permutation(wh) for _ in range(B)]).astype(np.float32)
+    ctr = rng.uniform(0, 512, (B, n, 2)).astype(np.float32)
+    rois = np.clip(np.concatenate([ctr - wh / 2, ctr + wh / 2], -1), 0, 512).astype(np.float32)
+    rois[:, :, 2:] = np.maximum(rois[:, :, 2:], rois[:, :, :2] + 4)
+    tiles = eng.to_device(synth.nuclei_tiles(B, 256, start=3))
+    eng.infer_fixed_load_async(tiles, torch.from_numpy(rois).to(tiles.device), 40, hip.CH_SWAP)
+    eng.check()
+    counts = eng.buffer('roi_fallback_count').cpu().numpy()
+    assert counts[0] > 512 and counts[1] > 1024, counts           # long lists: the one-workgroup-per-box / one-wave-per-RoI forms ran
+    R = B * n
+    feats_long = eng.buffer('bbox_feats')[:R].cpu().clone()
+    x = [_nchw(eng.buffer(f'x{i}')[:B]) for i in range(4)]
+    sem_feat = _nchw(eng.buffer('sem_feat')[:B])
+    r2 = eng.buffer('rois_stage2')[:R].cpu()
+    pick = torch.from_numpy(np.sort(rng.choice(R, 240, replace=False)))
+    with torch.no_grad():
+        ref = O.bbox_feats(x, sem_feat, r2[pick])
+    got = feats_long[pick].reshape(len(pick), 7, 7, 64).permute(0, 3, 1, 2)
+    err = float((got - ref).abs().max())
+    print(f'long lists: big {int(counts[0])}, mid {int(counts[1])}; max |err| against the oracle on 240 RoIs {err:.2e}')
+    assert err <= 2e-4, err
+    # the same tiles with the first m RoIs of each alone: short lists
+    eng.infer_fixed_load_async(tiles, torch.from_numpy(np.ascontiguousarray(rois[:, :m])).to(tiles.device), 40, hip.CH_SWAP)
+    eng.check()
+    c2 = eng.buffer('roi_fallback_count').cpu().numpy()
+    assert 0 < c2[0] <= 512 and 0 < c2[1] <= 1024, c2
+    feats_short = eng.buffer('bbox_feats')[:B * m].cpu()
+    for b in range(B):
+        assert torch.equal(feats_short[b * m:(b + 1) * m], feats_long[b * n:b * n + m]), f'tile {b}: features depend on the rest of the batch'
