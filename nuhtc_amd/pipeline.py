@@ -37,6 +37,7 @@ class EnginePipeline:
         self.streams = [e.stream for e in self.engines]
         self.pending = collections.deque()      # (slot, B, event, user tag, keep-alive, export turn)
         self.next = 0
+        self.last_turn = None                   # export buffer of the batch collect() returned last (Engine.export_read(turn))
         # Batches submitted with export=True leave the device through the engine's two host buffers, used in turn: a slot may hold
         # `per_slot` = 2 such batches, the second queued behind the first on the slot's stream.  The streams then never run dry while
         # the host waits for, unpacks and resubmits a batch -- with one batch per slot the batches in flight finish together and the
