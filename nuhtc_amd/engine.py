@@ -218,6 +218,7 @@ class Engine:
         ex['host'] = ex['hosts'][ex['turn']]
         ex['blob_hosts'][ex['turn']].copy_(ex['blob_dev'], non_blocking=True)
         ex['B'] = B
+        self._read_turn = None          # (EnginePipeline.collect points export_read() at the buffer of the batch it returns)
         return ex['turn']
 
     def export_read(self, turn=None):
@@ -227,6 +228,8 @@ class Engine:
         The views stay valid through the next export_async of this engine (two host buffers used in turn), not the one after;
         `turn` selects the buffer of an earlier export_async (its return value) when the next batch has been enqueued already.
         Raises on the capacity flag of that inference (what check() reports)."""
+        if turn is None:
+            turn = getattr(self, '_read_turn', None)
         ex = self._ex['hosts'][self._ex['turn'] if turn is None else turn]
         if int(ex['nk'][1]):
             raise HipError('connected-component proposals exceeded max_cc_proposals on at least one tile (NUHTC_E_CAPACITY)')

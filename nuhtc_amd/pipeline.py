@@ -100,6 +100,7 @@ class EnginePipeline:
         slot, B, ev, tag, _, turn = self.pending.popleft()
         ev.synchronize()
         self.last_turn = turn
+        self.engines[slot]._read_turn = turn      # export_read() of the returned engine reads THIS batch, not the slot's next one
         if turn is None:
             with torch.cuda.stream(self.streams[slot]):      # (the flags are read on the slot's own, by now idle, stream)
                 self.engines[slot].check()
