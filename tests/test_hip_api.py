@@ -428,6 +428,20 @@ def test_throughput_schedule_is_bit_identical(hip_device):
     assert n == int(b.buffer('roi_total').item()) and torch.equal(a.buffer('rois')[:n], b.buffer('rois')[:n])
     for f in ('counts', 'boxes', 'labels', 'masks', 'keep'):
         assert torch.equal(getattr(a, f), getattr(b, f)), f
+    # RoIs of every size class through the fixed-load entry point: the single-stream order of the RoI kernels gives the same features
+    rng = np.random.default_rng(5)
+    n = 300
+    wh = np.concatenate([rng.uniform(8, 44, (n // 3, 2)), rng.uniform(44, 112, (n // 3, 2)), rng.uniform(112, 300, (n // 3, 2))]).astype(np.float32)
+    ctr = rng.uniform(0, 512, (3, n, 2)).astype(np.float32)
+    rois = np.clip(np.concatenate([ctr - wh[None] / 2, ctr + wh[None] / 2], -1), 0, 512).astype(np.float32)
+    rois[:, :, 2:] = np.maximum(rois[:, :, 2:], rois[:, :, :2] + 4)
+    for e in (a, b):
+        t = e.to_device(tiles_np)
+        e.infer_fixed_load_async(t, torch.from_numpy(rois).to(t.device), 30, hip.CH_SWAP); e.check()
+    ca = a.buffer('roi_fallback_count').cpu().numpy()
+    assert ca[0] > 50 and ca[1] > 50, ca
+    assert torch.equal(a.buffer('bbox_feats')[:3 * n], b.buffer('bbox_feats')[:3 * n])
+    assert torch.equal(a.boxes, b.boxes) and torch.equal(a.masks, b.masks)
     a.close(); b.close()
     with pytest.raises(HipError):
         Engine(sd, device=0, max_batch=1, tile=(256, 256), schedule=7)
