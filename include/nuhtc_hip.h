@@ -240,10 +240,14 @@ int nuhtc_op_roi_align(nuhtc_engine* e, const float* feat_nhwc, int N, int H, in
 int nuhtc_op_nms(nuhtc_engine* e, const float* boxes, const float* scores, int n, float iou_thr, int32_t* keep_idx,
                  int32_t* count_dev, void* stream);
 
-/* A HIP stream owned by the engine (valid after nuhtc_finalize, destroyed with the engine) that a caller MAY run this engine on,
+/* A HIP stream owned by the engine (valid after nuhtc_finalize) that a caller MAY run this engine on,
  * and should when it keeps several engines busy at once or raises GPU_MAX_HW_QUEUES above the runtime's default of 4: the stream
  * is created next to the engine's two internal side streams, which puts the three on different pipes of the command processor
- * (batches in flight).  Any other stream remains valid for every entry point. */
+ * (batches in flight).  Any other stream remains valid for every entry point.
+ * LIFETIME: the engine's streams are POOLED for the life of the process, not destroyed: nuhtc_destroy hands the (own, side, side2)
+ * triple back to a per-device pool and the next engine created on that device reuses the same handles (PyTorch's allocator touches a
+ * block's allocation stream when it frees the block, long after the engine is gone).  A caller must therefore NOT use, wait on or
+ * record into the handle after nuhtc_destroy: it may already belong to an unrelated engine. */
 void* nuhtc_stream(nuhtc_engine* e);
 
 /* Per-kernel timing with HIP events recorded on the launch stream (process-wide switch; off by default).

@@ -118,13 +118,21 @@ def inference_detector(model, imgs):
         arrs, mode = [np.asarray(i) for i in imgs], hip.CH_SWAP
     else:
         arrs, mode = [_load_image_rgb(p) for p in imgs], hip.CH_AS_IS
-    shapes = {a.shape for a in arrs}
-    if len(shapes) != 1:
-        raise ValueError(f'all images of one inference_detector call must share one size, got {sorted(shapes)}')
-    if arrs[0].ndim != 3 or arrs[0].shape[2] != 3 or arrs[0].dtype != np.uint8:
-        raise ValueError('images must be uint8 HxWx3')
-    eng = model.engine(arrs[0].shape[:2])
-    results = eng(np.stack(arrs), mode)
+    for a in arrs:
+        if a.ndim != 3 or a.shape[2] != 3 or a.dtype != np.uint8:
+            raise ValueError('images must be uint8 HxWx3')
+    # A list may mix sizes (mmdet/apis/inference.py:118-139 collates whatever it is given).  Images are grouped by size, every size
+    # runs on its own engine (the Detector keeps the most recently used `max_engines` sizes) and the results go back in input order.
+    # Deviation, stated: the reference pads a mixed batch to its largest member, so there an image's features near its right / bottom
+    # edge depend on its batch mates; here every image is computed as the reference computes it in a batch of its own size.
+    by_shape = {}
+    for i, a in enumerate(arrs):
+        by_shape.setdefault(a.shape[:2], []).append(i)
+    results = [None] * len(arrs)
+    for hw, idx in by_shape.items():
+        eng = model.engine(hw)
+        for i, r in zip(idx, eng(np.stack([arrs[i] for i in idx]), mode)):
+            results[i] = r
     return results if is_batch else results[0]
 
 

@@ -117,12 +117,9 @@ struct GemmParams {
   const Conv3Fuse* fuse;        // host-side: pointwise layer fused into an A_CONV3 product (only on the conv.hip path; else NUHTC_E_INVALID)
 };
 int launch_gemm(const GemmParams& p, hipStream_t s);
-// exact three-way bf16 split of a constant weight matrix (host copy given), keyed by its fp32 device pointer: launch_gemm then
-// runs that product on the bf16 matrix pipe (gemm.hip).  gemm_unregister_split frees the split copy.
-int gemm_register_split(const float* w_dev, const float* w_host, int N, int K);
-void gemm_unregister_split(const float* w_dev);
-int gemm_make_split(const float* w_host, int N, int K, void** out_dev);      // unregistered split (caller hipFree()s it)
-const void* gemm_find_split(const float* w_dev, int N, int K);
+// exact three-way bf16 split of a constant weight matrix (host copy given) -> device buffer Wsplit[n][k/8][plane][8 bf16]; a launch whose
+// GemmParams.Wsplit points at it runs on the bf16 matrix pipe (gemm.hip).  The caller owns the buffer (hipFree).
+int gemm_make_split(const float* w_host, int N, int K, void** out_dev);
 
 // 3x3 convolution 64 -> 64 with the input halo resident in LDS as bf16 planes (conv.hip); launch_gemm routes A_CONV3 products with a
 // split weight there

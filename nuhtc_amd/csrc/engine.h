@@ -1,5 +1,7 @@
 // Engine state of libnuhtc_hip.so (host side).
 #pragma once
+#include <unordered_map>
+
 #include "common.h"
 
 struct StageGeom {
@@ -29,7 +31,9 @@ struct nuhtc_engine {
   std::map<std::string, std::vector<int64_t>> schema;   // names / shapes nuhtc_load_weight accepts
   std::map<std::string, BufInfo> bufs;
   std::vector<void*> allocs;
-  std::vector<const float*> split_weights;   // weights registered with gemm_register_split (bf16 matrix pipe)
+  // fp32 weight pointer -> its exact bf16 split (gemm_make_split), filled by upload_gemm_weight at finalize and read by egemm for every
+  // launch: the engine's own table (a handle is not thread-safe by contract, so no lock); the buffers are in `allocs`
+  std::unordered_map<const float*, const void*> wsplit;
   size_t bytes_allocated = 0;
   bool finalized = false;
   bool debug_tokens = false;
@@ -72,8 +76,10 @@ struct nuhtc_engine {
   struct RoiWs* rw = nullptr;
 };
 
-// uploads a GEMM weight [N][K] and, unless cfg.matrix_pipe == NUHTC_PIPE_FP32, registers its exact bf16 split (gemm.hip)
+// uploads a GEMM weight [N][K] and, unless cfg.matrix_pipe == NUHTC_PIPE_FP32, its exact bf16 split (gemm.hip) into e->wsplit
 int upload_gemm_weight(nuhtc_engine* e, float** dst, const std::vector<float>& v, int N, int K);
+// launch_gemm with the split of p.W taken from the engine's table (bf16 matrix pipe) when the engine has one
+int egemm(nuhtc_engine* e, GemmParams p, hipStream_t s);
 int finalize_roi(nuhtc_engine* e);
 int alloc_roi_workspace(nuhtc_engine* e);
 // rois_fixed != null -> fixed-load mode

@@ -8,6 +8,7 @@
 // aggregation products (nuhtc/models/roi_extractors_cus.py:228-235).
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <vector>
 #include <cstdio>
@@ -458,8 +459,14 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void gemm_split_kernel
   float* __restrict__ C = p.C + (long long)z * p.sC;
   const char* __restrict__ Wsp = reinterpret_cast<const char*>(p.Wsplit);
 
-  // ---- A staging assignment (as in gemm_kernel: clamped rows, out-of-image conv taps read a page of zeros)
-  const int kc = tid % KC, rbase = tid / KC;
+  // ---- A staging assignment (as in gemm_kernel: clamped rows, out-of-image conv taps read a page of zeros).  Four consecutive lanes
+  // fetch one 64-byte row segment (one request of the texture path).  ds_write_b128 is served in groups of 8 consecutive lanes against
+  // 32 banks, i.e. two rows of four 16-byte slots: with the row pitch of 20 dwords (5 slots: what makes the fragment reads conflict-free)
+  // rows r and r + 1 overlap in one slot (5 = 4 + 1), rows r and r + 4 do not (20 = 4 mod 8) -- so a lane quad q stages row
+  // 8 (q / 8) + 4 (q & 1) + ((q >> 1) & 3) of the pass: every staging store is conflict-free (round 3 paired rows r, r + 1: every
+  // store took twice its LDS cycles; PMC: 30 % of the kernel's LDS-active cycles were conflict cycles)
+  static_assert(KC == 4 && RPP == 64, "staging lane map below assumes BK = 16");
+  const int kc = tid & 3, rbase = ((tid >> 5) << 3) + (((tid >> 2) & 1) << 2) + ((tid >> 3) & 3);
   const float* a_ptr[NA];
   unsigned a_ok[NA];
 #pragma unroll
@@ -483,7 +490,12 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void gemm_split_kernel
       a_ptr[j] = A + (long long)m * p.cC + kc * 4;
     }
   }
-  // ---- B staging assignment: chunk q = tid + 256 j -> column q / 6, 16-byte piece q % 6 of its 96 bytes
+  // ---- B staging assignment: chunk q = tid + 256 j.  A column's 96 bytes are three 32-byte units (two 16-byte pieces, one lane pair
+  // each); a store group of 8 lanes = 4 units must hit 8 different slots of 8: slot(n, c) = 7 n + c = c - n (mod 8), so the units of
+  // the EVEN columns in natural order (column major, unit minor), then those of the odd columns, advance the slot pair by exactly 2
+  // per unit -- any four consecutive units tile the 8 slots (round 3 walked all columns in order: the 2 pieces of the next column
+  // landed on the banks of piece 0).  Lane quads still fetch 64 contiguous bytes or two 32-byte runs.
+  static_assert((3 * BN / 2) % 4 == 0, "a store group must not straddle the two column classes");
   const char* w_ptr[NB];
   int w_lds[NB];
   const long long wpitch = (long long)(p.K / 8) * 48;             // bytes per column of Wsplit
@@ -491,7 +503,8 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void gemm_split_kernel
   for (int j = 0; j < NB; ++j) {
     int q = tid + 256 * j;
     q = q < NCH ? q : NCH - 1;
-    const int n = q / 6, c = q - n * 6;
+    const int t = q >> 1, par = t / (3 * BN / 2), t2 = t - par * (3 * BN / 2), m = t2 / 3, u = t2 - 3 * m;
+    const int n = 2 * m + par, c = 2 * u + (q & 1);
     w_ptr[j] = Wsp + (long long)(n0 + n) * wpitch + c * 16;
     w_lds[j] = n * BP + c * 4;                                      // float index inside a Bs buffer
   }
@@ -726,11 +739,7 @@ static const float* zero_page() {
   return z;
 }
 
-// ---- registry of split weights: fp32 weight pointer -> Wsplit[n][k/8][3][8 bf16] on the same device
-struct SplitEnt { void* dev; int N, K; };
-static std::map<const float*, SplitEnt> g_split;
-static std::mutex g_split_mu;
-
+// ---- split weights: Wsplit[n][k/8][3][8 bf16] on the same device, owned by the engine that uploaded the weight (engine.hip egemm)
 static inline unsigned short bf16_rn_bits(float f) {     // round to nearest even; a NaN stays a NaN (the integer carry would turn some into 0 / Inf)
   unsigned u;
   memcpy(&u, &f, 4);
@@ -767,31 +776,6 @@ int gemm_make_split(const float* w_host, int N, int K, void** out) {
   return 0;
 }
 
-int gemm_register_split(const float* w_dev, const float* w_host, int N, int K) {
-  if (!w_dev) return NUHTC_E_INVALID;
-  void* d = nullptr;
-  int rc = gemm_make_split(w_host, N, K, &d);
-  if (rc) return rc;
-  std::lock_guard<std::mutex> lock(g_split_mu);
-  auto it = g_split.find(w_dev);
-  if (it != g_split.end()) hipFree(it->second.dev);         // a re-registered pointer (freed and reallocated weight): drop the stale split
-  g_split[w_dev] = SplitEnt{d, N, K};
-  return 0;
-}
-
-// the registered split of a weight (null when there is none): engines cache it at finalize so launches skip the lookup
-const void* gemm_find_split(const float* w_dev, int N, int K) {
-  std::lock_guard<std::mutex> lock(g_split_mu);
-  auto it = g_split.find(w_dev);
-  return (it != g_split.end() && it->second.N == N && it->second.K == K) ? it->second.dev : nullptr;
-}
-
-void gemm_unregister_split(const float* w_dev) {
-  std::lock_guard<std::mutex> lock(g_split_mu);
-  auto it = g_split.find(w_dev);
-  if (it != g_split.end()) { hipFree(it->second.dev); g_split.erase(it); }
-}
-
 template <int MT, int NT>
 static void launch_split(const GemmParams& q, hipStream_t s) {
   const int mtiles = cdiv(q.M, 128 * MT);
@@ -814,14 +798,9 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
   if ((p.res && (long long)p.M * p.ldr >= (1ll << 31)) || (p.up && (long long)p.M * p.N >= (1ll << 31))) return NUHTC_E_INVALID;
   GemmParams q = p;
   if (q.alpha == 0.f) q.alpha = 1.f;
-  // a weight registered at finalize runs on the bf16 pipe with exactly split operands; products of depth < 96 stay on the fp32
-  // MFMA kernel (4 k-tiles: prologue and epilogue dominate and the fp32 kernel keeps 4 workgroups per CU; measured 0.28 vs
-  // 0.32-0.40 ms per step for the 64x64 pointwise layers)
-  if (!q.Wsplit && q.batch <= 1 && q.K >= 96) {
-    std::lock_guard<std::mutex> lock(g_split_mu);
-    auto it = g_split.find(p.W);
-    if (it != g_split.end() && it->second.N == p.N && it->second.K == p.K) q.Wsplit = it->second.dev;
-  }
+  // a product whose caller passes the weight's exact bf16 split (GemmParams.Wsplit) runs on the bf16 pipe; the engine passes it for
+  // products of depth >= 96 only (engine.hip egemm)
+  if (q.Wsplit && q.batch > 1) q.Wsplit = nullptr;
   // column-tile width: the widest the shape allows, narrowed for small problems until the launch has enough workgroups for the
   // 256 CUs (a 128x96 tile grid of a few hundred blocks leaves most SIMDs with one wave or none).  Launches whose row count lives
   // on the device (RoI / detection lists) are sized by capacity; about half of it is populated at the bench load.

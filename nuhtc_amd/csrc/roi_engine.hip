@@ -282,12 +282,12 @@ int run_roi_path(nuhtc_engine* e, int B, const float* rois_fixed, int n_rois, in
       GemmParams p1 = gpr(e->x[l], e->x[l], nullptr, w->ap_S, HW, HW, 64);
       p1.act = ACT_COS; p1.cos_ri = w->ap_inv; p1.cos_rj = w->ap_inv; p1.cos_tau = c.att_thres;
       p1.batch = B; p1.sA = (long long)HW * 64; p1.sW = (long long)HW * 64; p1.sC = (long long)HW * HW; p1.sRi = HW; p1.sRj = HW;
-      RUN(launch_gemm(p1, s));
+      RUN(egemm(e, p1, s));
       RUN(launch_transpose(e->x[l], w->ap_Ft, B, HW, 64, s));
       GemmParams p2 = gpr(w->ap_S, w->ap_Ft, nullptr, G, HW, 64, HW);
       p2.alpha = 1.0f / (float)HW;
       p2.batch = B; p2.sA = (long long)HW * HW; p2.sW = (long long)HW * 64; p2.sC = (long long)HW * 64;
-      RUN(launch_gemm(p2, s));
+      RUN(egemm(e, p2, s));
     } else {
       RUN(launch_attn_pool(e->x[l], G, B, HW, c.att_thres, s));
     }
@@ -315,12 +315,12 @@ int run_roi_path(nuhtc_engine* e, int B, const float* rois_fixed, int n_rois, in
     {
       GemmParams p = gpr(w->feats, e->fc1_w[k], e->fc1_b[k], w->h1, Rcap, 256, 3136);
       p.act = ACT_RELU; p.m_dev = w->roi_total;
-      RUN(launch_gemm(p, s));
+      RUN(egemm(e, p, s));
     }
     {
       GemmParams p = gpr(w->h1, e->fc2_w[k], e->fc2_b[k], w->h2, Rcap, 256, 256);
       p.act = ACT_RELU; p.m_dev = w->roi_total;
-      RUN(launch_gemm(p, s));
+      RUN(egemm(e, p, s));
     }
     BboxTailParams tp;
     tp.h = w->h2; tp.w = e->head_w[k]; tp.b = e->head_b[k]; tp.nc = c.num_classes; tp.r_dev = w->roi_total; tp.cls = w->cls[k]; tp.reg = w->reg[k];
@@ -365,14 +365,14 @@ int run_roi_path(nuhtc_engine* e, int B, const float* rois_fixed, int n_rois, in
   for (int j = 0; j < 4; ++j) {
     GemmParams p = gpr(a, e->mk_w[j], e->mk_b[j], b, Dcap * 196, 64, 576);
     p.amode = A_CONV3; p.cH = 14; p.cW = 14; p.cC = 64; p.act = ACT_RELU; p.m_dev = w->det_total; p.m_mul = 196;
-    RUN(launch_gemm(p, s));
+    RUN(egemm(e, p, s));
     a = b;
     b = (b == w->mtmpA) ? w->mtmpB : w->mtmpA;
   }
   {
     GemmParams p = gpr(a, e->mk_up_w, e->mk_up_b, w->mup, Dcap * 196, 256, 64);
     p.act = ACT_RELU; p.store = ST_DECONV2; p.cH = 14; p.cW = 14; p.ldc = 64; p.m_dev = w->det_total; p.m_mul = 196;
-    RUN(launch_gemm(p, s));
+    RUN(egemm(e, p, s));
   }
   RUN(launch_conv1x1_n1_dev(w->mup, e->mk_lw, e->mk_lb, w->mprob, Dcap * 784, w->det_total, 784, 1, s));
   PasteParams pp;

@@ -30,6 +30,8 @@ _TORCH = {0: torch.float32, 1: torch.int32, 2: torch.uint8, 3: torch.int32}
 
 
 class Engine:
+    EXPORT_BUFFERS = 3          # pinned host buffers of export_async: batches per pipeline slot (2) + 1, see export_async
+
     def __init__(self, state_dict, device=0, max_batch=16, tile=(256, 256), num_classes=5, **cfg_overrides):
         if not torch.cuda.is_available():
             raise HipError('no HIP device visible: nuhtc_amd has no CPU path (the CPU oracle lives under oracle/ and is test-only)')
@@ -75,13 +77,16 @@ class Engine:
         # a stream of the engine's own (nuhtc_stream): EnginePipeline runs the engine on it; any other stream works as well
         self.stream = torch.cuda.ExternalStream(self.lib.nuhtc_stream(self.h), device=self.device)
         B, K = cfg.max_batch, cfg.max_per_img
-        with torch.cuda.device(self.device):
+        # allocated and zero-filled ON the engine's stream (hipStreamNonBlocking: nothing would order memsets of the caller's stream
+        # before the first batch there), so the blocks also live in the allocator pool of the stream they are used on
+        with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
             self.boxes = torch.zeros(B, K, 5, dtype=torch.float32, device=self.device)
             self.labels = torch.zeros(B, K, dtype=torch.int32, device=self.device)
             self.counts = torch.zeros(B, dtype=torch.int32, device=self.device)
             self.masks = torch.zeros(B, K, cfg.tile_h, cfg.tile_w // 32, dtype=torch.int32, device=self.device)
             self.areas = torch.zeros(B, K, dtype=torch.int32, device=self.device)
             self.keep = torch.zeros(B, K, dtype=torch.uint8, device=self.device)
+        self.stream.synchronize()       # creation is synchronous anyway (nuhtc_finalize): the zero fills are complete whatever stream the caller uses
         self.dets = hip.Dets(self.boxes.data_ptr(), self.labels.data_ptr(), self.counts.data_ptr(), self.masks.data_ptr(),
                              self.areas.data_ptr(), self.keep.data_ptr())
 
@@ -198,9 +203,11 @@ class Engine:
                 offs[k] = total
                 total += (int(np.prod(sh)) * torch.empty(0, dtype=dt).element_size() + 255) // 256 * 256
             blob_dev = torch.zeros(total, dtype=torch.uint8, device=self.device)
-            # two pinned host buffers, used in turn: the views export_read() hands out stay intact while the NEXT batch of this
-            # engine is enqueued and runs (the slide loop resubmits a slot before it unpacks what the slot just delivered)
-            blob_hosts = [torch.zeros(total, dtype=torch.uint8).pin_memory() for _ in range(2)]
+            # EXPORT_BUFFERS = 3 pinned host buffers, used in turn.  A pipeline slot holds up to two exported batches (A running or
+            # done, B queued behind it); when A has been collected and the slot is resubmitted (C) BEFORE A's views are unpacked, C's
+            # copy must not land in A's buffer nor in B's: three buffers.  The views of a collected batch stay intact until the second
+            # export_async after the one that filled them (i.e. until the slot's next-but-one batch is enqueued)
+            blob_hosts = [torch.zeros(total, dtype=torch.uint8).pin_memory() for _ in range(self.EXPORT_BUFFERS)]
             view = lambda blob, k: blob[offs[k]:offs[k] + int(np.prod(names[k][0])) * torch.empty(0, dtype=names[k][1]).element_size()].view(names[k][1]).view(*names[k][0])
             ex = self._ex = dict(cap=cap, ccap=contour_cap, pool=pool, blob_dev=blob_dev, blob_hosts=blob_hosts, turn=0,
                                  hosts=[{k: view(b, k) for k in names} for b in blob_hosts], dev={k: view(blob_dev, k) for k in names})
@@ -214,7 +221,7 @@ class Engine:
                                                self._stream()))
         self._check(self.lib.nuhtc_export_crops(self.h, vp(d['words']), vp(d['nk']), cap, vp(d['crop_box']), vp(d['crop_area']), vp(d['crop_off']),
                                                 vp(d['crop_words']), pool, self._stream()))
-        ex['turn'] ^= 1
+        ex['turn'] = (ex['turn'] + 1) % self.EXPORT_BUFFERS
         ex['host'] = ex['hosts'][ex['turn']]
         ex['blob_hosts'][ex['turn']].copy_(ex['blob_dev'], non_blocking=True)
         ex['B'] = B
@@ -225,7 +232,8 @@ class Engine:
         """-> dict of numpy views (n kept detections: tile index in the batch, slot, box+score, label, contour length
         (<= 0: traced by the host mirror), contour vertices, bit-packed mask words) of the pinned buffers export_async
         filled, or None when the batch held more kept detections than the buffers (use the synchronous path then).
-        The views stay valid through the next export_async of this engine (two host buffers used in turn), not the one after;
+        The views stay valid through the next TWO export_async calls of this engine (EXPORT_BUFFERS = 3 host buffers used in turn:
+        a slot of an EnginePipeline may be resubmitted before the batch it just delivered is unpacked), not the one after those;
         `turn` selects the buffer of an earlier export_async (its return value) when the next batch has been enqueued already.
         Raises on the capacity flag of that inference (what check() reports)."""
         if turn is None:

@@ -126,16 +126,21 @@ def profile_read():
 
 class ClockProbe:
     """Shader clock held while other kernels run: start() enqueues the one-wave probe for `ms` milliseconds, ghz() waits for it and
-    returns cycles / reference ticks x 0.1 GHz.  The probe goes to the device's NULL stream: an engine's three streams take three
-    of the runtime's four hardware queues, and a probe on a stream that shares a queue with the engine would run alone, ahead of
-    the steps it is meant to run beside (it then reports the idle clock).  The engine's streams are non-blocking: the null stream
-    does not synchronise with them."""
+    returns cycles / reference ticks x 0.1 GHz.  The probe runs on a NON-BLOCKING stream of its own (never the legacy null stream:
+    a kernel spinning there serialises every blocking stream of the process, torch's default stream included, for the whole probe).
+    Create the probe AFTER the engines: streams are dealt round the runtime's hardware queues in creation order, and a probe that
+    shares a queue with an engine runs alone, ahead of the steps it is meant to run beside (it then reports the idle clock: with
+    four one-stream engines on the default four queues that cannot be avoided, and ghz() is then the clock between their batches)."""
 
     def __init__(self, device=0, stream=None):
         import torch
         self.device = device
-        self.stream = stream if stream is not None else torch.cuda.default_stream(device)
-        self.out = torch.zeros(2, dtype=torch.int64, device=torch.device('cuda', device))
+        if stream is None:          # torch's pool streams are created with hipStreamNonBlocking
+            stream = torch.cuda.Stream(device=torch.device('cuda', device))
+        self.stream = stream
+        with torch.cuda.stream(self.stream):
+            self.out = torch.zeros(2, dtype=torch.int64, device=torch.device('cuda', device))
+        self.stream.synchronize()
 
     def start(self, ms):
         rc = load().nuhtc_clock_probe(self.device, int(ms * 1e5), ctypes.c_void_p(self.out.data_ptr()), ctypes.c_void_p(self.stream.cuda_stream))
@@ -144,5 +149,6 @@ class ClockProbe:
 
     def ghz(self):
         self.stream.synchronize()
-        c, r = (int(v) for v in self.out.cpu())
+        with __import__('torch').cuda.stream(self.stream):
+            c, r = (int(v) for v in self.out.cpu())
         return 0.1 * c / r if r else None

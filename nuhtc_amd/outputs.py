@@ -39,15 +39,16 @@ def coco_tile_image(annidx, h, w, labels, classes):
 
 
 def coco_annotation(mask, label, image_id, ann_id, score=None):
-    """Annotation with an RLE segmentation; `area` is the bounding-box area, as the reference computes it
-    (infer_wsi.py:613-626, infer_patch.py:273-286)."""
+    """Annotation with an RLE segmentation; `area` is the bounding-box area, as the reference computes it.  Key order as the reference
+    writes it: without a score the tile annotation of infer_wsi.py:613-626 (bbox first, id fifth), with a score the patch annotation of
+    infer_patch.py:308-317 (id first, score last)."""
     rle = cocomask.encode(mask)
     bbox = cocomask.to_bbox(rle)
-    ann = {'bbox': bbox, 'area': bbox[2] * bbox[3], 'image_id': int(image_id), 'category_id': int(label), 'id': int(ann_id),
-           'iscrowd': 0, 'segmentation': rle}
-    if score is not None:
-        ann['score'] = float(score)
-    return ann
+    if score is None:
+        return {'bbox': bbox, 'area': bbox[2] * bbox[3], 'image_id': int(image_id), 'category_id': int(label), 'id': int(ann_id),
+                'iscrowd': 0, 'segmentation': rle}
+    return {'id': int(ann_id), 'bbox': bbox, 'area': bbox[2] * bbox[3], 'image_id': int(image_id), 'category_id': int(label),
+            'iscrowd': 0, 'segmentation': rle, 'score': float(score)}
 
 
 def write_json(path, obj, **kw):

@@ -1,0 +1,86 @@
+"""TEST INFRASTRUCTURE ONLY (checker; never imported by the product).
+
+The tissue front end of the slide path as ONE sequence, restated from the reference with the scalar OpenCV restatements of
+oracle/cv_ops.py and the border-following oracle of oracle/contour.py (cv2 / openslide absent: PARITY UNPINNED against the libraries):
+
+    segment_tissue      tools/wsi_core/WholeSlideImage.py:105-199  segmentTissue + _filter_contours
+    contour_tile_coords tools/wsi_core/WholeSlideImage.py:407-493  process_contour + process_coord_candidate (:495-500),
+                        isInHoles (:353-358), tools/wsi_core/util_classes.py:48-111 (basic / center / four_pt / four_pt_hard)
+    tile_coords         WholeSlideImage.py:388-405 process_contours (contour after contour), parameters of tools/infer_wsi.py:385-389
+
+Written against the reference, not against nuhtc_amd/tissue.py: per-point Python loops, RETR_TREE borders turned into the two-level
+RETR_CCOMP grouping (a border at even depth is an outer border, its children are its holes; CHAIN_APPROX_SIMPLE instead of _NONE: the
+same polygons, so the same areas, bounding boxes and point tests).  The ORDER in which cv2 lists the outer borders is not restated:
+compare tile lists per contour, or as sets."""
+import numpy as np
+
+from . import contour as OC
+from . import cv_ops as C
+
+
+def segment_tissue(img, scale, sthresh=8, sthresh_up=255, mthresh=7, close=4, use_otsu=False, a_t=100, a_h=16, max_n_holes=8, ref_patch_size=512):
+    """-> [(outer contour, [hole contours])] in level-0 pixels ((n, 2) int arrays)."""
+    lvl = np.asarray(img)[::scale, ::scale]                     # the pyramid level `read_region` would return (:161)
+    sat = C.saturation_u8(lvl.tolist())                         # img_hsv[:, :, 1] (:162)
+    med = C.median_blur(sat, mthresh)                           # :163
+    thr = C.otsu_threshold(med) if use_otsu else sthresh        # :166-169 (THRESH_BINARY: v > thr -> maxval)
+    binary = [[sthresh_up if v > thr else 0 for v in row] for row in med]
+    if close > 0:
+        binary = C.morph_close(binary, close)                   # :172-174
+    scaled_ref = round(ref_patch_size / scale)                  # :179-182
+    a_t, a_h = a_t * scaled_ref, a_h * scaled_ref
+    conts, hier = OC.find_contours_tree(np.asarray(binary) > 0)
+    depth = [0] * len(conts)
+    for i in range(len(conts)):
+        p, d = hier[i][3], 0
+        while p >= 0:
+            p, d = hier[p][3], d + 1
+        depth[i] = d
+    out = []
+    for i in range(len(conts)):
+        if depth[i] % 2:
+            continue                                             # a hole border: belongs to its parent
+        holes = [conts[j] for j in range(len(conts)) if hier[j][3] == i]
+        a = C.contour_area(conts[i].tolist()) - sum(C.contour_area(h.tolist()) for h in holes)   # :128-133
+        if a == 0 or not a_t < a:
+            continue
+        holes = sorted(holes, key=lambda h: C.contour_area(h.tolist()), reverse=True)[:max_n_holes]   # :143-146
+        holes = [h for h in holes if C.contour_area(h.tolist()) > a_h]                                 # :150-152
+        out.append((np.asarray(conts[i], np.int64) * scale, [np.asarray(h, np.int64) * scale for h in holes]))   # scaleContourDim
+    return out
+
+
+def _bounding_rect(c):
+    x0, y0, x1, y1 = c[:, 0].min(), c[:, 1].min(), c[:, 0].max(), c[:, 1].max()
+    return int(x0), int(y0), int(x1 - x0 + 1), int(y1 - y0 + 1)
+
+
+def contour_tile_coords(cont, holes, patch_size, step_size, contour_fn='four_pt', center_shift=0.5):
+    """process_contour at patch_level 0 with use_padding=True: level-0 (x, y) origins, in the reference's candidate order
+    (meshgrid indexing='ij': x outer, y inner)."""
+    sx, sy, w, h = _bounding_rect(cont)
+    poly = cont.tolist()
+    shift = int(patch_size // 2 * center_shift)
+    out = []
+    for x in range(sx, sx + w, step_size):
+        for y in range(sy, sy + h, step_size):
+            cx, cy = x + patch_size // 2, y + patch_size // 2
+            if contour_fn == 'basic':
+                ok = C.point_polygon_test(poly, (x, y)) >= 0
+            elif contour_fn == 'center':
+                ok = C.point_polygon_test(poly, (cx, cy)) >= 0
+            else:
+                pts = [(cx - shift, cy - shift), (cx + shift, cy + shift), (cx + shift, cy - shift), (cx - shift, cy + shift)] if shift > 0 else [(cx, cy)]
+                tests = [C.point_polygon_test(poly, p) >= 0 for p in pts]
+                ok = all(tests) if contour_fn == 'four_pt_hard' else any(tests)
+            if not ok:
+                continue
+            if any(C.point_polygon_test(hh.tolist(), (x + patch_size / 2, y + patch_size / 2)) > 0 for hh in holes):   # isInHoles
+                continue
+            out.append((x, y))
+    return out if len(out) > 1 else []                           # `if len(results) > 1` (:476)
+
+
+def tile_coords(img, patch_size, step_size, scale, **seg):
+    """-> list over tissue contours of that contour's tile origins."""
+    return [contour_tile_coords(c, hs, patch_size, step_size) for c, hs in segment_tissue(img, scale, **seg)]

@@ -53,8 +53,18 @@ def test_inference_detector_formats_and_channel_modes(hip_device, model, tmp_pat
     # more images than max_batch are chunked
     many = inference_detector(model, [tiles[i % 3] for i in range(6)])
     assert len(many) == 6 and all(np.array_equal(a, b) for a, b in zip(many[3][0], many[0][0]))
+    # a list of mixed sizes (mmdet/apis/inference.py:118-139 accepts one): grouped by size, results in input order, each image as in a
+    # call of its own
+    small = synth.nuclei_tiles(2, 32, start=90)
+    mixed = inference_detector(model, [tiles[0], small[0], tiles[1], small[1]])
+    alone = [inference_detector(model, t) for t in (tiles[0], small[0], tiles[1], small[1])]
+    assert len(mixed) == 4
+    for m, a in zip(mixed, alone):
+        assert all(np.array_equal(x, y) for x, y in zip(m[0], a[0]))
+        assert all(len(x) == len(y) and all(np.array_equal(p, q) for p, q in zip(x, y)) for x, y in zip(m[1], a[1]))
+    assert mixed[1][1][0] == [] or mixed[1][1][0][0].shape == (32, 32)
     with pytest.raises(ValueError):
-        inference_detector(model, [tiles[0], np.zeros((32, 32, 3), np.uint8)])
+        inference_detector(model, [tiles[0], np.zeros((32, 32), np.uint8)])
 
 
 def test_wsi_host_path_single_rank(hip_device, model):
@@ -106,6 +116,92 @@ def test_infer_wsi_cli_writes_qupath_geojson(hip_device, tmp_path):
     assert m0.shape == (64, 64) and m0.sum() >= 10 and os.path.exists(tmp_path / 'out/imgs/slide' / f"{a0['image_id']}.png")
     n_sql = sqlite3.connect(str(tmp_path / 'out/nuclei/slide/slide_dql.db')).execute('SELECT COUNT(*) FROM contour').fetchone()[0]
     assert n_sql == len(feats)
+    # ---- every document against the reference's own statements: the reference's per-tile loop (tools/infer_wsi.py:486-546)
+    # and its writers (:549-693) restated in tests/ref_consume.py + oracle/writers.py + oracle/rle.py + oracle/contour.py, fed with what
+    # `inference_detector` returns for the same tiles from an engine of this process; object for object, key order included
+    import ref_consume as RC
+    from oracle import writers as W
+    from nuhtc_amd import wsi
+    from nuhtc_amd.apis import inference_detector, init_detector
+    tiles, coords = wsi.tile_grid(img, 64, 48)
+    det = init_detector(CFG, str(ck), device='cuda:0', max_batch=4)
+    results = inference_detector(det, [t for t in tiles])
+    ref, kept = RC.wsi_documents(results, coords, 64, margin=2, min_area=10)
+    rt = lambda x: json.loads(json.dumps(x))
+    assert len(ref['geojson']) == len(feats) > 20
+    assert feats == rt(ref['geojson']) and list(feats[0]) == list(ref['geojson'][0]) and list(feats[0]['properties']) == list(ref['geojson'][0]['properties'])
+    assert pts == rt(ref['pointjson'])
+    assert dsa == rt(W.dsa_file(ref['dsajson'])) and list(dsa['elements'][0]) == list(ref['dsajson'][0])
+    assert coco == rt(W.coco_file(ref['imgs'], ref['annts']))
+    rows = sqlite3.connect(str(tmp_path / 'out/nuclei/slide/slide_dql.db')).execute(
+        'SELECT annidx, elementidx, type, "group", score, color, xmin, ymin, xmax, ymax, bbox_area, coords_x, coords_y, keep FROM contour ORDER BY id').fetchall()
+    assert rows == ref['sql_rows']
+    # the tile images of --mode coco are the tiles themselves
+    from PIL import Image
+    for im in coco['images'][:3]:
+        assert np.array_equal(np.asarray(Image.open(tmp_path / 'out/imgs/slide' / im['file_name'])), tiles[im['id']])
+    # and the merged file holds exactly the features the sequential polygon merge of the reference keeps (oracle/merge_poly.py)
+    from oracle import merge_poly as MP
+    keep_ref = MP.merge_overlap([k[1] for k in kept], [k[3] for k in kept], 0.05)
+    assert 0 < len(keep_ref) <= len(feats) and merged == [feats[i] for i in keep_ref]
+
+
+def test_infer_wsi_tissue_coords_and_store_front_ends(hip_device, tmp_path):
+    """SURVEY 8f row 2 on the GPU box: `tools/infer_wsi.py --seg` (segmentTissue + process_contours, WholeSlideImage.py:105-199,388-502),
+    `--coords file.npz` (the role of patches/<name>.h5) and a store directory (Whole_Slide_Bag_FP, :832-898) on a synthetic slide with two
+    tissue regions, a hole and a speck.  The tile list is derived independently by oracle/tissue.py (the reference's sequence over the
+    scalar OpenCV restatements of oracle/cv_ops.py); the tiles are cut here by plain slicing and handed over as .npz: every front end must
+    write the SAME GeoJSON as that run, i.e. it used exactly the oracle's tiles, in the oracle's order, with the same pixels."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    from nuhtc_amd import tilestore, weights
+    from oracle import tissue as OT
+    from test_tissue import tissue_slide_with_holes
+    img, blob1, hole, blob2 = tissue_slide_with_holes()
+    P = 64
+    regions = OT.segment_tissue(img, 8)
+    assert len(regions) == 2 and sorted(len(hs) for _, hs in regions) == [0, 1]
+    # cv2's ORDER of the outer borders is not restated by the oracle: the regions are put in the product's contour order (matched by
+    # bounding box); contours, holes and the tiles of each region are the oracle's
+    from nuhtc_amd import tissue as T
+    _, conts, _ = T.tissue_tile_coords(img, P, P, scale=8)
+    bbox = lambda c: (int(c[:, 0].min()), int(c[:, 1].min()), int(c[:, 0].max()), int(c[:, 1].max()))
+    regions.sort(key=lambda r: [bbox(c) for c in conts].index(bbox(r[0])))
+    per_contour = [OT.contour_tile_coords(c, hs, P, P) for c, hs in regions]
+    assert all(len(pts) > 50 for pts in per_contour)
+    coords = np.array([p for pts in per_contour for p in pts], np.int64)
+    H, W = img.shape[:2]
+    tiles = np.zeros((len(coords), P, P, 3), np.uint8)
+    for i, (x, y) in enumerate(coords):
+        sub = img[y:min(y + P, H), x:min(x + P, W)]
+        tiles[i, :sub.shape[0], :sub.shape[1]] = sub
+    ck = tmp_path / 'w.pth'
+    torch.save(dict(state_dict=weights.bench_state_dict(0, obj_bias=0.0)), ck)
+    np.save(tmp_path / 'slide.npy', img)
+    np.savez(tmp_path / 'given.npz', tiles=tiles, coords=coords)
+    np.savez(tmp_path / 'coords.npz', coords=coords, patch_size=P)
+    tilestore.write_store(str(tmp_path / 'stored'), img, coords, patch_size=P)
+    tool = os.path.join(ROOT, 'tools/infer_wsi.py')
+    common = [CFG, str(ck), '--patch_size', str(P), '--step_size', str(P), '--batch_size', '16']
+
+    def run(name, src, *extra):
+        out = subprocess.run([sys.executable, tool, str(src)] + common + ['--save_dir', str(tmp_path / name)] + list(extra), check=True,
+                             capture_output=True, text=True).stdout
+        stem = os.path.splitext(os.path.basename(str(src)))[0]
+        return json.load(open(tmp_path / name / 'nuclei' / stem / f'{stem}.geojson')), out
+
+    ref, _ = run('o_npz', tmp_path / 'given.npz')
+    assert len(ref) > 300
+    seg, log = run('o_seg', tmp_path / 'slide.npy', '--seg', '--seg_downsample', '8')
+    assert f'2 contour(s), {len(coords)} tiles' in log
+    assert seg == ref
+    assert run('o_coords', tmp_path / 'slide.npy', '--coords', str(tmp_path / 'coords.npz'))[0] == ref
+    assert run('o_store', tmp_path / 'stored')[0] == ref
+    # nothing was detected on glass or inside the hole: every ring lies in a tile the oracle listed
+    xs = np.array([f['geometry']['coordinates'][0][0] for f in ref])
+    assert not hole[np.clip(xs[:, 1], 0, H - 1), np.clip(xs[:, 0], 0, W - 1)].all()
 
 
 def test_infer_patch_cli_writes_coco(hip_device, tmp_path):
@@ -141,6 +237,16 @@ def test_infer_patch_cli_writes_coco(hip_device, tmp_path):
     for rl in by_img.values():
         iou = cocomask.iou(rl, rl)
         assert (iou - np.eye(len(rl))).max() <= 0.05
+    # ---- the annotations against the reference's statements (tools/infer_patch.py:247-290 restated: tests/ref_consume.py,
+    # oracle/writers.py, oracle/rle.py) on what inference_detector returns for the same images in this process: object for object
+    import ref_consume as RC
+    from nuhtc_amd.apis import inference_detector, init_detector
+    det = init_detector(CFG, str(ck), device='cuda:0', max_batch=4)
+    results = inference_detector(det, [np.array(Image.open(tmp_path / f'im{i}.png').convert('RGB')) for i in range(5)])
+    want = RC.patch_annotations(results, first_image_id=1, thr=0.05)
+    assert len(want) == len(doc['annotations']) > 10 and doc['annotations'] == json.loads(json.dumps(want))
+    assert list(doc['annotations'][0]) == list(want[0])
+    assert doc['images'] == [{'id': i + 1, 'file_name': f'im{i}.png', 'img_path': str(tmp_path / f'im{i}.png'), 'height': 64, 'width': 64} for i in range(5)]
 
 
 def test_pannuke_dataset_cli_exports_and_scores(hip_device, tmp_path):

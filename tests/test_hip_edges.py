@@ -200,6 +200,45 @@ def test_pipeline_matches_single_engine(hip_device):
             pipe.submit(tiles[:4], hip.CH_SWAP)
 
 
+def test_exported_views_survive_a_resubmit_before_unpacking(hip_device):
+    """A pipeline slot holds two exported batches; the slide loop may resubmit a slot BEFORE it unpacks the batch the slot just
+    delivered.  The views export_read() hands out must then still be that batch's: three pinned host buffers per
+    engine (Engine.EXPORT_BUFFERS), not two.  One engine (depth 1 -> every submit goes to the same slot), batches A, B queued, A
+    collected, C submitted and COMPLETED before A's views are read: A's records must equal A's records read the orderly way."""
+    import torch
+    from nuhtc_amd import hip, synth, weights
+    from nuhtc_amd.pipeline import EnginePipeline
+    sd = weights.bench_state_dict(2, obj_bias=0.0)
+    batches = [synth.nuclei_tiles(4, 64, start=s) for s in (11, 31, 51, 71)]
+    pipe = EnginePipeline(sd, device=0, depth=1, max_batch=4, tile=(64, 64))
+    assert pipe.engines[0].EXPORT_BUFFERS >= pipe.per_slot + 1
+    snap = lambda g: {k: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v) for k, v in g.items()}
+    # orderly: every batch unpacked (copied) before the next submit
+    want = []
+    for t in batches:
+        pipe.submit(t, hip.CH_SWAP, export=True)
+        e, B, st, _ = pipe.collect()
+        want.append(snap(e.export_read(pipe.last_turn)))
+    assert all(w['n'] > 0 for w in want) and len({w['n'] for w in want}) > 1
+    # disorderly: A, B queued; collect A -> views (NOT copied); submit C, collect B, submit D: both later copies have landed
+    pipe.submit(batches[0], hip.CH_SWAP, export=True)
+    pipe.submit(batches[1], hip.CH_SWAP, export=True)
+    e, B, st, _ = pipe.collect()
+    views_a = e.export_read(pipe.last_turn)
+    pipe.submit(batches[2], hip.CH_SWAP, export=True)
+    e, B, st, _ = pipe.collect()
+    views_b = e.export_read(pipe.last_turn)
+    torch.cuda.synchronize()            # C's copy has completed: with two buffers it would have landed in A's
+    for got, ref in ((views_a, want[0]), (views_b, want[1])):
+        assert got['n'] == ref['n']
+        for k in ('tile', 'slot', 'boxes', 'labels', 'cn', 'crop_box', 'crop_area'):
+            assert np.array_equal(got[k], ref[k]), k
+        assert np.array_equal(got['xy'], ref['xy']) and np.array_equal(got['crop_words'][:ref['crop_total']], ref['crop_words'][:ref['crop_total']])
+    e, B, st, _ = pipe.collect()
+    assert e.export_read(pipe.last_turn)['n'] == want[2]['n']
+    pipe.close()
+
+
 def test_mag20_scale_factor_4(hip_device):
     """tools/infer_wsi.py:416-419 sets MultiScaleFlipAug.scale_factor = 80 / mag: a 20x slide runs at scale_factor 4 (a 64-px tile
     is a 256-px network input; cv2's x4 8-bit resize, boxes / masks scaled back by 4).  Engine vs oracle, strict."""

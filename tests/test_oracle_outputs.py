@@ -72,7 +72,7 @@ def test_infer_wsi_documents_field_by_field(tmp_path):
     for annidx, origin in enumerate([(0, 0), (192, 0), (1000, 2304)]):
         masks, labels, scores, boxes = _tile(rng, P)
         rings = [contours.mask_to_ring(m, origin=origin) for m in masks]                          # mask2inst + coord
-        keep = [i for i, r in enumerate(rings) if len(r) >= 4]                                    # :536 (closed ring: >= 3 + 1 points)
+        keep = [i for i, r in enumerate(rings) if len(r) >= 3]                                    # :536 (`len(con) >= 3` on the closed contour)
         org4 = np.array([origin[0], origin[1], origin[0], origin[1]], np.float64)
         per_tile = []
         for e, i in enumerate(keep):

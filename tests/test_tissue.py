@@ -92,3 +92,46 @@ def test_padding_and_edges():
     assert len(nopad) and (nopad[:, 0] + 256 <= 1600).all() and (nopad[:, 1] + 256 <= 1600).all()
     empty, c0, _ = T.tissue_tile_coords(np.full((512, 512, 3), 240, np.uint8), 256, 192, scale=8)
     assert len(empty) == 0 and len(c0) == 0
+
+
+def tissue_slide_with_holes(H=1536, W=2048, seed=0):
+    """Glass (grey 235) with two tissue regions textured like the synthetic H&E tiles; the first has a hole large enough to survive the
+    a_h filter at a segmentation downsample of 8 (> 16 * 64 level pixels), plus a speck below the a_t filter."""
+    from nuhtc_amd import synth
+    img = np.full((H, W, 3), 235, np.uint8)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    blob1 = ((yy - 620) / 540.0) ** 2 + ((xx - 700) / 640.0) ** 2 <= 1
+    hole = ((yy - 600) / 180.0) ** 2 + ((xx - 660) / 210.0) ** 2 <= 1
+    blob2 = ((yy - 1110) / 400.0) ** 2 + ((xx - 1690) / 340.0) ** 2 <= 1
+    speck = ((yy - 120) / 60.0) ** 2 + ((xx - 1900) / 60.0) ** 2 <= 1
+    tissue = (blob1 & ~hole) | blob2 | speck
+    tex = np.concatenate([np.concatenate([synth.nuclei_tile(500 + seed * 100 + 8 * r + c, 256) for c in range(W // 256)], 1) for r in range(H // 256)], 0)
+    img[tissue] = tex[tissue]
+    return img, blob1, hole, blob2
+
+
+def test_tile_list_equals_the_scalar_restatement_of_the_reference_sequence():
+    """nuhtc_amd.tissue.tissue_tile_coords (numpy / scipy) against oracle/tissue.py (segmentTissue + process_contour restated from the
+    reference over the scalar OpenCV restatements and the Suzuki-Abe oracle): the same tissue contours (bounding boxes, areas, holes)
+    and, per contour, the same tile origins in the same order."""
+    from oracle import cv_ops as C
+    from oracle import tissue as OT
+    img, blob1, hole, blob2 = tissue_slide_with_holes()
+    coords, conts, holes = T.tissue_tile_coords(img, patch_size=64, step_size=64, scale=8)
+    ref = OT.segment_tissue(img, 8)
+    assert len(conts) == len(ref) == 2 and sorted(len(h) for h in holes) == [0, 1] == sorted(len(h) for _, h in ref)
+    key = lambda c: (int(np.asarray(c)[:, 0].min()), int(np.asarray(c)[:, 1].min()), int(np.asarray(c)[:, 0].max()), int(np.asarray(c)[:, 1].max()))
+    by_box = {key(c): (c, hs) for c, hs in ref}
+    off = 0
+    for c, hs in zip(conts, holes):
+        rc, rhs = by_box[key(c)]                                  # same bounding box ...
+        assert T.contour_area(c) == C.contour_area(rc.tolist())   # ... same enclosed area, same holes
+        assert sorted(T.contour_area(h) for h in hs) == sorted(C.contour_area(h.tolist()) for h in rhs)
+        want = OT.contour_tile_coords(rc, rhs, 64, 64)
+        got = coords[off:off + len(want)]
+        off += len(want)
+        assert len(want) > 50 and got.tolist() == [list(p) for p in want]
+    assert off == len(coords)
+    # no tile is centred inside the hole, and the speck produced none
+    assert not hole[np.clip(coords[:, 1] + 32, 0, 1535), np.clip(coords[:, 0] + 32, 0, 2047)].any()
+    assert not ((coords[:, 0] > 1800) & (coords[:, 1] < 200)).any()

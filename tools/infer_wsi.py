@@ -89,7 +89,7 @@ def main():
     rec = wsi.infer_tiles(model, tiles, coords[lo:hi], args.batch_size)
     # contours are traced on the rank that owns the tile; two variable-length gathers: records, then ring vertices
     rings = rec['ring']                                              # traced on the GPU (nuhtc_mask_contours)
-    keep = [i for i, r in enumerate(rings) if len(r) >= 4]          # reference drops contours with < 3 points (:536)
+    keep = [i for i, r in enumerate(rings) if len(r) >= 3]          # reference :536 tests the CLOSED contour (mask2inst appends the first point): only one-pixel contours go
     n = len(keep)
     want = lambda m: args.mode in (m, 'all')
     P = bag.patch_size
