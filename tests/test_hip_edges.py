@@ -233,7 +233,9 @@ def test_exported_views_survive_a_resubmit_before_unpacking(hip_device):
         assert got['n'] == ref['n']
         for k in ('tile', 'slot', 'boxes', 'labels', 'cn', 'crop_box', 'crop_area'):
             assert np.array_equal(got[k], ref[k]), k
-        assert np.array_equal(got['xy'], ref['xy']) and np.array_equal(got['crop_words'][:ref['crop_total']], ref['crop_words'][:ref['crop_total']])
+        for k in range(ref['n']):          # (vertices past a contour's length are whatever an earlier batch left there)
+            assert np.array_equal(got['xy'][k, :max(int(ref['cn'][k]), 0)], ref['xy'][k, :max(int(ref['cn'][k]), 0)]), k
+        assert got['crop_total'] == ref['crop_total'] and np.array_equal(got['crop_words'][:ref['crop_total']], ref['crop_words'][:ref['crop_total']])
     e, B, st, _ = pipe.collect()
     assert e.export_read(pipe.last_turn)['n'] == want[2]['n']
     pipe.close()
