@@ -51,7 +51,7 @@ GROUPS = {
 }
 
 
-def cpu_baseline(sd, tiles, eng=None, mode=1, batch=4, timed=3):
+def cpu_baseline(sd, tiles, eng=None, mode=1, batch=4, timed=3, warm=2, warm_batches=1):
     """Oracle (CPU restatement of the reference path, oracle/model.py) timed on the host cores: reported next to the GPU
     number, never the thing shipped.  Bounded sample (about 30 s): one warm-up batch of 2 tiles, then `timed` batches of
     `batch` tiles each, timed one by one.  With `eng`, the same tiles are the parity check of the run: the HIP path's
@@ -62,7 +62,8 @@ def cpu_baseline(sd, tiles, eng=None, mode=1, batch=4, timed=3):
     import parity_util as P
     orc = O.Oracle(sd)
     threads = torch.get_num_threads()
-    orc(tiles[:2], mode)               # warm-up (also builds oracle/libnuhtc_oracle.so on first use)
+    for _ in range(warm_batches):
+        orc(tiles[:warm], mode)        # warm-up (also builds oracle/libnuhtc_oracle.so on first use)
     times, refs, vals = [], [], []
     n = min(batch * timed, len(tiles))
     for i in range(0, n, batch):
@@ -73,11 +74,15 @@ def cpu_baseline(sd, tiles, eng=None, mode=1, batch=4, timed=3):
         vals += P.oracle_paste_values(O, it, tiles.shape[1:3])
     dt = sum(times)
     out = dict(value=n / dt, unit='tiles/s', cores=threads, kind='port',
-               sample=f'{timed} timed batches of {batch} synthetic nuclei tiles after 1 warm-up batch of 2 (oracle/model.py, fp32 torch-cpu + C RoIAlign/NMS), '
-                      f'{dt:.1f} s; per batch {[round(batch / t, 3) for t in times]} tiles/s; bounded deviation from SURVEY 8d (2 warm-up + 10 timed batches of 16 tiles: about 6 minutes of host time)')
+               sample=f'{timed} timed batches of {batch} synthetic nuclei tiles after {warm_batches} warm-up batch(es) of {warm} (oracle/model.py, fp32 torch-cpu + C RoIAlign/NMS), '
+                      f'{dt:.1f} s; per batch {[round(batch / t, 3) for t in times]} tiles/s' +
+                      ('; the full protocol of SURVEY 8d (2 warm-up + 10 timed batches of 16 tiles)' if (batch, timed, warm, warm_batches) == (16, 10, 16, 2) else
+                       '; bounded deviation from SURVEY 8d (2 warm-up + 10 timed batches of 16 tiles: about 6 minutes of host time; `bench.py --cpu-full`, profiles/r04_cpu_baseline_full.json)'))
     if eng is not None:
-        eng.infer_async(eng.to_device(tiles[:n]), mode)
-        got = eng.results(n)
+        got = []
+        for i in range(0, n, eng.cfg.max_batch):
+            k = eng.infer_async(eng.to_device(tiles[i:i + eng.cfg.max_batch]), mode)
+            got += eng.results(k)
         tot = dict(n_ref=0, n_got=0, matched=0, mask_px_flipped=0, masks_below_0999=0)
         min_iou, max_dist, explained, failures = 1.0, 0.0, [], []
         for i, (r, g) in enumerate(zip(refs, got)):
@@ -95,6 +100,84 @@ def cpu_baseline(sd, tiles, eng=None, mode=1, batch=4, timed=3):
                              passed=not failures,
                              note='detections before the per-tile margin / mask-NMS filter; every tolerated entry names the threshold it sits on (tests/parity_util.py)')
     return out
+
+
+class PowerLog:
+    """GPU power / clock / temperature at ~10 Hz from the amdgpu hwmon files in sysfs (no GPU call, a reader thread of this process).  A box
+    shows every GPU of its host there: all are sampled and the busiest one -- the one this process ran on -- is reported."""
+
+    def __init__(self):
+        import glob
+        import threading
+        self.cards = []
+        for card in sorted(glob.glob('/sys/class/drm/card[0-9]*/device')):
+            hm = glob.glob(os.path.join(card, 'hwmon', 'hwmon*'))
+            if hm and any(os.path.exists(os.path.join(hm[0], f)) for f in ('power1_average', 'power1_input')):
+                lab = {}
+                for p in glob.glob(os.path.join(hm[0], 'temp*_label')):
+                    try:
+                        lab[open(p).read().strip()] = p.replace('_label', '_input')
+                    except OSError:
+                        pass
+                self.cards.append((card, hm[0], lab))
+        self.rows = {c[0]: [] for c in self.cards}
+        self.marks = []
+        self.stop = threading.Event()
+        self.t0 = time.time()
+        self.th = threading.Thread(target=self._loop, daemon=True)
+        if self.cards:
+            self.th.start()
+
+    @staticmethod
+    def _read(path, scale=1.0):
+        try:
+            with open(path) as f:
+                return float(f.read().split()[0]) * scale
+        except (OSError, ValueError, IndexError):
+            return None
+
+    def _loop(self):
+        while not self.stop.is_set():
+            for card, hm, lab in self.cards:
+                pw = self._read(os.path.join(hm, 'power1_average'), 1e-6)
+                if pw is None:
+                    pw = self._read(os.path.join(hm, 'power1_input'), 1e-6)
+                self.rows[card].append((time.time() - self.t0, pw, self._read(os.path.join(hm, 'freq1_input'), 1e-6),
+                                        self._read(lab['junction'], 1e-3) if 'junction' in lab else None,
+                                        self._read(lab['mem'], 1e-3) if 'mem' in lab else None, self._read(os.path.join(card, 'gpu_busy_percent'))))
+            time.sleep(0.1)
+
+    def mark(self, name):
+        self.marks.append((name, time.time() - self.t0))
+
+    def summary(self, csv_path=None):
+        """-> dict: per marked phase the mean / max power, mean shader clock and max temperatures; optionally the samples as CSV."""
+        self.stop.set()
+        if not self.cards:
+            return {'available': False, 'note': 'no amdgpu hwmon files readable on this box'}
+        self.th.join()
+        best = max(self.rows, key=lambda c: sum((r[5] or 0) for r in self.rows[c]))
+        rows = self.rows[best]
+        hm = [c for c in self.cards if c[0] == best][0][1]
+        out = {'available': True, 'device': os.path.realpath(best), 'power_cap_w': self._read(os.path.join(hm, 'power1_cap'), 1e-6), 'sample_hz': 10, 'phases': {}}
+        mean = lambda v: (sum(v) / len(v)) if v else None
+        for i, (name, t_a) in enumerate(self.marks):
+            t_b = self.marks[i + 1][1] if i + 1 < len(self.marks) else rows[-1][0] + 1
+            if name.startswith('_'):
+                continue
+            seg = [r for r in rows if t_a <= r[0] < t_b]
+            out['phases'][name] = {'seconds': round(t_b - t_a, 2), 'samples': len(seg),
+                                   'power_w_mean': mean([r[1] for r in seg if r[1] is not None]), 'power_w_max': max([r[1] for r in seg if r[1] is not None], default=None),
+                                   'sclk_mhz_mean': mean([r[2] for r in seg if r[2] is not None]),
+                                   'temp_junction_c_max': max([r[3] for r in seg if r[3] is not None], default=None),
+                                   'temp_mem_c_max': max([r[4] for r in seg if r[4] is not None], default=None)}
+        if csv_path:
+            with open(csv_path, 'w') as f:
+                f.write('t_s,power_w,sclk_mhz,temp_junction_c,temp_mem_c,gpu_busy_pct,phase\n')
+                for r in rows:
+                    ph = [n for n, t in self.marks if t <= r[0]]
+                    f.write(','.join('' if v is None else f'{v:.3f}' for v in r) + ',' + (ph[-1] if ph else '') + '\n')
+        return out
 
 
 def self_launch(n):
@@ -125,6 +208,7 @@ def main():
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=4, help='cpu_baseline: tiles per timed oracle batch (3 timed batches)')
+    ap.add_argument('--cpu-full', action='store_true', help="cpu_baseline by the full protocol of SURVEY 8d: 2 warm-up + 10 timed batches of 16 tiles (about 7 minutes of host time; the default line keeps the bounded sample)")
     ap.add_argument('--pipe', default='split', choices=['split', 'fp32'],
                     help="matrix pipe of the engine: 'split' (default: exact three-way bf16 operand split, six bf16 MFMAs per fp32 product step) "
                          "or 'fp32' (v_mfma_f32_32x32x2_f32)")
@@ -140,6 +224,7 @@ def main():
     ap.add_argument('--roi-size', default='12,40', help='--fixed-load: RoI side range in network pixels (SURVEY: 12,40; 40x nuclei: ~40,100)')
     ap.add_argument('--gemm-shapes', action='store_true', help='add the per-shape GEMM timings to the JSON line')
     ap.add_argument('--no-settle', action='store_true', help='skip the untimed settle phase (profiling passes that serialise kernels)')
+    ap.add_argument('--power-csv', default=None, help='write the 10 Hz power / clock / temperature samples of the run to this file (the summary is always on the line)')
     ap.add_argument('--roi-sort', action='store_true', help='--fixed-load (dev): hand the RoIs over sorted by position (locality experiment)')
     args = ap.parse_args()
 
@@ -169,6 +254,9 @@ def main():
 
     from nuhtc_amd import hip, synth, weights
     from nuhtc_amd.engine import Engine
+    plog = PowerLog() if rank == 0 else None          # 10 Hz power / clock / temperature beside every phase of the run (sysfs)
+    mark = (lambda name: plog.mark(name)) if plog else (lambda name: None)
+    mark('_setup')
     torch.cuda.set_device(local_rank)
     sd = weights.bench_state_dict()
     pipe = hip.PIPE_BF16_SPLIT if args.pipe == 'split' else hip.PIPE_FP32
@@ -205,6 +293,7 @@ def main():
     # A GPU that has been idle (a fresh box) runs its first second or so well below its sustained clocks: before the W
     # contractual warm-up steps, untimed steps are run until the step time has settled (three consecutive groups of 10 steps
     # within 1 % of each other, at most 8 s).  Nothing here is timed or counted.
+    mark('settle')
     settle_steps, hist = 0, []
     t_settle = time.perf_counter()
     while not args.no_settle and time.perf_counter() - t_settle < 8.0:
@@ -258,6 +347,7 @@ def main():
         if e is not eng:
             step_fn(e)
     torch.cuda.synchronize()
+    mark('warmup')
     run(args.warmup)
     last = engs[(args.steps - 1) % depth]          # the engine that will run step K
     for st in streams:
@@ -267,6 +357,7 @@ def main():
     for e in engs:
         e.check()
     sync_all()
+    mark('timed_in_flight' if depth > 1 else 'timed_sequential')
     t0 = time.perf_counter()
     run(args.steps)
     for st in streams:
@@ -278,12 +369,39 @@ def main():
     gathered_bytes = int(sum(t.numel() * t.element_size() for g in gathered for t in g))
     sync_all()
     dt = time.perf_counter() - t0
+    mark('_after_timed')
     dt = max_over_ranks(dt)
     for e in engs:
         e.check()
     total_tiles = args.steps * B * world
     counts = eng.counts[:B].cpu().numpy()
     roi_counts = eng.buffer('roi_counts')[:B].cpu().numpy()
+
+    # the step at the RoI sizes of a real slide, with the same engines in flight (throughput schedule): 40-100 px (40x nuclei after the
+    # x2 resize) and 100-200 px (clumps / component proposals); the sequential figures and the RoI kernels' share follow further down
+    roi_in_flight = {}
+    if depth > 1 and not args.no_roi_load and not args.fixed_load:
+        for key, size in (('40_100', (40.0, 100.0)), ('100_200', (100.0, 200.0))):
+            rois_b = torch.from_numpy(synth.fixed_load_rois(B, size=size)).to(tiles.device)
+            kf = max(8, min(40, args.steps))
+
+            def run_fixed(k):
+                for i in range(k):
+                    with torch.cuda.stream(streams[i % depth]):
+                        engs[i % depth].infer_fixed_load_async(tiles, rois_b, 64, mode)
+            for st in streams:
+                st.wait_stream(torch.cuda.current_stream())
+            run_fixed(2 * depth)
+            sync_all()
+            mark('roi_load_in_flight_' + key)
+            t0 = time.perf_counter()
+            run_fixed(kf)
+            sync_all()
+            df = max_over_ranks(time.perf_counter() - t0)
+            roi_in_flight[key] = {'value': kf * B * world / df, 'unit': 'tiles/s', 'ms_per_step': df / kf * 1e3, 'steps': kf, 'batches_in_flight': depth}
+        mark('_after_roi_in_flight')
+        for e in engs:
+            e.check()
 
     # the same K steps one batch at a time (what the per-kernel numbers below belong to)
     sequential = None
@@ -292,11 +410,13 @@ def main():
             e.close()
         engs = [eng]
         sync_all()
+        mark('sequential')
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step_fn()
         sync_all()
         dts = time.perf_counter() - t0
+        mark('_after_sequential')
         dts = max_over_ranks(dts)
         sequential = {'value': total_tiles / dts, 'unit': 'tiles/s', 'ms_per_step': dts / args.steps * 1e3, 'steps': args.steps,
                       'note': 'the same K steps one batch at a time; roofline / kernel_ms_per_step / kernel_groups are measured in this mode'}
@@ -306,6 +426,7 @@ def main():
     # the shader clock this box holds under the sequential step (the chip lowers its clock under matrix load and boxes differ:
     # a per-kernel fraction is only comparable between runs together with this figure): a one-wave probe on its own stream
     # (s_memtime against the 100 MHz s_memrealtime) beside untimed steps
+    mark('_clock_probe')
     k_clk = max(3, min(20, args.steps))
     # The probe needs a hardware queue of its own: a stream that shares a queue with the engine runs the probe alone, ahead of the
     # steps (it then reports the idle clock).  Streams are dealt round the runtime's queues in an order this script does not control,
@@ -329,6 +450,7 @@ def main():
 
     # live per-kernel timing (HIP events on the launch stream) over the same workload, separate steps so the
     # event records do not perturb the headline number
+    mark('per_kernel_events')
     hip.profile_enable(True)
     prof_steps = max(2, min(5, args.steps))
     for _ in range(prof_steps):
@@ -418,28 +540,40 @@ def main():
     # resize) instead of the synthetic weights' ~20 px boxes -- the 7x7 RoI features are the data-dependent part of the path
     roi_load = None
     if not args.no_roi_load and not args.fixed_load:
-        rois_b = torch.from_numpy(synth.fixed_load_rois(B, size=(40.0, 100.0))).to(tiles.device)
-        k2 = max(5, min(20, args.steps))
-        for _ in range(2):
-            eng.infer_fixed_load_async(tiles, rois_b, 64, mode)
-        sync_all()
-        t0 = time.perf_counter()
-        for _ in range(k2):
-            eng.infer_fixed_load_async(tiles, rois_b, 64, mode)
-        sync_all()
-        d2 = time.perf_counter() - t0
-        d2 = max_over_ranks(d2)
-        hip.profile_enable(True)
-        for _ in range(2):
-            eng.infer_fixed_load_async(tiles, rois_b, 64, mode)
-        p2 = hip.profile_read()
-        hip.profile_enable(False)
-        roi_ms = sum(v['ms'] for k, v in p2.items() if k.split('|')[0] in ('roi_feat7', 'roi_classify')) / 2
-        roi_load = {'workload': 'fixed load: 1064 given RoIs per tile with sides 40-100 network px, 64 detections per tile (nuhtc_infer_fixed_load)',
-                    'value': k2 * B * world / d2, 'unit': 'tiles/s', 'ms_per_step': d2 / k2 * 1e3, 'steps': k2, 'roi_feat7_ms_per_step': round(roi_ms, 3)}
+        def seq_fixed(size):
+            rois_b = torch.from_numpy(synth.fixed_load_rois(B, size=size)).to(tiles.device)
+            k2 = max(5, min(20, args.steps))
+            for _ in range(2):
+                eng.infer_fixed_load_async(tiles, rois_b, 64, mode)
+            sync_all()
+            t0 = time.perf_counter()
+            for _ in range(k2):
+                eng.infer_fixed_load_async(tiles, rois_b, 64, mode)
+            sync_all()
+            d2 = max_over_ranks(time.perf_counter() - t0)
+            hip.profile_enable(True)
+            for _ in range(2):
+                eng.infer_fixed_load_async(tiles, rois_b, 64, mode)
+            p2 = hip.profile_read()
+            hip.profile_enable(False)
+            roi_ms = sum(v['ms'] for k, v in p2.items() if k.split('|')[0] in ('roi_feat7', 'roi_classify')) / 2
+            return {'value': k2 * B * world / d2, 'unit': 'tiles/s', 'ms_per_step': d2 / k2 * 1e3, 'steps': k2, 'roi_feat7_ms_per_step': round(roi_ms, 3)}
+        mark('roi_load_sequential')
+        roi_load = {'workload': 'fixed load: 1064 given RoIs per tile with sides 40-100 network px, 64 detections per tile (nuhtc_infer_fixed_load)'}
+        roi_load.update(seq_fixed((40.0, 100.0)))
+        roi_load['note'] = '`value` here is the one-batch-at-a-time rate; `in_flight` is the same load with the engines of the headline in flight'
+        if '40_100' in roi_in_flight:
+            roi_load['in_flight'] = roi_in_flight['40_100']
+        big = {'workload': 'the same with RoI sides 100-200 network px (clumps, component proposals)'}
+        big.update(seq_fixed((100.0, 200.0)))
+        if '100_200' in roi_in_flight:
+            big['in_flight'] = roi_in_flight['100_200']
+        roi_load['roi_100_200'] = big
+        mark('_after_roi_load')
     # the same step on the fp32 MFMA kernels (NUHTC_PIPE_FP32), on the record beside the default pipe: same weights, same tiles
     fp32_pipe = None
     if args.pipe == 'split' and not args.no_fp32_pipe and not args.fixed_load:
+        mark('fp32_pipe')
         e32 = Engine(sd, device=local_rank, max_batch=args.batch, tile=(256, 256), matrix_pipe=hip.PIPE_FP32)
         k3 = max(5, min(30, args.steps))
         sync_all()
@@ -518,8 +652,13 @@ def main():
             out['sequential'] = sequential
         if args.gemm_shapes:
             out['gemm_shapes'] = shapes
+        mark('cpu_baseline_host')
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(sd, tiles_np, eng, mode, batch=args.cpu_batch)
+            if args.cpu_full:
+                out['cpu_baseline'] = cpu_baseline(sd, synth.nuclei_tiles(160, 256, start=0), eng, mode, batch=16, timed=10, warm=16, warm_batches=2)
+            else:
+                out['cpu_baseline'] = cpu_baseline(sd, tiles_np, eng, mode, batch=args.cpu_batch)
+        out['power'] = plog.summary(args.power_csv)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
