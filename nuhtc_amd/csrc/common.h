@@ -176,7 +176,7 @@ int launch_merge_ln(const float* x, const float* g, const float* b, float* y, in
 // shift mask packed per lane (engine.hip pack_attn_terms), mask_any [nW] flags the windows with a non-zero mask (maskP null: no shift);
 // window row r is written to out row out_map[r] (skipped when negative), or to row r when out_map is null
 int launch_window_attn(const float* qkv, const float* biasP, const float* maskP, const int* mask_any, const int* out_map, float* out,
-                       int nWinTotal, int nWperImg, int C, int nH, hipStream_t s);
+                       int nWinTotal, int nWperImg, int C, int nH, int split_pipe /* 1: bf16 pipe, exactly split operands */, hipStream_t s);
 
 // ----------------------------------------------------------------------------- dense heads (dense.hip)
 int launch_sem_fuse(const float* g0, const float* g1, const float* g2, const float* g3, float* out, int B, int H, int W,

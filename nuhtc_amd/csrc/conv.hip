@@ -161,6 +161,13 @@ __global__ __launch_bounds__(512, 1) void conv3_split_kernel(Conv3Params p) {
 #else
 #define CSTAMP(v_)
 #endif
+  // Deferred stores (plain convolution): the persistent workgroups of a launch run in step, so storing a tile in its epilogue made every
+  // CU write at once -- 8 MB bursts at the HBM write rate, 4-6 k of a tile's 27 k cycles with the matrix pipe idle (stamps: r04).  A tile's
+  // four 16-byte stores per lane are instead issued one per tap under the NEXT tile's main loop (each right after that tap's weight
+  // load, so the first vector-memory operation queued behind a store is the load of the tap after next: two taps for the store to be
+  // acknowledged before anything waits on it); the last tile's are flushed after the loop.
+  v4f pend[N2 ? 1 : 4];
+  float* pend_o = nullptr;
   for (; tile < t_end; tile += xstride) {
     const int img = tile / tiles_img, tr = tile - img * tiles_img;
     const int ty = tr / p.tiles_x, tx = tr - ty * p.tiles_x;
@@ -210,6 +217,9 @@ __global__ __launch_bounds__(512, 1) void conv3_split_kernel(Conv3Params p) {
           CV_W_STORE(tap + 1)
           if (tap < 7) CV_W_LOAD(tap + 2)
         }
+        if constexpr (N2 == 0) {
+          if (sidx == 0 && tap < 4 && pend_o) *reinterpret_cast<v4f*>(pend_o + 8 * tap) = pend[tap];     // the previous tile's output
+        }
         // next tile's halo: requested behind the last weight load of this tile (vector-memory operations complete in issue order: a
         // weight load queued behind these would make its tap wait for them), three taps before the epilogue
         if (sidx == 1 && tap == 6 && tile + xstride < t_end) CV_HALO_LOAD(tile + xstride)
@@ -233,16 +243,13 @@ __global__ __launch_bounds__(512, 1) void conv3_split_kernel(Conv3Params p) {
     const bool inside = y < p.H && x < p.W;
     const long long pix = ((long long)img * p.H + y) * p.W + x;
     if constexpr (N2 == 0) {
-      if (inside) {
-        const int cb = 32 * (wave >> 2) + 4 * half;
-        float* o = p.out + pix * 64 + cb;
+      pend_o = inside ? p.out + pix * 64 + 32 * (wave >> 2) + 4 * half : nullptr;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          v4f v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-          v += bias4[q];
-          if (p.act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-          *reinterpret_cast<v4f*>(o + 8 * q) = v;
-        }
+      for (int q = 0; q < 4; ++q) {
+        v4f v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+        v += bias4[q];
+        if (p.act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        pend[q] = v;
       }
     } else {
       const float* kst = reinterpret_cast<const float*>(lds + CV_K_OFF);
@@ -341,6 +348,12 @@ __global__ __launch_bounds__(512, 1) void conv3_split_kernel(Conv3Params p) {
     CSTAMP(sBar)
     ++nTiles;
 #endif
+  }
+  if constexpr (N2 == 0) {
+    if (pend_o) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<v4f*>(pend_o + 8 * q) = pend[q];
+    }
   }
 #ifdef NUHTC_CONV_STAMPS
   if (lane == 0 && p.stamps) {
@@ -462,7 +475,7 @@ int launch_conv3_split(const GemmParams& g, hipStream_t s) {
       std::vector<unsigned long long> h((size_t)grid * 8 * 8);
       hipMemcpy(h.data(), stamp_buf, h.size() * 8, hipMemcpyDeviceToHost);
       FILE* f = fopen("/tmp/conv_stamps.txt", "w");
-      fprintf(f, "# H %d W %d nimg %d ntile %d grid %d\n", p.H, p.W, p.nimg, ntile, grid);
+      fprintf(f, "# H %d W %d nimg %d ntile %d grid %d N2 %d store_out %d out3 %d\n", p.H, p.W, p.nimg, ntile, grid, n2, p.store_out, p.out3 ? 1 : 0);
       for (int b = 0; b < grid; ++b) for (int w = 0; w < 8; ++w) { auto* o = &h[((size_t)b * 8 + w) * 8]; fprintf(f, "%d %d %llu %llu %llu %llu %llu %llu %llu\n", b, w, o[0], o[1], o[2], o[3], o[4], o[5], o[6]); }
       fclose(f);
     }

@@ -591,7 +591,7 @@ int run_backbone(nuhtc_engine* e, int B, hipStream_t s) {
         RUN(linear(p));
       }
       }
-      RUN(launch_window_attn(e->qkv, w.relbT, sh ? g.mask : nullptr, sh ? g.mask_any : nullptr, g.cidx[sh], e->att, B * g.nW, g.nW, C, g.nH, s));
+      RUN(launch_window_attn(e->qkv, w.relbT, sh ? g.mask : nullptr, sh ? g.mask_any : nullptr, g.cidx[sh], e->att, B * g.nW, g.nW, C, g.nH, e->cfg.matrix_pipe != NUHTC_PIPE_FP32, s));
       {
         GemmParams p = gp(e->att, w.proj_w, w.proj_b, x, T, C, C);
         p.store = ST_ROWMAP; p.row_map = g.ctok[sh]; p.res = x; p.ldr = C;

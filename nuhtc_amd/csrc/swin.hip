@@ -12,6 +12,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "split_math.h"   // f32x16 / v4f typedefs, the exact bf16 split and its six products
 
 // ----------------------------------------------------------------------------- preproc
 // cv2.resize(INTER_LINEAR) on uint8 exactly as OpenCV's 8-bit fixed-point path computes it (the per-axis tables are
@@ -336,8 +337,6 @@ int launch_merge_ln(const float* x, const float* g, const float* b, float* y, in
 // second product (it sums over the accumulator's row index): no data movement between the two GEMMs.  Q/K fragments are
 // 64 contiguous bytes per lane read straight from the qkv rows; V is read one dword per MFMA step (a full 128-byte row per
 // half-wave).  biasT is the relative-position bias transposed to [head][key][query] so lanes read it contiguously.
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float v4f __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256, 3) void window_attn_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ biasP,
                                                                const float* __restrict__ maskP, const int* __restrict__ mask_any,
@@ -463,12 +462,189 @@ __global__ __launch_bounds__(256, 3) void window_attn_mfma_kernel(const float* _
   }
 }
 
+// ---- the same attention on the bf16 matrix pipe with exactly split operands (the default pipe, NUHTC_PIPE_BF16_SPLIT) -------------
+// Same arrangement (one wave per (window, head), transposed products, query on the lane, probability registers = B operand of the
+// second product); every fp32 operand is split into three bf16 planes and a 32 x 32 x 16 product step is six v_mfma_f32_32x32x16_bf16
+// (split_math.h: what gemm_split_kernel does): 84 MFMAs of 32 cycles per (window, head) instead of 114 of 64.
+//   S^T = K (sQ)^T: head_dim 32 = two k-steps; lane (j, half) element e of k-step s is channel 16 half + 8 s + e -- the 64 contiguous
+//   bytes of a K / Q row the fp32 kernel loads, so both operands keep their loads.
+//   O^T = V^T P^T: the keys are the k axis; accumulator register r of lane (i, half) holds key (r & 3) + 8 (r >> 2) + 4 half of its key
+//   tile, so registers 8 s' .. 8 s' + 7 of a probability tile ARE the 8 k elements of k-step s' when the V operand is loaded in the same
+//   key order (it always was).  Keys 0..47 are three such k-steps; key 48, alone in the fourth, is added by 16 fp32 FMAs per lane
+//   (V[48] broadcast, P[i][48] from the lane that holds it) instead of six MFMAs and two splits over one key.
+__global__ __launch_bounds__(256, 3) void window_attn_split_kernel(const float* __restrict__ qkv, const float* __restrict__ biasP,
+                                                                const float* __restrict__ maskP, const int* __restrict__ mask_any,
+                                                                const int* __restrict__ out_map, float* __restrict__ out, int nPairs,
+                                                                int nWperImg, int C, int nH) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pair = blockIdx.x * 4 + wave;
+  if (pair >= nPairs) return;
+  const int win = pair / nH, head = pair - win * nH;
+  const int l32 = lane & 31, half = lane >> 5;
+  const long long ld = 3LL * C;
+  const float* base = qkv + (long long)win * WS2 * ld + head * HEAD_DIM;
+  const float* bP = biasP + (long long)head * 4096 + (half * 32 + l32) * 32;                    // + ti * 2048
+  const int wimg = win % nWperImg;
+  const float* mP = (maskP && mask_any[wimg]) ? maskP + (long long)wimg * 4096 + (half * 32 + l32) * 32 : nullptr;
+  const float scale = 0.17677669529663687f;   // 32^-0.5
+
+  // K planes of both key tiles: kp[tj][s][plane], lane (j, half) holds channels 16 half + 8 s + 0..7 of key tj*32 + j
+  u32x4 kp[2][2][3];
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj) {
+    const int j = min(tj * 32 + l32, WS2 - 1);
+    const v4f* kptr = reinterpret_cast<const v4f*>(base + j * ld + C + half * 16);
+    v4f kf[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) kf[q] = kptr[q];
+#pragma unroll
+    for (int sk = 0; sk < 2; ++sk) {
+      NUHTC_SPLIT3_INTO(kp[tj][sk], 0, kf[2 * sk].x, kf[2 * sk].y)
+      NUHTC_SPLIT3_INTO(kp[tj][sk], 1, kf[2 * sk].z, kf[2 * sk].w)
+      NUHTC_SPLIT3_INTO(kp[tj][sk], 2, kf[2 * sk + 1].x, kf[2 * sk + 1].y)
+      NUHTC_SPLIT3_INTO(kp[tj][sk], 3, kf[2 * sk + 1].z, kf[2 * sk + 1].w)
+    }
+  }
+  u32x4 vp[3][3];
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti) {
+    if (ti) __builtin_amdgcn_sched_barrier(0);
+    const int i = min(ti * 32 + l32, WS2 - 1);
+    v4f qf[4];
+    {
+      const v4f* qp = reinterpret_cast<const v4f*>(base + i * ld + half * 16);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) qf[q] = qp[q];
+    }
+    // the additive score terms (relative-position bias + shift mask) are loaded straight into the score accumulators: the products are
+    // accumulated on top of them (the Q split below covers the latency of these loads; 25 registers less than adding them afterwards)
+    f32x16 st[2];
+    {
+      const v4f* bp = reinterpret_cast<const v4f*>(bP + ti * 2048);
+      v4f t4[7];
+#pragma unroll
+      for (int q = 0; q < 7; ++q) t4[q] = bp[q];          // registers 0..15 of key tile 0, 0..11 of key tile 1 (9 are used)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { st[0][4 * q] = t4[q].x; st[0][4 * q + 1] = t4[q].y; st[0][4 * q + 2] = t4[q].z; st[0][4 * q + 3] = t4[q].w; }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { st[1][4 * q] = t4[4 + q].x; st[1][4 * q + 1] = t4[4 + q].y; st[1][4 * q + 2] = t4[4 + q].z; st[1][4 * q + 3] = t4[4 + q].w; }
+#pragma unroll
+      for (int r = 12; r < 16; ++r) st[1][r] = 0.f;
+    }
+    // V operand of the second product (lane (d = l32, half)), keys 0..47 in the accumulator's key order: group g = keys of registers
+    // 8 (g & 1) .. + 7 of key tile g >> 1; requested with the first query tile's loads, split after its softmax
+    float vv[3][8];
+    if (ti == 0) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int r = 8 * (g & 1) + e;
+          vv[g][e] = base[((g >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * ld + 2 * C + l32];
+        }
+    }
+    u32x4 qpl[2][3];
+#pragma unroll
+    for (int sk = 0; sk < 2; ++sk) {
+      const v4f a = qf[2 * sk] * scale, b = qf[2 * sk + 1] * scale;
+      NUHTC_SPLIT3_INTO(qpl[sk], 0, a.x, a.y)
+      NUHTC_SPLIT3_INTO(qpl[sk], 1, a.z, a.w)
+      NUHTC_SPLIT3_INTO(qpl[sk], 2, b.x, b.y)
+      NUHTC_SPLIT3_INTO(qpl[sk], 3, b.z, b.w)
+    }
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int sk = 0; sk < 2; ++sk) st[tj] = mfma_split6(kp[tj][sk], qpl[sk], st[tj]);
+    if (mP) {      // the shift mask of the few windows that have one (last row / column of windows of a shifted block): after the products
+      const v4f* mp = reinterpret_cast<const v4f*>(mP + ti * 2048);
+      v4f m4[7];
+#pragma unroll
+      for (int q = 0; q < 7; ++q) m4[q] = mp[q];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { st[0][4 * q] += m4[q].x; st[0][4 * q + 1] += m4[q].y; st[0][4 * q + 2] += m4[q].z; st[0][4 * q + 3] += m4[q].w; }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { st[1][4 * q] += m4[4 + q].x; st[1][4 * q + 1] += m4[4 + q].y; st[1][4 * q + 2] += m4[4 + q].z; st[1][4 * q + 3] += m4[4 + q].w; }
+    }
+    // keys >= 49 masked out; softmax over the keys of query i
+    constexpr int NR1 = 9;
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int r = 0; r < (tj ? NR1 : 16); ++r) {
+        const int j = tj * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v = st[tj][r];
+        v = j < WS2 ? v : -3.0e38f;
+        st[tj][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int r = 0; r < (tj ? NR1 : 16); ++r) {
+        const float e = __expf(st[tj][r] - mx);
+        st[tj][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 32);
+    const float rsum = 1.0f / sum;
+    if (ti == 0) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        NUHTC_SPLIT3_INTO(vp[g], 0, vv[g][0], vv[g][1])
+        NUHTC_SPLIT3_INTO(vp[g], 1, vv[g][2], vv[g][3])
+        NUHTC_SPLIT3_INTO(vp[g], 2, vv[g][4], vv[g][5])
+        NUHTC_SPLIT3_INTO(vp[g], 3, vv[g][6], vv[g][7])
+      }
+    }
+    // O^T[d][i] = sum_j V[j][d] P[i][j]: A = V planes (lane = d), B = the planes of the probability registers themselves
+    f32x16 ot;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[r] = 0.f;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      u32x4 pp[3];
+      const int tj = g >> 1, r0 = 8 * (g & 1);
+      NUHTC_SPLIT3_INTO(pp, 0, st[tj][r0] * rsum, st[tj][r0 + 1] * rsum)
+      NUHTC_SPLIT3_INTO(pp, 1, st[tj][r0 + 2] * rsum, st[tj][r0 + 3] * rsum)
+      NUHTC_SPLIT3_INTO(pp, 2, st[tj][r0 + 4] * rsum, st[tj][r0 + 5] * rsum)
+      NUHTC_SPLIT3_INTO(pp, 3, st[tj][r0 + 6] * rsum, st[tj][r0 + 7] * rsum)
+      ot = mfma_split6(vp[g], pp, ot);
+    }
+    {   // key 48: register 8 of key tile 1 in the lower half-wave; V[48][d] for the 16 rows d = 8 g + 4 half + 0..3 of this lane's registers
+      v4f v48[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) v48[g] = *reinterpret_cast<const v4f*>(base + 48 * ld + 2 * C + 8 * g + 4 * half);
+      const float p48 = __shfl(st[1][8], l32) * rsum;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        ot[4 * g] = fmaf(v48[g].x, p48, ot[4 * g]); ot[4 * g + 1] = fmaf(v48[g].y, p48, ot[4 * g + 1]);
+        ot[4 * g + 2] = fmaf(v48[g].z, p48, ot[4 * g + 2]); ot[4 * g + 3] = fmaf(v48[g].w, p48, ot[4 * g + 3]);
+      }
+    }
+    long long orow = (long long)win * WS2 + ti * 32 + l32;
+    if (ti * 32 + l32 < WS2 && out_map) orow = out_map[orow];
+    if (ti * 32 + l32 < WS2 && orow >= 0) {
+      float* op = out + orow * C + head * HEAD_DIM + 4 * half;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)   // registers 4g..4g+3 are d = 8g + 4*half + 0..3
+        *reinterpret_cast<v4f*>(op + 8 * g) = (v4f){ot[4 * g], ot[4 * g + 1], ot[4 * g + 2], ot[4 * g + 3]};
+    }
+  }
+}
+
 int launch_window_attn(const float* qkv, const float* biasP, const float* maskP, const int* mask_any, const int* out_map, float* out,
-                       int nWinTotal, int nWperImg, int C, int nH, hipStream_t s) {
+                       int nWinTotal, int nWperImg, int C, int nH, int split_pipe, hipStream_t s) {
   ProfScope ps("window_attn", 4.0 * 49 * 49 * 32 * nWinTotal * nH, 16.0 * 49 * C * nWinTotal, s);
   int nPairs = nWinTotal * nH;
   if (nPairs <= 0) return 0;
   if (!biasP || (maskP && !mask_any)) return NUHTC_E_INVALID;
-  hipLaunchKernelGGL(window_attn_mfma_kernel, dim3(cdiv(nPairs, 4)), dim3(256), 0, s, qkv, biasP, maskP, mask_any, out_map, out, nPairs, nWperImg, C, nH);
+  if (split_pipe)
+    hipLaunchKernelGGL(window_attn_split_kernel, dim3(cdiv(nPairs, 4)), dim3(256), 0, s, qkv, biasP, maskP, mask_any, out_map, out, nPairs, nWperImg, C, nH);
+  else
+    hipLaunchKernelGGL(window_attn_mfma_kernel, dim3(cdiv(nPairs, 4)), dim3(256), 0, s, qkv, biasP, maskP, mask_any, out_map, out, nPairs, nWperImg, C, nH);
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
 }
