@@ -150,16 +150,24 @@ class PowerLog:
     def mark(self, name):
         self.marks.append((name, time.time() - self.t0))
 
-    def summary(self, csv_path=None):
-        """-> dict: per marked phase the mean / max power, mean shader clock and max temperatures; optionally the samples as CSV."""
+    def summary(self, csv_path=None, pci_bdf=None):
+        """-> dict: per marked phase the mean / max power, mean shader clock and max temperatures; optionally the samples as CSV.
+        `pci_bdf` ('0000:0a:00.0') names this process's GPU; without it (or without a match) the busiest card is taken -- which on a
+        shared host may be somebody else's."""
         self.stop.set()
         if not self.cards:
             return {'available': False, 'note': 'no amdgpu hwmon files readable on this box'}
         self.th.join()
-        best = max(self.rows, key=lambda c: sum((r[5] or 0) for r in self.rows[c]))
+        best = None
+        if pci_bdf:
+            hit = [c for c in self.rows if os.path.realpath(c).lower().endswith(pci_bdf.lower())]
+            best = hit[0] if hit else None
+        matched = best is not None
+        if best is None:
+            best = max(self.rows, key=lambda c: sum((r[5] or 0) for r in self.rows[c]))
         rows = self.rows[best]
         hm = [c for c in self.cards if c[0] == best][0][1]
-        out = {'available': True, 'device': os.path.realpath(best), 'power_cap_w': self._read(os.path.join(hm, 'power1_cap'), 1e-6), 'sample_hz': 10, 'phases': {}}
+        out = {'available': True, 'device': os.path.realpath(best), 'device_chosen_by': 'pci bus id of this process\'s GPU' if matched else 'busiest card in sysfs', 'power_cap_w': self._read(os.path.join(hm, 'power1_cap'), 1e-6), 'sample_hz': 10, 'phases': {}}
         mean = lambda v: (sum(v) / len(v)) if v else None
         for i, (name, t_a) in enumerate(self.marks):
             t_b = self.marks[i + 1][1] if i + 1 < len(self.marks) else rows[-1][0] + 1
@@ -658,7 +666,13 @@ def main():
                 out['cpu_baseline'] = cpu_baseline(sd, synth.nuclei_tiles(160, 256, start=0), eng, mode, batch=16, timed=10, warm=16, warm_batches=2)
             else:
                 out['cpu_baseline'] = cpu_baseline(sd, tiles_np, eng, mode, batch=args.cpu_batch)
-        out['power'] = plog.summary(args.power_csv)
+        bdf = None
+        try:
+            pr = torch.cuda.get_device_properties(local_rank)
+            bdf = f'{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0'
+        except Exception:
+            pass
+        out['power'] = plog.summary(args.power_csv, bdf)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

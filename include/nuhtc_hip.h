@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NUHTC_ABI_VERSION 5
+#define NUHTC_ABI_VERSION 6
 
 enum {
   NUHTC_OK = 0,
@@ -233,6 +233,12 @@ int nuhtc_op_gemm_split(nuhtc_engine* e, const float* A, const float* W_dev, con
  * everything else device memory.  C must be a width the fused kernel serves (96).  Synchronises `stream`. */
 int nuhtc_op_swin_mlp(nuhtc_engine* e, const float* x_dev, const float* ln_g_dev, const float* ln_b_dev, const float* w1_host,
                       const float* b1_dev, const float* w2_host, const float* b2_dev, float* out_dev, int T, int C, void* stream);
+/* ABI v6 (round 4).  The same kernel with the attention projection in front (mmdet swin.py:360-367, the second half of a Swin block from the
+ * attention output on):  x' = x + Wp att + bp;  out = x' + W2 gelu(W1 LN(x') + b1) + b2.  att [T,C] in token order, Wp [C][C] given as a HOST
+ * array, everything else as in nuhtc_op_swin_mlp.  Synchronises `stream`. */
+int nuhtc_op_swin_proj_mlp(nuhtc_engine* e, const float* x_dev, const float* att_dev, const float* wp_host, const float* bp_dev,
+                           const float* ln_g_dev, const float* ln_b_dev, const float* w1_host, const float* b1_dev, const float* w2_host,
+                           const float* b2_dev, float* out_dev, int T, int C, void* stream);
 /* mmcv RoIAlign(avg, aligned=True) on an NHWC map: feat [N,H,W,C=64], rois [R,5] -> out [R,P,P,C]. */
 int nuhtc_op_roi_align(nuhtc_engine* e, const float* feat_nhwc, int N, int H, int W, const float* rois, int R, int P,
                        float spatial_scale, int sampling_ratio, float* out, void* stream);

@@ -132,8 +132,12 @@ int launch_conv3_split(const GemmParams& p, hipStream_t s);
 bool mlp_supported(int C);
 size_t mlp_stream_bytes(int C);
 void mlp_pack_stream(const float* w1, const float* w2, int C, std::vector<unsigned short>& out);
+// With `att` (attention output [T][C] in token order), `pstream` (proj_pack_stream of the projection weight, device copy) and `bp`:
+// the attention projection and its residual run in front, x' = x_in + Wp att + bp, and the FFN half on x' (x_in == x_out required).
+size_t proj_stream_bytes(int C);
+void proj_pack_stream(const float* w, int C, std::vector<unsigned short>& out);
 int launch_swin_mlp(const float* x_in, float* x_out, const float* ln_g, const float* ln_b, const void* wstream, const float* b1, const float* b2,
-                    int T, int C, hipStream_t s);
+                    int T, int C, hipStream_t s, const float* att = nullptr, const void* pstream = nullptr, const float* bp = nullptr);
 
 // fused LN1 + QKV linear (mlp.hip, C = 96): qkv window image rows of the T real tokens + the bias rows of the padding tokens
 bool lnqkv_supported(int C);

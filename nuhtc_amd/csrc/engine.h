@@ -21,6 +21,7 @@ struct BlockW {
   float *n1g, *n1b, *relbT /* relative-position bias packed per lane [nH][4096] */, *qkv_w, *qkv_b, *proj_w, *proj_b, *n2g, *n2b, *f1_w, *f1_b, *f2_w, *f2_b;
   void* qkv_stream;    // fused LN1 + QKV (mlp.hip): k-permuted split planes of qkv_w, null where LN + GEMM run separately
   void* mlp_stream;    // fused FFN half (mlp.hip): chunk-major split planes of f1_w / f2_w, null where the three separate launches run
+  void* proj_stream;   // attention projection in front of the fused FFN half (mlp.hip): k-permuted split planes of proj_w, null where proj is a GEMM launch
 };
 
 struct nuhtc_engine {

@@ -408,6 +408,9 @@ int nuhtc_finalize(nuhtc_engine* e) {
         mlp_pack_stream(f1w->data.data(), f2w->data.data(), C, st);
         if ((rc = dev_alloc(e, &bw.mlp_stream, st.size() * 2))) return rc;
         HIP_CHECK(e, hipMemcpy(bw.mlp_stream, st.data(), st.size() * 2, hipMemcpyHostToDevice));
+        proj_pack_stream(pw->data.data(), C, st);
+        if ((rc = dev_alloc(e, &bw.proj_stream, st.size() * 2))) return rc;
+        HIP_CHECK(e, hipMemcpy(bw.proj_stream, st.data(), st.size() * 2, hipMemcpyHostToDevice));
       }
       e->blocks[s].push_back(bw);
     }
@@ -591,16 +594,21 @@ int run_backbone(nuhtc_engine* e, int B, hipStream_t s) {
         RUN(linear(p));
       }
       }
-      RUN(launch_window_attn(e->qkv, w.relbT, sh ? g.mask : nullptr, sh ? g.mask_any : nullptr, g.cidx[sh], e->att, B * g.nW, g.nW, C, g.nH, e->cfg.matrix_pipe != NUHTC_PIPE_FP32, s));
-      {
+      // x += W2·gelu(W1·LN2(x))      (swin.py:365-367, mmcv FFN)
+      static const int& fused_mlp = dev_knob_ref("FUSED_MLP", 1);
+      static const int& fused_proj = dev_knob_ref("FUSED_PROJ", 1);
+      const bool mlp1 = w.mlp_stream && fused_mlp, proj1 = mlp1 && w.proj_stream && fused_proj;
+      // Where the projection rides in front of the fused FFN kernel (stage 1, round 4) the attention kernel writes its rows in TOKEN
+      // order (window row -> token map) instead of the compact window order the projection GEMM scatters from
+      RUN(launch_window_attn(e->qkv, w.relbT, sh ? g.mask : nullptr, sh ? g.mask_any : nullptr, proj1 ? g.map[sh] : g.cidx[sh], e->att, B * g.nW, g.nW, C, g.nH,
+                             e->cfg.matrix_pipe != NUHTC_PIPE_FP32, s));
+      if (!proj1) {
         GemmParams p = gp(e->att, w.proj_w, w.proj_b, x, T, C, C);
         p.store = ST_ROWMAP; p.row_map = g.ctok[sh]; p.res = x; p.ldr = C;
         RUN(linear(p));
       }
-      // x += W2·gelu(W1·LN2(x))      (swin.py:365-367, mmcv FFN)
-      static const int& fused_mlp = dev_knob_ref("FUSED_MLP", 1);
-      if (w.mlp_stream && fused_mlp) {      // one kernel: LN2, both linears, GELU and the residual (mlp.hip)
-        RUN(launch_swin_mlp(x, x, w.n2g, w.n2b, w.mlp_stream, w.f1_b, w.f2_b, T, C, s));
+      if (mlp1) {      // one kernel: [attention projection + residual,] LN2, both linears, GELU and the residual (mlp.hip)
+        RUN(launch_swin_mlp(x, x, w.n2g, w.n2b, w.mlp_stream, w.f1_b, w.f2_b, T, C, s, proj1 ? e->att : nullptr, w.proj_stream, w.proj_b));
       } else {
       RUN(launch_layernorm(x, nullptr, w.n2g, w.n2b, e->xw, T, C, s));
       {
@@ -876,5 +884,29 @@ int nuhtc_op_swin_mlp(nuhtc_engine* e, const float* x_dev, const float* ln_g_dev
   hipFree(d);
   if (rc) FAIL(e, rc, "swin_mlp launch failed");
   if (he != hipSuccess) FAIL(e, NUHTC_E_HIP, "swin_mlp kernel failed");
+  return 0;
+}
+
+int nuhtc_op_swin_proj_mlp(nuhtc_engine* e, const float* x_dev, const float* att_dev, const float* wp_host, const float* bp_dev, const float* ln_g_dev,
+                           const float* ln_b_dev, const float* w1_host, const float* b1_dev, const float* w2_host, const float* b2_dev, float* out_dev,
+                           int T, int C, void* stream) {
+  if (!e || !x_dev || !att_dev || !wp_host || !bp_dev || !ln_g_dev || !ln_b_dev || !w1_host || !b1_dev || !w2_host || !b2_dev || !out_dev || T < 1) return NUHTC_E_INVALID;
+  if (!mlp_supported(C)) FAIL(e, NUHTC_E_INVALID, "nuhtc_op_swin_proj_mlp: unsupported channel count");
+  HIP_CHECK(e, hipSetDevice(e->device));
+  std::vector<unsigned short> st, sp;
+  mlp_pack_stream(w1_host, w2_host, C, st);
+  proj_pack_stream(wp_host, C, sp);
+  void *d = nullptr, *dp = nullptr;
+  HIP_CHECK(e, hipMalloc(&d, st.size() * 2));
+  if (hipMalloc(&dp, sp.size() * 2) != hipSuccess) { hipFree(d); FAIL(e, NUHTC_E_HIP, "hipMalloc failed"); }
+  bool ok = hipMemcpy(d, st.data(), st.size() * 2, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dp, sp.data(), sp.size() * 2, hipMemcpyHostToDevice) == hipSuccess;
+  // the kernel works in place (its FFN residual re-reads x' where the projection stored it): out <- x first
+  if (ok && out_dev != x_dev) ok = hipMemcpyAsync(out_dev, x_dev, (size_t)T * C * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess;
+  int rc = ok ? launch_swin_mlp(out_dev, out_dev, ln_g_dev, ln_b_dev, d, b1_dev, b2_dev, T, C, (hipStream_t)stream, att_dev, dp, bp_dev) : NUHTC_E_HIP;
+  hipError_t he = hipStreamSynchronize((hipStream_t)stream);
+  hipFree(d);
+  hipFree(dp);
+  if (rc) FAIL(e, rc, "swin_proj_mlp launch failed");
+  if (he != hipSuccess) FAIL(e, NUHTC_E_HIP, "swin_proj_mlp kernel failed");
   return 0;
 }

@@ -34,6 +34,10 @@ struct MlpParams {
   const float* b2;        // [C]
   int T;
   unsigned long long* stamps;   // dev instrumentation (-DNUHTC_MLP_STAMPS), null otherwise
+  // attention projection in front of the FFN (template PROJ):  x <- x + Wp att + bp  first (mmdet swin.py:360-363), then the FFN half on it
+  const float* att;       // [T][C] attention output in TOKEN order (the attention kernel scatters through the window -> token map)
+  const char* pstream;    // C rows x (C/8) k-groups x 3 planes x 8 bf16 of the k-permuted projection weight (lnqkv_pack_rows)
+  const float* bp;        // [C]
 };
 
 template <int C>
@@ -47,11 +51,13 @@ struct MlpGeom {
   static constexpr int W1BUF = 32 * P1, W2BUF = C * P2;   // bytes of one W1 / W2 chunk image
   static constexpr int W2OFF = 2 * W1BUF;           // W1 images: 2 slots (chunk & 1); W2 images: 3 slots (chunk % 3, see the stagger)
   static constexpr int VEC_OFF = W2OFF + 3 * W2BUF; // then: ln_g[C], ln_b[C], b2[C], b1[HID] as floats
-  static constexpr int LDS_BYTES = VEC_OFF + (3 * C + HID) * 4;
+  static constexpr int LDS_BYTES = VEC_OFF + (4 * C + HID) * 4;      // ln_g, ln_b, b2, b1, then the projection bias
+  static constexpr int PPIECES = C * (R1 / 16);     // the projection weight image: C rows at pitch P1, in the (not yet used) W2 slots
+  static_assert(C * P1 <= 3 * W2BUF, "projection image fits the three W2 slots");
   static_assert((P1 / 16) % 2 == 1 && (P2 / 16) % 2 == 1, "odd pitch");
 };
 
-template <int C, int NW, bool STAG>
+template <int C, int NW, bool STAG, bool PROJ>
 __global__ __launch_bounds__(64 * NW, 1) void swin_mlp_kernel(MlpParams p) {
   using G = MlpGeom<C>;
   constexpr int NT = 64 * NW;
@@ -100,23 +106,99 @@ __global__ __launch_bounds__(64 * NW, 1) void swin_mlp_kernel(MlpParams p) {
       if (NT * j + NT <= G::PIECES || tid + NT * j < G::PIECES)                                                   \
         *reinterpret_cast<u32x4*>(lds + st_lds[j] + (st_w2[j] ? o2 : o1)) = stg[j]; }
 
-  MLP_LOAD_CHUNK(0)
-  for (int i = tid; i < C; i += NT) { vec[i] = p.ln_g[i]; vec[C + i] = p.ln_b[i]; vec[2 * C + i] = p.b2[i]; }
-  for (int i = tid; i < G::HID; i += NT) vec[3 * C + i] = p.b1[i];
-
   // ---- this lane's token row (clamped: rows past T are computed on the last row and never stored)
   const long long tok = (long long)blockIdx.x * (32 * NW) + wave * 32 + i32;
   const bool tok_ok = tok < p.T;
   const float* xrow = p.x_in + (tok_ok ? tok : (long long)p.T - 1) * C + 4 * half;
 
-  // ---- LN2 of the token tile + operand split: xp[s][plane] = B operand of k-step s (8 channels: 32t + 8q + 4 half + i, q = 2(s&1) + e/4)
-  u32x4 xp[G::KS1][3];
-  {
-    v4f xv[G::CT][4];
+  v4f xv[G::CT][4];
+  if constexpr (PROJ) {
+    // ---- attention projection + residual first:  x' = x + Wp att + bp.  The projection weight (C x C, k axis permuted like W1) is staged
+    // into the three W2 slots, which chunk 0 does not need before the barrier below; the product is the transposed one of the FFN
+    // (out channel rows from LDS, the token tile's attention planes as the B operand), so its accumulators have the layout of the x
+    // loads and x' stays in the registers the LN reads.  x' is also written to x_out at once: the FFN's residual re-reads it there
+    // (the same lane, microseconds later, served by L2 like the re-read of x_in without the projection).
+    constexpr int NPP = (G::PPIECES + NT - 1) / NT;
+    u32x4 pst[NPP];
+#pragma unroll
+    for (int j = 0; j < NPP; ++j)
+      if (NT * j + NT <= G::PPIECES || tid + NT * j < G::PPIECES)
+        pst[j] = *reinterpret_cast<const u32x4*>(p.pstream + ((long long)tid + (long long)NT * j) * 16);
+    const float* arow = p.att + (tok_ok ? tok : (long long)p.T - 1) * C + 4 * half;
+    v4f av[G::CT][4];
+#pragma unroll
+    for (int t = 0; t < G::CT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) av[t][q] = *reinterpret_cast<const v4f*>(arow + 32 * t + 8 * q);
 #pragma unroll
     for (int t = 0; t < G::CT; ++t)
 #pragma unroll
       for (int q = 0; q < 4; ++q) xv[t][q] = *reinterpret_cast<const v4f*>(xrow + 32 * t + 8 * q);
+    for (int i = tid; i < C; i += NT) { vec[i] = p.ln_g[i]; vec[C + i] = p.ln_b[i]; vec[2 * C + i] = p.b2[i]; vec[3 * C + G::HID + i] = p.bp[i]; }
+    for (int i = tid; i < G::HID; i += NT) vec[3 * C + i] = p.b1[i];
+#pragma unroll
+    for (int j = 0; j < NPP; ++j) {
+      const int q = tid + NT * j;
+      if (NT * j + NT <= G::PPIECES || q < G::PPIECES) {
+        const int row = q / (G::R1 / 16), col = q - row * (G::R1 / 16);
+        *reinterpret_cast<u32x4*>(lds + G::W2OFF + row * G::P1 + col * 16) = pst[j];
+      }
+    }
+    __syncthreads();
+    MLP_LOAD_CHUNK(0)
+    u32x4 ap[G::KS1][3];
+#pragma unroll
+    for (int t = 0; t < G::CT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int sk = 2 * t + (q >> 1), d0 = 2 * (q & 1);
+        NUHTC_SPLIT3_INTO(ap[sk], d0, av[t][q].x, av[t][q].y)
+        NUHTC_SPLIT3_INTO(ap[sk], d0 + 1, av[t][q].z, av[t][q].w)
+      }
+    const float* lbp = vec + 3 * C + G::HID;
+    const char* wp_lane = lds + G::W2OFF + i32 * G::P1 + half * 48;
+#pragma unroll
+    for (int t = 0; t < G::CT; ++t) {
+      f32x16 pa;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pa[r] = 0.f;
+#pragma unroll
+      for (int sk = 0; sk < G::KS1; ++sk) {
+        u32x4 wf[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) wf[pl] = *reinterpret_cast<const u32x4*>(wp_lane + t * 32 * G::P1 + sk * 96 + pl * 16);
+        pa = mfma_split6(wf, ap[sk], pa);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const v4f bb = *reinterpret_cast<const v4f*>(lbp + 32 * t + 8 * q + 4 * half);
+        // (the GEMM epilogue this replaces: (sum + bias) + residual)
+        xv[t][q] = (v4f{pa[4 * q], pa[4 * q + 1], pa[4 * q + 2], pa[4 * q + 3]} + bb) + xv[t][q];
+      }
+    }
+    if (tok_ok) {
+      float* orow = p.x_out + tok * C + 4 * half;
+#pragma unroll
+      for (int t = 0; t < G::CT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<v4f*>(orow + 32 * t + 8 * q) = xv[t][q];
+    }
+    __syncthreads();               // every wave is done with the projection image before chunk 0's W2 part overwrites it
+  } else {
+    MLP_LOAD_CHUNK(0)
+    for (int i = tid; i < C; i += NT) { vec[i] = p.ln_g[i]; vec[C + i] = p.ln_b[i]; vec[2 * C + i] = p.b2[i]; }
+    for (int i = tid; i < G::HID; i += NT) vec[3 * C + i] = p.b1[i];
+#pragma unroll
+    for (int t = 0; t < G::CT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xv[t][q] = *reinterpret_cast<const v4f*>(xrow + 32 * t + 8 * q);
+  }
+  // with PROJ the residual of the epilogue is x', which lives in x_out (x_in == x_out in the engine's in-place use)
+  const float* rrow = PROJ ? p.x_out + (tok_ok ? tok : (long long)p.T - 1) * C + 4 * half : xrow;
+
+  // ---- LN2 of the token tile + operand split: xp[s][plane] = B operand of k-step s (8 channels: 32t + 8q + 4 half + i, q = 2(s&1) + e/4)
+  u32x4 xp[G::KS1][3];
+  {
     float sum = 0.f;
 #pragma unroll
     for (int t = 0; t < G::CT; ++t)
@@ -230,7 +312,7 @@ __global__ __launch_bounds__(64 * NW, 1) void swin_mlp_kernel(MlpParams p) {
     for (int t = 0; t < G::CT; ++t) {
       v4f res[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) res[q] = *reinterpret_cast<const v4f*>(xrow + 32 * t + 8 * q);
+      for (int q = 0; q < 4; ++q) res[q] = *reinterpret_cast<const v4f*>(rrow + 32 * t + 8 * q);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const v4f bb = *reinterpret_cast<const v4f*>(lb2 + 32 * t + 8 * q + 4 * half);
@@ -479,21 +561,40 @@ void mlp_pack_stream(const float* w1, const float* w2, int C, std::vector<unsign
 
 bool mlp_supported(int C) { return C == 96; }
 
+size_t proj_stream_bytes(int C) { return (size_t)C * (C / 8) * 48; }
+// w [C][C] -> rows in order, k axis permuted like the MLP's W1 (the image swin_mlp_kernel<PROJ> stages)
+void proj_pack_stream(const float* w, int C, std::vector<unsigned short>& out) {
+  out.assign(proj_stream_bytes(C) / 2, 0);
+  unsigned short* o = out.data();
+  for (int r = 0; r < C; ++r)
+    for (int kg = 0; kg < C / 8; ++kg) {
+      for (int e = 0; e < 8; ++e) {
+        const int kp = 8 * kg + e, k = (kp & ~15) + mlp_perm16(kp & 15);
+        mlp_split3(w[(size_t)r * C + k], o + e);
+      }
+      o += 24;
+    }
+}
+
 int launch_swin_mlp(const float* x_in, float* x_out, const float* ln_g, const float* ln_b, const void* wstream, const float* b1, const float* b2,
-                    int T, int C, hipStream_t s) {
+                    int T, int C, hipStream_t s, const float* att, const void* pstream, const float* bp) {
   if (T <= 0) return 0;
   if (!mlp_supported(C) || !wstream) return NUHTC_E_INVALID;
-  MlpParams p{x_in, x_out, ln_g, ln_b, reinterpret_cast<const char*>(wstream), b1, b2, T, nullptr};
+  const bool proj = att != nullptr;
+  if (proj && (!pstream || !bp)) return NUHTC_E_INVALID;
+  MlpParams p{x_in, x_out, ln_g, ln_b, reinterpret_cast<const char*>(wstream), b1, b2, T, nullptr, att, reinterpret_cast<const char*>(pstream), bp};
 #ifdef NUHTC_MLP_STAMPS
   static unsigned long long* stamp_buf = nullptr;
   if (!stamp_buf && hipMalloc(&stamp_buf, 8ull * 8 * 8 * 4096) != hipSuccess) return NUHTC_E_HIP;
   p.stamps = stamp_buf;
 #endif
   // algorithmic work: both products; bytes: x read and written once (+ the weight stream once)
-  ProfScope ps("swin_mlp", 16.0 * T * C * C, 8.0 * T * C + (double)mlp_stream_bytes(C), s);
+  // (with the projection: + 2 T C^2 flop, + the attention rows read once)
+  ProfScope ps("swin_mlp", (proj ? 18.0 : 16.0) * T * C * C, (proj ? 12.0 : 8.0) * T * C + (double)mlp_stream_bytes(C) + (proj ? (double)proj_stream_bytes(C) : 0.0), s);
   constexpr int NW = 8;
   static const int& stagger = dev_knob_ref("MLP_STAGGER", 1);
-  auto kern = stagger ? &swin_mlp_kernel<96, NW, true> : &swin_mlp_kernel<96, NW, false>;
+  auto kern = proj ? (stagger ? &swin_mlp_kernel<96, NW, true, true> : &swin_mlp_kernel<96, NW, false, true>)
+                   : (stagger ? &swin_mlp_kernel<96, NW, true, false> : &swin_mlp_kernel<96, NW, false, false>);
   {
     static std::set<std::pair<int, const void*>> done;      // the kernel needs more than the default 64 KB of dynamic LDS: raised once per device
     static std::mutex mu;

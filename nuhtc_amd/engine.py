@@ -330,6 +330,18 @@ class Engine:
                                                w2h.ctypes.data_as(ctypes.c_void_p), b2.data_ptr(), out.data_ptr(), T, C, self._stream()))
         return out
 
+    def op_swin_proj_mlp(self, x, att, wp, bp, ln_g, ln_b, w1, b1, w2, b2):
+        """x' = x + Wp att + bp; x' + W2 gelu(W1 LN(x') + b1) + b2: the fused second half of a Swin block (csrc/mlp.hip with the attention
+        projection in front); x, att (T, C) and the vectors on the device, the weight matrices anywhere."""
+        T, C = x.shape
+        out = torch.empty_like(x)
+        h = lambda w: np.ascontiguousarray(w.detach().cpu().numpy(), dtype=np.float32)
+        wph, w1h, w2h = h(wp), h(w1), h(w2)
+        cp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        self._check(self.lib.nuhtc_op_swin_proj_mlp(self.h, x.data_ptr(), att.data_ptr(), cp(wph), bp.data_ptr(), ln_g.data_ptr(), ln_b.data_ptr(), cp(w1h),
+                                                    b1.data_ptr(), cp(w2h), b2.data_ptr(), out.data_ptr(), T, C, self._stream()))
+        return out
+
     def op_roi_align(self, feat_nhwc, rois, P, scale, sr):
         N, H, W, C = feat_nhwc.shape
         R = rois.shape[0]

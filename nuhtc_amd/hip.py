@@ -40,7 +40,7 @@ class Dets(ctypes.Structure):
 EXPORTS = ['nuhtc_default_config', 'nuhtc_create', 'nuhtc_destroy', 'nuhtc_last_error', 'nuhtc_load_weight',
            'nuhtc_finalize', 'nuhtc_infer', 'nuhtc_infer_fixed_load', 'nuhtc_check', 'nuhtc_get_buffer',
            'nuhtc_op_gemm', 'nuhtc_op_gemm_split', 'nuhtc_op_roi_align', 'nuhtc_op_nms', 'nuhtc_profile_enable', 'nuhtc_profile_read', 'nuhtc_dev_knob', 'nuhtc_export_crops',
-           'nuhtc_mask_contours', 'nuhtc_merge_overlap', 'nuhtc_export_kept', 'nuhtc_clock_probe', 'nuhtc_op_swin_mlp', 'nuhtc_stream']
+           'nuhtc_mask_contours', 'nuhtc_merge_overlap', 'nuhtc_export_kept', 'nuhtc_clock_probe', 'nuhtc_op_swin_mlp', 'nuhtc_stream', 'nuhtc_op_swin_proj_mlp']
 
 _lib = None
 
@@ -71,6 +71,7 @@ def load():
     lib.nuhtc_op_gemm.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
     lib.nuhtc_op_gemm_split.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
     lib.nuhtc_op_swin_mlp.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp]
+    lib.nuhtc_op_swin_proj_mlp.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp]
     lib.nuhtc_op_roi_align.argtypes = [vp, vp, ci, ci, ci, vp, ci, ci, cf, ci, vp, vp]
     lib.nuhtc_op_nms.argtypes = [vp, vp, vp, ci, cf, vp, vp, vp]
     lib.nuhtc_mask_contours.argtypes = [vp, ctypes.POINTER(Dets), ci, ci, vp, vp, vp]

@@ -235,3 +235,47 @@ def test_fused_mlp_kernel_vs_fp64(hip_device):
         eng._check(eng.lib.nuhtc_op_swin_mlp(eng.h, xd.data_ptr(), d['g'].data_ptr(), d['b'].data_ptr(), w1h.ctypes.data, d['b1'].data_ptr(),
                                              w2h.ctypes.data, d['b2'].data_ptr(), xd.data_ptr(), T, C, eng._stream()))
         assert torch.equal(xd.cpu(), out)
+
+
+def test_fused_proj_mlp_kernel_vs_fp64(hip_device):
+    """csrc/mlp.hip with the attention projection in front (round 4: x' = x + Wp att + bp, then LN2 + fc1 + GELU + fc2 + residual on x',
+    one kernel: the second half of a Swin block from the attention output on, mmdet swin.py:360-367) against an fp64 evaluation and beside
+    the fp32 torch chain; ragged token counts, large activations, and the engine's in-place use (out aliases x)."""
+    g = G.load('small_b2')
+    eng, _ = _engine(g)
+    gen = torch.Generator().manual_seed(7)
+    C = 96
+    for T, scale in [(256, 1.0), (1000, 1.0), (31, 3.0), (4096 + 17, 10.0)]:
+        x = torch.randn(T, C, generator=gen) * scale + 0.3
+        att = torch.randn(T, C, generator=gen) * scale
+        wp = torch.randn(C, C, generator=gen) / C ** 0.5
+        bp = 0.1 * torch.randn(C, generator=gen)
+        ln_g = 1 + 0.1 * torch.randn(C, generator=gen)
+        ln_b = 0.1 * torch.randn(C, generator=gen)
+        w1 = torch.randn(4 * C, C, generator=gen) / C ** 0.5
+        b1 = 0.1 * torch.randn(4 * C, generator=gen)
+        w2 = torch.randn(C, 4 * C, generator=gen) / (4 * C) ** 0.5
+        b2 = 0.1 * torch.randn(C, generator=gen)
+
+        def ref(dt):
+            xd = x.to(dt) + att.to(dt) @ wp.to(dt).T + bp.to(dt)
+            xn = torch.nn.functional.layer_norm(xd, (C,), ln_g.to(dt), ln_b.to(dt), 1e-5)
+            h = torch.nn.functional.gelu(xn @ w1.to(dt).T + b1.to(dt))
+            return xd + h @ w2.to(dt).T + b2.to(dt)
+        r64, r32 = ref(torch.float64), ref(torch.float32)
+        d = {k: v.cuda() for k, v in dict(x=x, att=att, bp=bp, g=ln_g, b=ln_b, b1=b1, b2=b2).items()}
+        out = eng.op_swin_proj_mlp(d['x'], d['att'], wp, d['bp'], d['g'], d['b'], w1, d['b1'], w2, d['b2']).cpu()
+        e_hip = float((out.double() - r64).abs().max())
+        e_f32 = float((r32.double() - r64).abs().max())
+        mag = float(r64.abs().max())
+        print(f'fused proj + mlp T{T} scale {scale}: max abs err {e_hip:.2e} (torch fp32 chain {e_f32:.2e}), |out| max {mag:.2f}')
+        assert torch.isfinite(out).all()
+        assert e_hip <= max(4.0 * e_f32, 2e-6 * mag), (T, e_hip, e_f32)
+        assert torch.equal(d['x'].cpu(), x)                      # the input is left alone when out is another buffer
+        xd = d['x'].clone()                                      # in place (the engine's use)
+        h = lambda w: np.ascontiguousarray(w.numpy(), dtype=np.float32)
+        wph, w1h, w2h = h(wp), h(w1), h(w2)
+        eng._check(eng.lib.nuhtc_op_swin_proj_mlp(eng.h, xd.data_ptr(), d['att'].data_ptr(), wph.ctypes.data, d['bp'].data_ptr(), d['g'].data_ptr(),
+                                                  d['b'].data_ptr(), w1h.ctypes.data, d['b1'].data_ptr(), w2h.ctypes.data, d['b2'].data_ptr(),
+                                                  xd.data_ptr(), T, C, eng._stream()))
+        assert torch.equal(xd.cpu(), out)
