@@ -488,15 +488,35 @@ __global__ __launch_bounds__(256, 3) void window_attn_split_kernel(const float* 
   const float* mP = (maskP && mask_any[wimg]) ? maskP + (long long)wimg * 4096 + (half * 32 + l32) * 32 : nullptr;
   const float scale = 0.17677669529663687f;   // 32^-0.5
 
-  // K planes of both key tiles: kp[tj][s][plane], lane (j, half) holds channels 16 half + 8 s + 0..7 of key tj*32 + j
-  u32x4 kp[2][2][3];
+  // Every row the (window, head) pair needs -- K and Q of both tiles, V -- is requested up front, before the first split: the kernel is
+  // bound by the latency of these lane-per-row loads, and with Q of the second tile and V in flight beside K the wave waits once
+  // instead of three times (0.735 -> 0.67 ms per step; a persistent form that also prefetches the NEXT pair needs 256 registers,
+  // spills and runs at two waves per SIMD: 0.86 ms, not kept)
+  v4f kfa[2][4], qfa[2][4];
 #pragma unroll
   for (int tj = 0; tj < 2; ++tj) {
     const int j = min(tj * 32 + l32, WS2 - 1);
     const v4f* kptr = reinterpret_cast<const v4f*>(base + j * ld + C + half * 16);
+    const v4f* qptr = reinterpret_cast<const v4f*>(base + j * ld + half * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { kfa[tj][q] = kptr[q]; qfa[tj][q] = qptr[q]; }
+  }
+  float vv[3][8];
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int r = 8 * (g & 1) + e;
+      vv[g][e] = base[((g >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * ld + 2 * C + l32];
+    }
+  __builtin_amdgcn_sched_barrier(0);
+  // K planes of both key tiles: kp[tj][s][plane], lane (j, half) holds channels 16 half + 8 s + 0..7 of key tj*32 + j
+  u32x4 kp[2][2][3];
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj) {
     v4f kf[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) kf[q] = kptr[q];
+    for (int q = 0; q < 4; ++q) kf[q] = kfa[tj][q];
 #pragma unroll
     for (int sk = 0; sk < 2; ++sk) {
       NUHTC_SPLIT3_INTO(kp[tj][sk], 0, kf[2 * sk].x, kf[2 * sk].y)
@@ -508,14 +528,10 @@ __global__ __launch_bounds__(256, 3) void window_attn_split_kernel(const float* 
   u32x4 vp[3][3];
 #pragma unroll
   for (int ti = 0; ti < 2; ++ti) {
-    if (ti) __builtin_amdgcn_sched_barrier(0);
     const int i = min(ti * 32 + l32, WS2 - 1);
     v4f qf[4];
-    {
-      const v4f* qp = reinterpret_cast<const v4f*>(base + i * ld + half * 16);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) qf[q] = qp[q];
-    }
+    for (int q = 0; q < 4; ++q) qf[q] = qfa[ti][q];
     // the additive score terms (relative-position bias + shift mask) are loaded straight into the score accumulators: the products are
     // accumulated on top of them (the Q split below covers the latency of these loads; 25 registers less than adding them afterwards)
     f32x16 st[2];
@@ -530,18 +546,6 @@ __global__ __launch_bounds__(256, 3) void window_attn_split_kernel(const float* 
       for (int q = 0; q < 3; ++q) { st[1][4 * q] = t4[4 + q].x; st[1][4 * q + 1] = t4[4 + q].y; st[1][4 * q + 2] = t4[4 + q].z; st[1][4 * q + 3] = t4[4 + q].w; }
 #pragma unroll
       for (int r = 12; r < 16; ++r) st[1][r] = 0.f;
-    }
-    // V operand of the second product (lane (d = l32, half)), keys 0..47 in the accumulator's key order: group g = keys of registers
-    // 8 (g & 1) .. + 7 of key tile g >> 1; requested with the first query tile's loads, split after its softmax
-    float vv[3][8];
-    if (ti == 0) {
-#pragma unroll
-      for (int g = 0; g < 3; ++g)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int r = 8 * (g & 1) + e;
-          vv[g][e] = base[((g >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * ld + 2 * C + l32];
-        }
     }
     u32x4 qpl[2][3];
 #pragma unroll
