@@ -56,7 +56,10 @@ def gather_blobs(parts, group=None):
     list of tensors -- any dtypes, any leading lengths (0 allowed), trailing shapes equal on all ranks -- and every rank gets
     back, per rank, the list of that rank's tensors.  All parts travel as ONE byte buffer: an all_gather of the small header
     (leading lengths; this is the "counts" exchange of mmdet/apis/test.py:161-191) followed by one all_gather of the buffers
-    padded to the longest."""
+    padded to the longest.
+    Every rank receives every rank's records although only rank 0 merges: that is the collective the north star names, and at ~0.25 KB per
+    detection (45 MB per rank for a 10 000-tile slide shard) the ring all-gather over xGMI is milliseconds; a gather to rank 0 alone would
+    save the other ranks' receive buffers, nothing on the critical path."""
     parts = [p.contiguous() for p in parts]
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return [parts]
