@@ -136,6 +136,18 @@ class PowerLog:
         except (OSError, ValueError, IndexError):
             return None
 
+    @staticmethod
+    def _dpm(path):
+        """MHz of the active level of a pp_dpm_* file ('1: 1250Mhz *'), None when unreadable."""
+        try:
+            with open(path) as f:
+                for line in f:
+                    if line.rstrip().endswith('*'):
+                        return float(line.split(':')[1].lower().replace('mhz', '').replace('*', '').strip())
+        except (OSError, ValueError, IndexError):
+            pass
+        return None
+
     def _loop(self):
         while not self.stop.is_set():
             for card, hm, lab in self.cards:
@@ -144,7 +156,9 @@ class PowerLog:
                     pw = self._read(os.path.join(hm, 'power1_input'), 1e-6)
                 self.rows[card].append((time.time() - self.t0, pw, self._read(os.path.join(hm, 'freq1_input'), 1e-6),
                                         self._read(lab['junction'], 1e-3) if 'junction' in lab else None,
-                                        self._read(lab['mem'], 1e-3) if 'mem' in lab else None, self._read(os.path.join(card, 'gpu_busy_percent'))))
+                                        self._read(lab['mem'], 1e-3) if 'mem' in lab else None, self._read(os.path.join(card, 'gpu_busy_percent')),
+                                        self._dpm(os.path.join(card, 'pp_dpm_fclk')), self._dpm(os.path.join(card, 'pp_dpm_socclk')),
+                                        self._dpm(os.path.join(card, 'pp_dpm_mclk'))))
             time.sleep(0.1)
 
     def mark(self, name):
@@ -178,10 +192,12 @@ class PowerLog:
                                    'power_w_mean': mean([r[1] for r in seg if r[1] is not None]), 'power_w_max': max([r[1] for r in seg if r[1] is not None], default=None),
                                    'sclk_mhz_mean': mean([r[2] for r in seg if r[2] is not None]),
                                    'temp_junction_c_max': max([r[3] for r in seg if r[3] is not None], default=None),
-                                   'temp_mem_c_max': max([r[4] for r in seg if r[4] is not None], default=None)}
+                                   'temp_mem_c_max': max([r[4] for r in seg if r[4] is not None], default=None),
+                                   'fclk_mhz_mean': mean([r[6] for r in seg if r[6] is not None]), 'socclk_mhz_mean': mean([r[7] for r in seg if r[7] is not None]),
+                                   'mclk_mhz_mean': mean([r[8] for r in seg if r[8] is not None])}
         if csv_path:
             with open(csv_path, 'w') as f:
-                f.write('t_s,power_w,sclk_mhz,temp_junction_c,temp_mem_c,gpu_busy_pct,phase\n')
+                f.write('t_s,power_w,sclk_mhz,temp_junction_c,temp_mem_c,gpu_busy_pct,fclk_mhz,socclk_mhz,mclk_mhz,phase\n')
                 for r in rows:
                     ph = [n for n, t in self.marks if t <= r[0]]
                     f.write(','.join('' if v is None else f'{v:.3f}' for v in r) + ',' + (ph[-1] if ph else '') + '\n')
