@@ -406,6 +406,15 @@ def _two_rank_env():
     return env
 
 
+def _free_port():
+    """A free TCP port on the loopback interface (as bench.self_launch picks one): concurrent test runs on one box, or a socket of an earlier
+    run still in TIME_WAIT, must not make the rendezvous fail."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
 def test_infer_wsi_two_ranks_equal_one_rank_byte_for_byte(hip_device, tmp_path):
     """The multi-rank path end to end (north star: tiles sharded across ranks, one gather, merge on rank 0): tools/infer_wsi.py as
     two processes under torch.distributed.run writes the same files as one process, byte for byte -- per-tile GeoJSON, point
@@ -423,7 +432,7 @@ def test_infer_wsi_two_ranks_equal_one_rank_byte_for_byte(hip_device, tmp_path):
               '--merge', '--mode', 'qupath']
     subprocess.check_call([sys.executable] + common + ['--save_dir', str(tmp_path / 'one')])
     out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
-                          '--master-port', '29731'] + common + ['--save_dir', str(tmp_path / 'two')], env=_two_rank_env(),
+                          '--master-port', str(_free_port())] + common + ['--save_dir', str(tmp_path / 'two')], env=_two_rank_env(),
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     print(out.stdout[-2000:])
     assert out.returncode == 0
