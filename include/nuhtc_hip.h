@@ -46,7 +46,8 @@ enum {
  *   1: tools/infer_wsi.py  (RGB ndarray run through the BGR pipeline): channels are reversed first     */
 enum { NUHTC_CH_AS_IS = 0, NUHTC_CH_SWAP = 1 };
 
-/* How the fp32 matrix products of the path (Swin linears, convolutions, FCs) are executed.  Both are fp32 arithmetic: fp32
+/* How the fp32 matrix products of the path (Swin linears, convolutions, FCs and -- since ABI v6 -- the two products of window attention)
+ * are executed.  Both are fp32 arithmetic: fp32
  * operands and results, exact products, fp32 accumulation.
  *   NUHTC_PIPE_BF16_SPLIT (default): every fp32 operand is split exactly into three bf16 numbers (8 + 8 + 8 significand bits)
  *       and the product runs as six v_mfma_f32_32x32x16_bf16 per 16-deep step.  The six products are exact; the three cross terms
