@@ -106,11 +106,11 @@ class PowerLog:
     """GPU power / clock / temperature at ~10 Hz from the amdgpu hwmon files in sysfs (no GPU call, a reader thread of this process).  A box
     shows every GPU of its host there: all are sampled and the busiest one -- the one this process ran on -- is reported."""
 
-    def __init__(self):
+    def __init__(self, sysfs='/sys'):
         import glob
         import threading
         self.cards = []
-        for card in sorted(glob.glob('/sys/class/drm/card[0-9]*/device')):
+        for card in sorted(glob.glob(os.path.join(sysfs, 'class/drm/card[0-9]*/device'))):
             hm = glob.glob(os.path.join(card, 'hwmon', 'hwmon*'))
             if hm and any(os.path.exists(os.path.join(hm[0], f)) for f in ('power1_average', 'power1_input')):
                 lab = {}
