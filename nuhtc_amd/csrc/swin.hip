@@ -528,7 +528,6 @@ __global__ __launch_bounds__(256, 3) void window_attn_split_kernel(const float* 
   u32x4 vp[3][3];
 #pragma unroll
   for (int ti = 0; ti < 2; ++ti) {
-    const int i = min(ti * 32 + l32, WS2 - 1);
     v4f qf[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) qf[q] = qfa[ti][q];
