@@ -133,6 +133,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
       __builtin_amdgcn_sched_barrier(0);
       if (t + 1 < NT) EPI_LOADS(t + 1)          // requested before this tile's stores are issued
       __builtin_amdgcn_sched_barrier(0);
+#ifdef NUHTC_GEMM_NOSTORE   // dev probe: the launch without its output stores (results are lost): what hiding the store phase could buy at most
+      if (p.alpha == 12345.f)
+#endif
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (!((okmask >> j) & 1u)) continue;
