@@ -45,7 +45,7 @@ def test_power_log_phases_and_card_choice(tmp_path):
     assert out['available'] and out['device'].endswith('0000:0a:00.0') and out['device_chosen_by'].startswith('pci bus id') and out['power_cap_w'] == 1400.0
     assert list(out['phases']) == ['timed_in_flight']                          # phases whose name starts with '_' are not reported
     ph = out['phases']['timed_in_flight']
-    assert 3 <= ph['samples'] <= 6 and ph['power_w_mean'] == 1300.0 and ph['sclk_mhz_mean'] == 2000.0
+    assert 2 <= ph["samples"] <= 7 and ph['power_w_mean'] == 1300.0 and ph['sclk_mhz_mean'] == 2000.0
     assert ph['temp_junction_c_max'] == 55.0 and ph['temp_mem_c_max'] == 48.0 and ph['fclk_mhz_mean'] == 1250.0 and ph['mclk_mhz_mean'] == 2000.0
     lines = open(csv).read().splitlines()
     assert lines[0].startswith('t_s,power_w,sclk_mhz') and lines[-1].endswith('_after') and any(l.endswith('timed_in_flight') for l in lines)
