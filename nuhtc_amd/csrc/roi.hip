@@ -960,30 +960,44 @@ __global__ __launch_bounds__(256) void roi_feat7_giant_kernel(RoiFeatParams p) {
 }
 
 // pre-pass: which RoIs fit the LDS tiles (one wave per RoI, the same plan code as the main kernel)
-__global__ __launch_bounds__(256) void roi_classify_kernel(RoiFeatParams p) {
+__global__ __launch_bounds__(1024) void roi_classify_kernel(RoiFeatParams p) {
+  // 16 RoIs per workgroup, and ONE atomicAdd per workgroup and list: the RoIs of a list count themselves in LDS first.  With an atomicAdd per
+  // RoI a real slide's load -- every one of 17 k boxes mid-size -- queued 17 k atomics on one counter: 193 us per stage against 8 us at the
+  // synthetic load, a quarter of the RoI-feature time (round 4, rocprofv3 trace of the 40-100 px fixed load)
+  __shared__ int cnt[3], base[3];          // lists: 0 = big boxes (class 2), 1 = mid-size (class 1), 2 = giant (class 4)
   const int lane = threadIdx.x & 63;
-  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= *p.r_dev) return;
-  const float* roi = p.rois + (long long)r * 5;
-  const RoiGeom g0 = roi_geom(roi, 0.25f, 7, 2), g1 = roi_geom(roi, 0.125f, 7, 2), gs = roi_geom(roi, 0.25f, 14, 0);
-  const bool sem_g1 = gs.gw == 1 && gs.gh == 1;
-  const LevelPlan l0 = plan_level(g0, 7, 2, p.H0, p.W0, TP0, lane);
-  const LevelPlan l1 = plan_level(g1, 7, 2, p.H1, p.W1, TP1, lane);
-  // 0: LDS tiles; 1: stream kernel (at most 2x2 semantic samples per 14x14 bin, sides up to SM_MAXSIDE px: footprints of at
-  // most 30 x 30 pixels on stride 4, bins spanning at most SM_J pixels); 2: one block per bin (big proposals)
-  const float rwn = roi[3] - roi[1], rhn = roi[4] - roi[2];
-  int cls = (sem_g1 && l0.ok && l1.ok) ? 0 : (gs.gw <= 2 && gs.gh <= 2 && rwn <= (float)SM_MAXSIDE && rhn <= (float)SM_MAXSIDE) ? 1 : 2;
-  // class 0 is split by footprint: 0 = fits the small tiles (8x8 / 5x5 pixels: boxes up to ~24 px, the usual nucleus), 3 = needs
-  // the 12x12 / 7x7 tiles; the small variant takes a third of the LDS, so twice as many RoIs are in flight per CU
-  if (cls == 0 && !(l0.fw <= TS0 && l0.fh <= TS0 && l1.fw <= TS1 && l1.fh <= TS1)) cls = 3;
-  // class 2 boxes beyond the tables of the big-box kernel (samples per bin, footprint rows, taps per bin column): class 4
-  if (cls == 2 && (2 * gs.gw > BG_S || 2 * gs.gh > BG_S || rhn * 0.25f + 4.f > (float)BG_FH || rwn * 0.25f / 7.f + 3.f > (float)BG_J)) cls = 4;
-  if (lane == 0) {
-    p.fb_flag[r] = (unsigned char)cls;
-    if (cls == 2) p.fb_list[atomicAdd(&p.fb_count[0], 1)] = r;
-    else if (cls == 4) p.fb_list[p.list_cap - 1 - atomicAdd(&p.fb_count[2], 1)] = r;      // from the end of the same list
-    else if (cls == 1) p.mid_list[atomicAdd(&p.fb_count[1], 1)] = r;
+  const int r = blockIdx.x * 16 + (threadIdx.x >> 6);
+  const bool valid = r < *p.r_dev;
+  if (threadIdx.x < 3) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  int li = -1, slot = -1;
+  if (valid) {
+    const float* roi = p.rois + (long long)r * 5;
+    const RoiGeom g0 = roi_geom(roi, 0.25f, 7, 2), g1 = roi_geom(roi, 0.125f, 7, 2), gs = roi_geom(roi, 0.25f, 14, 0);
+    const bool sem_g1 = gs.gw == 1 && gs.gh == 1;
+    const LevelPlan l0 = plan_level(g0, 7, 2, p.H0, p.W0, TP0, lane);
+    const LevelPlan l1 = plan_level(g1, 7, 2, p.H1, p.W1, TP1, lane);
+    // 0: LDS tiles; 1: stream kernel (at most 2x2 semantic samples per 14x14 bin, sides up to SM_MAXSIDE px: footprints of at
+    // most 30 x 30 pixels on stride 4, bins spanning at most SM_J pixels); 2: one block per bin (big proposals)
+    const float rwn = roi[3] - roi[1], rhn = roi[4] - roi[2];
+    int cls = (sem_g1 && l0.ok && l1.ok) ? 0 : (gs.gw <= 2 && gs.gh <= 2 && rwn <= (float)SM_MAXSIDE && rhn <= (float)SM_MAXSIDE) ? 1 : 2;
+    // class 0 is split by footprint: 0 = fits the small tiles (8x8 / 5x5 pixels: boxes up to ~24 px, the usual nucleus), 3 = needs
+    // the 12x12 / 7x7 tiles; the small variant takes a third of the LDS, so twice as many RoIs are in flight per CU
+    if (cls == 0 && !(l0.fw <= TS0 && l0.fh <= TS0 && l1.fw <= TS1 && l1.fh <= TS1)) cls = 3;
+    // class 2 boxes beyond the tables of the big-box kernel (samples per bin, footprint rows, taps per bin column): class 4
+    if (cls == 2 && (2 * gs.gw > BG_S || 2 * gs.gh > BG_S || rhn * 0.25f + 4.f > (float)BG_FH || rwn * 0.25f / 7.f + 3.f > (float)BG_J)) cls = 4;
+    if (lane == 0) {
+      p.fb_flag[r] = (unsigned char)cls;
+      li = cls == 2 ? 0 : cls == 1 ? 1 : cls == 4 ? 2 : -1;
+      if (li >= 0) slot = atomicAdd(&cnt[li], 1);
+    }
   }
+  __syncthreads();
+  if (threadIdx.x < 3 && cnt[threadIdx.x] > 0) base[threadIdx.x] = atomicAdd(&p.fb_count[threadIdx.x], cnt[threadIdx.x]);
+  __syncthreads();
+  if (li == 0) p.fb_list[base[0] + slot] = r;
+  else if (li == 2) p.fb_list[p.list_cap - 1 - (base[2] + slot)] = r;      // giant boxes from the end of the same list
+  else if (li == 1) p.mid_list[base[1] + slot] = r;
 }
 
 template <int T0, int T1, int FLAG>
@@ -1137,7 +1151,7 @@ int launch_roi_feat(const RoiFeatParams& p, int P, int r_cap, hipStream_t s, hip
   if (r_cap <= 0) return 0;
   if (P == 7) {
     if (hipMemsetAsync(p.fb_count, 0, 8 * sizeof(int), s) != hipSuccess) return NUHTC_E_HIP;      // three list lengths, two job counters
-    hipLaunchKernelGGL(roi_classify_kernel, dim3(cdiv(r_cap, 4)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(roi_classify_kernel, dim3(cdiv(r_cap, 16)), dim3(1024), 0, s, p);
     // three size classes side by side: the LDS-tile kernels on the caller's stream, the mid-size stream kernel on `side`, the
     // big-box kernels on `side2` (at the usual load the latter two hold a few dozen boxes each and are latency chains of ~0.2 ms:
     // one after the other they outlasted the LDS kernels, which take as long for thousands of nucleus-sized boxes)
