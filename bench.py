@@ -51,7 +51,7 @@ GROUPS = {
 }
 
 
-def cpu_baseline(sd, tiles, eng=None, mode=1, batch=4, timed=3, warm=2, warm_batches=1):
+def cpu_baseline(sd, tiles, eng=None, mode=1, batch=4, timed=3, warm=2, warm_batches=1, host_cpus=None):
     """Oracle (CPU restatement of the reference path, oracle/model.py) timed on the host cores: reported next to the GPU
     number, never the thing shipped.  Bounded sample (about 30 s): one warm-up batch of 2 tiles, then `timed` batches of
     `batch` tiles each, timed one by one.  With `eng`, the same tiles are the parity check of the run: the HIP path's
@@ -60,6 +60,12 @@ def cpu_baseline(sd, tiles, eng=None, mode=1, batch=4, timed=3, warm=2, warm_bat
     from oracle import model as O
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tests'))
     import parity_util as P
+    if host_cpus:       # the GPU legs ran on the GPU's NUMA node (hip.bind_host_thread); the CPU baseline gets every core the process started with
+        for tid in os.listdir('/proc/self/task'):
+            try:
+                os.sched_setaffinity(int(tid), host_cpus)
+            except OSError:
+                pass
     orc = O.Oracle(sd)
     threads = torch.get_num_threads()
     for _ in range(warm_batches):
@@ -249,6 +255,7 @@ def main():
     ap.add_argument('--gemm-shapes', action='store_true', help='add the per-shape GEMM timings to the JSON line')
     ap.add_argument('--no-settle', action='store_true', help='skip the untimed settle phase (profiling passes that serialise kernels)')
     ap.add_argument('--power-csv', default=None, help='write the 10 Hz power / clock / temperature samples of the run to this file (the summary is always on the line)')
+    ap.add_argument('--no-host-bind', action='store_true', help="leave the process on whatever CPUs the scheduler picks instead of the GPU's NUMA node (A/B of hip.bind_host_thread)")
     ap.add_argument('--roi-sort', action='store_true', help='--fixed-load (dev): hand the RoIs over sorted by position (locality experiment)')
     args = ap.parse_args()
 
@@ -265,6 +272,14 @@ def main():
     # test hooks for a box with fewer GPUs than ranks (tests/test_hip_api.py): every rank on device 0, gloo instead of RCCL
     if os.environ.get('NUHTC_ONE_DEVICE') == '1':
         local_rank = 0
+    # the submitting thread runs on the NUMA node its GPU is attached to (Engine() would do it too; here it precedes the process group so
+    # that RCCL's threads inherit the mask); the CPU baseline gets the original mask back
+    cpus0 = os.sched_getaffinity(0)
+    if args.no_host_bind:
+        os.environ['NUHTC_HOST_AFFINITY'] = '0'
+    from nuhtc_amd import hip as _hip
+    host_bound = False if os.environ.get('NUHTC_HOST_AFFINITY', '1') == '0' else _hip.bind_host_thread(local_rank)
+    cpus_gpu = os.sched_getaffinity(0)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -679,9 +694,9 @@ def main():
         mark('cpu_baseline_host')
         if world == 1 and not args.no_cpu_baseline:
             if args.cpu_full:
-                out['cpu_baseline'] = cpu_baseline(sd, synth.nuclei_tiles(160, 256, start=0), eng, mode, batch=16, timed=10, warm=16, warm_batches=2)
+                out['cpu_baseline'] = cpu_baseline(sd, synth.nuclei_tiles(160, 256, start=0), eng, mode, batch=16, timed=10, warm=16, warm_batches=2, host_cpus=cpus0)
             else:
-                out['cpu_baseline'] = cpu_baseline(sd, tiles_np, eng, mode, batch=args.cpu_batch)
+                out['cpu_baseline'] = cpu_baseline(sd, tiles_np, eng, mode, batch=args.cpu_batch, host_cpus=cpus0)
         bdf = None
         try:
             pr = torch.cuda.get_device_properties(local_rank)
@@ -689,6 +704,14 @@ def main():
         except Exception:
             pass
         out['power'] = plog.summary(args.power_csv, bdf)
+        node = None
+        try:
+            node = int(open(f'/sys/bus/pci/devices/{bdf}/numa_node').read())
+        except (OSError, ValueError, TypeError):
+            pass
+        out['host'] = dict(submitting_thread_bound_to_gpu_numa_node=bool(host_bound), gpu_pci=bdf, gpu_numa_node=node, cpus_during_gpu_legs=len(cpus_gpu), cpus_of_process=len(cpus0),
+                           note='hip.bind_host_thread (nuhtc_bind_host_thread): from the other socket every dispatch packet costs the command processor 1.4-2.9 us more '
+                                '(0.3-0.4 ms per sequential step); the CPU baseline runs on the process\'s original CPUs')
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

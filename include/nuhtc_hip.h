@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NUHTC_ABI_VERSION 6
+#define NUHTC_ABI_VERSION 7
 
 enum {
   NUHTC_OK = 0,
@@ -256,6 +256,17 @@ int nuhtc_op_nms(nuhtc_engine* e, const float* boxes, const float* scores, int n
  * block's allocation stream when it frees the block, long after the engine is gone).  A caller must therefore NOT use, wait on or
  * record into the handle after nuhtc_destroy: it may already belong to an unrelated engine. */
 void* nuhtc_stream(nuhtc_engine* e);
+
+/* Host-thread placement (v7).  Restricts the CALLING thread (threads it creates later inherit the mask) to the CPUs of the NUMA node the
+ * device is attached to (/sys/bus/pci/devices/<bdf>/local_cpulist), intersected with the mask it has.  The thread that submits an engine's
+ * work should run there: the command processor reads every dispatch packet from host memory last written by the submitter, and from
+ * the other socket of a two-socket host that costs 1.4-2.9 us per packet -- 0.3-0.4 ms per step of the back-to-back dense launches
+ * (DESIGN.md section 5).  Returns 0 (bound, or already inside the node), NUHTC_E_NOTFOUND when the host exposes no NUMA node for the
+ * device (nothing changed), NUHTC_E_STATE when the caller's mask has no CPU of that node (nothing changed: the caller chose otherwise),
+ * NUHTC_E_HIP for a bad device.  Never called implicitly by the library; the Python host calls it from Engine() unless
+ * NUHTC_HOST_AFFINITY=0.  _pci takes the PCI address ("0000:75:00.0") instead of a device index. */
+int nuhtc_bind_host_thread(int device);
+int nuhtc_bind_host_thread_pci(const char* pci_bdf);
 
 /* Per-kernel timing with HIP events recorded on the launch stream (process-wide switch; off by default).
  * nuhtc_profile_read synchronises the device and writes one text line per kernel tag,

@@ -910,3 +910,25 @@ int nuhtc_op_swin_proj_mlp(nuhtc_engine* e, const float* x_dev, const float* att
   if (he != hipSuccess) FAIL(e, NUHTC_E_HIP, "swin_proj_mlp kernel failed");
   return 0;
 }
+
+#ifdef NUHTC_DEV
+// dev (tools/dev/r04_state_buffers.py): gives one of the Swin activation buffers new memory (the old allocation stays until nuhtc_destroy, so the
+// new one lands elsewhere).  which: 0 tokA, 1 tokB, 2 xw, 3 qkv, 4 att, 5 hid; returns the new device address through *addr
+extern "C" int nuhtc_dev_realloc(nuhtc_engine* e, int which, unsigned long long* addr) {
+  if (!e || which < 0 || which > 5) return NUHTC_E_INVALID;
+  HIP_CHECK(e, hipSetDevice(e->device));
+  HIP_CHECK(e, hipDeviceSynchronize());
+  float** slots[6] = {&e->tokA, &e->tokB, &e->xw, &e->qkv, &e->att, &e->hid};
+  void* base = nullptr;
+  size_t bytes = 0;
+  HIP_CHECK(e, hipMemGetAddressRange((hipDeviceptr_t*)&base, &bytes, (hipDeviceptr_t)*slots[which]));
+  void* p = nullptr;
+  HIP_CHECK(e, hipMalloc(&p, bytes));
+  HIP_CHECK(e, hipMemset(p, 0, bytes));
+  e->allocs.push_back(p);
+  *slots[which] = (float*)p;
+  if (which == 0) e->bufs["tokens"].ptr = p;
+  if (addr) *addr = (unsigned long long)p;
+  return 0;
+}
+#endif

@@ -6,6 +6,7 @@ exact format `inference_detector` returns (mmdet/apis/inference.py:90-153; SURVE
 device buffers and the current stream only; every computation happens inside the HIP library.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -59,6 +60,9 @@ class Engine:
             else:
                 setattr(cfg, k, v)
         self.cfg = cfg
+        # the submitting thread belongs on the GPU's NUMA node (hip.bind_host_thread) -- before the first queue exists
+        if os.environ.get('NUHTC_HOST_AFFINITY', '1') != '0':
+            hip.bind_host_thread(self.device.index)
         self.h = ctypes.c_void_p()
         rc = self.lib.nuhtc_create(ctypes.byref(cfg), self.device.index, ctypes.byref(self.h))
         if rc:

@@ -353,3 +353,45 @@ def test_image_size_not_a_multiple_of_32(hip_device):
     assert n > 50 and all(m.shape == (h, w) and m.dtype == bool for cl in segm_res for m in cl)
     allb = np.concatenate(bbox_res, 0)
     assert allb[:, 2].max() <= w and allb[:, 3].max() <= h
+
+
+def test_engine_creation_puts_the_submitting_thread_on_the_gpus_numa_node(hip_device, monkeypatch):
+    """Engine() calls nuhtc_bind_host_thread (the command processor reads every dispatch packet from host memory the
+    submitter wrote; from the other socket that costs 0.3-0.4 ms per step): afterwards the calling thread runs on the CPUs sysfs lists as
+    local to the GPU; NUHTC_HOST_AFFINITY=0 leaves the mask alone; results do not depend on it."""
+    import os
+    import torch
+    from nuhtc_amd import synth, weights
+    from nuhtc_amd.engine import Engine
+    pr = torch.cuda.get_device_properties(0)
+    bdf = f'{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0'
+    try:
+        text = open(f'/sys/bus/pci/devices/{bdf}/local_cpulist').read().strip()
+    except OSError:
+        text = ''
+    local = set()
+    for part in filter(None, text.split(',')):
+        a, _, b = part.partition('-')
+        local |= set(range(int(a), int(b or a) + 1))
+    before = os.sched_getaffinity(0)
+    sd = weights.seeded_state_dict(0)
+    tiles = synth.nuclei_tiles(2, 64)
+    try:
+        monkeypatch.setenv('NUHTC_HOST_AFFINITY', '0')
+        os.sched_setaffinity(0, before)
+        e0 = Engine(sd, device=0, max_batch=2, tile=(64, 64))
+        assert os.sched_getaffinity(0) == before
+        r0 = e0(tiles)
+        monkeypatch.setenv('NUHTC_HOST_AFFINITY', '1')
+        e1 = Engine(sd, device=0, max_batch=2, tile=(64, 64))
+        now = os.sched_getaffinity(0)
+        if local and (local & before):
+            assert now == (local & before), (sorted(now)[:4], len(now), text)
+        else:
+            assert now == before           # no NUMA information for the device, or the caller's mask excludes the node
+        r1 = e1(tiles)
+        for (b0, m0), (b1, m1) in zip(r0, r1):
+            assert all(np.array_equal(x, y) for x, y in zip(b0, b1))
+            assert all(len(x) == len(y) and all(np.array_equal(p, q) for p, q in zip(x, y)) for x, y in zip(m0, m1))
+    finally:
+        os.sched_setaffinity(0, before)

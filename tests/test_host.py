@@ -240,3 +240,35 @@ def test_packed_masks_behave_like_the_crop_list():
     for kp in (None, keep):
         for a, b in zip(wsi.pack_records(rec_packed, kp, tile_base=7), wsi.pack_records(rec_list, kp, tile_base=7)):
             assert a.shape == b.shape and bool((a == b).all())
+
+
+def test_bind_host_thread_follows_the_devices_numa_node(tmp_path, monkeypatch):
+    """nuhtc_bind_host_thread_pci against a fake sysfs: the calling thread ends up on the device's local CPUs intersected with its own
+    mask; nothing changes when the host has no node for the device or the caller's mask excludes it."""
+    from nuhtc_amd import hip
+    hip.load()
+    before = os.sched_getaffinity(0)
+    if len(before) < 2:
+        pytest.skip('needs two CPUs')
+    cpus = sorted(before)
+    dev = tmp_path / 'bus/pci/devices/0000:75:00.0'
+    dev.mkdir(parents=True)
+    monkeypatch.setenv('NUHTC_SYSFS_ROOT', str(tmp_path))
+    try:
+        (dev / 'local_cpulist').write_text(f'{cpus[0]},{cpus[-1]}-{cpus[-1] + 3}\n')          # part of it outside the caller's mask
+        assert hip.bind_host_thread(pci_bdf='0000:75:00.0') is True
+        assert os.sched_getaffinity(0) == {cpus[0], cpus[-1]}
+        assert hip.bind_host_thread(pci_bdf='0000:75:00.0') is True                            # already there
+        os.sched_setaffinity(0, before)
+        (dev / 'local_cpulist').write_text(f'{cpus[-1] + 1}-{cpus[-1] + 8}\n')                # none of the caller's CPUs: the caller chose otherwise
+        assert hip.bind_host_thread(pci_bdf='0000:75:00.0') is False and os.sched_getaffinity(0) == before
+        (dev / 'local_cpulist').write_text('\n')                                               # no NUMA information
+        assert hip.bind_host_thread(pci_bdf='0000:75:00.0') is False and os.sched_getaffinity(0) == before
+        assert hip.bind_host_thread(pci_bdf='0000:76:00.0') is False and os.sched_getaffinity(0) == before   # unknown device
+        (dev / 'local_cpulist').write_text(f'{cpus[1]}\n')
+        assert hip.bind_host_thread(pci_bdf='0000:75:00.0'.upper()) is True and os.sched_getaffinity(0) == {cpus[1]}
+    finally:
+        os.sched_setaffinity(0, before)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            hip.bind_host_thread(0)
