@@ -20,7 +20,8 @@
 // ---- epilogue shared by the fp32 and the split-bf16 main loops
 template <int MT, int NT, int WM, int WN>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[MT][NT], float* lds, float* __restrict__ C, int z, int m0, int n0,
-                                              int Meff, int tid) {
+                                              int Meff) {
+  const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int i32 = lane & 31, half = lane >> 5;
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 3 ? 4 : 3)) void gemm_kernel(GemmP
 #undef MFMA_GROUP
 
   STAMP(st2 = __builtin_amdgcn_s_memtime();)
-  gemm_epilogue<MT, NT, WM, WN>(p, acc, lds, C, z, m0, n0, Meff, threadIdx.x);
+  gemm_epilogue<MT, NT, WM, WN>(p, acc, lds, C, z, m0, n0, Meff);
 #ifdef NUHTC_GEMM_STAMPS
   st3 = __builtin_amdgcn_s_memtime();
   __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0)
@@ -436,30 +437,20 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void gemm_split_kernel
   __shared__ __attribute__((aligned(16))) float lds[2 * (LDK * BM + BP * BN) > 4 * 32 * 32 ? 2 * (LDK * BM + BP * BN) : 4 * 32 * 32];
   float* As = lds;                       // [2][BM][LDK]
   float* Bs = lds + 2 * LDK * BM;        // [2][BN][BP]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int i32 = lane & 31, half = lane >> 5;
   const int nTilesN = p.N / BN;
-  const int xcd = blockIdx.x & 7;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tile_m = (slot / nTilesN) * 8 + xcd, tile_n = slot % nTilesN;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int z = blockIdx.z;
   int Meff = p.M;
   if (p.m_dev) {
     int md = *p.m_dev * p.m_mul;
     Meff = md < Meff ? md : Meff;
   }
-  // Persistent form (launch_split): the grid holds as many workgroups as the chip has places for them and workgroup (xcd, s) walks the
-  // tile slots s, s + S, s + 2 S ... of its XCD (S = gridDim.x / 8; the slot order is the one-tile-per-workgroup launch's, so
-  // the workgroups of an XCD still meet on neighbouring tiles).  The command processor then dispatches every workgroup once, at the
-  // start: a launch that it has to keep feeding while it also serves the queues loses 8-12 us when the host side of the queue is far
-  // (DESIGN section 5), and some of that even when it is near.  With S = the slots of an XCD the loop runs once.
-  const int slots_xcd = (((p.M + BM - 1) / BM + 7) >> 3) * nTilesN, slot_stride = gridDim.x >> 3;
-  constexpr bool PERS = NT != 4;             // (the 128-column instantiation spills 43 registers as a loop; its launches are one tile per workgroup)
-  for (int slot = blockIdx.x >> 3; slot < slots_xcd; slot += PERS ? slot_stride : slots_xcd) {
-  const int tile_m = (slot / nTilesN) * 8 + xcd, tile_n = slot % nTilesN;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-  if (m0 >= Meff) continue;
-  if (slot != (int)(blockIdx.x >> 3)) __syncthreads();      // the previous tile's epilogue is done with the LDS images
-  int tid = threadIdx.x;
-  if (PERS) asm volatile("" : "+v"(tid));     // opaque per tile: whatever is derived from the thread index is recomputed, not carried in registers across the epilogue
-  const int lane = tid & 63, wave = tid >> 6;
-  const int i32 = lane & 31, half = lane >> 5;
+  if (m0 >= Meff) return;
 #ifdef NUHTC_GEMM_STAMPS
   unsigned long long st0 = __builtin_amdgcn_s_memtime(), st1 = 0, st2 = 0, st3 = 0, st5 = 0, st6 = 0;
   const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
@@ -711,11 +702,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void gemm_split_kernel
 #undef S_LOAD_TILE
 #undef S_STORE_TILE
   STAMP(st2 = __builtin_amdgcn_s_memtime();)
-  {
-    int tid_e = threadIdx.x;                   // opaque: nothing the epilogue derives from the thread index is computed (and kept) above the k-loop
-    if (PERS) asm volatile("" : "+v"(tid_e));
-    gemm_epilogue<MT, NT, WM, WN>(p, acc, lds, C, z, m0, n0, Meff, tid_e);
-  }
+  gemm_epilogue<MT, NT, WM, WN>(p, acc, lds, C, z, m0, n0, Meff);
 #ifdef NUHTC_GEMM_STAMPS
   st3 = __builtin_amdgcn_s_memtime();
   __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0)
@@ -728,7 +715,6 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void gemm_split_kernel
   }
 #endif
 #undef STAMP
-  }   // tile slots of this workgroup
 }
 
 // block tile 128 x (32·NT): one 32-row strip per wave, NT accumulators (128x128 with 64x64 per wave, 256x64 and BK = 32 were
@@ -793,29 +779,10 @@ int gemm_make_split(const float* w_host, int N, int K, void** out) {
   return 0;
 }
 
-static int cu_count() {          // compute units of the current device (cached per device)
-  static std::map<int, int> cus;
-  static std::mutex mu;
-  std::lock_guard<std::mutex> lock(mu);
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return 256;
-  auto it = cus.find(dev);
-  if (it == cus.end()) {
-    hipDeviceProp_t prop;
-    it = cus.emplace(dev, hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256).first;
-  }
-  return it->second;
-}
-
 template <int MT, int NT>
 static void launch_split(const GemmParams& q, hipStream_t s) {
   const int mtiles = cdiv(q.M, 128 * MT);
-  int gx = cdiv(mtiles, 8) * 8 * (q.N / (32 * NT));
-  // persistent workgroups: at most as many as the chip has places for (the kernel's launch bounds), a multiple of the 8 XCDs; each
-  // walks its XCD's tile slots (gemm_split_kernel).  NUHTC_SPLIT_PERSIST=0 (dev): one workgroup per tile
-  static const int& persist = dev_knob_ref("SPLIT_PERSIST", 1);
-  if (persist && NT != 4) gx = std::min(gx, cu_count() * (MT * NT <= 4 ? 3 : 2) / 8 * 8);
-  dim3 grid(gx, 1, q.batch > 0 ? q.batch : 1);
+  dim3 grid(cdiv(mtiles, 8) * 8 * (q.N / (32 * NT)), 1, q.batch > 0 ? q.batch : 1);
   if (q.amode == A_CONV3) hipLaunchKernelGGL((gemm_split_kernel<MT, NT, A_CONV3>), grid, dim3(256), 0, s, q);
   else hipLaunchKernelGGL((gemm_split_kernel<MT, NT, A_PLAIN>), grid, dim3(256), 0, s, q);
 }
