@@ -229,7 +229,14 @@ __global__ __launch_bounds__(512, 1) void conv3_split_kernel(Conv3Params p) {
         for (int k = 0; k < 6; ++k) {
           CV_MFMA_ONE(k, i % 3)
           __builtin_amdgcn_sched_barrier(0);
+#ifdef NUHTC_CONV_PROBE_READS   // dev probe (wrong results): the weight fragments of every other step are not read -- a quarter of the main loop's LDS reads
+          if (i < 34 && k < 3) {
+            if (!((ns & 1) && 2 * k < 3)) CV_READ_ONE(2 * k, (i + 2) % 3, ntap, ns)
+            if (!((ns & 1) && 2 * k + 1 < 3)) CV_READ_ONE(2 * k + 1, (i + 2) % 3, ntap, ns)
+          }
+#else
           if (i < 34 && k < 3) { CV_READ_ONE(2 * k, (i + 2) % 3, ntap, ns) CV_READ_ONE(2 * k + 1, (i + 2) % 3, ntap, ns) }
+#endif
           __builtin_amdgcn_sched_barrier(0);
         }
       }
