@@ -278,7 +278,12 @@ def main():
     if args.no_host_bind:
         os.environ['NUHTC_HOST_AFFINITY'] = '0'
     from nuhtc_amd import hip as _hip
-    host_bound = False if os.environ.get('NUHTC_HOST_AFFINITY', '1') == '0' else _hip.bind_host_thread(local_rank)
+    host_bound = False
+    if os.environ.get('NUHTC_HOST_AFFINITY', '1') != '0':
+        try:
+            host_bound = _hip.bind_host_thread(local_rank)
+        except RuntimeError:
+            pass
     cpus_gpu = os.sched_getaffinity(0)
     dist = None
     if world > 1:

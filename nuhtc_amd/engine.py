@@ -62,7 +62,10 @@ class Engine:
         self.cfg = cfg
         # the submitting thread belongs on the GPU's NUMA node (hip.bind_host_thread) -- before the first queue exists
         if os.environ.get('NUHTC_HOST_AFFINITY', '1') != '0':
-            hip.bind_host_thread(self.device.index)
+            try:
+                hip.bind_host_thread(self.device.index)
+            except RuntimeError:          # placement is an optimisation: a device the runtime cannot name is reported by nuhtc_create below
+                pass
         self.h = ctypes.c_void_p()
         rc = self.lib.nuhtc_create(ctypes.byref(cfg), self.device.index, ctypes.byref(self.h))
         if rc:
