@@ -195,6 +195,10 @@ int egemm(nuhtc_engine* e, GemmParams p, hipStream_t s) {
     auto it = e->wsplit.find(p.W);
     if (it != e->wsplit.end()) p.Wsplit = it->second;
   }
+  {   // dev: ablation of the step (tools/dev/r04_ablate.py): 4 = 3x3 convolutions, 8 = 96-column split GEMMs, 64 = every other product
+    static const int& skip_ = dev_knob_ref("SKIP", 0);
+    if (skip_ && (p.amode == A_CONV3 ? (skip_ & 4) : (p.Wsplit && p.N % 96 == 0) ? (skip_ & 8) : (skip_ & 64))) return 0;
+  }
   return launch_gemm(p, s);
 }
 

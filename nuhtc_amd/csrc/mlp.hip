@@ -582,6 +582,7 @@ void proj_pack_stream(const float* w, int C, std::vector<unsigned short>& out) {
 
 int launch_swin_mlp(const float* x_in, float* x_out, const float* ln_g, const float* ln_b, const void* wstream, const float* b1, const float* b2,
                     int T, int C, hipStream_t s, const float* att, const void* pstream, const float* bp) {
+  { static const int& skip_ = dev_knob_ref("SKIP", 0); if (skip_ & 16) return 0; }   // dev: ablation of the step (tools/dev/r04_ablate.py)
   if (T <= 0) return 0;
   if (!mlp_supported(C) || !wstream) return NUHTC_E_INVALID;
   const bool proj = att != nullptr;
@@ -651,6 +652,7 @@ void lnqkv_pack_stream(const float* w, int C, std::vector<unsigned short>& out) 
 
 int launch_swin_lnqkv(const float* x, float* qkv, const int* src_tok, const int* dst_row, const int* pad_rows, int n_pad, const float* ln_g, const float* ln_b,
                       const void* wstream, const float* bias, int T, int C, hipStream_t s) {
+  { static const int& skip_ = dev_knob_ref("SKIP", 0); if (skip_ & 16) return 0; }   // dev: ablation of the step (tools/dev/r04_ablate.py)
   if (T <= 0) return 0;
   if (!lnqkv_supported(C) || !wstream) return NUHTC_E_INVALID;
   LnQkvParams p{x, qkv, src_tok, dst_row, ln_g, ln_b, reinterpret_cast<const char*>(wstream), bias, T};

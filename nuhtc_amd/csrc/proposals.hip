@@ -249,6 +249,7 @@ __global__ __launch_bounds__(1024) void rpn_level_kernel(RpnLevels lv, RpnSelPar
 }
 
 int launch_rpn_select(const RpnLevels& lv, const RpnSelParams& p, int B, hipStream_t s) {
+  { static const int& skip_ = dev_knob_ref("SKIP", 0); if (skip_ & 128) return 0; }   // dev: ablation of the step (tools/dev/r04_ablate.py)
   ProfScope ps("rpn_select", 0, 0, s);
   if (p.nms_pre > 4096 || p.slot < p.nms_pre || !p.keys) return NUHTC_E_INVALID;
   for (int l = 0; l < 4; ++l)
@@ -404,6 +405,7 @@ __global__ __launch_bounds__(256) void nms_reduce_kernel(NmsParams p) {
 // rows of `mask` that nms_mask_kernel never writes must read as zero: words cb < rb are unused by the reduce (it only
 // reads words >= its chunk), words beyond n likewise; so no clearing pass is needed.
 int launch_nms(const NmsParams& p, int B, hipStream_t s) {
+  { static const int& skip_ = dev_knob_ref("SKIP", 0); if (skip_ & 128) return 0; }   // dev: ablation of the step (tools/dev/r04_ablate.py)
   ProfScope ps("nms", 0, 0, s);
   if (p.cap % 64 || p.cap > NMS_MAX_CAP || p.n_groups > NMS_MAX_GROUPS) return NUHTC_E_INVALID;
   size_t lds = (size_t)p.cap_pow2 * sizeof(u64);
@@ -613,6 +615,7 @@ __global__ __launch_bounds__(1024) void nms_select_kernel(NmsParams p) {
 }
 
 int launch_nms_levels(const NmsParams& p, int B, hipStream_t s) {
+  { static const int& skip_ = dev_knob_ref("SKIP", 0); if (skip_ & 128) return 0; }   // dev: ablation of the step (tools/dev/r04_ablate.py)
   ProfScope ps("nms", 0, 0, s);
   if (p.cap % 64 || p.cap > NMS_MAX_CAP + 64 * NMS_MAX_GROUPS || p.cap >= 65536 || p.n_groups > NMS_MAX_GROUPS || p.ids ||
       p.n_groups * p.max_keep > 8192 || !p.seg_start || !p.seg_n || !p.sorted_pos || !p.keepbits)
@@ -922,6 +925,7 @@ __global__ __launch_bounds__(1024) void cc_emit_kernel(const int* __restrict__ s
 }
 
 int launch_cc_proposals(const CcParams& p, int B, hipStream_t s) {
+  { static const int& skip_ = dev_knob_ref("SKIP", 0); if (skip_ & 128) return 0; }   // dev: ablation of the step (tools/dev/r04_ablate.py)
   ProfScope ps("cc_proposals", 0, 0, s);
   const int H = p.img_h, W = p.img_w, HW = H * W;
   const long long total = (long long)B * HW;

@@ -1147,6 +1147,7 @@ __global__ __launch_bounds__(256) void roi_feat14_kernel(RoiFeatParams p) {
 
 int launch_roi_feat(const RoiFeatParams& p, int P, int r_cap, hipStream_t s, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, hipStream_t side2,
                     hipEvent_t ev_join2) {
+  { static const int& skip_ = dev_knob_ref("SKIP", 0); if (skip_ & 32) return 0; }   // dev: ablation of the step (tools/dev/r04_ablate.py)
   ProfScope ps(P == 7 ? "roi_feat7" : "roi_feat14", 0, 0, s);
   if (r_cap <= 0) return 0;
   if (P == 7) {

@@ -274,12 +274,14 @@ static int layernorm_any(const float* x, const int* src_map, const int* dst_map,
 }
 
 int launch_layernorm(const float* x, const int* src_map, const float* g, const float* b, float* y, int rows, int C, hipStream_t s) {
+  { static const int& skip_ = dev_knob_ref("SKIP", 0); if (skip_ & 2) return 0; }   // dev: ablation of the step (tools/dev/r04_ablate.py)
   ProfScope ps("layernorm", 0, 8.0 * rows * C, s);
   return layernorm_any(x, src_map, nullptr, g, b, y, nullptr, nullptr, rows, C, s);
 }
 
 int launch_layernorm_windows(const float* x, const int* src_map, const int* dst_map, const float* g, const float* b, float* y,
                              float* pad_dst, const float* pad_val, int rows, int C, hipStream_t s) {
+  { static const int& skip_ = dev_knob_ref("SKIP", 0); if (skip_ & 2) return 0; }   // dev: ablation of the step (tools/dev/r04_ablate.py)
   ProfScope ps("layernorm", 0, 8.0 * rows * C, s);
   if (!src_map || !dst_map || !pad_dst || !pad_val) return NUHTC_E_INVALID;
   return layernorm_any(x, src_map, dst_map, g, b, y, pad_dst, pad_val, rows, C, s);
@@ -317,6 +319,7 @@ __global__ __launch_bounds__(256) void merge_ln_kernel(const float* __restrict__
 }
 
 int launch_merge_ln(const float* x, const float* g, const float* b, float* y, int B, int H, int W, int C, hipStream_t s) {
+  { static const int& skip_ = dev_knob_ref("SKIP", 0); if (skip_ & 2) return 0; }   // dev: ablation of the step (tools/dev/r04_ablate.py)
   ProfScope ps("merge_ln", 0, 8.0 * B * H * W * C, s);
   int rows = B * (H / 2) * (W / 2);
   dim3 grid(cdiv(rows, 4)), blk(256);
@@ -641,6 +644,7 @@ __global__ __launch_bounds__(256, 3) void window_attn_split_kernel(const float* 
 
 int launch_window_attn(const float* qkv, const float* biasP, const float* maskP, const int* mask_any, const int* out_map, float* out,
                        int nWinTotal, int nWperImg, int C, int nH, int split_pipe, hipStream_t s) {
+  { static const int& skip_ = dev_knob_ref("SKIP", 0); if (skip_ & 1) return 0; }   // dev: ablation of the step (tools/dev/r04_ablate.py)
   ProfScope ps("window_attn", 4.0 * 49 * 49 * 32 * nWinTotal * nH, 16.0 * 49 * C * nWinTotal, s);
   int nPairs = nWinTotal * nH;
   if (nPairs <= 0) return 0;
