@@ -263,7 +263,8 @@ void* nuhtc_stream(nuhtc_engine* e);
  * the other socket of a two-socket host that costs 1.4-2.9 us per packet -- 0.3-0.4 ms per step of the back-to-back dense launches
  * (DESIGN.md section 5).  Returns 0 (bound, or already inside the node), NUHTC_E_NOTFOUND when the host exposes no NUMA node for the
  * device (nothing changed), NUHTC_E_STATE when the caller's mask has no CPU of that node (nothing changed: the caller chose otherwise),
- * NUHTC_E_HIP for a bad device.  Never called implicitly by the library; the Python host calls it from Engine() unless
+ * NUHTC_E_HIP for a bad device.  No counterpart in the reference: its launcher (tools/test.py:100-103,179-183 -> mmcv init_dist) leaves the placement
+ * of a rank to the operating system.  Never called implicitly by the library; the Python host calls it from Engine() unless
  * NUHTC_HOST_AFFINITY=0.  _pci takes the PCI address ("0000:75:00.0") instead of a device index. */
 int nuhtc_bind_host_thread(int device);
 int nuhtc_bind_host_thread_pci(const char* pci_bdf);
