@@ -253,7 +253,9 @@ static std::vector<float> pack_conv3(const HostTensor& w, int O, int I) {
 // =============================================================================== finalize
 // window_attn_mfma_kernel reads the additive score terms (relative-position bias, shift mask) per lane: the lane of query i = 32 ti + l32
 // in half-wave `half` needs, for key tile tj, the 16 accumulator registers r <-> key 32 tj + (r & 3) + 8 (r >> 2) + 4 half.  Packed
-// as [ti][half][l32][tj][16] (4096 floats per 49 x 49 table) a lane's terms of a query tile are 32 contiguous floats = a few 16-byte loads.
+// as [ti][q][lane = 32 half + l32][4] with q = (16 tj + r) / 4 (4096 floats per 49 x 49 table): the q-th 16-byte load of a wave covers 1 KB of
+// contiguous memory (round 4: with a lane's 32 floats contiguous, [ti][lane][32], every load instruction touched 64 different cache lines; the
+// loads of a table that is the same for every window cost 0.08 of the launches' 0.66 ms per step, tools/dev/r04_attn_probe.sh).
 static void pack_attn_terms(const float* qk /* [49][49] query-major */, float* out /* 4096 */) {
   for (int ti = 0; ti < 2; ++ti)
     for (int half = 0; half < 2; ++half)
@@ -261,7 +263,8 @@ static void pack_attn_terms(const float* qk /* [49][49] query-major */, float* o
         for (int tj = 0; tj < 2; ++tj)
           for (int r = 0; r < 16; ++r) {
             const int i = ti * 32 + l, j = tj * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            out[(((ti * 2 + half) * 32 + l) * 2 + tj) * 16 + r] = (i < WS2 && j < WS2) ? qk[i * WS2 + j] : 0.f;
+            const int f = tj * 16 + r, lane = half * 32 + l;
+            out[ti * 2048 + ((f >> 2) * 64 + lane) * 4 + (f & 3)] = (i < WS2 && j < WS2) ? qk[i * WS2 + j] : 0.f;
           }
 }
 

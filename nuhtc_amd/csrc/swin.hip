@@ -352,11 +352,11 @@ __global__ __launch_bounds__(256, 3) void window_attn_mfma_kernel(const float* _
   const int l32 = lane & 31, half = lane >> 5;
   const long long ld = 3LL * C;
   const float* base = qkv + (long long)win * WS2 * ld + head * HEAD_DIM;
-  // additive score terms, packed per lane ([ti][half][l32][tj][16], engine.hip pack_attn_terms): 32 contiguous floats per query tile.
+  // additive score terms, packed for the lanes ([ti][q][lane][4], engine.hip pack_attn_terms): the q-th 16-byte load of a wave is 1 KB of contiguous memory.
   // Only the windows on the shifted image's last row / column of windows carry a non-zero shift mask.
-  const float* bP = biasP + (long long)head * 4096 + (half * 32 + l32) * 32;                    // + ti * 2048
+  const float* bP = biasP + (long long)head * 4096 + (half * 32 + l32) * 4;                      // + ti * 2048
   const int wimg = win % nWperImg;
-  const float* mP = (maskP && mask_any[wimg]) ? maskP + (long long)wimg * 4096 + (half * 32 + l32) * 32 : nullptr;
+  const float* mP = (maskP && mask_any[wimg]) ? maskP + (long long)wimg * 4096 + (half * 32 + l32) * 4 : nullptr;
   const float scale = 0.17677669529663687f;   // 32^-0.5
 
   // K fragments of both key tiles: lane (j, half) holds K[tj*32 + j][half*16 .. +16)
@@ -395,11 +395,11 @@ __global__ __launch_bounds__(256, 3) void window_attn_mfma_kernel(const float* _
       const v4f* bp = reinterpret_cast<const v4f*>(bP + ti * 2048);
       v4f t4[7];
 #pragma unroll
-      for (int q = 0; q < 7; ++q) t4[q] = bp[q];          // registers 0..15 of key tile 0, 0..11 of key tile 1 (NR1 = 9 are used)
+      for (int q = 0; q < 7; ++q) t4[q] = bp[q * 64];          // registers 0..15 of key tile 0, 0..11 of key tile 1 (NR1 = 9 are used)
       if (mP) {
         const v4f* mp = reinterpret_cast<const v4f*>(mP + ti * 2048);
 #pragma unroll
-        for (int q = 0; q < 7; ++q) t4[q] += mp[q];
+        for (int q = 0; q < 7; ++q) t4[q] += mp[q * 64];
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) { bb[0][4 * q] = t4[q].x; bb[0][4 * q + 1] = t4[q].y; bb[0][4 * q + 2] = t4[q].z; bb[0][4 * q + 3] = t4[q].w; }
@@ -486,9 +486,9 @@ __global__ __launch_bounds__(256, 3) void window_attn_split_kernel(const float* 
   const int l32 = lane & 31, half = lane >> 5;
   const long long ld = 3LL * C;
   const float* base = qkv + (long long)win * WS2 * ld + head * HEAD_DIM;
-  const float* bP = biasP + (long long)head * 4096 + (half * 32 + l32) * 32;                    // + ti * 2048
+  const float* bP = biasP + (long long)head * 4096 + (half * 32 + l32) * 4;                      // + ti * 2048
   const int wimg = win % nWperImg;
-  const float* mP = (maskP && mask_any[wimg]) ? maskP + (long long)wimg * 4096 + (half * 32 + l32) * 32 : nullptr;
+  const float* mP = (maskP && mask_any[wimg]) ? maskP + (long long)wimg * 4096 + (half * 32 + l32) * 4 : nullptr;
   const float scale = 0.17677669529663687f;   // 32^-0.5
 
   // Every row the (window, head) pair needs -- K and Q of both tiles, V -- is requested up front, before the first split: the kernel is
@@ -502,7 +502,11 @@ __global__ __launch_bounds__(256, 3) void window_attn_split_kernel(const float* 
     const v4f* kptr = reinterpret_cast<const v4f*>(base + j * ld + C + half * 16);
     const v4f* qptr = reinterpret_cast<const v4f*>(base + j * ld + half * 16);
 #pragma unroll
+#if defined(NUHTC_ATTN_PROBE) && (NUHTC_ATTN_PROBE & 4)     // dev probe (wrong results): no K / Q loads
+    for (int q = 0; q < 4; ++q) { kfa[tj][q] = (v4f){0.01f * lane, 0.02f, 0.03f * q, 0.04f}; qfa[tj][q] = (v4f){0.02f, 0.01f * lane, 0.01f, 0.03f * q}; }
+#else
     for (int q = 0; q < 4; ++q) { kfa[tj][q] = kptr[q]; qfa[tj][q] = qptr[q]; }
+#endif
   }
   float vv[3][8];
 #pragma unroll
@@ -510,7 +514,11 @@ __global__ __launch_bounds__(256, 3) void window_attn_split_kernel(const float* 
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int r = 8 * (g & 1) + e;
+#if defined(NUHTC_ATTN_PROBE) && (NUHTC_ATTN_PROBE & 2)     // dev probe: no V loads
+      vv[g][e] = 0.001f * (lane + r);
+#else
       vv[g][e] = base[((g >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * ld + 2 * C + l32];
+#endif
     }
   __builtin_amdgcn_sched_barrier(0);
   // K planes of both key tiles: kp[tj][s][plane], lane (j, half) holds channels 16 half + 8 s + 0..7 of key tj*32 + j
@@ -541,7 +549,11 @@ __global__ __launch_bounds__(256, 3) void window_attn_split_kernel(const float* 
       const v4f* bp = reinterpret_cast<const v4f*>(bP + ti * 2048);
       v4f t4[7];
 #pragma unroll
-      for (int q = 0; q < 7; ++q) t4[q] = bp[q];          // registers 0..15 of key tile 0, 0..11 of key tile 1 (9 are used)
+#if defined(NUHTC_ATTN_PROBE) && (NUHTC_ATTN_PROBE & 1)     // dev probe: no bias loads
+      for (int q = 0; q < 7; ++q) t4[q] = (v4f){0.f, 0.01f, 0.f, 0.02f};
+#else
+      for (int q = 0; q < 7; ++q) t4[q] = bp[q * 64];          // registers 0..15 of key tile 0, 0..11 of key tile 1 (9 are used)
+#endif
 #pragma unroll
       for (int q = 0; q < 4; ++q) { st[0][4 * q] = t4[q].x; st[0][4 * q + 1] = t4[q].y; st[0][4 * q + 2] = t4[q].z; st[0][4 * q + 3] = t4[q].w; }
 #pragma unroll
@@ -566,7 +578,7 @@ __global__ __launch_bounds__(256, 3) void window_attn_split_kernel(const float* 
       const v4f* mp = reinterpret_cast<const v4f*>(mP + ti * 2048);
       v4f m4[7];
 #pragma unroll
-      for (int q = 0; q < 7; ++q) m4[q] = mp[q];
+      for (int q = 0; q < 7; ++q) m4[q] = mp[q * 64];
 #pragma unroll
       for (int q = 0; q < 4; ++q) { st[0][4 * q] += m4[q].x; st[0][4 * q + 1] += m4[q].y; st[0][4 * q + 2] += m4[q].z; st[0][4 * q + 3] += m4[q].w; }
 #pragma unroll
@@ -623,7 +635,11 @@ __global__ __launch_bounds__(256, 3) void window_attn_split_kernel(const float* 
     {   // key 48: register 8 of key tile 1 in the lower half-wave; V[48][d] for the 16 rows d = 8 g + 4 half + 0..3 of this lane's registers
       v4f v48[4];
 #pragma unroll
+#if defined(NUHTC_ATTN_PROBE) && (NUHTC_ATTN_PROBE & 2)
+      for (int g = 0; g < 4; ++g) v48[g] = (v4f){0.1f, 0.2f, 0.3f, 0.4f};
+#else
       for (int g = 0; g < 4; ++g) v48[g] = *reinterpret_cast<const v4f*>(base + 48 * ld + 2 * C + 8 * g + 4 * half);
+#endif
       const float p48 = __shfl(st[1][8], l32) * rsum;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
