@@ -495,18 +495,35 @@ __global__ __launch_bounds__(256, 3) void window_attn_split_kernel(const float* 
   // bound by the latency of these lane-per-row loads, and with Q of the second tile and V in flight beside K the wave waits once
   // instead of three times (0.735 -> 0.67 ms per step; a persistent form that also prefetches the NEXT pair needs 256 registers,
   // spills and runs at two waves per SIMD: 0.86 ms, not kept)
+  // The operands want a row per lane (lane (j, half) = the 64 bytes 16 half .. of row j), which as a LOAD is 64 separate requests per
+  // instruction.  The rows are therefore fetched the way memory likes it -- instruction q of a 32-row tile covers rows 8q .. 8q+7, eight
+  // consecutive lanes one 128-byte row: 16 requests of 64 bytes -- and each tile is turned into the operand layout through a private
+  // 4.5 KB slice of LDS (4 ds_write_b128 + 4 ds_read_b128, 144-byte row pitch: both conflict-free; DS operations of a wave execute in
+  // order, no barrier).  The texture path's request rate, not HBM, was what the launches waited for (tools/dev/r04_attn_probe.sh).
+  __shared__ __attribute__((aligned(16))) float tbuf[4][32 * 36];
+  float* tb = tbuf[wave];
+  const int lr = lane >> 3, lc = lane & 7;
   v4f kfa[2][4], qfa[2][4];
 #pragma unroll
   for (int tj = 0; tj < 2; ++tj) {
-    const int j = min(tj * 32 + l32, WS2 - 1);
-    const v4f* kptr = reinterpret_cast<const v4f*>(base + j * ld + C + half * 16);
-    const v4f* qptr = reinterpret_cast<const v4f*>(base + j * ld + half * 16);
 #pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int j = min(tj * 32 + 8 * q + lr, WS2 - 1);
 #if defined(NUHTC_ATTN_PROBE) && (NUHTC_ATTN_PROBE & 4)     // dev probe (wrong results): no K / Q loads
-    for (int q = 0; q < 4; ++q) { kfa[tj][q] = (v4f){0.01f * lane, 0.02f, 0.03f * q, 0.04f}; qfa[tj][q] = (v4f){0.02f, 0.01f * lane, 0.01f, 0.03f * q}; }
+      kfa[tj][q] = (v4f){0.01f * lane, 0.02f, 0.03f * q, 0.04f}; qfa[tj][q] = (v4f){0.02f, 0.01f * lane, 0.01f, 0.03f * q};
 #else
-    for (int q = 0; q < 4; ++q) { kfa[tj][q] = kptr[q]; qfa[tj][q] = qptr[q]; }
+      kfa[tj][q] = *reinterpret_cast<const v4f*>(base + j * ld + C + lc * 4);
+      qfa[tj][q] = *reinterpret_cast<const v4f*>(base + j * ld + lc * 4);
 #endif
+    }
+  }
+  // raw_[q] (rows 8q + lr, chunk lc) -> out_[p] (row l32, chunk 4 half + p)
+#define ATTN_TO_OPERAND(raw_, out_)                                                                            \
+  {                                                                                                            \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) *reinterpret_cast<v4f*>(tb + (8 * q + lr) * 36 + lc * 4) = raw_[q];   \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                     \
+    _Pragma("unroll") for (int p_ = 0; p_ < 4; ++p_) out_[p_] = *reinterpret_cast<const v4f*>(tb + l32 * 36 + (4 * half + p_) * 4);   \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                                     \
   }
   float vv[3][8];
 #pragma unroll
@@ -526,8 +543,7 @@ __global__ __launch_bounds__(256, 3) void window_attn_split_kernel(const float* 
 #pragma unroll
   for (int tj = 0; tj < 2; ++tj) {
     v4f kf[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) kf[q] = kfa[tj][q];
+    ATTN_TO_OPERAND(kfa[tj], kf)
 #pragma unroll
     for (int sk = 0; sk < 2; ++sk) {
       NUHTC_SPLIT3_INTO(kp[tj][sk], 0, kf[2 * sk].x, kf[2 * sk].y)
@@ -540,8 +556,7 @@ __global__ __launch_bounds__(256, 3) void window_attn_split_kernel(const float* 
 #pragma unroll
   for (int ti = 0; ti < 2; ++ti) {
     v4f qf[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) qf[q] = qfa[ti][q];
+    ATTN_TO_OPERAND(qfa[ti], qf)
     // the additive score terms (relative-position bias + shift mask) are loaded straight into the score accumulators: the products are
     // accumulated on top of them (the Q split below covers the latency of these loads; 25 registers less than adding them afterwards)
     f32x16 st[2];
@@ -657,6 +672,7 @@ __global__ __launch_bounds__(256, 3) void window_attn_split_kernel(const float* 
     }
   }
 }
+#undef ATTN_TO_OPERAND
 
 int launch_window_attn(const float* qkv, const float* biasP, const float* maskP, const int* mask_any, const int* out_map, float* out,
                        int nWinTotal, int nWperImg, int C, int nH, int split_pipe, hipStream_t s) {
