@@ -23,6 +23,9 @@
 #include "common.h"
 #include "split_math.h"
 
+#ifndef NUHTC_CONV_PROBE_EPI
+#define NUHTC_CONV_PROBE_EPI 0   // dev probe of the fused epilogue (wrong results): 1 no stores, 2 no residual loads, 4 no exchange barrier, 8 no second product
+#endif
 #define CV_TH 8
 #define CV_TW 16
 #define CV_PIX 400                         // bytes per halo pixel in LDS
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(512, 1) void conv3_split_kernel(Conv3Params p) {
       // every vector-memory operation issued before it, and stores under load take microseconds to be acknowledged
       v4f res[N2 == 64 ? 4 : 1];
       if constexpr (N2 == 64) {
-        if (p.out3 && inside) {
+        if (p.out3 && inside && !(NUHTC_CONV_PROBE_EPI & 2)) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) res[q] = *reinterpret_cast<const v4f*>(p.res2 + pix * 64 + 32 * chalf + 4 * half + 8 * q);
         }
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(512, 1) void conv3_split_kernel(Conv3Params p) {
         v4f v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
         v += *reinterpret_cast<const v4f*>(kst + cb + 8 * q);
         if (p.act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        if (p.store_out && inside) *reinterpret_cast<v4f*>(p.out + pix * 64 + cb + 8 * q) = v;
+        if (p.store_out && inside && !(NUHTC_CONV_PROBE_EPI & 1)) *reinterpret_cast<v4f*>(p.out + pix * 64 + cb + 8 * q) = v;
         if (p.outn1) {
           const v4f wv = *reinterpret_cast<const v4f*>(kst + 128 + cb + 8 * q);
           n1 = fmaf(v.x, wv.x, n1); n1 = fmaf(v.y, wv.y, n1); n1 = fmaf(v.z, wv.z, n1); n1 = fmaf(v.w, wv.w, n1);
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(512, 1) void conv3_split_kernel(Conv3Params p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[ob][r] = 0.f;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) acc2[ob] = mfma_split6_wa(w2f[ob][u], vp[u], acc2[ob]);
+        for (int u = 0; u < 2; ++u) if (!(NUHTC_CONV_PROBE_EPI & 8)) acc2[ob] = mfma_split6_wa(w2f[ob][u], vp[u], acc2[ob]);
       }
       // the other channel half's partial sums: N2 = 64: this wave keeps output block `chalf` and hands over the other one;
       // N2 = 32: it keeps registers 8 chalf .. 8 chalf + 7 of the one block and hands over the other eight
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(512, 1) void conv3_split_kernel(Conv3Params p) {
         n1 += __shfl_xor(n1, 32);
         xn[wave * 64 + lane] = n1;
       }
-      CV_RAW_BARRIER()
+      if (!(NUHTC_CONV_PROBE_EPI & 4)) CV_RAW_BARRIER()
       if (p.outn1 && chalf == 0 && half == 0 && inside) p.outn1[pix] = (n1 + xn[(wave ^ 4) * 64 + lane]) + kst[192];
       if constexpr (N2 == 64) {
         const int c2 = 32 * chalf + 4 * half;
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(512, 1) void conv3_split_kernel(Conv3Params p) {
           // channel half 0's partial first, whichever wave does the addition
           v4f v = (chalf ? other + mine : mine + other) + *reinterpret_cast<const v4f*>(kst + 64 + c2 + 8 * q);
           if (p.act2 == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-          if (inside) {
+          if (inside && !(NUHTC_CONV_PROBE_EPI & 1)) {
             *reinterpret_cast<v4f*>(p.out2 + pix * 64 + c2 + 8 * q) = v;
             if (p.out3) *reinterpret_cast<v4f*>(p.out3 + pix * 64 + c2 + 8 * q) = res[q] + v;
           }
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(512, 1) void conv3_split_kernel(Conv3Params p) {
           const int c2 = 16 * chalf + 8 * q + 4 * half;          // registers 8 chalf + 4 q .. + 3  ->  channels 8 (2 chalf + q) + 4 half ..
           v4f v = (chalf ? other + mine : mine + other) + *reinterpret_cast<const v4f*>(kst + 64 + c2);
           if (p.act2 == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-          if (inside) *reinterpret_cast<v4f*>(p.out2 + pix * 32 + c2) = v;
+          if (inside && !(NUHTC_CONV_PROBE_EPI & 1)) *reinterpret_cast<v4f*>(p.out2 + pix * 32 + c2) = v;
         }
       }
     }
