@@ -664,7 +664,11 @@ __global__ __launch_bounds__(256, 3) void window_attn_split_kernel(const float* 
     }
     long long orow = (long long)win * WS2 + ti * 32 + l32;
     if (ti * 32 + l32 < WS2 && out_map) orow = out_map[orow];
+#if defined(NUHTC_ATTN_PROBE) && (NUHTC_ATTN_PROBE & 8)     // dev probe: no output stores
+    if (ti * 32 + l32 < WS2 && orow >= 0 && ot[0] == 12345.f) {
+#else
     if (ti * 32 + l32 < WS2 && orow >= 0) {
+#endif
       float* op = out + orow * C + head * HEAD_DIM + 4 * half;
 #pragma unroll
       for (int g = 0; g < 4; ++g)   // registers 4g..4g+3 are d = 8g + 4*half + 0..3

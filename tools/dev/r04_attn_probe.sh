@@ -1,13 +1,13 @@
-# dev: what the window-attention launches wait for: the kernel with its bias (1), V (2) or K / Q (4) loads left out (-DNUHTC_ATTN_PROBE=mask, wrong
+# dev: what the window-attention launches wait for: the kernel with its bias (1), V (2) or K / Q (4) loads or its output stores (8) left out (-DNUHTC_ATTN_PROBE=mask, wrong
 # results; the attention launches' own work does not depend on the data) -- `window_attn` ms per step, one batch at a time
 mkdir -p gpurun_out tmp_ab; O=gpurun_out/attn_probe.txt; : > $O
-for m in 0 1 2 4 7; do
+for m in 0 8 15; do
   if [ $m = 0 ]; then unset NUHTC_EXTRA_CFLAGS_SWIN; else export NUHTC_EXTRA_CFLAGS_SWIN=-DNUHTC_ATTN_PROBE=$m; fi
   python -m nuhtc_amd.build --force > /dev/null || exit 1
   cp nuhtc_amd/libnuhtc_hip.so tmp_ab/attn$m.so
 done
 unset NUHTC_EXTRA_CFLAGS_SWIN
-for r in 1 2; do for m in 0 1 2 4 7; do cp tmp_ab/attn$m.so nuhtc_amd/libnuhtc_hip.so
+for r in 1 2; do for m in 0 8 15; do cp tmp_ab/attn$m.so nuhtc_amd/libnuhtc_hip.so
   timeout 200 python - >> $O 2>/dev/null <<PY
 import torch
 from nuhtc_amd import hip, synth, weights
