@@ -53,6 +53,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f'{LIB_PATH} not found: the HIP extension is required (no CPU fallback exists). '
                           'Build it with `python -m nuhtc_amd.build` (hipcc, --offload-arch=gfx950).')
+    # torch first: it brings its own copy of the HIP runtime, and a process must hold ONE -- loaded after torch, this library's libamdhip64
+    # dependency resolves to the copy torch loaded; loaded before it (e.g. __graft_entry__.build() followed by smoke() in one process), the
+    # process ends up with two runtimes and the second one finds no device (nuhtc_create: "no such HIP device")
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
     lib.nuhtc_default_config.argtypes = [ctypes.POINTER(Config)]

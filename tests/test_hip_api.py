@@ -560,3 +560,14 @@ def test_throughput_schedule_is_bit_identical(hip_device):
     a.close(); b.close()
     with pytest.raises(HipError):
         Engine(sd, device=0, max_batch=1, tile=(256, 256), schedule=7)
+
+
+def test_build_then_smoke_in_one_process(hip_device):
+    """The driver's two entry points in ONE process, build() first: build() loads libnuhtc_hip.so to check its exports, and if that happened
+    before torch was imported the process held two HIP runtimes (torch brings its own copy) and the engine found no device.  hip.load()
+    imports torch first."""
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+    out = subprocess.run([sys.executable, '-c', 'import __graft_entry__ as g; g.build(); g.smoke()'], cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and 'smoke ok' in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
