@@ -265,7 +265,8 @@ void* nuhtc_stream(nuhtc_engine* e);
  * device (nothing changed), NUHTC_E_STATE when the caller's mask has no CPU of that node (nothing changed: the caller chose otherwise),
  * NUHTC_E_HIP for a bad device.  No counterpart in the reference: its launcher (tools/test.py:100-103,179-183 -> mmcv init_dist) leaves the placement
  * of a rank to the operating system.  Never called implicitly by the library; the Python host calls it from Engine() unless
- * NUHTC_HOST_AFFINITY=0.  _pci takes the PCI address ("0000:75:00.0") instead of a device index. */
+ * NUHTC_HOST_AFFINITY=0.  _pci takes the PCI address ("0000:75:00.0") instead of a device index (the sysfs root can be
+ * redirected with NUHTC_SYSFS_ROOT: the CPU test of the parser and the mask arithmetic uses that). */
 int nuhtc_bind_host_thread(int device);
 int nuhtc_bind_host_thread_pci(const char* pci_bdf);
 
