@@ -252,6 +252,9 @@ __global__ __launch_bounds__(64 * NW, 1) void swin_mlp_kernel(MlpParams p) {
       h = mfma_split6(wf, xp[s], h);                                                                              \
     } }
   // + b1, GELU, split in place: registers 8u .. 8u+7 are the B operand of k-step u of the second product
+#ifdef NUHTC_MLP_PROBE_NOGELU      // dev probe (wrong results): the activation left out -- what the erf costs the fused FFN
+#define gelu_erf(x_) (x_)
+#endif
 #define MLP_ACT(c_)                                                                                               \
   { _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                               \
       const v4f bb = *reinterpret_cast<const v4f*>(lb1 + (c_) * 32 + 8 * q + 4 * half);                           \
@@ -301,6 +304,9 @@ __global__ __launch_bounds__(64 * NW, 1) void swin_mlp_kernel(MlpParams p) {
   MSTAMP(sk2 = __builtin_amdgcn_s_memtime();)
 #undef MLP_GEMM1
 #undef MLP_ACT
+#ifdef NUHTC_MLP_PROBE_NOGELU
+#undef gelu_erf
+#endif
 #undef MLP_GEMM2
 #undef MLP_LOAD_CHUNK
 #undef MLP_STORE_CHUNK
