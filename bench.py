@@ -255,6 +255,7 @@ def main():
     ap.add_argument('--gemm-shapes', action='store_true', help='add the per-shape GEMM timings to the JSON line')
     ap.add_argument('--no-settle', action='store_true', help='skip the untimed settle phase (profiling passes that serialise kernels)')
     ap.add_argument('--power-csv', default=None, help='write the 10 Hz power / clock / temperature samples of the run to this file (the summary is always on the line)')
+    ap.add_argument('--no-force-collective', action='store_true', help='N = 1: do not form the one-rank RCCL communicator; the exchange short-circuits (rounds 1-4)')
     ap.add_argument('--no-host-bind', action='store_true', help="leave the process on whatever CPUs the scheduler picks instead of the GPU's NUMA node (A/B of hip.bind_host_thread)")
     ap.add_argument('--roi-sort', action='store_true', help='--fixed-load (dev): hand the RoIs over sorted by position (locality experiment)')
     args = ap.parse_args()
@@ -286,6 +287,7 @@ def main():
             pass
     cpus_gpu = os.sched_getaffinity(0)
     dist = None
+    collective_note = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -295,6 +297,21 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         else:
             dist.init_process_group(backend)
+    elif not args.no_force_collective and os.environ.get('NUHTC_FORCE_COLLECTIVE', '1') != '0':
+        # N = 1: the job still forms its RCCL communicator (of one rank) and the timed exchange goes through both all_gathers on device
+        # buffers (nuhtc_amd.parallel.force_collective) -- the branch the N > 1 runs take, on the hardware this run has.  No scaling claim.
+        import torch.distributed as _d
+        from nuhtc_amd import parallel as _par
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        try:
+            torch.cuda.set_device(local_rank)
+            _d.init_process_group(os.environ.get('NUHTC_DIST_BACKEND', 'nccl'), init_method=f'tcp://127.0.0.1:{_par._free_port()}', rank=0, world_size=1,
+                                  device_id=torch.device('cuda', local_rank))
+            os.environ['NUHTC_FORCE_COLLECTIVE'] = '1'
+            dist = _d
+        except Exception as e:                  # the communicator is evidence, not a dependency of the N = 1 line
+            collective_note = f'process group of one rank not formed ({type(e).__name__}: {e}); the exchange short-circuits'
+            print(collective_note, file=sys.stderr)
 
     from nuhtc_amd import hip, synth, weights
     from nuhtc_amd.engine import Engine
@@ -685,6 +702,9 @@ def main():
             'kernel_ms_per_step': breakdown,
             'kernel_groups': groups,
             'exchange': {'collective': 'all_gather (header) + all_gather (one packed byte buffer): nuhtc_amd.parallel.gather_blobs',
+                         'backend': (dist.get_backend() if dist is not None else 'none: one rank, short-circuit'),
+                         'communicator_ranks': (dist.get_world_size() if dist is not None else 1),
+                         **({'note': collective_note} if collective_note else {}),
                          'ranks_seen': ranks_seen, 'records': gathered_records, 'bytes': gathered_bytes,
                          'layout': 'head f64[n,9] | ring vertices i32[*,2] | crop boxes i64[n,6] | bit-packed mask crops i32[*] | rank id'},
         }

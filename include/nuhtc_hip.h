@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NUHTC_ABI_VERSION 7
+#define NUHTC_ABI_VERSION 8
 
 enum {
   NUHTC_OK = 0,
@@ -257,18 +257,24 @@ int nuhtc_op_nms(nuhtc_engine* e, const float* boxes, const float* scores, int n
  * record into the handle after nuhtc_destroy: it may already belong to an unrelated engine. */
 void* nuhtc_stream(nuhtc_engine* e);
 
-/* Host-thread placement (v7).  Restricts the CALLING thread (threads it creates later inherit the mask) to the CPUs of the NUMA node the
- * device is attached to (/sys/bus/pci/devices/<bdf>/local_cpulist), intersected with the mask it has.  The thread that submits an engine's
- * work should run there: the command processor reads every dispatch packet from host memory last written by the submitter, and from
- * the other socket of a two-socket host that costs 1.4-2.9 us per packet -- 0.3-0.4 ms per step of the back-to-back dense launches
- * (DESIGN.md section 5).  Returns 0 (bound, or already inside the node), NUHTC_E_NOTFOUND when the host exposes no NUMA node for the
- * device (nothing changed), NUHTC_E_STATE when the caller's mask has no CPU of that node (nothing changed: the caller chose otherwise),
- * NUHTC_E_HIP for a bad device.  No counterpart in the reference: its launcher (tools/test.py:100-103,179-183 -> mmcv init_dist) leaves the placement
- * of a rank to the operating system.  Never called implicitly by the library; the Python host calls it from Engine() unless
- * NUHTC_HOST_AFFINITY=0.  _pci takes the PCI address ("0000:75:00.0") instead of a device index (the sysfs root can be
- * redirected with NUHTC_SYSFS_ROOT: the CPU test of the parser and the mask arithmetic uses that). */
+/* Host-thread placement (v7; v8: original-mask bookkeeping, restore, explicit-root test entry).  Restricts the CALLING thread (threads
+ * it creates later inherit the mask) to the CPUs of the NUMA node the device is attached to (/sys/bus/pci/devices/<bdf>/local_cpulist),
+ * intersected with the mask the thread had BEFORE its first placement (kept per thread: a thread placed for a GPU of one socket can be
+ * placed again for a GPU of the other).  The thread that submits an engine's work should run there: the command processor reads every
+ * dispatch packet from host memory last written by the submitter, and from the other socket of a two-socket host that costs 1.4-2.9 us
+ * per packet -- 0.3-0.4 ms per step of the back-to-back dense launches.  Returns 0 (bound, or already inside the
+ * node), NUHTC_E_NOTFOUND when the host exposes no NUMA node for the device (nothing changed), NUHTC_E_STATE when the caller's own mask
+ * has no CPU of that node (nothing changed: the caller chose otherwise), NUHTC_E_INVALID for a string that is not a PCI address (hex
+ * digits, ':' and '.'), NUHTC_E_HIP for a bad device.  nuhtc_restore_host_thread gives the calling thread the mask it had before its first
+ * placement (0 also when it was never placed).  No counterpart in the reference: its launcher (tools/test.py:100-103,179-183 -> mmcv
+ * init_dist) leaves the placement of a rank to the operating system.  NEVER called implicitly by the library, and since v8 not by the
+ * Python host either unless asked (`init_detector(..., bind_host=True)`, NUHTC_HOST_AFFINITY=1, or the entry points that own their
+ * process: bench.py, tools/infer_wsi.py, tools/bench_wsi.py).  _pci takes the PCI address ("0000:75:00.0") instead of a device index;
+ * _at is the test entry point: the same code against a sysfs tree under `sysfs_root` (the NUHTC_SYSFS_ROOT variable of v7 is gone). */
 int nuhtc_bind_host_thread(int device);
 int nuhtc_bind_host_thread_pci(const char* pci_bdf);
+int nuhtc_bind_host_thread_at(const char* sysfs_root, const char* pci_bdf);
+int nuhtc_restore_host_thread(void);
 
 /* Per-kernel timing with HIP events recorded on the launch stream (process-wide switch; off by default).
  * nuhtc_profile_read synchronises the device and writes one text line per kernel tag,

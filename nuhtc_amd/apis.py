@@ -19,8 +19,9 @@ class Detector:
     """Stands in for the nn.Module `init_detector` returns: callers set `.CLASSES` and read `.cfg`
     (tools/infer.py:49, tools/infer_wsi.py:424-428)."""
 
-    def __init__(self, cfg, state_dict, device, max_batch=16, max_cc_proposals=512):
+    def __init__(self, cfg, state_dict, device, max_batch=16, max_cc_proposals=512, bind_host=None):
         self.cfg = cfg
+        self.bind_host = bind_host
         self.state_dict = state_dict
         self.device = device
         self.max_batch = max_batch
@@ -48,7 +49,7 @@ class Detector:
             opts = dict(self.opts)
             nc = opts.pop('num_classes')
             return Engine(self.state_dict, device=self.device, max_batch=self.max_batch, tile=key, num_classes=nc,
-                          max_cc_proposals=self.max_cc_proposals, **opts)
+                          max_cc_proposals=self.max_cc_proposals, bind_host=self.bind_host, **opts)
         return self._cached(key, make)
 
     def pipeline(self, tile_hw, depth=4):
@@ -60,7 +61,7 @@ class Detector:
             opts = dict(self.opts)
             nc = opts.pop('num_classes')
             return EnginePipeline(self.state_dict, device=self.device, depth=depth, max_batch=self.max_batch, tile=key[:2],
-                                  num_classes=nc, max_cc_proposals=self.max_cc_proposals, **opts)
+                                  num_classes=nc, max_cc_proposals=self.max_cc_proposals, bind_host=self.bind_host, **opts)
         return self._cached(key, make)
 
     def eval(self):
@@ -78,7 +79,12 @@ def _device_index(device):
     raise ValueError(f'unsupported device {device!r}')
 
 
-def init_detector(config, checkpoint=None, device='cuda:0', cfg_options=None, max_batch=16):
+def init_detector(config, checkpoint=None, device='cuda:0', cfg_options=None, max_batch=16, bind_host=None):
+    """nuhtc/apis/inference.py:11-57.  Beyond the reference's arguments: `max_batch` (capacity of the engines the detector creates) and
+    `bind_host` -- True places the thread that creates an engine on the CPUs of the GPU's NUMA node (nuhtc_bind_host_thread: worth
+    8 % on the dense launches of a two-socket host; the thread's mask is restored when the engine is closed).  A
+    library does not change its caller's CPU affinity unasked: the default (None) follows NUHTC_HOST_AFFINITY, which defaults to off;
+    the entry points that own their process (bench.py, tools/infer_wsi.py, tools/bench_wsi.py) switch it on."""
     if isinstance(config, str):
         config = Config.fromfile(config)
     elif not isinstance(config, dict):
@@ -91,12 +97,21 @@ def init_detector(config, checkpoint=None, device='cuda:0', cfg_options=None, ma
     config.model.train_cfg = None
     dev = _device_index(device)
     opts = engine_options(config)   # validates the model description before touching the GPU
+    classes = None
     if checkpoint is not None:
-        sd = weights.load_checkpoint(checkpoint, opts['num_classes'])
+        sd, meta = weights.load_checkpoint(checkpoint, opts['num_classes'], return_meta=True)
+        if 'CLASSES' in meta:                       # nuhtc/apis/inference.py:45-46
+            classes = tuple(meta['CLASSES'])
+        else:
+            # :47-53: the reference falls back to the 80 COCO names here (wrong for every nuclei model; both tools overwrite
+            # CLASSES right after, tools/infer.py:49, tools/infer_wsi.py:425); class indices are kept instead
+            warnings.warn("Class names are not saved in the checkpoint's meta data, use the class indices '0'..'N-1' by default.")
     else:
         warnings.warn('init_detector called without a checkpoint: using seeded synthetic weights (the reference would keep its random init)')
         sd = weights.seeded_state_dict(0, opts['num_classes'])
-    model = Detector(config, sd, dev, max_batch=max_batch)
+    model = Detector(config, sd, dev, max_batch=max_batch, bind_host=bind_host)
+    if classes is not None:
+        model.CLASSES = classes
     return model
 
 
@@ -129,7 +144,12 @@ def inference_detector(model, imgs):
     for i, a in enumerate(arrs):
         by_shape.setdefault(a.shape[:2], []).append(i)
     results = [None] * len(arrs)
-    for hw, idx in by_shape.items():
+    if len(by_shape) > model.max_engines:
+        warnings.warn(f'inference_detector: {len(by_shape)} image sizes in one call but the detector keeps {model.max_engines} engines '
+                      '(Detector.max_engines): engines are rebuilt (seconds each) within this call; raise max_engines or group the images by size')
+    # sizes whose engine is already cached run first, so that this call evicts none of the engines it is about to use
+    cached = {k for k in model._engines if len(k) == 2}
+    for hw, idx in sorted(by_shape.items(), key=lambda kv: (int(kv[0][0]), int(kv[0][1])) not in cached):
         eng = model.engine(hw)
         for i, r in zip(idx, eng(np.stack([arrs[i] for i in idx]), mode)):
             results[i] = r

@@ -88,7 +88,7 @@ int conv3_pack_fuse(const float* w2_host, int N2, void** out_dev);      // calle
 struct GemmParams {
   const float* A;
   const float* W;      // [N][K] row-major
-  const void* Wsplit;  // optional: W split into three bf16 planes (gemm_register_split); then the bf16 matrix pipe is used
+  const void* Wsplit;  // optional: W split into three bf16 planes (gemm_make_split, kept in the engine's wsplit table); then the bf16 matrix pipe is used
   const float* bias;   // [N] or null
   float* C;
   int M, N, K;
@@ -192,3 +192,12 @@ int launch_transpose(const float* x, float* y, int batch, int rows, int cols, hi
 // ----------------------------------------------------------------------------- RoI path (roi.hip)
 int launch_roi_align(const float* feat, int N, int H, int W, int C, const float* rois, int R, const int* r_dev, int P,
                      float scale, int sr, float* out, int accumulate, hipStream_t s);
+
+// Result-altering dev probes (macros that leave loads, stores or arithmetic out to time what is left: WRONG RESULTS).  Each
+// translation unit that has such switches reports the ones it was compiled with (nullptr = none); nuhtc_create refuses to make an
+// engine from a library that carries any unless the process says NUHTC_DEV=1 (a stray NUHTC_EXTRA_CFLAGS in the environment of a
+// production build must not corrupt outputs silently).
+const char* nuhtc_tu_probe_conv();
+const char* nuhtc_tu_probe_gemm();
+const char* nuhtc_tu_probe_mlp();
+const char* nuhtc_tu_probe_swin();

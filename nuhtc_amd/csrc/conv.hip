@@ -493,3 +493,13 @@ int launch_conv3_split(const GemmParams& g, hipStream_t s) {
 #endif
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
 }
+
+const char* nuhtc_tu_probe_conv() {
+#if NUHTC_CONV_PROBE_EPI
+  return "NUHTC_CONV_PROBE_EPI";
+#elif defined(NUHTC_CONV_PROBE_READS)
+  return "NUHTC_CONV_PROBE_READS";
+#else
+  return nullptr;
+#endif
+}

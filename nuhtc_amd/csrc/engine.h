@@ -34,7 +34,9 @@ struct nuhtc_engine {
   std::vector<void*> allocs;
   // fp32 weight pointer -> its exact bf16 split (gemm_make_split), filled by upload_gemm_weight at finalize and read by egemm for every
   // launch: the engine's own table (a handle is not thread-safe by contract, so no lock); the buffers are in `allocs`
-  std::unordered_map<const float*, const void*> wsplit;
+  // the entry records the [N][K] geometry the split was made for: egemm hands it out only to a launch of exactly that geometry
+  struct WSplit { const void* planes; int N, K; };
+  std::unordered_map<const float*, WSplit> wsplit;
   size_t bytes_allocated = 0;
   bool finalized = false;
   bool debug_tokens = false;

@@ -2,6 +2,7 @@
 // htc_lite_swin tile-inference path (reference call stack: SURVEY §3.3; nuhtc/models/htc_cus.py:110-121,
 // nuhtc/models/htc_roi_head_cus.py:2184-2372).  Host code only enqueues kernels; there is no CPU fallback.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -61,6 +62,15 @@ int nuhtc_create(const nuhtc_config* cfg, int device, nuhtc_engine** out) {
   if (cfg->max_cc_proposals < 0 || cfg->max_cc_proposals > 4096) { g_create_error = "max_cc_proposals out of range"; return NUHTC_E_INVALID; }
   if (cfg->schedule != NUHTC_SCHED_LATENCY && cfg->schedule != NUHTC_SCHED_THROUGHPUT) { g_create_error = "schedule must be NUHTC_SCHED_LATENCY or NUHTC_SCHED_THROUGHPUT"; return NUHTC_E_INVALID; }
   if (cfg->matrix_pipe != NUHTC_PIPE_BF16_SPLIT && cfg->matrix_pipe != NUHTC_PIPE_FP32) { g_create_error = "matrix_pipe must be NUHTC_PIPE_BF16_SPLIT or NUHTC_PIPE_FP32"; return NUHTC_E_INVALID; }
+  {
+    const char* probes[4] = {nuhtc_tu_probe_conv(), nuhtc_tu_probe_gemm(), nuhtc_tu_probe_mlp(), nuhtc_tu_probe_swin()};
+    const char* dev = getenv("NUHTC_DEV");
+    for (const char* pr : probes)
+      if (pr && !(dev && dev[0] == '1')) {
+        g_create_error = std::string("this library was compiled with the result-altering dev probe ") + pr + " (wrong results by design); rebuild without it, or set NUHTC_DEV=1 for a timing experiment";
+        return NUHTC_E_STATE;
+      }
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { g_create_error = "no such HIP device"; return NUHTC_E_HIP; }
   hipDeviceProp_t prop;
@@ -184,7 +194,7 @@ int upload_gemm_weight(nuhtc_engine* e, float** dst, const std::vector<float>& v
   rc = gemm_make_split(v.data(), N, K, &sp);
   if (rc) FAIL(e, rc, "gemm_make_split failed");
   e->allocs.push_back(sp);
-  e->wsplit[*dst] = sp;
+  e->wsplit[*dst] = {sp, N, K};
   return 0;
 }
 
@@ -193,7 +203,12 @@ int egemm(nuhtc_engine* e, GemmParams p, hipStream_t s) {
   // workgroups per CU; measured 0.28 vs 0.32-0.40 ms per step for the 64x64 pointwise layers), batched products too
   if (!p.Wsplit && p.batch <= 1 && p.K >= 96) {
     auto it = e->wsplit.find(p.W);
-    if (it != e->wsplit.end()) p.Wsplit = it->second;
+    if (it != e->wsplit.end()) {
+      // a split of another geometry under this pointer would be read out of bounds by the kernel, silently: refuse it (the first
+      // rows of a weight with the same K are a valid product: the split is row-major in n)
+      if (it->second.K != p.K || p.N > it->second.N) FAIL(e, NUHTC_E_STATE, "egemm: the weight's bf16 split was made for another [N][K]");
+      p.Wsplit = it->second.planes;
+    }
   }
   {   // dev: ablation of the step (tools/dev/r04_ablate.py): 4 = 3x3 convolutions, 8 = 96-column split GEMMs, 64 = every other product
     static const int& skip_ = dev_knob_ref("SKIP", 0);

@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 3 ? 4 : 3)) void gemm_kernel(GemmP
 // (tools/dev/probe/bf16split_probe.hip, K = 96 .. 3136, normal and wide-range operands): max error 1.2-1.6e-7 of sum|a*b|
 // against 1.4-2.1e-7 for the fp32 MFMA chain, identical with all nine products -- the result is fp32 arithmetic (exact
 // products, fp32 accumulation), only the summation order differs, and the 16-deep dot products round less often.
-//   W is split once at nuhtc_finalize (gemm_register_split) into Wsplit[n][k/8][plane 0..2][8 bf16]: the 96 bytes a column
+//   W is split once at nuhtc_finalize (gemm_make_split) into Wsplit[n][k/8][plane 0..2][8 bf16]: the 96 bytes a column
 //   needs per 16-deep k-tile are contiguous in HBM and in the LDS image (112-byte column pitch: conflict-free b128 reads);
 //   A stays fp32 in HBM and LDS (same staging as the fp32 kernel, implicit 3x3-conv loader included) and is split in
 //   registers after the fragment read: 44 VALU instructions per k-tile and wave beside 6*NT MFMAs.
@@ -894,4 +894,12 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
   }
 #endif
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
+}
+
+const char* nuhtc_tu_probe_gemm() {
+#ifdef NUHTC_GEMM_NOSTORE
+  return "NUHTC_GEMM_NOSTORE";
+#else
+  return nullptr;
+#endif
 }

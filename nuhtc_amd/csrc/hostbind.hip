@@ -7,6 +7,7 @@
 
 #include <cctype>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -29,10 +30,16 @@ static bool parse_cpulist(const char* s, cpu_set_t* out) {
   return n > 0;
 }
 
-// the cpulist file of a PCI function, optionally under another sysfs root (tests)
-static bool read_local_cpulist(const char* bdf, std::string* out) {
-  const char* root = getenv("NUHTC_SYSFS_ROOT");
-  std::string path = std::string(root ? root : "/sys") + "/bus/pci/devices/" + bdf + "/local_cpulist";
+// a PCI address as sysfs spells it -- "0000:75:00.0": hex digits, ':' and '.' only (the string becomes part of a path)
+static bool valid_bdf(const std::string& b) {
+  if (b.empty() || b.size() > 32) return false;
+  for (char c : b)
+    if (!isxdigit((unsigned char)c) && c != ':' && c != '.') return false;
+  return b.find(':') != std::string::npos;
+}
+
+static bool read_local_cpulist(const char* root, const char* bdf, std::string* out) {
+  std::string path = std::string(root) + "/bus/pci/devices/" + bdf + "/local_cpulist";
   FILE* f = fopen(path.c_str(), "r");
   if (!f) return false;
   char buf[4096];
@@ -43,23 +50,45 @@ static bool read_local_cpulist(const char* bdf, std::string* out) {
   return true;
 }
 
-extern "C" int nuhtc_bind_host_thread_pci(const char* pci_bdf) {
-  if (!pci_bdf) return NUHTC_E_INVALID;
+// The mask a thread had before its FIRST placement: every later placement intersects the device's node with THIS mask, not with the
+// narrowed one (so a thread that served a GPU of one socket can be re-placed for a GPU of the other), and nuhtc_restore_host_thread
+// gives it back.
+static thread_local bool t_saved = false;
+static thread_local cpu_set_t t_orig;
+
+static int bind_at(const char* root, const char* pci_bdf) {
+  if (!root || !pci_bdf) return NUHTC_E_INVALID;
   std::string bdf(pci_bdf);
   for (auto& c : bdf) c = (char)tolower((unsigned char)c);
+  if (!valid_bdf(bdf)) return NUHTC_E_INVALID;
   std::string list;
-  if (!read_local_cpulist(bdf.c_str(), &list)) return NUHTC_E_NOTFOUND;
+  if (!read_local_cpulist(root, bdf.c_str(), &list)) return NUHTC_E_NOTFOUND;
   cpu_set_t local, cur, both;
   if (!parse_cpulist(list.c_str(), &local)) return NUHTC_E_NOTFOUND;      // no NUMA information for the device (single-node host, VM)
   if (sched_getaffinity(0, sizeof(cur), &cur) != 0) return NUHTC_E_STATE;
-  CPU_AND(&both, &local, &cur);
-  if (CPU_COUNT(&both) == 0) return NUHTC_E_STATE;                        // the caller's mask excludes the local node: left as it is
+  const cpu_set_t base = t_saved ? t_orig : cur;
+  CPU_AND(&both, &local, &base);
+  if (CPU_COUNT(&both) == 0) return NUHTC_E_STATE;                        // the caller's own mask excludes the local node: left as it is
   if (CPU_EQUAL(&both, &cur)) return 0;                                   // already there
-  return sched_setaffinity(0, sizeof(both), &both) == 0 ? 0 : NUHTC_E_STATE;
+  if (sched_setaffinity(0, sizeof(both), &both) != 0) return NUHTC_E_STATE;
+  if (!t_saved) { t_orig = cur; t_saved = true; }
+  return 0;
 }
+
+extern "C" int nuhtc_bind_host_thread_pci(const char* pci_bdf) { return bind_at("/sys", pci_bdf); }
+
+// test entry point: the same parser and mask arithmetic against a sysfs tree somewhere else (tests/test_host.py builds one)
+extern "C" int nuhtc_bind_host_thread_at(const char* sysfs_root, const char* pci_bdf) { return bind_at(sysfs_root, pci_bdf); }
 
 extern "C" int nuhtc_bind_host_thread(int device) {
   char bdf[64] = {0};
   if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), device) != hipSuccess) return NUHTC_E_HIP;
   return nuhtc_bind_host_thread_pci(bdf);
+}
+
+extern "C" int nuhtc_restore_host_thread(void) {
+  if (!t_saved) return 0;
+  if (sched_setaffinity(0, sizeof(t_orig), &t_orig) != 0) return NUHTC_E_STATE;
+  t_saved = false;
+  return 0;
 }

@@ -680,3 +680,11 @@ int launch_swin_lnqkv(const float* x, float* qkv, const int* src_tok, const int*
   hipLaunchKernelGGL(kern, dim3(cdiv(T, 32 * NW)), dim3(64 * NW), QkvGeom<96>::LDS_BYTES, s, p);
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
 }
+
+const char* nuhtc_tu_probe_mlp() {
+#ifdef NUHTC_MLP_PROBE_NOGELU
+  return "NUHTC_MLP_PROBE_NOGELU";
+#else
+  return nullptr;
+#endif
+}

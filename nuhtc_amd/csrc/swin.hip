@@ -691,3 +691,11 @@ int launch_window_attn(const float* qkv, const float* biasP, const float* maskP,
     hipLaunchKernelGGL(window_attn_mfma_kernel, dim3(cdiv(nPairs, 4)), dim3(256), 0, s, qkv, biasP, maskP, mask_any, out_map, out, nPairs, nWperImg, C, nH);
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
 }
+
+const char* nuhtc_tu_probe_swin() {
+#if defined(NUHTC_ATTN_PROBE) && NUHTC_ATTN_PROBE
+  return "NUHTC_ATTN_PROBE";
+#else
+  return nullptr;
+#endif
+}

@@ -7,6 +7,7 @@ device buffers and the current stream only; every computation happens inside the
 """
 import ctypes
 import os
+import sys
 
 import numpy as np
 import torch
@@ -33,7 +34,10 @@ _TORCH = {0: torch.float32, 1: torch.int32, 2: torch.uint8, 3: torch.int32}
 class Engine:
     EXPORT_BUFFERS = 3          # pinned host buffers of export_async: batches per pipeline slot (2) + 1, see export_async
 
-    def __init__(self, state_dict, device=0, max_batch=16, tile=(256, 256), num_classes=5, **cfg_overrides):
+    _bound = {}                 # thread id -> number of live engines that placed that thread (the last one to close restores its mask)
+    _logged = False
+
+    def __init__(self, state_dict, device=0, max_batch=16, tile=(256, 256), num_classes=5, bind_host=None, **cfg_overrides):
         if not torch.cuda.is_available():
             raise HipError('no HIP device visible: nuhtc_amd has no CPU path (the CPU oracle lives under oracle/ and is test-only)')
         self.lib = hip.load()
@@ -60,10 +64,28 @@ class Engine:
             else:
                 setattr(cfg, k, v)
         self.cfg = cfg
-        # the submitting thread belongs on the GPU's NUMA node (hip.bind_host_thread) -- before the first queue exists
-        if os.environ.get('NUHTC_HOST_AFFINITY', '1') != '0':
+        # The submitting thread belongs on the GPU's NUMA node (hip.bind_host_thread) -- before the first queue
+        # exists.  Opt-in (bind_host=True, or NUHTC_HOST_AFFINITY=1 when the argument is None): narrowing the caller's CPU mask is
+        # the caller's decision; close() gives the mask back when the last engine that placed this thread goes.
+        self._placed_thread = None
+        if bind_host is None:
+            bind_host = os.environ.get('NUHTC_HOST_AFFINITY', '0') == '1'
+        if bind_host:
+            import threading
             try:
-                hip.bind_host_thread(self.device.index)
+                before = os.sched_getaffinity(0)
+                if hip.bind_host_thread(self.device.index):
+                    tid = threading.get_ident()
+                    Engine._bound[tid] = Engine._bound.get(tid, 0) + 1
+                    self._placed_thread = tid
+                    now = os.sched_getaffinity(0)
+                    if not Engine._logged and now != before:
+                        Engine._logged = True
+                        print(f'nuhtc_amd: the submitting thread now runs on {len(now)} of its {len(before)} CPUs, the NUMA node of GPU {self.device.index} '
+                              '(bind_host=True / NUHTC_HOST_AFFINITY=1; the mask is restored when the engine is closed)', file=sys.stderr)
+                else:
+                    import warnings
+                    warnings.warn(f'nuhtc_amd: bind_host requested but the submitting thread was not placed: {hip.bind_reason}')
             except RuntimeError:          # placement is an optimisation: a device the runtime cannot name is reported by nuhtc_create below
                 pass
         self.h = ctypes.c_void_p()
@@ -109,6 +131,15 @@ class Engine:
         if getattr(self, 'h', None) and self.h.value:
             self.lib.nuhtc_destroy(self.h)
             self.h = ctypes.c_void_p()
+        tid = getattr(self, '_placed_thread', None)
+        if tid is not None:
+            self._placed_thread = None
+            import threading
+            Engine._bound[tid] = Engine._bound.get(tid, 1) - 1
+            if Engine._bound[tid] <= 0:
+                Engine._bound.pop(tid, None)
+                if threading.get_ident() == tid:          # only the placed thread itself can take its mask back
+                    hip.restore_host_thread()
 
     def __del__(self):
         try:

@@ -41,7 +41,7 @@ EXPORTS = ['nuhtc_default_config', 'nuhtc_create', 'nuhtc_destroy', 'nuhtc_last_
            'nuhtc_finalize', 'nuhtc_infer', 'nuhtc_infer_fixed_load', 'nuhtc_check', 'nuhtc_get_buffer',
            'nuhtc_op_gemm', 'nuhtc_op_gemm_split', 'nuhtc_op_roi_align', 'nuhtc_op_nms', 'nuhtc_profile_enable', 'nuhtc_profile_read', 'nuhtc_dev_knob', 'nuhtc_export_crops',
            'nuhtc_mask_contours', 'nuhtc_merge_overlap', 'nuhtc_export_kept', 'nuhtc_clock_probe', 'nuhtc_op_swin_mlp', 'nuhtc_stream', 'nuhtc_op_swin_proj_mlp', 'nuhtc_bind_host_thread',
-           'nuhtc_bind_host_thread_pci']
+           'nuhtc_bind_host_thread_pci', 'nuhtc_bind_host_thread_at', 'nuhtc_restore_host_thread']
 
 _lib = None
 
@@ -88,6 +88,8 @@ def load():
     lib.nuhtc_dev_knob.argtypes = [ctypes.c_char_p, ci]
     lib.nuhtc_bind_host_thread.argtypes = [ci]
     lib.nuhtc_bind_host_thread_pci.argtypes = [ctypes.c_char_p]
+    lib.nuhtc_bind_host_thread_at.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+    lib.nuhtc_restore_host_thread.argtypes = []
     lib.nuhtc_stream.argtypes = [vp]
     lib.nuhtc_profile_read.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
     for name in EXPORTS:
@@ -108,16 +110,33 @@ def default_config():
     return cfg
 
 
-def bind_host_thread(device=0, pci_bdf=None):
+BIND_REASON = {0: 'bound', -1: 'not a PCI address', -2: 'no such HIP device', -3: "the thread's own CPU mask excludes the GPU's NUMA node",
+               -5: 'the host exposes no NUMA node for the device'}
+bind_reason = 'never called'          # why the last bind_host_thread of this process returned what it did (BIND_REASON)
+
+
+def bind_host_thread(device=0, pci_bdf=None, sysfs_root=None):
     """Restrict the calling thread to the CPUs of the NUMA node the GPU is attached to (nuhtc_bind_host_thread: the thread that submits
-    an engine's work should run there -- from the other socket every dispatch packet costs the command processor 1.4-2.9 us more).
-    Returns True when the thread now runs inside that node, False when the host exposes no node for the device or the caller's own mask
-    excludes it (nothing is changed then).  NUHTC_HOST_AFFINITY=0 turns the call Engine() makes into a no-op."""
+    an engine's work should run there -- from the other socket every dispatch packet costs the command processor 1.4-2.9 us more),
+    intersected with the mask the thread had before its first placement (`restore_host_thread` gives that mask back).
+    Returns True when the thread now runs inside that node, False when nothing was changed; `hip.bind_reason` then says why (no NUMA
+    node for the device / the caller's own mask excludes it / not a PCI address).  A device the runtime cannot name raises.
+    `sysfs_root`: the test entry point (nuhtc_bind_host_thread_at)."""
+    global bind_reason
     lib = load()
-    rc = lib.nuhtc_bind_host_thread_pci(pci_bdf.encode()) if pci_bdf else lib.nuhtc_bind_host_thread(int(device))
+    if sysfs_root is not None:
+        rc = lib.nuhtc_bind_host_thread_at(str(sysfs_root).encode(), pci_bdf.encode())
+    else:
+        rc = lib.nuhtc_bind_host_thread_pci(pci_bdf.encode()) if pci_bdf else lib.nuhtc_bind_host_thread(int(device))
+    bind_reason = BIND_REASON.get(rc, f'error {rc}')
     if rc == -2:
         raise RuntimeError(f'nuhtc_bind_host_thread: no such device ({device})')
     return rc == 0
+
+
+def restore_host_thread():
+    """The calling thread gets back the CPU mask it had before its first bind_host_thread (no-op when it was never placed)."""
+    return load().nuhtc_restore_host_thread() == 0
 
 
 def profile_enable(on=True):

@@ -8,6 +8,20 @@ import torch
 import torch.distributed as dist
 
 
+def force_collective():
+    """NUHTC_FORCE_COLLECTIVE=1: a job of ONE rank still forms its process group and sends the exchange through the collectives
+    (two all_gathers over a communicator of size 1) instead of short-circuiting them -- the way to run the RCCL branch of
+    `gather_blobs` (device buffers in, device buffers out) on a one-GPU box.  Results are byte-equal to the short-circuit."""
+    return os.environ.get('NUHTC_FORCE_COLLECTIVE') == '1'
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
 def init_from_env(backend=None):
     """One process per GPU, launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -15,7 +29,12 @@ def init_from_env(backend=None):
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     if os.environ.get('NUHTC_ONE_DEVICE') == '1':       # test hook: several ranks on a one-GPU box (with NUHTC_DIST_BACKEND=gloo)
         local_rank = 0
-    if world > 1 and not dist.is_initialized():
+    if world == 1 and force_collective() and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', str(_free_port()))
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+    if (world > 1 or force_collective()) and not dist.is_initialized():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         backend = backend or os.environ.get('NUHTC_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
@@ -61,7 +80,7 @@ def gather_blobs(parts, group=None):
     detection (45 MB per rank for a 10 000-tile slide shard) the ring all-gather over xGMI is milliseconds; a gather to rank 0 alone would
     save the other ranks' receive buffers, nothing on the critical path."""
     parts = [p.contiguous() for p in parts]
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force_collective()):
         return [parts]
     world = dist.get_world_size(group)
     if dist.get_backend(group) == 'gloo':       # gloo moves host memory: hand it host tensors

@@ -38,12 +38,15 @@ class EnginePipeline:
         self.pending = collections.deque()      # (slot, B, event, user tag, keep-alive, export turn)
         self.next = 0
         self.last_turn = None                   # export buffer of the batch collect() returned last (Engine.export_read(turn))
-        # Batches submitted with export=True leave the device through the engine's two host buffers, used in turn: a slot may hold
-        # `per_slot` = 2 such batches, the second queued behind the first on the slot's stream.  The streams then never run dry while
+        # Batches submitted with export=True leave the device through the engine's pinned host buffers (Engine.EXPORT_BUFFERS = 3), used
+        # in turn: a slot may hold `per_slot` = 2 such batches, the second queued behind the first on the slot's stream, and the third
+        # buffer is what lets the host resubmit to the slot BEFORE it has unpacked the batch it just collected.  The streams then never run dry while
         # the host waits for, unpacks and resubmits a batch -- with one batch per slot the batches in flight finish together and the
         # GPU idles until the host has refilled the slots (1.51k tiles/s against 1.9k for the same four engines fed without pause).
         # Batches whose results are read from the engine's own tensors (export=False) stay one per slot.
         self.per_slot = max(1, min(2, int(per_slot)))
+        if Engine.EXPORT_BUFFERS < self.per_slot + 1:
+            raise RuntimeError('EnginePipeline needs Engine.EXPORT_BUFFERS >= per_slot + 1 (a collected batch is read while the slot already holds per_slot new ones)')
 
     @property
     def depth(self):

@@ -1,0 +1,265 @@
+"""Slide folders: the `seg_and_patch` half of the reference's tools/infer_wsi.py (:117-306) behind the same arguments.
+
+    source folder -> process list (`initialize_df`, tools/wsi_core/batch_process_utils.py:17-82; written to
+    <save_dir>/process_list_autogen.csv before every slide and at the end, :159,291) -> per slide: auto-skip when its coordinate
+    file exists (:168-171), tissue segmentation (`--seg`, :254-265), mask picture (:267-270), tile coordinates (`--patch`,
+    :272-276 -> patches/<slide_id>), stitched picture (`--stitch`, :278-284), status column.
+
+Differences, all forced by the image (no OpenSlide, no HDF5, no OpenCV) and stated where they apply:
+  * a slide is a level-0 RGB array (`.npy`, memory-mapped) or a store directory (nuhtc_amd.tilestore); other files of the folder
+    get status `failed_open` and the loop goes on (the reference would raise inside OpenSlide);
+  * the pyramid is virtual and dyadic: level k is the [::2^k] view of the array, so `seg_level = -1` resolves to the level whose
+    downsample is `seg_downsample` (64, what `get_best_level_for_downsample(64)` gives for a pyramid that has it);
+  * the coordinate file is patches/<slide_id>.npz (`coords`, `patch_size`, `patch_level`, `name`: the datasets / attributes of
+    the reference's .h5, tools/wsi_core/wsi_utils.py `initialize_hdf5_bag` / `save_hdf5`), written uncompressed;
+  * the two pictures are drawn with PIL (outline width as `visWSI` computes it; not pixel-equal to cv2.drawContours).
+"""
+import math
+import os
+import time
+
+import numpy as np
+
+from . import tilestore, tissue
+
+# tools/infer_wsi.py:378-382
+SEG_PARAMS = {'seg_level': -1, 'sthresh': 8, 'mthresh': 7, 'close': 4, 'use_otsu': False, 'keep_ids': 'none', 'exclude_ids': 'none'}
+FILTER_PARAMS = {'a_t': 100, 'a_h': 16, 'max_n_holes': 8}
+VIS_PARAMS = {'vis_level': -1, 'line_thickness': 250}
+PATCH_PARAMS = {'use_padding': True, 'contour_fn': 'four_pt'}
+
+
+def default_parameters(preset=None, preset_dir='presets'):
+    """The four parameter dicts of main() (:378-398); `preset` = a .csv under presets/ whose first row overrides them."""
+    seg, flt, vis, pat = dict(SEG_PARAMS), dict(FILTER_PARAMS), dict(VIS_PARAMS), dict(PATCH_PARAMS)
+    if preset:
+        import pandas as pd
+        df = pd.read_csv(os.path.join(preset_dir, preset))
+        for d in (seg, flt, vis, pat):
+            for key in d:
+                d[key] = df.loc[0, key]
+    return seg, flt, vis, pat
+
+
+def initialize_df(slides, seg_params, filter_params, vis_params, patch_params):
+    """batch_process_utils.py:17-82 without the heatmap / save_patches columns infer_wsi.py never asks for: same columns, same
+    order, same dtypes (the CSV text is pinned to the reference's own function in tests/golden/process_list_autogen.csv)."""
+    import pandas as pd
+    total = len(slides)
+    slide_ids = slides.slide_id.values if isinstance(slides, pd.DataFrame) else slides
+    d = {'slide_id': slide_ids, 'process': np.full((total), 1, dtype=np.uint8),
+         'status': np.full((total), 'tbp'),
+         'seg_level': np.full((total), int(seg_params['seg_level']), dtype=np.int8),
+         'sthresh': np.full((total), int(seg_params['sthresh']), dtype=np.uint8),
+         'mthresh': np.full((total), int(seg_params['mthresh']), dtype=np.uint8),
+         'close': np.full((total), int(seg_params['close']), dtype=np.uint32),
+         'use_otsu': np.full((total), bool(seg_params['use_otsu']), dtype=bool),
+         'keep_ids': np.full((total), seg_params['keep_ids']),
+         'exclude_ids': np.full((total), seg_params['exclude_ids']),
+         'a_t': np.full((total), int(filter_params['a_t']), dtype=np.float32),
+         'a_h': np.full((total), int(filter_params['a_h']), dtype=np.float32),
+         'max_n_holes': np.full((total), int(filter_params['max_n_holes']), dtype=np.uint32),
+         'vis_level': np.full((total), int(vis_params['vis_level']), dtype=np.int8),
+         'line_thickness': np.full((total), int(vis_params['line_thickness']), dtype=np.uint32),
+         'use_padding': np.full((total), bool(patch_params['use_padding']), dtype=bool),
+         'contour_fn': np.full((total), patch_params['contour_fn'])}
+    if isinstance(slides, pd.DataFrame):
+        temp = pd.DataFrame(d)
+        for key in d:
+            if key in slides.columns:
+                mask = slides[key].isna()
+                slides.loc[mask, key] = temp.loc[mask, key]
+            else:
+                slides.insert(len(slides.columns), key, d[key])
+        return slides
+    return pd.DataFrame(d)
+
+
+def coords_path(patch_save_dir, slide_id):
+    """patches/<slide_id>.npz -- the role of the reference's patches/<slide_id>.h5."""
+    return os.path.join(patch_save_dir, slide_id + '.npz')
+
+
+def save_coords(path, coords, patch_size, patch_level, name):
+    np.savez(path, coords=np.asarray(coords, np.int64).reshape(-1, 2), patch_size=np.int64(patch_size), patch_level=np.int64(patch_level),
+             name=np.str_(name))
+
+
+def open_array_slide(path):
+    """-> (H, W, 3) uint8 array (memory-mapped) of a `.npy` slide or of a store directory's slide.npy."""
+    if os.path.isdir(path):
+        path = os.path.join(path, 'slide.npy')
+    return tilestore.open_slide(path)
+
+
+def _ids(v):
+    v = str(v)
+    return [] if v == 'none' or len(v) == 0 else [int(t) for t in v.split(',')]
+
+
+def _level_of(downsample):
+    lvl = int(round(math.log2(downsample)))
+    if downsample < 1 or 2 ** lvl != downsample:
+        raise ValueError(f'seg_downsample must be a power of two (virtual dyadic pyramid), got {downsample}')
+    return lvl
+
+
+def vis_mask(slide, contours, holes, level, line_thickness=250, color=(0, 255, 0), hole_color=(0, 0, 255)):
+    """`visWSI` (WholeSlideImage.py:201-256): the level image with the tissue contours (green) and their holes (blue) outlined;
+    outline width int(line_thickness * sqrt(scale_x * scale_y)) like :221."""
+    from PIL import Image, ImageDraw
+    ds = 2 ** int(level)
+    img = Image.fromarray(np.ascontiguousarray(np.asarray(slide)[::ds, ::ds, :3]))
+    width = max(1, int(line_thickness * math.sqrt((1 / ds) * (1 / ds))))
+    dr = ImageDraw.Draw(img)
+
+    def outline(c, col):
+        pts = [(int(x * (1 / ds)), int(y * (1 / ds))) for x, y in np.asarray(c).reshape(-1, 2)]      # scaleContourDim: astype(int32)
+        if len(pts) > 1:
+            dr.line(pts + pts[:1], fill=col, width=width)
+        elif pts:
+            dr.point(pts, fill=col)
+    for c in contours or []:
+        outline(c, color)
+    for hs in holes or []:
+        for h in hs:
+            outline(h, hole_color)
+    return img
+
+
+def stitch_coords(slide, coords, patch_size, downscale=64, bg_color=(0, 0, 0)):
+    """`StitchCoords` + `DrawMapFromCoords` (wsi_utils.py:259-293,200-225): the tiles of the coordinate file pasted, down-scaled,
+    onto a black canvas of the level nearest `downscale`."""
+    from PIL import Image
+    lvl = _level_of(downscale)
+    ds = 2 ** lvl
+    lv = np.asarray(slide)[::ds, ::ds, :3]
+    h, w = lv.shape[:2]
+    canvas = np.zeros((h, w, 3), np.uint8)
+    canvas[:] = bg_color
+    ps = int(math.ceil(patch_size / ds))
+    for x, y in np.asarray(coords, np.int64).reshape(-1, 2):
+        cx, cy = int(math.ceil(x / ds)), int(math.ceil(y / ds))
+        sub = lv[cy:cy + ps, cx:cx + ps]                                  # read_region(coord, vis_level, patch_size)
+        canvas[cy:cy + sub.shape[0], cx:cx + sub.shape[1]] = sub
+    return Image.fromarray(canvas)
+
+
+def seg_and_patch(source, save_dir, patch_save_dir, mask_save_dir, stitch_save_dir, patch_size=256, step_size=256,
+                  seg_params=None, filter_params=None, vis_params=None, patch_params=None, patch_level=0, use_default_params=False,
+                  seg=False, save_mask=True, stitch=False, patch=False, no_auto_skip=False, process_list=None,
+                  slides=None, seg_downsample=64, log=print):
+    """tools/infer_wsi.py:117-306 with the same arguments (+ `slides`: an explicit list of file names instead of the folder listing,
+    `seg_downsample`: the downsample `seg_level = -1` / `vis_level = -1` resolve to).  Returns (seg_times, patch_times)."""
+    import pandas as pd
+    seg_params = dict(SEG_PARAMS if seg_params is None else seg_params)
+    filter_params = dict(FILTER_PARAMS if filter_params is None else filter_params)
+    vis_params = dict(VIS_PARAMS if vis_params is None else vis_params)
+    patch_params = dict(PATCH_PARAMS if patch_params is None else patch_params)
+    if patch_level != 0:
+        raise ValueError('--patch_level: array slides have one level; only patch_level 0 is supported')
+    if slides is None:
+        slides = sorted(os.listdir(source))
+        # the reference keeps regular files only (:136); a store directory (slide.npy + coords.npy) is this build's other slide form
+        slides = [s for s in slides if os.path.isfile(os.path.join(source, s)) or os.path.isfile(os.path.join(source, s, 'slide.npy'))]
+    if process_list is None:
+        df = initialize_df(slides, seg_params, filter_params, vis_params, patch_params)
+    else:
+        df = initialize_df(pd.read_csv(process_list), seg_params, filter_params, vis_params, patch_params)
+    if 'a' in df.keys():
+        raise NotImplementedError('legacy segmentation csv files (column "a") are not supported')
+    process_stack = df[df['process'] == 1]
+    total = len(process_stack)
+    seg_times = patch_times = stitch_times = 0.
+    auto_level = _level_of(seg_downsample)
+    for i in range(total):
+        df.to_csv(os.path.join(save_dir, 'process_list_autogen.csv'), index=False)
+        idx = process_stack.index[i]
+        slide = process_stack.loc[idx, 'slide_id']
+        log('\n\nprogress: {:.2f}, {}/{}'.format(i / total, i, total))
+        log('processing {}'.format(slide))
+        df.loc[idx, 'process'] = 0
+        slide_id, _ = os.path.splitext(slide)
+        cpath = coords_path(patch_save_dir, slide_id)
+        if not no_auto_skip and os.path.isfile(cpath):
+            log('{} already exist in destination location, skipped'.format(slide_id))
+            df.loc[idx, 'status'] = 'already_exist'
+            continue
+        try:
+            img = open_array_slide(os.path.join(source, slide))
+        except Exception as e:                                     # not an array slide (OpenSlide formats cannot be read here)
+            log('cannot open {} as an array slide ({}): skipped'.format(slide, e))
+            df.loc[idx, 'status'] = 'failed_open'
+            continue
+        H, W = img.shape[:2]
+        cur_vis = {k: (vis_params if use_default_params else df.loc[idx])[k] for k in vis_params}
+        cur_filter = {k: (filter_params if use_default_params else df.loc[idx])[k] for k in filter_params}
+        cur_seg = {k: (seg_params if use_default_params else df.loc[idx])[k] for k in seg_params}
+        cur_patch = {k: (patch_params if use_default_params else df.loc[idx])[k] for k in patch_params}
+        if cur_vis['vis_level'] < 0:
+            cur_vis['vis_level'] = auto_level
+        if cur_seg['seg_level'] < 0:
+            cur_seg['seg_level'] = auto_level
+        keep_ids, exclude_ids = _ids(cur_seg['keep_ids']), _ids(cur_seg['exclude_ids'])
+        sds = 2 ** int(cur_seg['seg_level'])
+        w, h = -(-W // sds), -(-H // sds)
+        if w * h > 1e8:
+            log('level_dim {} x {} is likely too large for successful segmentation, aborting'.format(w, h))
+            df.loc[idx, 'status'] = 'failed_seg'
+            continue
+        df.loc[idx, 'vis_level'] = cur_vis['vis_level']
+        df.loc[idx, 'seg_level'] = cur_seg['seg_level']
+        conts = holes = None
+        seg_time = -1
+        if seg:
+            t0 = time.time()
+            conts, holes = tissue.segment_tissue(img, scale=sds, sthresh=int(cur_seg['sthresh']), mthresh=int(cur_seg['mthresh']),
+                                                 close=int(cur_seg['close']), use_otsu=bool(cur_seg['use_otsu']),
+                                                 filter_params=dict(a_t=cur_filter['a_t'], a_h=cur_filter['a_h'], max_n_holes=int(cur_filter['max_n_holes'])),
+                                                 keep_ids=keep_ids, exclude_ids=exclude_ids)
+            seg_time = time.time() - t0
+        if save_mask:
+            vis_mask(img, conts, holes, int(cur_vis['vis_level']), int(cur_vis['line_thickness'])).save(os.path.join(mask_save_dir, slide_id + '.png'))
+        patch_time = -1
+        if patch:
+            t0 = time.time()
+            if conts is None:
+                # the reference cannot patch without --seg (contours_tissue is None, process_contours raises); here the whole slide
+                # is tiled on the grid np.arange(0, size, step)
+                coords = tilestore.grid_coords(H, W, step_size)
+            else:
+                parts = [tissue.contour_coords(c, hs, (W, H), patch_size, step_size, str(cur_patch['contour_fn']), bool(cur_patch['use_padding']))
+                         for c, hs in zip(conts, holes)]
+                coords = np.concatenate(parts, 0) if parts else np.zeros((0, 2), np.int64)
+            if len(coords):                                        # the reference creates the .h5 with the first contour that yields tiles (:397-403)
+                save_coords(cpath, coords, patch_size, patch_level, slide_id)
+            log('tissue segmentation: {} contour(s), {} tiles'.format(0 if conts is None else len(conts), len(coords)))
+            patch_time = time.time() - t0
+        stitch_time = -1
+        if stitch and os.path.isfile(cpath):
+            t0 = time.time()
+            z = np.load(cpath)
+            stitch_coords(img, z['coords'], int(z['patch_size']), downscale=64).save(os.path.join(stitch_save_dir, slide_id + '.jpg'))
+            stitch_time = time.time() - t0
+        log('segmentation took {} seconds'.format(seg_time))
+        log('patching took {} seconds'.format(patch_time))
+        log('stitching took {} seconds'.format(stitch_time))
+        df.loc[idx, 'status'] = 'processed'
+        seg_times += seg_time
+        patch_times += patch_time
+        stitch_times += stitch_time
+    if total:
+        seg_times /= total
+        patch_times /= total
+        stitch_times /= total
+    df.to_csv(os.path.join(save_dir, 'process_list_autogen.csv'), index=False)
+    log('average segmentation time in s per slide: {}'.format(seg_times))
+    log('average patching time in s per slide: {}'.format(patch_times))
+    log('average stiching time in s per slide: {}'.format(stitch_times))
+    return seg_times, patch_times
+
+
+def slide_list(save_dir):
+    """`Dataset_All_Bags` (WholeSlideImage.py:900-909): the slide_id column of <save_dir>/process_list_autogen.csv."""
+    import pandas as pd
+    return [str(s) for s in pd.read_csv(os.path.join(save_dir, 'process_list_autogen.csv'))['slide_id']]

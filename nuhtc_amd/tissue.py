@@ -145,8 +145,11 @@ def find_contours_ccomp(binary):
         sl = obj[i - 1]
         comp = lab[sl] == i
         c = _trace_all(comp) + np.array([sl[1].start, sl[0].start])
-        out.append((c, holes_of[i]))
-    return out
+        out.append((c, holes_of[i][::-1]))
+    # cv2's list order: every new border is linked at the head of its parent's list, so the outer borders come in the REVERSE of
+    # the order the raster scan finds them (scipy labels components and background regions in scan order of their first pixel),
+    # and so do the holes of one component
+    return out[::-1]
 
 
 _DXY = ((1, 0), (1, -1), (0, -1), (-1, -1), (-1, 0), (-1, 1), (0, 1), (1, 1))     # chain codes counter-clockwise from east (dx, dy), y down

@@ -152,16 +152,19 @@ def relative_position_index(ws=WINDOW):
     return ((ii[:, None] - ii[None, :] + ws - 1) * (2 * ws - 1) + (jj[:, None] - jj[None, :] + ws - 1)).astype(np.int64)
 
 
-def load_checkpoint(path, num_classes=5):
+def load_checkpoint(path, num_classes=5, return_meta=False):
     """Load an mmdet checkpoint ({'meta','state_dict',...} or a bare state_dict), non-strict like
     nuhtc/apis/inference.py:44: EMA buffers, optimizer state and recomputable buffers are ignored;
     a missing or mis-shaped tensor on the inference path is an error (the reference would silently
-    keep random init there, which is never what a user wants)."""
+    keep random init there, which is never what a user wants).  return_meta: also the checkpoint's
+    `meta` dict ({} when it has none; `init_detector` takes CLASSES from it, :45-46)."""
+    meta = {}
     if path.endswith('.npz'):
         raw = {k: torch.from_numpy(v) for k, v in np.load(path).items()}
     else:
         raw = torch.load(path, map_location='cpu', weights_only=False)
     if isinstance(raw, dict) and 'state_dict' in raw:
+        meta = raw.get('meta') or {}
         raw = raw['state_dict']
     raw = {(k[7:] if k.startswith('module.') else k): v for k, v in raw.items()}
     sd = OrderedDict()
@@ -175,7 +178,7 @@ def load_checkpoint(path, num_classes=5):
         if tuple(t.shape) != tuple(shape):
             raise ValueError(f'{name}: checkpoint shape {tuple(t.shape)} != expected {tuple(shape)}')
         sd[name] = t
-    return sd
+    return (sd, meta) if return_meta else sd
 
 
 def bench_state_dict(seed=0, num_classes=5, obj_bias=-0.2):

@@ -81,9 +81,9 @@ def _follow(f, i, j, nbd, is_hole, simple=True):
     return pts
 
 
-def find_contours_tree(mask, simple=True):
-    """-> (contours, hierarchy) like cv2.findContours(mask, RETR_TREE, CHAIN_APPROX_SIMPLE | NONE): contours is a list of
-    (n,2) int arrays (x, y); hierarchy (n,4) = [next, previous, first_child, parent] indices (-1 = none)."""
+def _scan(mask, simple=True):
+    """The raster scan of Algorithm 1 with the full (RETR_TREE) parent rule -> the frame border; every border hangs in its
+    parent's `children` (newest first) and carries `start`, the pixel (x, y) at which the scan discovered it."""
     m = np.asarray(mask) != 0
     H, W = m.shape
     f = np.zeros((H + 2, W + 2), np.int64)
@@ -118,6 +118,11 @@ def find_contours_tree(mask, simple=True):
                 borders[nbd] = b
             if f[i, j] != 1:
                 lnbd = abs(int(f[i, j]))
+    return frame
+
+
+def _flatten(frame):
+    """Pre-order walk from the frame's first child -> (contours, hierarchy [next, previous, first_child, parent])."""
     order = []
 
     def walk(b):
@@ -141,6 +146,39 @@ def find_contours_tree(mask, simple=True):
         if b.parent is not frame:
             hier[k, 3] = idx[id(b.parent)]
     return contours, hier
+
+
+def find_contours_tree(mask, simple=True):
+    """-> (contours, hierarchy) like cv2.findContours(mask, RETR_TREE, CHAIN_APPROX_SIMPLE | NONE): contours is a list of
+    (n,2) int arrays (x, y); hierarchy (n,4) = [next, previous, first_child, parent] indices (-1 = none)."""
+    return _flatten(_scan(mask, simple))
+
+
+def find_contours_ccomp(mask, simple=False):
+    """cv2.findContours(mask, RETR_CCOMP, CHAIN_APPROX_NONE | SIMPLE) (`segmentTissue`, tools/wsi_core/WholeSlideImage.py:187):
+    the same scan and the same borders, in the two-level hierarchy of RETR_CCOMP -- every outer border hangs on the frame
+    (an island inside a hole too), every hole border on the outer border of the component it is a hole of (`contours.cpp`:
+    in CCOMP mode `par_info` of a non-hole is the frame; a hole keeps the parent the paper's table gives it, which is an outer
+    border).  Each new border is still linked at the HEAD of its parent's list, so the pre-order walk lists the outer borders
+    in the REVERSE of the order the scan found them (the component whose first raster pixel comes last is index 0), each
+    followed by its holes, newest first."""
+    frame = _scan(mask, simple)
+    allb = []
+
+    def collect(b):
+        for c in b.children:
+            allb.append(c)
+            collect(c)
+    collect(frame)
+    found = sorted(allb, key=lambda b: b.nbd)        # NBD counts the borders in the order the scan found them
+    top = Border(1, True, None)
+    for b in found:
+        b.children = []
+    for b in found:
+        par = top if not b.is_hole else b.parent   # a hole's table parent is an outer border (never the frame: the frame pads the image)
+        b.parent = par
+        par.children.insert(0, b)
+    return _flatten(top)
 
 
 def mask2inst(mask):

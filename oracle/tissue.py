@@ -8,10 +8,11 @@ oracle/cv_ops.py and the border-following oracle of oracle/contour.py (cv2 / ope
                         isInHoles (:353-358), tools/wsi_core/util_classes.py:48-111 (basic / center / four_pt / four_pt_hard)
     tile_coords         WholeSlideImage.py:388-405 process_contours (contour after contour), parameters of tools/infer_wsi.py:385-389
 
-Written against the reference, not against nuhtc_amd/tissue.py: per-point Python loops, RETR_TREE borders turned into the two-level
-RETR_CCOMP grouping (a border at even depth is an outer border, its children are its holes; CHAIN_APPROX_SIMPLE instead of _NONE: the
-same polygons, so the same areas, bounding boxes and point tests).  The ORDER in which cv2 lists the outer borders is not restated:
-compare tile lists per contour, or as sets."""
+Written against the reference, not against nuhtc_amd/tissue.py: per-point Python loops over `oracle.contour.find_contours_ccomp`
+(CHAIN_APPROX_SIMPLE instead of _NONE: the same polygons, so the same areas, bounding boxes and point tests), followed by
+`_filter_contours` statement by statement.  Round 5: the ORDER of the list is restated too -- RETR_CCOMP lists the outer borders in
+the reverse of the order the raster scan finds them, each followed by its holes, newest first (oracle/contour.py) -- so the tile
+list of a slide with several tissue regions is compared as ONE sequence."""
 import numpy as np
 
 from . import contour as OC
@@ -29,24 +30,23 @@ def segment_tissue(img, scale, sthresh=8, sthresh_up=255, mthresh=7, close=4, us
         binary = C.morph_close(binary, close)                   # :172-174
     scaled_ref = round(ref_patch_size / scale)                  # :179-182
     a_t, a_h = a_t * scaled_ref, a_h * scaled_ref
-    conts, hier = OC.find_contours_tree(np.asarray(binary) > 0)
-    depth = [0] * len(conts)
-    for i in range(len(conts)):
-        p, d = hier[i][3], 0
-        while p >= 0:
-            p, d = hier[p][3], d + 1
-        depth[i] = d
-    out = []
-    for i in range(len(conts)):
-        if depth[i] % 2:
-            continue                                             # a hole border: belongs to its parent
-        holes = [conts[j] for j in range(len(conts)) if hier[j][3] == i]
-        a = C.contour_area(conts[i].tolist()) - sum(C.contour_area(h.tolist()) for h in holes)   # :128-133
-        if a == 0 or not a_t < a:
+    conts, hier = OC.find_contours_ccomp(np.asarray(binary) > 0, simple=True)       # :187
+    hier = hier[:, 2:]                                                              # :188 -> [first_child, parent]
+    area = lambda c: C.contour_area(c.tolist())
+    filtered, all_holes = [], []
+    for cont_idx in [i for i in range(len(conts)) if hier[i, 1] == -1]:             # :117-133, in list order
+        holes = [j for j in range(len(conts)) if hier[j, 1] == cont_idx]
+        a = area(conts[cont_idx]) - sum(area(conts[j]) for j in holes)
+        if a == 0:
             continue
-        holes = sorted(holes, key=lambda h: C.contour_area(h.tolist()), reverse=True)[:max_n_holes]   # :143-146
-        holes = [h for h in holes if C.contour_area(h.tolist()) > a_h]                                 # :150-152
-        out.append((np.asarray(conts[i], np.int64) * scale, [np.asarray(h, np.int64) * scale for h in holes]))   # scaleContourDim
+        if a_t < a:
+            filtered.append(cont_idx)
+            all_holes.append(holes)
+    out = []
+    for cont_idx, hole_ids in zip(filtered, all_holes):                             # :136-152
+        hs = sorted([conts[j] for j in hole_ids], key=area, reverse=True)[:max_n_holes]     # stable: equal areas keep list order
+        hs = [h for h in hs if area(h) > a_h]
+        out.append((np.asarray(conts[cont_idx], np.int64) * scale, [np.asarray(h, np.int64) * scale for h in hs]))   # scaleContourDim
     return out
 
 

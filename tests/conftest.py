@@ -7,8 +7,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
-# Engine() moves the calling thread onto the GPU's NUMA node (hip.bind_host_thread); the suite's CPU work (the oracle) would then run on half
-# of the host for the rest of the session.  The placement has its own test (test_hip_edges.py), which switches it on.
+# Engines place the submitting thread on the GPU's NUMA node only when asked (bind_host=True / NUHTC_HOST_AFFINITY=1) -- except the tools
+# that own their process (tools/infer_wsi.py, tools/bench_wsi.py, bench.py), which ask unless NUHTC_HOST_AFFINITY=0.  The suite runs them
+# as subprocesses beside the oracle's CPU work: keep them off.  The placement has its own tests (test_hip_edges.py, test_host.py).
 os.environ.setdefault('NUHTC_HOST_AFFINITY', '0')
 
 

@@ -96,7 +96,7 @@ def test_infer_wsi_cli_writes_qupath_geojson(hip_device, tmp_path):
     ck = tmp_path / 'w.pth'
     torch.save(dict(state_dict=weights.bench_state_dict(0, obj_bias=0.0)), ck)
     subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools/infer_wsi.py'), str(src), CFG, str(ck), '--patch_size', '64', '--step_size', '48',
-                           '--batch_size', '4', '--save_dir', str(tmp_path / 'out'), '--merge', '--mode', 'all'])
+                           '--batch_size', '4', '--margin', '2', '--save_dir', str(tmp_path / 'out'), '--merge', '--mode', 'all'])
     feats = json.load(open(tmp_path / 'out/nuclei/slide/slide.geojson'))
     merged = json.load(open(tmp_path / 'out/nuclei/slide/slide_merged.geojson'))
     pts = json.load(open(tmp_path / 'out/nuclei/slide/slide_point.geojson'))
@@ -163,12 +163,7 @@ def test_infer_wsi_tissue_coords_and_store_front_ends(hip_device, tmp_path):
     P = 64
     regions = OT.segment_tissue(img, 8)
     assert len(regions) == 2 and sorted(len(hs) for _, hs in regions) == [0, 1]
-    # cv2's ORDER of the outer borders is not restated by the oracle: the regions are put in the product's contour order (matched by
-    # bounding box); contours, holes and the tiles of each region are the oracle's
-    from nuhtc_amd import tissue as T
-    _, conts, _ = T.tissue_tile_coords(img, P, P, scale=8)
-    bbox = lambda c: (int(c[:, 0].min()), int(c[:, 1].min()), int(c[:, 0].max()), int(c[:, 1].max()))
-    regions.sort(key=lambda r: [bbox(c) for c in conts].index(bbox(r[0])))
+    # regions in cv2's RETR_CCOMP list order (restated in oracle/contour.py: newest border first)
     per_contour = [OT.contour_tile_coords(c, hs, P, P) for c, hs in regions]
     assert all(len(pts) > 50 for pts in per_contour)
     coords = np.array([p for pts in per_contour for p in pts], np.int64)
@@ -202,6 +197,66 @@ def test_infer_wsi_tissue_coords_and_store_front_ends(hip_device, tmp_path):
     # nothing was detected on glass or inside the hole: every ring lies in a tile the oracle listed
     xs = np.array([f['geometry']['coordinates'][0][0] for f in ref])
     assert not hole[np.clip(xs[:, 1], 0, H - 1), np.clip(xs[:, 0], 0, W - 1)].all()
+
+
+def test_readme_command_lines_on_a_folder_of_slides(hip_device, tmp_path):
+    """The reference's documented invocations (README.md:55-63 and :221-223), unchanged except for the paths and `--slide_ext .npy`:
+    a FOLDER of slides -> process_list_autogen.csv, masks/, patches/, stitches/, nuclei/<id>/<id>.geojson per slide; each slide's GeoJSON
+    equals the single-slide run of the same flags; a slide with a merged file is skipped on the next run (tools/infer_wsi.py:456-458);
+    --det writes the per-tile overlays (:504-512)."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    from nuhtc_amd import synth, weights
+    H = W = 3072
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    blob = ((yy - 1500) / 1250.0) ** 2 + ((xx - 1600) / 1300.0) ** 2 <= 1
+    tex = np.concatenate([np.concatenate([synth.nuclei_tile(900 + 12 * r + c, 256) for c in range(W // 256)], 1) for r in range(H // 256)], 0)
+    img = np.full((H, W, 3), 235, np.uint8)
+    img[blob] = tex[blob]
+    src = tmp_path / 'wsi'
+    src.mkdir()
+    np.save(src / 'a.npy', img)
+    np.save(src / 'b.npy', np.ascontiguousarray(img[::-1, ::-1]))
+    ck = tmp_path / 'pannuke.pth'
+    torch.save(dict(state_dict=weights.bench_state_dict(0)), ck)
+    tool = os.path.join(ROOT, 'tools/infer_wsi.py')
+    out = tmp_path / 'wsi_infer'
+    # README.md:55-63
+    line1 = f'{src} {CFG} {ck} --patch --seg --stitch --patch_size 256 --step_size 192 --batch_size 16 --save_dir {out} --mode qupath --slide_ext .npy'
+    log = subprocess.run([sys.executable, tool] + line1.split(), check=True, capture_output=True, text=True).stdout
+    rows = open(out / 'process_list_autogen.csv').read().splitlines()
+    assert rows[0].startswith('slide_id,process,status,seg_level') and rows[1].startswith('a.npy,0,processed,6,') and rows[2].startswith('b.npy,0,processed,6,')
+    docs = {}
+    for sid in ('a', 'b'):
+        for f in (out / 'masks' / f'{sid}.png', out / 'patches' / f'{sid}.npz', out / 'stitches' / f'{sid}.jpg', out / 'nuclei' / sid / f'{sid}_point.geojson'):
+            assert os.path.exists(f), f
+        docs[sid] = json.load(open(out / 'nuclei' / sid / f'{sid}.geojson'))
+        assert len(docs[sid]) > 2000
+        n_tiles = len(np.load(out / 'patches' / f'{sid}.npz')['coords'])
+        assert 100 < n_tiles < 260 and f'{n_tiles} tiles on 1 rank(s)' in log
+    # the single-slide form of the same flags gives the same documents
+    one = tmp_path / 'one'
+    subprocess.run([sys.executable, tool, str(src / 'b.npy')] + line1.split()[1:-6] + ['--save_dir', str(one), '--mode', 'qupath'], check=True, capture_output=True)
+    assert json.load(open(one / 'nuclei/b/b.geojson')) == docs['b']
+    # README.md:221-223 into the same directory: the coordinate files exist (auto-skip), both slides are inferred again with margin 1
+    line2 = f'{src} {CFG} {ck} --patch --seg --stitch --patch_size 256 --step_size 192 --margin 1 --min_area 10 --batch_size 32 --save_dir {out} --mode qupath --slide_ext .npy'
+    log2 = subprocess.run([sys.executable, tool] + line2.split() + ['--merge', '--det', '--score-thr', '0.5'], check=True, capture_output=True, text=True).stdout
+    assert 'a already exist in destination location, skipped' in log2
+    m1 = json.load(open(out / 'nuclei/a/a.geojson'))
+    assert 0 < len(m1) < len(docs['a'])                                  # margin 1 drops the boxes that touch the tile edge
+    merged = json.load(open(out / 'nuclei/a/a_merged.geojson'))
+    assert 0 < len(merged) < len(m1)
+    dets = os.listdir(out / 'a' / 'infer')
+    xs = np.load(out / 'patches' / 'a.npz')['coords']
+    assert len(dets) > 50 and all(d.startswith('img_') and d.endswith('.jpg') for d in dets) and f'img_{xs[0][0]}_{xs[0][1]}.jpg' in dets
+    # third run: both slides have their merged file -> skipped
+    log3 = subprocess.run([sys.executable, tool] + line2.split(), check=True, capture_output=True, text=True).stdout
+    assert 'skip a due to existing results' in log3 and 'skip b due to existing results' in log3 and 'rank(s)' not in log3
+    # wrong extension: slide ids keep their suffix and no coordinate file matches (the reference's behaviour for a wrong --slide_ext)
+    log4 = subprocess.run([sys.executable, tool] + line2.split()[:-1] + ['.svs'], check=True, capture_output=True, text=True).stdout
+    assert 'skip a.npy due to no coord file' in log4
 
 
 def test_infer_patch_cli_writes_coco(hip_device, tmp_path):
@@ -441,6 +496,20 @@ def test_infer_wsi_two_ranks_equal_one_rank_byte_for_byte(hip_device, tmp_path):
         a = open(tmp_path / 'one/nuclei/slide' / f, 'rb').read()
         b = open(tmp_path / 'two/nuclei/slide' / f, 'rb').read()
         assert len(a) > 1000 and a == b, f
+
+
+def test_rccl_branch_of_the_exchange_on_one_gpu(hip_device):
+    """The nccl (= RCCL) branch of `gather_blobs` on the hardware at hand: NUHTC_FORCE_COLLECTIVE=1 forms a communicator of one rank on
+    the MI355X and both all_gathers run on DEVICE buffers; what comes back is byte-equal to the short-circuit path (the script of
+    tests/test_host.py, which runs it over gloo on the CPU box)."""
+    import subprocess
+    import sys
+    from test_host import _FORCED
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'NUHTC_FORCE_COLLECTIVE')}
+    env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    out = subprocess.run([sys.executable, '-c', _FORCED, 'nccl'], env=env, capture_output=True, text=True, timeout=600)
+    print(out.stdout[-500:], out.stderr[-1500:])
+    assert out.returncode == 0 and 'FORCED OK nccl' in out.stdout
 
 
 def test_bench_launches_its_own_ranks(hip_device):

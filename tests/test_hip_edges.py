@@ -356,12 +356,14 @@ def test_image_size_not_a_multiple_of_32(hip_device):
 
 
 def test_engine_creation_puts_the_submitting_thread_on_the_gpus_numa_node(hip_device, monkeypatch):
-    """Engine() calls nuhtc_bind_host_thread (the command processor reads every dispatch packet from host memory the
-    submitter wrote; from the other socket that costs 0.3-0.4 ms per step): afterwards the calling thread runs on the CPUs sysfs lists as
-    local to the GPU; NUHTC_HOST_AFFINITY=0 leaves the mask alone; results do not depend on it."""
+    """Engine(bind_host=True) calls nuhtc_bind_host_thread (the command processor reads every dispatch packet from host
+    memory the submitter wrote; from the other socket that costs 0.3-0.4 ms per step): afterwards the calling thread runs on the CPUs sysfs
+    lists as local to the GPU, and gets its mask back when the LAST engine that placed it is closed.  The default leaves the caller's mask
+    alone (a library does not change process state unasked; NUHTC_HOST_AFFINITY=1 switches the default); results do not depend on it."""
     import os
     import torch
     from nuhtc_amd import synth, weights
+    from nuhtc_amd.apis import init_detector
     from nuhtc_amd.engine import Engine
     pr = torch.cuda.get_device_properties(0)
     bdf = f'{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0'
@@ -377,14 +379,14 @@ def test_engine_creation_puts_the_submitting_thread_on_the_gpus_numa_node(hip_de
     sd = weights.seeded_state_dict(0)
     tiles = synth.nuclei_tiles(2, 64)
     try:
-        monkeypatch.setenv('NUHTC_HOST_AFFINITY', '0')
-        os.sched_setaffinity(0, before)
+        monkeypatch.delenv('NUHTC_HOST_AFFINITY', raising=False)
         e0 = Engine(sd, device=0, max_batch=2, tile=(64, 64))
-        assert os.sched_getaffinity(0) == before
+        assert os.sched_getaffinity(0) == before                  # the default: untouched
         r0 = e0(tiles)
-        monkeypatch.setenv('NUHTC_HOST_AFFINITY', '1')
-        e1 = Engine(sd, device=0, max_batch=2, tile=(64, 64))
+        e1 = Engine(sd, device=0, max_batch=2, tile=(64, 64), bind_host=True)
+        e2 = Engine(sd, device=0, max_batch=2, tile=(64, 64), bind_host=True)
         now = os.sched_getaffinity(0)
+        placed = bool(local and (local & before) and (local & before) != before)
         if local and (local & before):
             assert now == (local & before), (sorted(now)[:4], len(now), text)
         else:
@@ -393,5 +395,22 @@ def test_engine_creation_puts_the_submitting_thread_on_the_gpus_numa_node(hip_de
         for (b0, m0), (b1, m1) in zip(r0, r1):
             assert all(np.array_equal(x, y) for x, y in zip(b0, b1))
             assert all(len(x) == len(y) and all(np.array_equal(p, q) for p, q in zip(x, y)) for x, y in zip(m0, m1))
+        e1.close()
+        assert os.sched_getaffinity(0) == now                     # e2 still needs the placement
+        e2.close()
+        assert os.sched_getaffinity(0) == before                  # the last one gives the mask back
+        monkeypatch.setenv('NUHTC_HOST_AFFINITY', '1')            # the environment switches the default of the argument
+        e3 = Engine(sd, device=0, max_batch=2, tile=(64, 64))
+        assert os.sched_getaffinity(0) == now
+        e3.close()
+        assert os.sched_getaffinity(0) == before
+        monkeypatch.delenv('NUHTC_HOST_AFFINITY')
+        det = init_detector(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'configs/nuhtc/htc_lite_swin_pannuke_infer.py'),
+                            None, device='cuda:0', max_batch=2, bind_host=True)
+        eng = det.engine((64, 64))                                # surfaced through init_detector
+        assert os.sched_getaffinity(0) == now
+        eng.close()
+        assert os.sched_getaffinity(0) == before
+        assert placed or now == before
     finally:
         os.sched_setaffinity(0, before)

@@ -2,6 +2,7 @@
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -242,9 +243,11 @@ def test_packed_masks_behave_like_the_crop_list():
             assert a.shape == b.shape and bool((a == b).all())
 
 
-def test_bind_host_thread_follows_the_devices_numa_node(tmp_path, monkeypatch):
-    """nuhtc_bind_host_thread_pci against a fake sysfs: the calling thread ends up on the device's local CPUs intersected with its own
-    mask; nothing changes when the host has no node for the device or the caller's mask excludes it."""
+def test_bind_host_thread_follows_the_devices_numa_node(tmp_path):
+    """nuhtc_bind_host_thread_at (the test entry point of nuhtc_bind_host_thread_pci) against a fake sysfs: the calling thread ends up on
+    the device's local CPUs intersected with the mask it had BEFORE its first placement; nothing changes when the host has no node for
+    the device or the caller's mask excludes it; a string that is not a PCI address is refused (it would become part of a path);
+    restore gives the original mask back."""
     from nuhtc_amd import hip
     hip.load()
     before = os.sched_getaffinity(0)
@@ -253,22 +256,151 @@ def test_bind_host_thread_follows_the_devices_numa_node(tmp_path, monkeypatch):
     cpus = sorted(before)
     dev = tmp_path / 'bus/pci/devices/0000:75:00.0'
     dev.mkdir(parents=True)
-    monkeypatch.setenv('NUHTC_SYSFS_ROOT', str(tmp_path))
+    bind = lambda bdf='0000:75:00.0': hip.bind_host_thread(pci_bdf=bdf, sysfs_root=tmp_path)
     try:
         (dev / 'local_cpulist').write_text(f'{cpus[0]},{cpus[-1]}-{cpus[-1] + 3}\n')          # part of it outside the caller's mask
-        assert hip.bind_host_thread(pci_bdf='0000:75:00.0') is True
+        assert bind() is True and hip.bind_reason == 'bound'
         assert os.sched_getaffinity(0) == {cpus[0], cpus[-1]}
-        assert hip.bind_host_thread(pci_bdf='0000:75:00.0') is True                            # already there
-        os.sched_setaffinity(0, before)
+        assert bind() is True                                                                  # already there
+        # a second device on "the other node": intersected with the ORIGINAL mask, not with the narrowed one (advisor, round 4)
+        dev2 = tmp_path / 'bus/pci/devices/0000:f5:00.0'
+        dev2.mkdir(parents=True)
+        (dev2 / 'local_cpulist').write_text(f'{cpus[1]}\n')
+        assert bind('0000:f5:00.0') is True and os.sched_getaffinity(0) == {cpus[1]}
+        assert hip.restore_host_thread() and os.sched_getaffinity(0) == before
+        assert hip.restore_host_thread() and os.sched_getaffinity(0) == before                 # never placed since: a no-op
         (dev / 'local_cpulist').write_text(f'{cpus[-1] + 1}-{cpus[-1] + 8}\n')                # none of the caller's CPUs: the caller chose otherwise
-        assert hip.bind_host_thread(pci_bdf='0000:75:00.0') is False and os.sched_getaffinity(0) == before
+        assert bind() is False and os.sched_getaffinity(0) == before and 'excludes' in hip.bind_reason
         (dev / 'local_cpulist').write_text('\n')                                               # no NUMA information
-        assert hip.bind_host_thread(pci_bdf='0000:75:00.0') is False and os.sched_getaffinity(0) == before
-        assert hip.bind_host_thread(pci_bdf='0000:76:00.0') is False and os.sched_getaffinity(0) == before   # unknown device
+        assert bind() is False and os.sched_getaffinity(0) == before and 'no NUMA node' in hip.bind_reason
+        assert bind('0000:76:00.0') is False and os.sched_getaffinity(0) == before             # unknown device
+        for bad in ('../../../etc', '0000:75:00.0/../0000:75:00.0', '', 'x' * 40, '75'):
+            assert bind(bad) is False and hip.bind_reason == 'not a PCI address', bad
         (dev / 'local_cpulist').write_text(f'{cpus[1]}\n')
-        assert hip.bind_host_thread(pci_bdf='0000:75:00.0'.upper()) is True and os.sched_getaffinity(0) == {cpus[1]}
+        assert bind('0000:75:00.0'.upper()) is True and os.sched_getaffinity(0) == {cpus[1]}
     finally:
+        hip.restore_host_thread()
         os.sched_setaffinity(0, before)
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError):
             hip.bind_host_thread(0)
+
+
+def test_eight_ranks_on_two_nodes_each_bind_to_their_own_node(tmp_path):
+    """A node of 8 GPUs on 2 sockets (fake sysfs: GPUs 0-3 local to the first half of this machine's CPUs, 4-7 to the second): each of
+    8 ranks -- threads here, affinity is per thread -- places itself with its own GPU's address and ends up on its own node's CPUs."""
+    import threading
+    from nuhtc_amd import hip
+    hip.load()
+    cpus = sorted(os.sched_getaffinity(0))
+    if len(cpus) < 2:
+        pytest.skip('needs two CPUs')
+    half = len(cpus) // 2
+    nodes = [cpus[:half], cpus[half:]]
+
+    def cpulist(cs):
+        return ','.join(str(c) for c in cs) + '\n'
+    bdfs = [f'0000:{0x05 + 0x10 * g:02x}:00.0' for g in range(8)]
+    for g, bdf in enumerate(bdfs):
+        d = tmp_path / 'bus/pci/devices' / bdf
+        d.mkdir(parents=True)
+        (d / 'local_cpulist').write_text(cpulist(nodes[g // 4]))
+    got, errs = {}, []
+
+    def rank(r):
+        try:
+            ok = hip.bind_host_thread(pci_bdf=bdfs[r], sysfs_root=tmp_path)
+            got[r] = (ok, os.sched_getaffinity(0))
+            hip.restore_host_thread()
+            got[r] += (os.sched_getaffinity(0),)
+        except Exception as e:      # pragma: no cover
+            errs.append(e)
+    ts = [threading.Thread(target=rank, args=(r,)) for r in range(8)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs
+    for r in range(8):
+        ok, now, after = got[r]
+        assert ok and now == set(nodes[r // 4]) and after == set(cpus), (r, now)
+    assert os.sched_getaffinity(0) == set(cpus)        # the main thread was never touched
+
+
+def test_probe_build_is_refused_by_nuhtc_create(tmp_path):
+    """A library compiled with a result-altering dev probe (here -DNUHTC_GEMM_NOSTORE: the split GEMM without its output stores) must
+    not make engines: nuhtc_create returns NUHTC_E_STATE and names the macro, unless the process says NUHTC_DEV=1 (then the check
+    passes and, on this GPU-less box, the next one -- the device -- fails instead).  Only gemm.hip is recompiled; the other objects are
+    those of the in-tree build."""
+    import ctypes
+    import glob
+    import subprocess
+    from nuhtc_amd import build, hip
+    build.build()
+    objs = [o for o in glob.glob(os.path.join(build.HERE, 'build', '*.o')) if not o.endswith('gemm.hip.o')]
+    assert len(objs) >= 10
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    obj = str(tmp_path / 'gemm_probe.o')
+    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O1', '-std=c++17', '-fPIC', '-Wno-unused-value', '-DNUHTC_GEMM_NOSTORE', '-c',
+                           os.path.join(build.CSRC, 'gemm.hip'), '-o', obj])
+    so = str(tmp_path / 'libprobe.so')
+    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + [obj, '-o', so])
+    code = ("import ctypes, sys; sys.path.insert(0, %r); import torch; from nuhtc_amd import hip; lib = ctypes.CDLL(%r); cfg = hip.Config(); "
+            "lib.nuhtc_default_config(ctypes.byref(cfg)); h = ctypes.c_void_p(); rc = lib.nuhtc_create(ctypes.byref(cfg), 0, ctypes.byref(h)); "
+            "lib.nuhtc_last_error.restype = ctypes.c_char_p; print(rc, lib.nuhtc_last_error(None).decode())") % (ROOT, so)
+    env = {k: v for k, v in os.environ.items() if k != 'NUHTC_DEV'}
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.startswith('-3 ') and 'NUHTC_GEMM_NOSTORE' in out.stdout
+    out = subprocess.run([sys.executable, '-c', code], env=dict(env, NUHTC_DEV='1'), capture_output=True, text=True)
+    assert out.returncode == 0 and 'NUHTC_GEMM_NOSTORE' not in out.stdout
+    if not torch.cuda.is_available():
+        assert out.stdout.startswith('-2 ')
+
+
+_FORCED = r"""
+import os, sys
+sys.path.insert(0, %r)
+import torch
+from nuhtc_amd import parallel
+backend = sys.argv[1]
+dev = torch.device('cuda', 0) if backend == 'nccl' else torch.device('cpu')
+g = torch.Generator().manual_seed(3)
+parts = [torch.rand(7, 9, generator=g, dtype=torch.float64), torch.randint(0, 1000, (23, 2), generator=g, dtype=torch.int32),
+         torch.randint(0, 1 << 40, (7, 6), generator=g, dtype=torch.int64), torch.randint(-2 ** 31, 2 ** 31 - 1, (301,), generator=g, dtype=torch.int32),
+         torch.zeros(0, dtype=torch.uint8)]
+parts = [p.to(dev) for p in parts]
+plain = parallel.gather_blobs(parts)                       # no process group: the short-circuit
+assert len(plain) == 1 and all(a is b or torch.equal(a, b) for a, b in zip(plain[0], parts))
+os.environ['NUHTC_FORCE_COLLECTIVE'] = '1'
+rank, local_rank, world = parallel.init_from_env(backend)
+import torch.distributed as dist
+assert dist.is_initialized() and dist.get_world_size() == 1 and dist.get_backend() == backend and (rank, world) == (0, 1)
+calls = []
+real = dist.all_gather
+def counting(out, t, group=None):
+    calls.append((t.device.type, t.dtype, t.numel()))
+    return real(out, t, group=group)
+dist.all_gather = counting
+forced = parallel.gather_blobs(parts)
+dist.all_gather = real
+assert len(calls) == 2 and calls[0][1] == torch.int64 and calls[1][1] == torch.uint8, calls      # the header, then ONE packed byte buffer
+assert all(c[0] == dev.type for c in calls), calls                                               # device buffers in the RCCL branch
+assert len(forced) == 1 and len(forced[0]) == len(parts)
+for a, b in zip(forced[0], parts):
+    assert a.dtype == b.dtype and a.shape == b.shape and a.device.type == dev.type and torch.equal(a, b)
+rec = parallel.gather_records(parts[0])
+assert len(rec) == 1 and torch.equal(rec[0], parts[0])
+dist.destroy_process_group()
+print('FORCED OK', backend, calls[1][2])
+""" % ROOT
+
+
+def test_forced_collective_of_one_rank_equals_the_short_circuit():
+    """NUHTC_FORCE_COLLECTIVE=1 (nuhtc_amd.parallel.force_collective): a one-rank job forms its process group and `gather_blobs` runs its two
+    all_gathers instead of returning early; the tensors that come back are byte-equal to the short-circuit's.  gloo here; the same script
+    runs with nccl (RCCL, device buffers) on the GPU box (tests/test_hip_api.py)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'NUHTC_FORCE_COLLECTIVE')}
+    out = subprocess.run([sys.executable, '-c', _FORCED, 'gloo'], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and 'FORCED OK gloo' in out.stdout, out.stderr[-3000:]

@@ -120,18 +120,41 @@ def test_tile_list_equals_the_scalar_restatement_of_the_reference_sequence():
     coords, conts, holes = T.tissue_tile_coords(img, patch_size=64, step_size=64, scale=8)
     ref = OT.segment_tissue(img, 8)
     assert len(conts) == len(ref) == 2 and sorted(len(h) for h in holes) == [0, 1] == sorted(len(h) for _, h in ref)
-    key = lambda c: (int(np.asarray(c)[:, 0].min()), int(np.asarray(c)[:, 1].min()), int(np.asarray(c)[:, 0].max()), int(np.asarray(c)[:, 1].max()))
-    by_box = {key(c): (c, hs) for c, hs in ref}
+    # ONE sequence: cv2 lists the outer borders in the reverse of the order the raster scan finds them (oracle/contour.py
+    # find_contours_ccomp), so blob2 (first pixel further down) comes first; contours, holes and tiles line up index by index
+    assert int(conts[0][:, 1].min()) > int(conts[1][:, 1].min())
     off = 0
-    for c, hs in zip(conts, holes):
-        rc, rhs = by_box[key(c)]                                  # same bounding box ...
-        assert T.contour_area(c) == C.contour_area(rc.tolist())   # ... same enclosed area, same holes
-        assert sorted(T.contour_area(h) for h in hs) == sorted(C.contour_area(h.tolist()) for h in rhs)
+    for (c, hs), (rc, rhs) in zip(zip(conts, holes), ref):
+        assert T.bounding_rect(c) == OT._bounding_rect(np.asarray(rc))
+        assert T.contour_area(c) == C.contour_area(rc.tolist())
+        assert [T.contour_area(h) for h in hs] == [C.contour_area(h.tolist()) for h in rhs]
         want = OT.contour_tile_coords(rc, rhs, 64, 64)
         got = coords[off:off + len(want)]
         off += len(want)
         assert len(want) > 50 and got.tolist() == [list(p) for p in want]
     assert off == len(coords)
+    assert coords.tolist() == [list(p) for pts in OT.tile_coords(img, 64, 64, 8) for p in pts]
     # no tile is centred inside the hole, and the speck produced none
     assert not hole[np.clip(coords[:, 1] + 32, 0, 1535), np.clip(coords[:, 0] + 32, 0, 2047)].any()
     assert not ((coords[:, 0] > 1800) & (coords[:, 1] < 200)).any()
+
+
+def test_ccomp_list_order_of_regions_and_holes():
+    """RETR_CCOMP list order (every new border linked at the head of its parent's list): product == oracle on a mask with three
+    components (one an island inside a hole) and two holes in one component."""
+    from oracle import contour as OC
+    m = np.zeros((12, 20), np.uint8)
+    m[1:4, 1:4] = 1; m[2, 2] = 0                # A: found first, one 1-pixel hole
+    m[5:11, 5:18] = 1                            # B
+    m[6:10, 6:12] = 0                            # B's hole 1 (found first)
+    m[7:9, 8:10] = 1                             # C: an island in hole 1 -- top level in CCOMP
+    m[6:8, 14:16] = 0                            # B's hole 2
+    conts, hier = OC.find_contours_ccomp(m, simple=False)
+    tops = [i for i in range(len(conts)) if hier[i, 3] == -1]
+    assert [tuple(conts[i][0]) for i in tops] == [(8, 7), (5, 5), (1, 1)]                      # C, B, A: newest first
+    assert [tuple(conts[j][0]) for j in range(len(conts)) if hier[j, 3] == tops[1]] == [(13, 6), (5, 6)]   # hole 2, hole 1
+    got = T.find_contours_ccomp(m * 255)
+    assert [tuple(c[0]) for c, _ in got] == [(8, 7), (5, 5), (1, 1)]
+    assert [[tuple(h[0]) for h in hs] for _, hs in got] == [[], [(13, 6), (5, 6)], [(1, 2)]]
+    for (c, hs), i in zip(got, tops):
+        assert c.tolist() == conts[i].tolist()

@@ -52,7 +52,7 @@ def main():
     if ck is None:
         ck = f'/tmp/nuhtc_bench_wsi_{os.getpid()}.pth'
         torch.save(dict(state_dict=weights.bench_state_dict(0)), ck)
-    model = init_detector(args.config, ck, device=f'cuda:{local_rank}', max_batch=args.batch_size)
+    model = init_detector(args.config, ck, device=f'cuda:{local_rank}', max_batch=args.batch_size, bind_host=os.environ.get('NUHTC_HOST_AFFINITY', '1') != '0')   # this script owns its process
     model.opts.update(margin=2, min_area=10, mask_nms_thr=0.05)
     dev = torch.device('cuda', local_rank)
     wsi.infer_tiles(model, tiles[0:args.depth * args.batch_size], tiles.coords[:args.depth * args.batch_size], args.batch_size, args.depth)   # warm-up

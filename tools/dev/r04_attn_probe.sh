@@ -1,4 +1,5 @@
 # dev: what the window-attention launches wait for: the kernel with its bias (1), V (2) or K / Q (4) loads or its output stores (8) left out (-DNUHTC_ATTN_PROBE=mask, wrong
+export NUHTC_DEV=1   # the probe builds below give wrong results by design: nuhtc_create refuses them without this
 # results; the attention launches' own work does not depend on the data) -- `window_attn` ms per step, one batch at a time
 mkdir -p gpurun_out tmp_ab; O=gpurun_out/attn_probe.txt; : > $O
 for m in 0 8 15; do

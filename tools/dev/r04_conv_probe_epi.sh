@@ -1,4 +1,5 @@
 # dev: what the fused conv epilogue spends its cycles on: -DNUHTC_CONV_PROBE_EPI=mask (1 no stores, 2 no residual loads, 4 no exchange barrier,
+export NUHTC_DEV=1   # the probe builds below give wrong results by design: nuhtc_create refuses them without this
 # 8 no second product; wrong results) -- the fixed-size fused conv tags in ms per step, one batch at a time
 mkdir -p gpurun_out tmp_ab; O=gpurun_out/conv_probe_epi.txt; : > $O
 for m in 0 1 2 4 8 15; do

@@ -1,4 +1,5 @@
 # dev: is the conv main loop bound by its LDS reads?  The kernel with a quarter of them left out (-DNUHTC_CONV_PROBE_READS, wrong results)
+export NUHTC_DEV=1   # the probe builds below give wrong results by design: nuhtc_create refuses them without this
 # against the real one: conv tags per step, alternating processes (results -> gpurun_out/conv_probe_reads.txt)
 mkdir -p gpurun_out tmp_ab; O=gpurun_out/conv_probe_reads.txt; : > $O
 python -m nuhtc_amd.build --force > /dev/null && cp nuhtc_amd/libnuhtc_hip.so tmp_ab/real.so

@@ -20,22 +20,35 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def parse_args():
-    p = argparse.ArgumentParser(description='Segment nuclei from images and save to COCO format')
-    p.add_argument('--csv', required=True, help='CSV file with an image path column')
-    p.add_argument('--image-col', default='image_path')
-    p.add_argument('--config', required=True)
-    p.add_argument('--checkpoint', required=True)
-    p.add_argument('--output', default='nuclei_coco.json')
+def build_parser():
+    """tools/infer_patch.py:106-190 of the reference, flag for flag and default for default (tests/test_cli_parity.py)."""
+    p = argparse.ArgumentParser(description='Segment nuclei from images and save to COCO format', allow_abbrev=False)
+    p.add_argument('--csv', type=str, required=True, help='CSV file with an image path column')
+    p.add_argument('--image-col', type=str, default='image_path')
+    p.add_argument('--config', type=str, required=True)
+    p.add_argument('--checkpoint', type=str, required=True)
+    p.add_argument('--output', type=str, default='nuclei_coco.json')
     p.add_argument('--score-thr', type=float, default=0.35)
-    p.add_argument('--device', default='cuda:0')
+    p.add_argument('--device', type=str, default='cuda:1')
     p.add_argument('--mag', type=int, default=40)
     p.add_argument('--batch-size', type=int, default=16)
-    p.add_argument('--num-workers', type=int, default=0, help='accepted for compatibility (images are read in-process)')
-    p.add_argument('--vis-dir', default=None)
+    p.add_argument('--num-workers', type=int, default=8, help='accepted (images are read in-process)')
+    p.add_argument('--vis-dir', type=str, default=None)
     p.add_argument('--vis-samples', type=int, default=10)
     p.add_argument('--mask-nms-thr', type=float, default=0.05)
-    return p.parse_args()
+    return p
+
+
+def parse_args(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    a = build_parser().parse_args(argv)
+    if not any(t == '--device' or t.startswith('--device=') for t in argv):
+        # the reference's default is its authors' second GPU; an un-flagged run on a box without one takes the first instead of failing
+        import torch
+        if torch.cuda.device_count() < 2:
+            print("--device not given and there is no cuda:1 on this machine: using cuda:0")
+            a.device = 'cuda:0'
+    return a
 
 
 def main():

@@ -1,24 +1,29 @@
 #!/usr/bin/env python
-"""WSI tile inference with the reference's flags (tools/infer_wsi.py:309-356) over array inputs, sharded across GPUs.
+"""WSI inference with the reference's command line (tools/infer_wsi.py:309-356: same flags, same defaults) over array slides,
+sharded across GPUs.
 
-    python tools/infer_wsi.py <source> <config> <checkpoint> [--patch_size 256 --step_size 192 --batch_size 16
-                               --margin 2 --min_area 10 --save_dir out --mode qupath]
+    python tools/infer_wsi.py <source> <config> <checkpoint> --patch --seg --stitch --patch_size 256 --step_size 192 \
+                               --batch_size 16 --save_dir out --mode qupath [--slide_ext .npy]
     python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/infer_wsi.py ...   (one rank per GPU)
 
-<source>: .npy image (H,W,3) uint8 (memory-mapped) that is tiled on a grid (np.arange(0, size, step), zero padded; with --seg only the
-tissue found by nuhtc_amd.tissue is tiled, as the reference's seg_and_patch does; with --coords the given level-0 origins, the role
-of the reference's patches/<name>.h5), a store directory (nuhtc_amd.tilestore.write_store), or .npz with `tiles` (N,P,P,3) and
-`coords` (N,2).  Every rank cuts only the tiles of its own shard.  OpenSlide / HDF5 reading is out of scope (neither library
-exists offline).
+<source> is the reference's folder of slides: every file in it goes through `seg_and_patch` (nuhtc_amd/slides.py: process list
+-> <save_dir>/process_list_autogen.csv, `--seg` tissue segmentation, masks/<id>.png, `--patch` tile coordinates ->
+patches/<id>.npz, `--stitch` stitches/<id>.jpg; a slide whose coordinate file exists is skipped unless --no_auto_skip), then every
+slide of the process list that has a coordinate file and no <id>_merged.geojson yet (:445-458) is tiled, inferred and written.
+A slide is a level-0 RGB array (`.npy`, memory-mapped; pass `--slide_ext .npy`) or a store directory: OpenSlide / HDF5 do not
+exist offline.  Beyond the reference, <source> may be ONE slide: a `.npy` file (`--patch` is then implied: the
+grid np.arange(0, size, step), or the tissue tiles with --seg, or the origins of --coords), a store directory
+(nuhtc_amd.tilestore.write_store) or an `.npz` with `tiles` (N,P,P,3) + `coords` (N,2).  Every rank cuts only the tiles of its
+own shard; tissue segmentation runs on rank 0.
 Output (like the reference, :659-693), for every detection that survives the per-tile filter + mask-NMS:
-  --mode qupath : <save_dir>/nuclei/<name>/<name>.geojson and <name>_point.geojson (flat lists of QuPath features); run
+  --mode qupath : <save_dir>/nuclei/<id>/<id>.geojson and <id>_point.geojson (flat lists of QuPath features); run
                   tools/nuclei_merge.py on the .geojson for the cross-tile merge (or pass --merge to do it here on rank 0)
-  --mode dsa    : <name>_dsa.json (HistomicsUI polyline elements)
-  --mode coco   : coco_nuclei.json (per-tile images + RLE annotations) and <save_dir>/imgs/<name>/<annidx>.png
-  --mode sql    : <name>_dql.db (contour table + R-tree)
-  --mode all    : everything."""
+  --mode dsa    : <id>_dsa.json (HistomicsUI polyline elements)
+  --mode coco   : coco_nuclei.json (per-tile images + RLE annotations) and <save_dir>/imgs/<id>/<annidx>.png
+  --mode sql    : <id>_dql.db (contour table + R-tree)
+  --mode all    : everything.
+  --det         : <save_dir>/<id>/infer/img_<x>_<y>.jpg overlays of every tile with detections (score >= --score-thr; :504-512)."""
 import argparse
-import json
 import os
 import sys
 
@@ -30,67 +35,59 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def parse_args():
-    p = argparse.ArgumentParser()
-    p.add_argument('source')
-    p.add_argument('config')
-    p.add_argument('checkpoint', nargs='?', default=None)
-    p.add_argument('--device', default='cuda:0')
-    p.add_argument('--patch_size', type=int, default=256)
-    p.add_argument('--step_size', type=int, default=192)
-    p.add_argument('--batch_size', type=int, default=16)
-    p.add_argument('--num_workers', type=int, default=0)
-    p.add_argument('--margin', type=int, default=2)
-    p.add_argument('--min_area', type=int, default=10)
-    p.add_argument('--mag', type=int, default=40)
-    p.add_argument('--mode', default='qupath', choices=['qupath', 'dsa', 'coco', 'sql', 'all'])
-    p.add_argument('--seg', action='store_true', help='segment tissue first and tile only the tissue contours (reference --seg --patch)')
-    p.add_argument('--seg_downsample', type=int, default=64, help='downsample factor of the segmentation level (reference: pyramid level nearest 64x)')
-    p.add_argument('--coords', default=None, help='coordinate file of a .npy slide: .npy (N,2) or .npz with `coords` [+ `patch_size`] -- the role of the reference\'s patches/<name>.h5')
-    p.add_argument('--merge', action='store_true', help='also run the cross-tile merge (nuclei_merge.py) on rank 0')
+def build_parser():
+    """The reference's parser (tools/infer_wsi.py:309-356), flag for flag and default for default (pinned by
+    tests/test_cli_parity.py against a table read off the reference), plus this build's own flags at the end.
+    allow_abbrev=False: with abbreviations `--patch` would be taken for a prefix of `--patch_size`."""
+    p = argparse.ArgumentParser(allow_abbrev=False)
+    p.add_argument('source', help='path to folder containing raw wsi image files (or one array slide / tile store)')
+    p.add_argument('config', help='Config file')
+    p.add_argument('checkpoint', help='Checkpoint file')
+    p.add_argument('--device', default='cuda:0', help='Device used for inference')
+    p.add_argument('--score-thr', type=float, default=0.35, help='score threshold')
+    p.add_argument('--async-test', action='store_true', help='whether to set async options for async inference.')
+    p.add_argument('--step_size', type=int, default=256, help='step_size')
+    p.add_argument('--patch_size', type=int, default=256, help='patch_size')
+    p.add_argument('--patch', default=False, action='store_true')
+    p.add_argument('--seg', default=False, action='store_true')
+    p.add_argument('--stitch', default=False, action='store_true')
+    p.add_argument('--no_auto_skip', default=False, action='store_true')
+    p.add_argument('--save_dir', type=str, help='directory to save processed data')
+    p.add_argument('--preset', default=None, type=str, help='predefined profile of default segmentation and filter parameters (.csv)')
+    p.add_argument('--patch_level', type=int, default=0, help='downsample level at which to patch')
+    p.add_argument('--mag', '--magnification', type=int, default=40, help='magnification for the slide', dest='mag')
+    p.add_argument('--batch_size', type=int, default=32, help='batch size of image dataset during inference')
+    p.add_argument('--num_workers', type=int, default=8, help='number workers of image dataset during inference')
+    p.add_argument('--margin', type=int, default=0, help='discard the contour which distance is less than margin number pixels to edges')
+    p.add_argument('--min_area', type=int, default=10, help='discard the area less than min_area')
+    p.add_argument('--process_list', type=str, default=None, help='name of list of images to process with parameters (.csv)')
+    p.add_argument('--slide_ext', type=str, default='.svs', help='ext name of wsi')
+    p.add_argument('--mode', type=str, default='qupath', help='mode of save format')
+    p.add_argument('--det', default=False, action='store_true')
+    # ---- not in the reference
+    p.add_argument('--seg_downsample', type=int, default=64, help='downsample of the (virtual) pyramid level seg_level / vis_level -1 resolve to (reference: the level nearest 64x)')
+    p.add_argument('--coords', default=None, help="coordinate file of a single .npy slide: .npy (N,2) or .npz with `coords` [+ `patch_size`] -- the role of the reference's patches/<id>.h5")
+    p.add_argument('--merge', action='store_true', help='also run the cross-tile merge (tools/nuclei_merge.py) on rank 0 -> <id>_merged.geojson')
     p.add_argument('--overlap_threshold', type=float, default=0.05)
-    p.add_argument('--save_dir', default='wsi_out')
-    return p.parse_args()
+    return p
 
 
-def main():
-    args = parse_args()
+def parse_args(argv=None):
+    return build_parser().parse_args(argv)
+
+
+def run_slide(args, model, bag, slide_id, rank, local_rank, world):
+    """The reference's per-slide loop (:460-693): tiles -> detections -> per-tile filter + mask-NMS -> records -> the one gather ->
+    rank 0 writes the documents.  The tile list is sharded in contiguous blocks over the ranks."""
     import torch
     from nuhtc_amd import contours, parallel, wsi
-    from nuhtc_amd.apis import init_detector
-    rank, local_rank, world = parallel.init_from_env()
-    # tile source with per-rank lazy reads (nuhtc_amd.tilestore): the slide stays memory-mapped, every rank knows all
-    # coordinates (16 bytes per tile) and cuts only the tiles of its own shard; tissue segmentation runs on rank 0 only
-    from nuhtc_amd import tilestore
-    coords_fn = None
-    if args.seg:
-        def coords_fn(slide):
-            c = [None]
-            if rank == 0:
-                from nuhtc_amd import tissue
-                c[0], conts, _ = tissue.tissue_tile_coords(slide, args.patch_size, args.step_size, scale=args.seg_downsample)
-                print(f'tissue segmentation: {len(conts)} contour(s), {len(c[0])} tiles')
-            if world > 1:
-                import torch.distributed as dist
-                dist.broadcast_object_list(c, src=0)
-            return c[0]
-    bag = tilestore.open_source(args.source, args.patch_size, args.step_size, coords=args.coords, coords_fn=coords_fn)
     coords = bag.coords
     lo, hi = parallel.shard_range(len(bag), rank, world)
     tiles = bag.read(lo, hi)                                  # this rank's tiles only
-    from nuhtc_amd.config import Config, set_test_scale_factor
-    cfg = Config.fromfile(args.config)
-    sf = set_test_scale_factor(cfg, args.mag)          # reference :416-419: scale_factor = 80 / mag
-    if rank == 0:
-        print('scale_factor: ', sf)
-    model = init_detector(cfg, args.checkpoint, device=f'cuda:{local_rank}' if world > 1 else args.device, max_batch=args.batch_size)
-    model.CLASSES = ('T', 'I', 'C', 'D', 'E')[:model.opts['num_classes']]
-    model.opts.update(margin=args.margin, min_area=args.min_area, mask_nms_thr=0.05)
     rec = wsi.infer_tiles(model, tiles, coords[lo:hi], args.batch_size)
     # contours are traced on the rank that owns the tile; two variable-length gathers: records, then ring vertices
     rings = rec['ring']                                              # traced on the GPU (nuhtc_mask_contours)
     keep = [i for i, r in enumerate(rings) if len(r) >= 3]          # reference :536 tests the CLOSED contour (mask2inst appends the first point): only one-pixel contours go
-    n = len(keep)
     want = lambda m: args.mode in (m, 'all')
     P = bag.patch_size
     rles = []
@@ -102,67 +99,162 @@ def main():
             full = np.zeros((P, P), np.uint8)
             full[y0 - oy:y0 - oy + crop.shape[0], x0 - ox:x0 - ox + crop.shape[1]] = crop
             rles.append(cocomask.encode(full)['counts'].encode('ascii'))
+    if args.det:                                                      # :504-512, per tile with detections; a second pass through the API (debug output)
+        from nuhtc_amd.apis import inference_detector, save_result
+        det_dir = os.path.join(args.save_dir, slide_id, 'infer')
+        os.makedirs(det_dir, exist_ok=True)
+        for i0 in range(0, len(tiles), args.batch_size):
+            batch = [t for t in tiles[i0:i0 + args.batch_size]]
+            for k, res in enumerate(inference_detector(model, batch)):
+                if sum(len(b) for b in res[0]):
+                    x, y = (int(v) for v in coords[lo + i0 + k])
+                    save_result(model, batch[k], res, score_thr=args.score_thr, out_file=os.path.join(det_dir, f'img_{x}_{y}.jpg'))
     # the one exchange of the path: every rank's records (head, ring vertices, mask crops, RLE strings) in a single all-gather
     dev = torch.device('cuda', local_rank) if world > 1 and torch.cuda.is_available() else torch.device('cpu')
     gathered = parallel.gather_blobs([t.to(dev) for t in wsi.pack_records(rec, keep, tile_base=lo, rles=rles)])
     heads = [g[0] for g in gathered]
     vparts = [g[1] for g in gathered]
     bparts = [g[4] if want('coco') else None for g in gathered]
+    if rank != 0:
+        return
+    from nuhtc_amd import outputs
+    name = slide_id
+    out_dir = os.path.join(args.save_dir, 'nuclei', name)
+    os.makedirs(out_dir, exist_ok=True)
+    feats, points, dsa, annts, per_tile = [], [], [], [], {}
+    sql = outputs.SqlContourWriter(os.path.join(out_dir, name + '_dql.db')) if want('sql') else None
+    for h, v, bl in zip(heads, vparts, bparts):
+        h, v = h.cpu().numpy(), v.cpu().numpy()
+        bl = bl.cpu().numpy().tobytes() if bl is not None else b''
+        off = boff = 0
+        for row in h:
+            nv, annidx, nb = int(row[6]), int(row[7]), int(row[8])
+            ring = v[off:off + nv].astype(np.int64)
+            off += nv
+            label, score = int(row[5]), float(row[4])
+            elementidx = len(per_tile.setdefault(annidx, []))
+            per_tile[annidx].append(label)
+            if want('qupath'):
+                feats.append(contours.feature(ring, label, score, model.CLASSES))
+                points.append(contours.point_feature(row[:4], label, score, model.CLASSES))
+            if want('dsa'):
+                dsa.append(outputs.dsa_element(ring, label, model.CLASSES))
+            if want('coco'):
+                rle = {'size': [P, P], 'counts': bl[boff:boff + nb].decode('ascii')}
+                boff += nb
+                bbox = cocomask.to_bbox(rle)
+                annts.append({'bbox': bbox, 'area': bbox[2] * bbox[3], 'image_id': annidx, 'category_id': label, 'id': len(annts),
+                              'iscrowd': 0, 'segmentation': rle})
+            if sql:
+                sql.add(annidx, elementidx, ring, label, score, model.CLASSES)
+    msg = f'{len(bag)} tiles on {world} rank(s): {sum(len(v) for v in per_tile.values())} nuclei after per-tile mask-NMS'
+    if want('qupath'):
+        outputs.write_json(os.path.join(out_dir, name + '.geojson'), feats)
+        outputs.write_json(os.path.join(out_dir, name + '_point.geojson'), points)
+        if args.merge:
+            kept = wsi.merge_gathered(gathered, args.overlap_threshold, device=local_rank if world > 1 else (torch.device(args.device).index or 0))
+            merged = [feats[i] for i in kept]
+            outputs.write_json(os.path.join(out_dir, name + '_merged.geojson'), merged)
+            msg += f', {len(merged)} after the cross-tile merge'
+    if want('dsa'):
+        outputs.write_json(os.path.join(out_dir, name + '_dsa.json'), outputs.dsa_document(dsa))
+    if want('coco'):
+        from PIL import Image
+        img_dir = os.path.join(args.save_dir, 'imgs', name)
+        os.makedirs(img_dir, exist_ok=True)
+        imgs = []
+        for annidx in sorted(per_tile):
+            imgs.append(outputs.coco_tile_image(annidx, P, P, per_tile[annidx], model.CLASSES))
+            Image.fromarray(bag[annidx][0]).save(os.path.join(img_dir, f'{annidx}.png'))
+        outputs.write_json(os.path.join(out_dir, 'coco_nuclei.json'),
+                           {'images': imgs, 'annotations': annts, 'categories': outputs.coco_categories(model.CLASSES)})
+    if sql:
+        sql.close()
+    print(msg)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if args.save_dir is None:
+        raise SystemExit('--save_dir is required (the reference joins it with "patches" / "masks" / "stitches" at once, :360-362)')
+    if args.mode not in ('qupath', 'dsa', 'coco', 'sql', 'all'):
+        raise SystemExit(f'--mode {args.mode}: one of qupath, dsa, coco, sql, all')
+    import torch
+    from nuhtc_amd import parallel, slides, tilestore
+    from nuhtc_amd.apis import init_detector
+    rank, local_rank, world = parallel.init_from_env()
+    say = print if rank == 0 else (lambda *a, **k: None)
+    if args.async_test:
+        say('--async-test: accepted; the reference never reads it in this tool either')
+    say(f'--num_workers {args.num_workers}: accepted; tiles are cut from memory-mapped arrays by the rank that owns them (no DataLoader workers)')
+    patch_save_dir = os.path.join(args.save_dir, 'patches')
+    mask_save_dir = os.path.join(args.save_dir, 'masks')
+    stitch_save_dir = os.path.join(args.save_dir, 'stitches')
+    process_list = os.path.join(args.save_dir, args.process_list) if args.process_list else None
+    directories = {'source': args.source, 'save_dir': args.save_dir, 'patch_save_dir': patch_save_dir, 'mask_save_dir': mask_save_dir,
+                   'stitch_save_dir': stitch_save_dir}
+    src = os.path.normpath(args.source)
+    is_store = os.path.isdir(src) and os.path.isfile(os.path.join(src, 'slide.npy')) and os.path.isfile(os.path.join(src, 'coords.npy'))
+    single = is_store or os.path.isfile(src)                  # beyond the reference: ONE slide instead of a folder
     if rank == 0:
-        from nuhtc_amd import outputs
-        name = os.path.splitext(os.path.basename(os.path.normpath(args.source)))[0]
-        out_dir = os.path.join(args.save_dir, 'nuclei', name)
-        os.makedirs(out_dir, exist_ok=True)
-        feats, points, dsa, annts, per_tile = [], [], [], [], {}
-        sql = outputs.SqlContourWriter(os.path.join(out_dir, name + '_dql.db')) if want('sql') else None
-        for h, v, bl in zip(heads, vparts, bparts):
-            h, v = h.cpu().numpy(), v.cpu().numpy()
-            bl = bl.cpu().numpy().tobytes() if bl is not None else b''
-            off = boff = 0
-            for row in h:
-                nv, annidx, nb = int(row[6]), int(row[7]), int(row[8])
-                ring = v[off:off + nv].astype(np.int64)
-                off += nv
-                label, score = int(row[5]), float(row[4])
-                elementidx = len(per_tile.setdefault(annidx, []))
-                per_tile[annidx].append(label)
-                if want('qupath'):
-                    feats.append(contours.feature(ring, label, score, model.CLASSES))
-                    points.append(contours.point_feature(row[:4], label, score, model.CLASSES))
-                if want('dsa'):
-                    dsa.append(outputs.dsa_element(ring, label, model.CLASSES))
-                if want('coco'):
-                    rle = {'size': [P, P], 'counts': bl[boff:boff + nb].decode('ascii')}
-                    boff += nb
-                    bbox = cocomask.to_bbox(rle)
-                    annts.append({'bbox': bbox, 'area': bbox[2] * bbox[3], 'image_id': annidx, 'category_id': label, 'id': len(annts),
-                                  'iscrowd': 0, 'segmentation': rle})
-                if sql:
-                    sql.add(annidx, elementidx, ring, label, score, model.CLASSES)
-        msg = f'{len(bag)} tiles on {world} rank(s): {sum(len(v) for v in per_tile.values())} nuclei after per-tile mask-NMS'
-        if want('qupath'):
-            outputs.write_json(os.path.join(out_dir, name + '.geojson'), feats)
-            outputs.write_json(os.path.join(out_dir, name + '_point.geojson'), points)
-            if args.merge:
-                kept = wsi.merge_gathered(gathered, args.overlap_threshold, device=local_rank if world > 1 else (torch.device(args.device).index or 0))
-                merged = [feats[i] for i in kept]
-                outputs.write_json(os.path.join(out_dir, name + '_merged.geojson'), merged)
-                msg += f', {len(merged)} after the cross-tile merge'
-        if want('dsa'):
-            outputs.write_json(os.path.join(out_dir, name + '_dsa.json'), outputs.dsa_document(dsa))
-        if want('coco'):
-            from PIL import Image
-            img_dir = os.path.join(args.save_dir, 'imgs', name)
-            os.makedirs(img_dir, exist_ok=True)
-            imgs = []
-            for annidx in sorted(per_tile):
-                imgs.append(outputs.coco_tile_image(annidx, P, P, per_tile[annidx], model.CLASSES))
-                Image.fromarray(bag[annidx][0]).save(os.path.join(img_dir, f'{annidx}.png'))
-            outputs.write_json(os.path.join(out_dir, 'coco_nuclei.json'),
-                               {'images': imgs, 'annotations': annts, 'categories': outputs.coco_categories(model.CLASSES)})
-        if sql:
-            sql.close()
-        print(msg)
+        for key, val in directories.items():
+            print('{} : {}'.format(key, val))
+            if key not in ['source']:
+                os.makedirs(val, exist_ok=True)
+    seg_params, filter_params, vis_params, patch_params = slides.default_parameters(args.preset)
+    say({'seg_params': seg_params, 'filter_params': filter_params, 'patch_params': patch_params, 'vis_params': vis_params})
+    from nuhtc_amd.config import Config, set_test_scale_factor
+    cfg = Config.fromfile(args.config)
+    sf = set_test_scale_factor(cfg, args.mag)          # reference :416-419: scale_factor = 80 / mag
+    say('scale_factor: ', sf)
+    # this tool owns its process: the submitting thread goes onto the GPU's NUMA node (NUHTC_HOST_AFFINITY=0 leaves it alone)
+    model = init_detector(cfg, args.checkpoint, device=f'cuda:{local_rank}' if world > 1 else args.device, max_batch=args.batch_size,
+                          bind_host=os.environ.get('NUHTC_HOST_AFFINITY', '1') != '0')
+    model.CLASSES = ('T', 'I', 'C', 'D', 'E')[:model.opts['num_classes']]
+    model.opts.update(margin=args.margin, min_area=args.min_area, mask_nms_thr=0.05)
+
+    # ---- seg_and_patch on rank 0 (:430-435), everybody else waits for the process list and the coordinate files
+    jobs = []                                                 # (slide_id, bag factory)
+    if single and (is_store or src.endswith('.npz')):         # the tiles / coordinates come with the source: nothing to segment or patch
+        slide_id = os.path.splitext(os.path.basename(src))[0]
+        jobs.append((slide_id, lambda: tilestore.open_source(src, args.patch_size, args.step_size)))
+    else:
+        folder, names, ext = (os.path.dirname(src) or '.', [os.path.basename(src)], os.path.splitext(src)[1]) if single else (src, None, args.slide_ext)
+        if rank == 0:
+            if single and args.coords is not None:            # explicit origins: they ARE the coordinate file
+                c, ps = tilestore._load_coords(args.coords)
+                sid = os.path.splitext(names[0])[0]
+                slides.save_coords(slides.coords_path(patch_save_dir, sid), c, ps or args.patch_size, 0, sid)
+            slides.seg_and_patch(folder, args.save_dir, patch_save_dir, mask_save_dir, stitch_save_dir, seg_params=seg_params,
+                                 filter_params=filter_params, vis_params=vis_params, patch_params=patch_params,
+                                 patch_size=args.patch_size, step_size=args.step_size, seg=args.seg, use_default_params=False,
+                                 save_mask=True, stitch=args.stitch, patch_level=args.patch_level, patch=args.patch or single,
+                                 process_list=process_list, no_auto_skip=args.no_auto_skip or (single and args.coords is None),
+                                 slides=names, seg_downsample=args.seg_downsample)
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        for entry in slides.slide_list(args.save_dir):        # Dataset_All_Bags over process_list_autogen.csv (:437-439)
+            slide_id = entry.split(ext)[0] if ext else entry
+            cpath = slides.coords_path(patch_save_dir, slide_id)
+            if not os.path.exists(cpath):
+                say(f'\nskip {slide_id} due to no coord file')
+                continue
+            spath = os.path.join(folder, slide_id + ext)
+
+            def make(spath=spath, cpath=cpath):
+                z = np.load(cpath)
+                return tilestore.TileBag(slides.open_array_slide(spath), z['coords'], int(z['patch_size']))
+            jobs.append((slide_id, make))
+    total = len(jobs)
+    for k, (slide_id, make) in enumerate(jobs):
+        say('\nprogress: {}/{}'.format(k, total))
+        say(slide_id)
+        # a slide that already has its merged file is done (:456-458); in single-slide mode the run is the request: always redone
+        if not single and os.path.exists(os.path.join(args.save_dir, 'nuclei', slide_id, f'{slide_id}_merged.geojson')):
+            say(f'skip {slide_id} due to existing results')
+            continue
+        run_slide(args, model, make(), slide_id, rank, local_rank, world)
 
 
 if __name__ == '__main__':

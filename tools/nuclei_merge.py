@@ -13,14 +13,19 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nuhtc_amd.contours import merge_features  # noqa: E402
 
 
-def parse_args():
-    p = ArgumentParser()
+def build_parser():
+    """tools/nuclei_merge.py:221-230 of the reference (tests/test_cli_parity.py)."""
+    p = ArgumentParser(allow_abbrev=False)
     p.add_argument('--geojson', help='geojson file name')
     p.add_argument('--output_name', default=None, type=str, help='output geojson file name')
     p.add_argument('--overlap_threshold', type=float, default=0.01, help='area overlap percentage threshold to be removed')
     p.add_argument('--merge_strategy', default='probability', help="'probability' or 'area'")
     p.add_argument('--uniform_classification', action='store_true')
-    return p.parse_args()
+    return p
+
+
+def parse_args(argv=None):
+    return build_parser().parse_args(argv)
 
 
 def main():
