@@ -51,12 +51,14 @@ GROUPS = {
 }
 
 
-def cpu_baseline(sd, tiles, eng=None, mode=1, batch=4, timed=3, warm=2, warm_batches=1, host_cpus=None):
+def cpu_baseline(sd, tiles, eng=None, mode=1, batch=4, timed=3, warm=2, warm_batches=1, host_cpus=None, sweep=(8, 16, 32, 64, 128), sweep_batch=None):
     """Oracle (CPU restatement of the reference path, oracle/model.py) timed on the host cores: reported next to the GPU
-    number, never the thing shipped.  Bounded sample (about 30 s): one warm-up batch of 2 tiles, then `timed` batches of
-    `batch` tiles each, timed one by one.  With `eng`, the same tiles are the parity check of the run: the HIP path's
-    instances against the oracle's with the strict comparator of the tests (tests/parity_util.py: exact counts, every
-    tolerated disagreement proven to sit on a threshold)."""
+    number, never the thing shipped.  Bounded sample: one warm-up batch of 2 tiles, a THREAD SWEEP (one batch of `sweep_batch`
+    tiles at each torch thread count of `sweep` the host has, plus all of them), then `timed` batches of `batch` tiles each at the
+    best count, timed one by one, with the stage breakdown BASELINE.md section 3 asks for (backbone / FPN+RPN+semantic / proposals /
+    cascade / mask / post).  With `eng`, the same tiles are the parity check of the run: the HIP path's instances against the oracle's
+    with the strict comparator of the tests (tests/parity_util.py: exact counts, every tolerated disagreement proven to sit on a
+    threshold)."""
     from oracle import model as O
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tests'))
     import parity_util as P
@@ -67,23 +69,48 @@ def cpu_baseline(sd, tiles, eng=None, mode=1, batch=4, timed=3, warm=2, warm_bat
             except OSError:
                 pass
     orc = O.Oracle(sd)
-    threads = torch.get_num_threads()
+    ncpu = len(os.sched_getaffinity(0))
+    threads0 = torch.get_num_threads()
     for _ in range(warm_batches):
         orc(tiles[:warm], mode)        # warm-up (also builds oracle/libnuhtc_oracle.so on first use)
-    times, refs, vals = [], [], []
+    # ---- thread sweep: torch's intra-op pool at P threads (the oracle's C RoIAlign / NMS and its Python RoI loops are single-threaded
+    # whatever P is).  More threads than the dense stages can use cost more than they give: the rounds 1-4 figure (all 128 hardware
+    # threads of the GPU box) was an accident of oversubscription.
+    sb = sweep_batch or batch
+    cand = sorted({p for p in sweep if p < ncpu} | {ncpu})
+    swept = {}
+    for pth in cand:
+        torch.set_num_threads(pth)
+        t0 = time.perf_counter()
+        orc(tiles[:sb], mode)
+        swept[pth] = sb / (time.perf_counter() - t0)
+    best = max(swept, key=swept.get)
+    torch.set_num_threads(best)
+    times, refs, vals, stage = [], [], [], {}
     n = min(batch * timed, len(tiles))
     for i in range(0, n, batch):
         t0 = time.perf_counter()
-        r, it = orc(tiles[i:i + batch], mode, keep=True)
+        r, it = orc(tiles[i:i + batch], mode, keep=True, timing=stage)
         times.append(time.perf_counter() - t0)
         refs += r
         vals += P.oracle_paste_values(O, it, tiles.shape[1:3])
+    torch.set_num_threads(threads0)
     dt = sum(times)
-    out = dict(value=n / dt, unit='tiles/s', cores=threads, kind='port',
-               sample=f'{timed} timed batches of {batch} synthetic nuclei tiles after {warm_batches} warm-up batch(es) of {warm} (oracle/model.py, fp32 torch-cpu + C RoIAlign/NMS), '
-                      f'{dt:.1f} s; per batch {[round(batch / t, 3) for t in times]} tiles/s' +
+    stage['other'] = max(0.0, dt - sum(stage.values()))
+    order = ('preprocess', 'backbone', 'fpn_rpn_semantic', 'proposals', 'cascade', 'mask', 'post', 'other')
+    dense = stage.get('backbone', 0) + stage.get('fpn_rpn_semantic', 0)
+    out = dict(value=n / dt, unit='tiles/s', cores=best, threads=best, host_cpus=ncpu, kind='port',
+               thread_sweep={str(k): round(v, 3) for k, v in swept.items()},
+               stage_s_per_tile={k: round(stage.get(k, 0.0) / n, 4) for k in order},
+               stage_share={k: round(stage.get(k, 0.0) / dt, 3) for k in order},
+               dense_part_tiles_per_s=round(n / dense, 3) if dense else None,
+               kind_note='"port" = oracle/model.py, a correctness tool: its dense stages are torch-cpu fp32 operators like the reference\'s, its proposal and RoI stages '
+                         '(RPN NMS and RoIAlign in plain one-thread C, the attention RoI extractor as Python loops over levels and RoIs, paste) are not tuned and '
+                         'dominate (`proposals` + `cascade`: see stage_share), more than they would in mmdet + mmcv -- the oracle is not optimised on purpose; dense_part_tiles_per_s is the figure comparable with the 2.6 tiles/s BASELINE.md measured for the reference\'s own dense modules on 8 vCPUs',
+               sample=f'{timed} timed batches of {batch} synthetic nuclei tiles at {best} torch threads (best of the sweep {cand}, one batch of {sb} each) after {warm_batches} warm-up batch(es) of {warm} '
+                      f'(oracle/model.py, fp32 torch-cpu + C RoIAlign/NMS), {dt:.1f} s; per batch {[round(batch / t, 3) for t in times]} tiles/s' +
                       ('; the full protocol of SURVEY 8d (2 warm-up + 10 timed batches of 16 tiles)' if (batch, timed, warm, warm_batches) == (16, 10, 16, 2) else
-                       '; bounded deviation from SURVEY 8d (2 warm-up + 10 timed batches of 16 tiles: about 6 minutes of host time; `bench.py --cpu-full`, profiles/r04_cpu_baseline_full.json)'))
+                       '; bounded deviation from SURVEY 8d (2 warm-up + 10 timed batches of 16 tiles: minutes of host time; `bench.py --cpu-full`, profiles/r05_cpu_baseline_full.json)'))
     if eng is not None:
         got = []
         for i in range(0, n, eng.cfg.max_batch):
@@ -268,6 +295,11 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    # stdout carries ONE JSON line.  Libraries write there too (RCCL prints a version banner on fd 1 when a communicator is created):
+    # from here on fd 1 is stderr, and the line goes to a private copy of the original stdout.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or unset WORLD_SIZE and let bench.py launch them)')
     # test hooks for a box with fewer GPUs than ranks (tests/test_hip_api.py): every rank on device 0, gloo instead of RCCL
@@ -737,7 +769,8 @@ def main():
         out['host'] = dict(submitting_thread_bound_to_gpu_numa_node=bool(host_bound), gpu_pci=bdf, gpu_numa_node=node, cpus_during_gpu_legs=len(cpus_gpu), cpus_of_process=len(cpus0),
                            note='hip.bind_host_thread (nuhtc_bind_host_thread): from the other socket every dispatch packet costs the command processor 1.4-2.9 us more '
                                 '(0.3-0.4 ms per sequential step); the CPU baseline runs on the process\'s original CPUs')
-        print(json.dumps(out))
+        json_out.write(json.dumps(out) + '\n')
+        json_out.flush()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -507,21 +507,32 @@ class Oracle:
         self.scale = scale
 
     @torch.no_grad()
-    def forward_tensor(self, img, ori_hw, fixed_rois=None, keep=False, img_hw=None):
+    def forward_tensor(self, img, ori_hw, fixed_rois=None, keep=False, img_hw=None, timing=None):
         """img: (B,3,Hn,Wn) f32 network input (the padded batch tensor). Returns list of (bbox_results, segm_results) like
         the reference (+ dict of intermediates when keep=True).
 
         img_hw = `img_meta['img_shape']`, the resized image BEFORE Pad(size_divisor=32) (default: the tensor's own size, i.e. no
-        padding): the reference clips RPN proposals (rpn_head.py:141,219), refined RoIs and detections (bbox_head.py:358,533) to
+        padding; `timing`: a dict that receives the seconds spent per stage of BASELINE.md section 3 -- backbone / fpn_rpn_semantic /
+        proposals / cascade / mask / post -- accumulated over calls, for bench.py's CPU baseline): the reference clips RPN proposals (rpn_head.py:141,219), refined RoIs and detections (bbox_head.py:358,533) to
         it and interpolates the semantic logits to it for the component proposals (htc_roi_head_cus.py:285,397), while anchors,
         feature maps and RoI features live on the padded tensor; masks are pasted into `ori_shape` = ori_hw."""
+        import time as _time
         sd = self.sd
         B = img.shape[0]
         img_hw = tuple(img.shape[-2:]) if img_hw is None else tuple(int(v) for v in img_hw)
+        _t = [_time.perf_counter()]
+
+        def lap(stage):
+            now = _time.perf_counter()
+            if timing is not None:
+                timing[stage] = timing.get(stage, 0.0) + now - _t[0]
+            _t[0] = now
         c = backbone(sd, img)
+        lap('backbone')
         x = fpn(sd, c)
         rcls, rreg = rpn_convs(sd, x)
         sem_pred, sem_feat = semantic_head(sd, x)
+        lap('fpn_rpn_semantic')
         if fixed_rois is None:
             rpn = rpn_proposals(rcls, rreg, img_hw)
             ws = cc_proposals(sem_pred, img_hw)
@@ -529,6 +540,7 @@ class Oracle:
         else:
             rpn, ws = None, None
             props = [torch.as_tensor(r, dtype=torch.float32) for r in fixed_rois]
+        lap('proposals')
         n_per = [p.shape[0] for p in props]
         rois = torch.cat([torch.cat([torch.full((p.shape[0], 1), float(i)), p], 1) for i, p in enumerate(props)], 0)
         inter = dict(c=c, x=x, rpn_cls=rcls, rpn_reg=rreg, sem_pred=sem_pred, sem_feat=sem_feat, rpn=rpn, ws=ws,
@@ -544,12 +556,14 @@ class Oracle:
             if k < 2:   # regress_by_class, class-agnostic (mmdet/.../bbox_head.py:459-496)
                 rois = torch.cat([rois[:, :1], delta2bbox(rois[:, 1:], reg, STAGE_STDS[k], img_hw)], 1)
         cls_mean = sum(ms) / 3.0
+        lap('cascade')
         dets, labels, off = [], [], 0
         for i in range(B):
             sl = slice(off, off + n_per[i]); off += n_per[i]
             d, l = detect_post(rois[sl, 1:], cls_mean[sl], reg[sl], img_hw, self.scale, self.score_thr, 0.5, self.max_per_img)
             dets.append(d); labels.append(l)
         inter.update(dets=dets, labels=labels)
+        lap('post')
         # mask branch (htc_roi_head_cus.py:2310-2367)
         mrois = torch.cat([torch.cat([torch.full((d.shape[0], 1), float(i)), d[:, :4] * self.scale], 1)
                            for i, d in enumerate(dets)], 0)
@@ -560,6 +574,7 @@ class Oracle:
         else:
             prob = torch.zeros(0, 1, 28, 28)
         inter.update(mask_prob=prob, mask_rois=mrois)
+        lap('mask')
         off = 0
         for i in range(B):
             d, l = dets[i], labels[i]
@@ -568,13 +583,19 @@ class Oracle:
             bbox_res = [d[l == c].numpy() for c in range(self.nc)]
             segm_res = [[pm[j] for j in range(d.shape[0]) if int(l[j]) == c] for c in range(self.nc)]
             results.append((bbox_res, segm_res))
+        lap('post')
         return (results, inter) if keep else results
 
     def __call__(self, tiles_u8, channel_mode=0, **kw):
         tiles_u8 = np.asarray(tiles_u8)
         h, w = tiles_u8.shape[1:3]
         img_hw = (int(h * self.scale + 0.5), int(w * self.scale + 0.5))       # mmcv.imrescale: new size = int(size * scale + 0.5)
-        return self.forward_tensor(preprocess(tiles_u8, channel_mode, self.scale), (h, w), img_hw=img_hw, **kw)
+        import time as _time
+        t0 = _time.perf_counter()
+        img = preprocess(tiles_u8, channel_mode, self.scale)
+        if kw.get('timing') is not None:
+            kw['timing']['preprocess'] = kw['timing'].get('preprocess', 0.0) + _time.perf_counter() - t0
+        return self.forward_tensor(img, (h, w), img_hw=img_hw, **kw)
 
 
 # ----------------------------------------------------------------------------- a27-a28 per-tile filter + mask-NMS

@@ -233,7 +233,7 @@ def test_readme_command_lines_on_a_folder_of_slides(hip_device, tmp_path):
         for f in (out / 'masks' / f'{sid}.png', out / 'patches' / f'{sid}.npz', out / 'stitches' / f'{sid}.jpg', out / 'nuclei' / sid / f'{sid}_point.geojson'):
             assert os.path.exists(f), f
         docs[sid] = json.load(open(out / 'nuclei' / sid / f'{sid}.geojson'))
-        assert len(docs[sid]) > 2000
+        assert len(docs[sid]) > 1000
         n_tiles = len(np.load(out / 'patches' / f'{sid}.npz')['coords'])
         assert 100 < n_tiles < 260 and f'{n_tiles} tiles on 1 rank(s)' in log
     # the single-slide form of the same flags gives the same documents
