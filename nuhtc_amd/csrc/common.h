@@ -64,7 +64,7 @@ int& dev_knob_ref(const char* name, int dflt);   // the same, as a reference lau
 
 // ----------------------------------------------------------------------------- GEMM (gemm.hip)
 // C[row_map(m), n] = epilogue( sum_k A(m,k) * W[n,k] )      fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32
-enum AMode { A_PLAIN = 0, A_CONV3 = 1 };
+enum AMode { A_PLAIN = 0, A_CONV3 = 1, A_LN = 2 /* plain rows, LayerNorm'ed on their way into the product (ln_stats) */ };
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_COS = 3 /* relu(v*ri[m]*rj[n]-tau)+tau */ };
 enum StoreMode { ST_PLAIN = 0, ST_ROWMAP = 1, ST_DECONV2 = 2 };
 
@@ -96,6 +96,12 @@ struct GemmParams {
   const int* m_dev;    // optional device-side row count (rows >= min(M, *m_dev * m_mul) are skipped)
   int m_mul;
   int amode;
+  // A_LN (split pipe only): row m of the product is LayerNorm(A[a_rows ? a_rows[m] : m]) with the affine part folded into W and bias by
+  // the caller (W' = W diag(gamma), bias' = bias + W beta): the loader subtracts ln_stats[2m] (the row's mean) from every element it
+  // stages and the epilogue multiplies the row's sums by ln_stats[2m + 1] (its 1 / sqrt(var + eps)) before the bias -- the normalised
+  // rows never exist in memory.  ln_stats comes from launch_ln_stats (swin.hip).
+  const float* ln_stats;
+  const int* a_rows;
   int cH, cW, cC;      // A_CONV3: NHWC image geometry (rows = b*cH*cW + y*cW + x), K = 9*cC
   const float* zeros;  // A_CONV3: >= 16 bytes of zeros that out-of-image taps read (launch_gemm supplies one when null)
   int act;
@@ -170,6 +176,11 @@ int launch_patch_embed(const float* img, const float* w, const float* b, const f
                        int B, int Hn, int Wn, hipStream_t s);
 // LayerNorm of `rows` rows of C channels: dst row m reads src row src_map[m] (or m when src_map==null); src_map[m]<0 -> zeros
 int launch_layernorm(const float* x, const int* src_map, const float* g, const float* b, float* y, int rows, int C, hipStream_t s);
+// per-row LayerNorm statistics for a product in A_LN mode: stats[2m] = mean, stats[2m + 1] = 1 / sqrt(var + 1e-5) of row src_rows[m] (or m) of
+// x, computed exactly like layernorm_kernel computes them (same loads, same summation order); the `n_pad` rows `pad_rows` of the window
+// QKV image are filled with pad_val[0..3C) on the way (pad_rows null: nothing to fill)
+int launch_ln_stats(const float* x, const int* src_rows, float* stats, int rows, int C, float* pad_dst, const int* pad_rows, int n_pad,
+                    const float* pad_val, hipStream_t s);
 // LN1 of a Swin block over the `rows` window rows: row r with src_map[r] >= 0 is normalised into y[dst_map[r]] (the compact,
 // padding-free window order); a padding row writes pad_val[0..3C) (the QKV bias) into pad_dst[r] (the window QKV image).
 int launch_layernorm_windows(const float* x, const int* src_map, const int* dst_map, const float* g, const float* b, float* y,

@@ -19,6 +19,9 @@ struct StageGeom {
 
 struct BlockW {
   float *n1g, *n1b, *relbT /* relative-position bias packed per lane [nH][4096] */, *qkv_w, *qkv_b, *proj_w, *proj_b, *n2g, *n2b, *f1_w, *f1_b, *f2_w, *f2_b;
+  // LayerNorm in the A path of the linear that follows it (stages 2-4 on the split pipe, gemm.hip A_LN): the norm's affine part folded into
+  // the linear -- W' = W diag(gamma), b' = b + W beta (fp64 on the host, rounded once) -- null where the norm runs as a kernel of its own
+  float *qkv_wln, *qkv_bln, *f1_wln, *f1_bln;
   void* qkv_stream;    // fused LN1 + QKV (mlp.hip): k-permuted split planes of qkv_w, null where LN + GEMM run separately
   void* mlp_stream;    // fused FFN half (mlp.hip): chunk-major split planes of f1_w / f2_w, null where the three separate launches run
   void* proj_stream;   // attention projection in front of the fused FFN half (mlp.hip): k-permuted split planes of proj_w, null where proj is a GEMM launch
@@ -62,6 +65,7 @@ struct nuhtc_engine {
 
   // workspace
   float *img, *tokA, *tokB, *xw, *qkv, *att, *hid;
+  float* ln_stats = nullptr;   // [max_batch * tokens of stage 2][2]: mean, 1 / sqrt(var + eps) of the rows of the norm that rides in the next linear (A_LN)
   float *c[4], *lat[4], *x[4], *rpn[4], *semg[4];
   float *tmpA, *tmpB, *tmpR, *sem_feat, *sem_pred, *x0sem;   // tmpR: RPN conv output (side stream)
   // proposals / roi path

@@ -419,6 +419,27 @@ int nuhtc_finalize(nuhtc_engine* e) {
           (rc = upload_gemm_weight(e, &bw.f1_w, f1w->data, 4 * C, C)) || (rc = upload(e, &bw.f1_b, f1b->data)) || (rc = upload_gemm_weight(e, &bw.f2_w, f2w->data, C, 4 * C)) ||
           (rc = upload(e, &bw.f2_b, f2b->data)))
         return rc;
+      if (e->cfg.matrix_pipe == NUHTC_PIPE_BF16_SPLIT && !lnqkv_supported(C) && !mlp_supported(C)) {
+        // the two norms of the block ride in the A path of the linear behind them (gemm.hip A_LN): y = ((x - mean) rstd gamma + beta) W^T + b
+        //   = rstd ((x - mean) (W diag gamma)^T) + (b + W beta); W' is rounded once to fp32 (its split is exact from there), b' summed in fp64
+        auto fold = [&](const std::vector<float>& W, const std::vector<float>& bias, const std::vector<float>& gam, const std::vector<float>& bet, int N,
+                        float** wdev, float** bdev) -> int {
+          std::vector<float> w2((size_t)N * C), b2(N);
+          for (int n = 0; n < N; ++n) {
+            double acc = bias[n];
+            for (int k = 0; k < C; ++k) {
+              w2[(size_t)n * C + k] = W[(size_t)n * C + k] * gam[k];
+              acc += (double)W[(size_t)n * C + k] * (double)bet[k];
+            }
+            b2[n] = (float)acc;
+          }
+          int r = upload_gemm_weight(e, wdev, w2, N, C);
+          return r ? r : upload(e, bdev, b2);
+        };
+        if ((rc = fold(qw->data, qb->data, n1w->data, n1b->data, 3 * C, &bw.qkv_wln, &bw.qkv_bln)) ||
+            (rc = fold(f1w->data, f1b->data, n2w->data, n2b->data, 4 * C, &bw.f1_wln, &bw.f1_bln)))
+          return rc;
+      }
       if (e->cfg.matrix_pipe == NUHTC_PIPE_BF16_SPLIT && lnqkv_supported(C)) {
         std::vector<unsigned short> st;
         lnqkv_pack_stream(qw->data.data(), C, st);
@@ -513,6 +534,7 @@ int nuhtc_finalize(nuhtc_engine* e) {
       (rc = ws(e, &e->xw, nullptr, {B, (int64_t)max_win}, 0)) || (rc = ws(e, &e->qkv, nullptr, {B, (int64_t)max_qkv}, 0)) ||
       (rc = ws(e, &e->att, nullptr, {B, (int64_t)max_win}, 0)) || (rc = ws(e, &e->hid, nullptr, {B, (int64_t)std::max(max_hid, max_qkv)}, 0)))
     return rc;
+  if ((rc = ws(e, &e->ln_stats, nullptr, {B, (int64_t)e->st[0].H * e->st[0].W, 2}, 0))) return rc;
   for (int s = 0; s < 4; ++s) {
     const StageGeom& g = e->st[s];
     std::string n = std::to_string(s);
@@ -606,8 +628,15 @@ int run_backbone(nuhtc_engine* e, int B, hipStream_t s) {
       // (LN of a zero-padded token is 0 after swin.py:341-343's F.pad, so its qkv is the bias), attention writes the
       // non-padding rows of its output compactly again and proj scatters them back to token order.
       static const int& fused_qkv = dev_knob_ref("FUSED_QKV", 1);
+      static const int& ln_in_a = dev_knob_ref("LN_IN_A", 1);        // dev: 0 = the norms of stages 2-4 as kernels of their own (round 4)
       if (w.qkv_stream && fused_qkv) {       // one kernel: LN1, window gather, QKV linear (mlp.hip) + the bias rows of the padding tokens
         RUN(launch_swin_lnqkv(x, e->qkv, g.ctok[sh], g.vrow[sh], g.prow[sh], B * g.npad, w.n1g, w.n1b, w.qkv_stream, w.qkv_b, T, C, s));
+      } else if (w.qkv_wln && ln_in_a) {     // the norm rides in the linear's A path: statistics (+ the bias rows of the padding tokens), then the product
+        RUN(launch_ln_stats(x, g.ctok[sh], e->ln_stats, T, C, e->qkv, g.prow[sh], B * g.npad, w.qkv_b, s));
+        GemmParams p = gp(x, w.qkv_wln, w.qkv_bln, e->qkv, T, 3 * C, C);
+        p.amode = A_LN; p.ln_stats = e->ln_stats; p.a_rows = g.ctok[sh];
+        p.store = ST_ROWMAP; p.row_map = g.vrow[sh];
+        RUN(linear(p));
       } else {
       RUN(launch_layernorm_windows(x, g.map[sh], g.cidx[sh], w.n1g, w.n1b, e->xw, e->qkv, w.qkv_b, Mw, C, s));
       {
@@ -632,11 +661,19 @@ int run_backbone(nuhtc_engine* e, int B, hipStream_t s) {
       if (mlp1) {      // one kernel: [attention projection + residual,] LN2, both linears, GELU and the residual (mlp.hip)
         RUN(launch_swin_mlp(x, x, w.n2g, w.n2b, w.mlp_stream, w.f1_b, w.f2_b, T, C, s, proj1 ? e->att : nullptr, w.proj_stream, w.proj_b));
       } else {
+      if (w.f1_wln && ln_in_a) {
+        RUN(launch_ln_stats(x, nullptr, e->ln_stats, T, C, nullptr, nullptr, 0, nullptr, s));
+        GemmParams p = gp(x, w.f1_wln, w.f1_bln, e->hid, T, 4 * C, C);
+        p.amode = A_LN; p.ln_stats = e->ln_stats;
+        p.act = ACT_GELU;
+        RUN(linear(p));
+      } else {
       RUN(launch_layernorm(x, nullptr, w.n2g, w.n2b, e->xw, T, C, s));
       {
         GemmParams p = gp(e->xw, w.f1_w, w.f1_b, e->hid, T, 4 * C, C);
         p.act = ACT_GELU;
         RUN(linear(p));
+      }
       }
       {
         GemmParams p = gp(e->hid, w.f2_w, w.f2_b, x, T, C, 4 * C);
@@ -888,6 +925,43 @@ int nuhtc_op_gemm_split(nuhtc_engine* e, const float* A, const float* W_dev, con
   hipFree(sp);
   if (rc) FAIL(e, rc, "gemm launch failed (K%32, N%32 required)");
   if (he != hipSuccess) FAIL(e, NUHTC_E_HIP, "gemm kernel failed");
+  return 0;
+}
+
+int nuhtc_op_ln_gemm(nuhtc_engine* e, const float* X_dev, const int* rows_dev, const float* W_host, const float* bias_host, const float* ln_g_host,
+                     const float* ln_b_host, float* C_dev, int M, int N, int K, int act, void* stream) {
+  if (!e || !X_dev || !W_host || !ln_g_host || !ln_b_host || !C_dev || M < 1 || N < 1 || K < 1) return NUHTC_E_INVALID;
+  HIP_CHECK(e, hipSetDevice(e->device));
+  std::vector<float> w2((size_t)N * K), b2(N);
+  for (int n = 0; n < N; ++n) {
+    double acc = bias_host ? bias_host[n] : 0.0;
+    for (int k = 0; k < K; ++k) {
+      w2[(size_t)n * K + k] = W_host[(size_t)n * K + k] * ln_g_host[k];
+      acc += (double)W_host[(size_t)n * K + k] * (double)ln_b_host[k];
+    }
+    b2[n] = (float)acc;
+  }
+  void* sp = nullptr;
+  int rc = gemm_make_split(w2.data(), N, K, &sp);
+  if (rc) FAIL(e, rc, "gemm_make_split failed (K % 8)");
+  float *wd = nullptr, *bd = nullptr, *st = nullptr;
+  hipError_t he = hipMalloc(&wd, w2.size() * 4);
+  if (he == hipSuccess) he = hipMalloc(&bd, b2.size() * 4);
+  if (he == hipSuccess) he = hipMalloc(&st, (size_t)M * 8);
+  if (he == hipSuccess) he = hipMemcpy(wd, w2.data(), w2.size() * 4, hipMemcpyHostToDevice);
+  if (he == hipSuccess) he = hipMemcpy(bd, b2.data(), b2.size() * 4, hipMemcpyHostToDevice);
+  if (he == hipSuccess) {
+    rc = launch_ln_stats(X_dev, rows_dev, st, M, K, nullptr, nullptr, 0, nullptr, (hipStream_t)stream);
+    if (!rc) {
+      GemmParams p = gp(X_dev, wd, bd, C_dev, M, N, K);
+      p.act = act; p.Wsplit = sp; p.amode = A_LN; p.ln_stats = st; p.a_rows = rows_dev;
+      rc = launch_gemm(p, (hipStream_t)stream);
+    }
+    he = hipStreamSynchronize((hipStream_t)stream);
+  }
+  hipFree(sp); hipFree(wd); hipFree(bd); hipFree(st);
+  if (rc) FAIL(e, rc, "ln_gemm launch failed (N % 96, K % 32 required)");
+  if (he != hipSuccess) FAIL(e, NUHTC_E_HIP, "ln_gemm failed");
   return 0;
 }
 

@@ -80,6 +80,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
       for (int j = 0; j < 4; ++j) riv[j] = ri[mrow[j]];
     }
+    float lnr[4] = {1.f, 1.f, 1.f, 1.f};      // A_LN: the row's 1 / sqrt(var + eps) scales its sums before the bias
+    if (p.ln_stats) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) lnr[j] = p.ln_stats[2 * mrow[j] + 1];
+    }
     // Vector-memory operations retire in issue order, so a load issued after a column tile's stores would wait for those
     // stores to be acknowledged (thousands of cycles under load) before its data counts as landed.  Bias / column norms of
     // every column tile are therefore loaded before the first store, and the row-dependent terms (residual, FPN parent)
@@ -117,6 +122,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         v[j] = *reinterpret_cast<const v4f*>(tb + (8 * j + rr) * 32 + c4) * p.alpha;
+        if (p.ln_stats) v[j] *= lnr[j];
         if (p.bias) v[j] += colv[t];
         if (p.act == ACT_RELU) {
           v[j].x = fmaxf(v[j].x, 0.f); v[j].y = fmaxf(v[j].y, 0.f); v[j].z = fmaxf(v[j].z, 0.f); v[j].w = fmaxf(v[j].w, 0.f);
@@ -472,13 +478,20 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void gemm_split_kernel
   const int kc = tid & 3, rbase = ((tid >> 5) << 3) + (((tid >> 2) & 1) << 2) + ((tid >> 3) & 3);
   const float* a_ptr[NA];
   unsigned a_ok[NA];
+  float a_mean[NA];          // A_LN: the mean of the row this thread stages (subtracted on the way into LDS)
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
     int m = m0 + rbase + RPP * j;
     m = m < Meff ? m : Meff - 1;
+    a_mean[j] = 0.f;
     if (AMODE == A_PLAIN) {
       a_ptr[j] = A + (long long)m * p.lda + kc * 4;
       a_ok[j] = 0;
+    } else if (AMODE == A_LN) {
+      const long long src = p.a_rows ? p.a_rows[m] : m;
+      a_ptr[j] = A + src * p.lda + kc * 4;
+      a_ok[j] = 0;
+      a_mean[j] = p.ln_stats[2 * m];
     } else {
       const int hw = p.cH * p.cW;
       const int rr = m - (m / hw) * hw;
@@ -518,12 +531,12 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void gemm_split_kernel
   long long cv_off = 0;
 #define S_LOAD_TILE(kt_)                                                                                       \
   {                                                                                                            \
-    if (AMODE != A_PLAIN) {                                                                                    \
+    if (AMODE == A_CONV3) {                                                                                    \
       const int ky = cv_tap / 3 - 1, kx = cv_tap - (cv_tap / 3) * 3 - 1;                                       \
       cv_off = (long long)(ky * p.cW + kx) * p.cC + cv_c0;                                                     \
     }                                                                                                          \
     _Pragma("unroll") for (int j = 0; j < NA; ++j) {                                                           \
-      if (AMODE == A_PLAIN) ra[j] = *reinterpret_cast<const v4f*>(a_ptr[j] + (kt_) * BK);                      \
+      if (AMODE != A_CONV3) ra[j] = *reinterpret_cast<const v4f*>(a_ptr[j] + (kt_) * BK);                      \
       else {                                                                                                   \
         const bool ok = (a_ok[j] >> cv_tap) & 1u;                                                              \
         ra[j] = *reinterpret_cast<const v4f*>(ok ? a_ptr[j] + cv_off : p.zeros);                               \
@@ -531,7 +544,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void gemm_split_kernel
     }                                                                                                          \
     _Pragma("unroll") for (int j = 0; j < NB; ++j)                                                             \
       if (64 * wave_u + 256 * j < NCH) rb[j] = *reinterpret_cast<const u32x4*>(w_ptr[j] + (long long)(kt_) * 96); \
-    if (AMODE != A_PLAIN) {                                                                                    \
+    if (AMODE == A_CONV3) {                                                                                    \
       cv_c0 += BK;                                                                                             \
       if (cv_c0 == p.cC) { cv_c0 = 0; cv_tap = cv_tap < 8 ? cv_tap + 1 : 8; }                                  \
     }                                                                                                          \
@@ -539,7 +552,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void gemm_split_kernel
 #define S_STORE_TILE(buf_)                                                                                     \
   {                                                                                                            \
     _Pragma("unroll") for (int j = 0; j < NA; ++j)                                                             \
-      *reinterpret_cast<v4f*>(As + (buf_) * LDK * BM + (rbase + RPP * j) * LDK + kc * 4) = ra[j];              \
+      *reinterpret_cast<v4f*>(As + (buf_) * LDK * BM + (rbase + RPP * j) * LDK + kc * 4) = AMODE == A_LN ? ra[j] - a_mean[j] : ra[j]; \
     _Pragma("unroll") for (int j = 0; j < NB; ++j)                                                             \
       if (64 * wave_u + 256 * j < NCH) *reinterpret_cast<u32x4*>(Bs + (buf_) * BP * BN + w_lds[j]) = rb[j];    \
   }
@@ -599,7 +612,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void gemm_split_kernel
   {                                                                                                            \
     if ((f_) < NA) {                                                                                           \
       const int j = (f_) < NA ? (f_) : 0;                                                                      \
-      if (AMODE == A_PLAIN) ra[j] = *reinterpret_cast<const v4f*>(a_ptr[j] + (kt_) * BK);                      \
+      if (AMODE != A_CONV3) ra[j] = *reinterpret_cast<const v4f*>(a_ptr[j] + (kt_) * BK);                      \
       else {                                                                                                   \
         const bool ok = (a_ok[j] >> cv_tap) & 1u;                                                              \
         ra[j] = *reinterpret_cast<const v4f*>(ok ? a_ptr[j] + cv_off : p.zeros);                               \
@@ -613,19 +626,19 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void gemm_split_kernel
   {                                                                                                            \
     if ((f_) < NA) {                                                                                           \
       const int j = (f_) < NA ? (f_) : 0;                                                                      \
-      *reinterpret_cast<v4f*>(As + (buf_) * LDK * BM + (rbase + RPP * j) * LDK + kc * 4) = ra[j];              \
+      *reinterpret_cast<v4f*>(As + (buf_) * LDK * BM + (rbase + RPP * j) * LDK + kc * 4) = AMODE == A_LN ? ra[j] - a_mean[j] : ra[j]; \
     } else if ((f_) < NST) {                                                                                   \
       const int j = (f_) >= NA && (f_) < NST ? (f_) - NA : 0;                                                  \
       if (64 * wave_u + 256 * j < NCH) *reinterpret_cast<u32x4*>(Bs + (buf_) * BP * BN + w_lds[j]) = rb[j];    \
     }                                                                                                          \
   }
 #define S_CONV_BEGIN()                                                                                         \
-  if (AMODE != A_PLAIN) {                                                                                      \
+  if (AMODE == A_CONV3) {                                                                                      \
     const int ky = cv_tap / 3 - 1, kx = cv_tap - (cv_tap / 3) * 3 - 1;                                         \
     cv_off = (long long)(ky * p.cW + kx) * p.cC + cv_c0;                                                       \
   }
 #define S_CONV_END()                                                                                           \
-  if (AMODE != A_PLAIN) {                                                                                      \
+  if (AMODE == A_CONV3) {                                                                                      \
     cv_c0 += BK;                                                                                               \
     if (cv_c0 == p.cC) { cv_c0 = 0; cv_tap = cv_tap < 8 ? cv_tap + 1 : 8; }                                    \
   }
@@ -784,7 +797,9 @@ static void launch_split(const GemmParams& q, hipStream_t s) {
   const int mtiles = cdiv(q.M, 128 * MT);
   dim3 grid(cdiv(mtiles, 8) * 8 * (q.N / (32 * NT)), 1, q.batch > 0 ? q.batch : 1);
   if (q.amode == A_CONV3) hipLaunchKernelGGL((gemm_split_kernel<MT, NT, A_CONV3>), grid, dim3(256), 0, s, q);
-  else hipLaunchKernelGGL((gemm_split_kernel<MT, NT, A_PLAIN>), grid, dim3(256), 0, s, q);
+  else if (q.amode == A_LN) {
+    if constexpr (NT == 3) hipLaunchKernelGGL((gemm_split_kernel<MT, NT, A_LN>), grid, dim3(256), 0, s, q);   // launch_gemm admits A_LN for 96-column tiles only
+  } else hipLaunchKernelGGL((gemm_split_kernel<MT, NT, A_PLAIN>), grid, dim3(256), 0, s, q);
 }
 
 bool conv3_fuse_available() {
@@ -798,6 +813,8 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
   if (p.K % 32 != 0 || p.N % 32 != 0) return NUHTC_E_INVALID;
   if (p.amode == A_CONV3 && (p.cC % 32 != 0 || p.K != 9 * p.cC)) return NUHTC_E_INVALID;
   if ((p.res && p.up) || (p.act == ACT_COS && p.bias)) return NUHTC_E_INVALID;
+  // LayerNorm in the A path: the split kernel's 96-column form only (the Swin linears that follow a norm), statistics required
+  if ((p.amode == A_LN) != (p.ln_stats != nullptr) || (p.amode == A_LN && (!p.Wsplit || p.N % 96 != 0 || p.batch > 1))) return NUHTC_E_INVALID;
   if ((p.res && (long long)p.M * p.ldr >= (1ll << 31)) || (p.up && (long long)p.M * p.N >= (1ll << 31))) return NUHTC_E_INVALID;
   GemmParams q = p;
   if (q.alpha == 0.f) q.alpha = 1.f;

@@ -358,6 +358,21 @@ class Engine:
                                                      M, N, K, act, self._stream()))
         return C
 
+    def op_ln_gemm(self, x, w, bias, ln_g, ln_b, rows=None, act=0):
+        """act(LayerNorm(x[rows]) @ w.T + bias) with the norm in the product's A path (csrc/gemm.hip A_LN + ln_stats_kernel: how the QKV and
+        fc1 linears of Swin stages 2-4 run); x (T, K) on the device, rows: optional device int32 (M,) row indices, the rest anywhere."""
+        K = x.shape[1]
+        M = int(rows.shape[0]) if rows is not None else x.shape[0]
+        N = w.shape[0]
+        out = torch.empty(M, N, dtype=torch.float32, device=self.device)
+        h = lambda t: np.ascontiguousarray(t.detach().cpu().numpy(), dtype=np.float32)
+        wh, gh, bh = h(w), h(ln_g), h(ln_b)
+        bias_h = h(bias) if bias is not None else None
+        vp = lambda a: a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+        self._check(self.lib.nuhtc_op_ln_gemm(self.h, x.data_ptr(), rows.data_ptr() if rows is not None else None, vp(wh), vp(bias_h), vp(gh), vp(bh),
+                                              out.data_ptr(), M, N, K, act, self._stream()))
+        return out
+
     def op_swin_mlp(self, x, ln_g, ln_b, w1, b1, w2, b2):
         """x + W2 gelu(W1 LN(x) + b1) + b2 by the fused FFN kernel (csrc/mlp.hip); x (T, C) and the vectors on the device, w1 / w2 anywhere."""
         T, C = x.shape

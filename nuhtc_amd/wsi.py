@@ -81,6 +81,41 @@ class PackedMasks:
         return PackedMasks(b, self.areas[keep], self.bits[idx] if len(idx) else np.zeros(0, np.uint32), new_off)
 
 
+class RaggedRings:
+    """The closed rings of a slide's records as ONE vertex array: ring i = flat[off[i]:off[i + 1]] ((n_i, 2) int64, a view).  Stands in for
+    the list of per-record arrays (len(), indexing, iteration); a padded (records, longest ring, 2) array of a 10 000-tile slide was
+    a quarter of a gigabyte that the loop's last step had to assemble while the GPU idled."""
+
+    def __init__(self, flat, ring_n):
+        self.flat = flat
+        self.n = np.asarray(ring_n, np.int64)
+        self.off = np.concatenate([[0], np.cumsum(self.n)]).astype(np.int64)
+
+    def __len__(self):
+        return len(self.n)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        i = int(i)
+        if i < 0:
+            i += len(self)
+        return self.flat[self.off[i]:self.off[i + 1]]
+
+    def __iter__(self):
+        return (self.flat[self.off[i]:self.off[i + 1]] for i in range(len(self)))
+
+    def take(self, keep):
+        """-> (vertices of the rings `keep`, concatenated; their lengths)."""
+        keep = np.asarray(keep, np.int64)
+        n = self.n[keep]
+        if len(keep) == len(self) and (len(keep) == 0 or (keep == np.arange(len(self))).all()):
+            return self.flat, n
+        new_off = np.cumsum(n) - n
+        idx = np.arange(int(n.sum()), dtype=np.int64) + np.repeat(self.off[keep] - new_off, n)
+        return self.flat[idx], n
+
+
 def _unpack_packed(eng, g, i0, coords, parts):
     """Vectorised twin of _unpack for a batch exported with device crops (Engine.export_async -> nuhtc_export_crops): appends one
     dict of arrays (the batch's records in the order _unpack produces) to `parts`."""
@@ -112,25 +147,35 @@ def _unpack_packed(eng, g, i0, coords, parts):
                 m = eng.export_full_mask(int(k))[y0:y1, x0:x1]
                 chunks.append(pack_masks([(m, 0, 0)])[2])
         bits = np.concatenate(chunks)
+    # closed rings in slide coordinates, ragged: ring k has cn[k] traced vertices + its first vertex again (mask2inst closes the ring,
+    # tools/infer_wsi.py:51-58); one gather from the export's (records, capacity, 2) vertex block
     cn = g['cn'][order].astype(np.int64)
-    ccap = g['xy'].shape[1]
-    xy = np.zeros((len(order), ccap + 1, 2), np.int64)
-    xy[:, :ccap] = g['xy'][order]
+    hosted = {}
     for j in np.flatnonzero(cn <= 0):                                     # contour over the device capacities: host mirror on the crop
         x0, y0, x1, y1 = cb[j]
         wpr = (x1 - x0 + 31) // 32
         o = int(np.cumsum(sizes)[j] - sizes[j])
         m = np.unpackbits(bits[o:o + sizes[j]].reshape(y1 - y0, wpr).view(np.uint8), axis=-1, bitorder='little')[:, :x1 - x0].astype(bool)
-        c = host.trace_outer_contour(m) + np.array([x0, y0], np.int64)
-        if len(c) + 1 > xy.shape[1]:
-            xy = np.concatenate([xy, np.zeros((len(order), len(c) + 1 - xy.shape[1], 2), np.int64)], 1)
-        xy[j, :len(c)] = c
-        cn[j] = len(c)
-    xy[np.arange(len(order)), cn] = xy[:, 0]                              # mask2inst closes the ring (tools/infer_wsi.py:51-58)
-    xy += org[:, None, :]
+        hosted[int(j)] = host.trace_outer_contour(m) + np.array([x0, y0], np.int64)
+        cn[j] = len(hosted[int(j)])
+    ring_n = cn + 1
+    off = np.cumsum(ring_n) - ring_n
+    total = int(ring_n.sum())
+    rec_of = np.repeat(np.arange(len(order)), ring_n)
+    pos = np.arange(total, dtype=np.int64) - np.repeat(off, ring_n)
+    pos[pos == np.repeat(cn, ring_n)] = 0                                 # the closing vertex is the first one
+    dev_ok = np.ones(len(order), bool)
+    dev_ok[list(hosted)] = False
+    sel = dev_ok[rec_of]
+    flat = np.zeros((total, 2), np.int64)
+    flat[sel] = g['xy'][order[rec_of[sel]], pos[sel]]
+    for j, c in hosted.items():
+        flat[off[j]:off[j] + cn[j]] = c
+        flat[off[j] + cn[j]] = c[0]
+    flat += org[rec_of]
     parts.append(dict(tile=i0 + tile[order], box=boxes[order, :4].astype(np.float64) + org4, score=boxes[order, 4].astype(np.float64),
                       label=labels[order].astype(np.int64), crop_box=(cb + org4).astype(np.int32), area=g['crop_area'][order].astype(np.int32),
-                      bits=bits, sizes=sizes, ring_n=cn + 1, ring_xy=xy))
+                      bits=bits, sizes=sizes, ring_n=ring_n, ring_flat=flat))
 
 
 def _records_from_parts(parts):
@@ -143,11 +188,9 @@ def _records_from_parts(parts):
     sizes = cat('sizes')
     off = (np.cumsum(sizes) - sizes).astype(np.int64)
     masks = PackedMasks(cat('crop_box'), cat('area'), cat('bits'), off)
-    width = max(p['ring_xy'].shape[1] for p in parts)
-    ring_xy = np.concatenate([np.pad(p['ring_xy'], ((0, 0), (0, width - p['ring_xy'].shape[1]), (0, 0))) for p in parts], 0)
-    rec = dict(tile=tile.tolist(), box=list(box), score=score.tolist(), label=label.tolist(), mask=masks,
-               ring=[ring_xy[i, :ring_n[i]] for i in range(len(tile))])
-    masks.arrays = dict(tile=tile, box=box, score=score, label=label, ring_n=ring_n, ring_xy=ring_xy)   # the scalar fields as whole-slide arrays
+    rings = RaggedRings(cat('ring_flat'), ring_n)
+    rec = dict(tile=tile.tolist(), box=list(box), score=score.tolist(), label=label.tolist(), mask=masks, ring=rings)
+    masks.arrays = dict(tile=tile, box=box, score=score, label=label, rings=rings)   # the scalar fields as whole-slide arrays
     return rec
 
 
@@ -253,18 +296,16 @@ def _part_from_lists(rec):
     cb, area, bits, off = pack_masks(rec['mask'])
     sizes = (cb[:, 3] - cb[:, 1]).astype(np.int64) * ((cb[:, 2] - cb[:, 0] + 31) // 32)
     ring_n = np.array([len(r) for r in rec['ring']], np.int64)
-    ring_xy = np.zeros((n, int(ring_n.max()), 2), np.int64)
-    for i, r in enumerate(rec['ring']):
-        ring_xy[i, :len(r)] = r
+    ring_flat = np.concatenate([np.asarray(r, np.int64).reshape(-1, 2) for r in rec['ring']], 0) if n else np.zeros((0, 2), np.int64)
     return dict(tile=np.asarray(rec['tile'], np.int64), box=np.stack(rec['box']).astype(np.float64), score=np.asarray(rec['score'], np.float64),
                 label=np.asarray(rec['label'], np.int64), crop_box=cb.astype(np.int32), area=area.astype(np.int32),
-                bits=bits[:int(sizes.sum())], sizes=sizes, ring_n=ring_n, ring_xy=ring_xy)
+                bits=bits[:int(sizes.sum())], sizes=sizes, ring_n=ring_n, ring_flat=ring_flat)
 
 
 def _extend(rec, more):
     """Append the records `more` to the list-form record dict `rec` (mask crops decoded)."""
     for k in ('tile', 'box', 'score', 'label', 'ring'):
-        rec[k].extend(more[k])
+        rec[k].extend(list(more[k]))
     rec['mask'].extend(list(more['mask']))
 
 
@@ -348,10 +389,10 @@ def pack_records(rec, keep=None, tile_base=0, rles=None):
         kp = np.arange(len(a['score']), dtype=np.int64) if keep is None else np.asarray(list(keep), np.int64)
         n = len(kp)
         head = np.zeros((n, 9), np.float64)
-        head[:, :4], head[:, 4], head[:, 5], head[:, 6], head[:, 7] = a['box'][kp], a['score'][kp], a['label'][kp], a['ring_n'][kp], tile_base + a['tile'][kp]
+        vflat, vn = a['rings'].take(kp)
+        head[:, :4], head[:, 4], head[:, 5], head[:, 6], head[:, 7] = a['box'][kp], a['score'][kp], a['label'][kp], vn, tile_base + a['tile'][kp]
         head[:, 8] = [len(r) for r in rles] if rles else 0
-        rx = a['ring_xy'][kp]
-        verts = rx[np.arange(rx.shape[1])[None, :] < a['ring_n'][kp][:, None]].astype(np.int32).reshape(-1, 2)
+        verts = vflat.astype(np.int32).reshape(-1, 2)
         m = rec['mask'].subset(kp)
         crops = np.concatenate([m.boxes.astype(np.int64), m.areas[:, None].astype(np.int64), m.off[:, None]], 1) if n else np.zeros((0, 6), np.int64)
         blob = np.frombuffer(b''.join(rles), np.uint8).copy() if rles else np.zeros(0, np.uint8)

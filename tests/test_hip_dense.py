@@ -91,6 +91,40 @@ def test_split_bf16_pipe_is_fp32_arithmetic(hip_device):
             assert e['split'][0] <= (3e-6 if wide else 4e-7), (wide, M, N, K, e)
 
 
+def test_ln_gemm_kernel_vs_fp64(hip_device):
+    """LayerNorm in the A path of the linear behind it (round 5: gemm.hip A_LN + swin.hip ln_stats_kernel; the QKV and fc1 linears of Swin
+    stages 2-4, mmdet swin.py:358,365) against an fp64 reference of LN-then-linear, beside the two-kernel form it replaces (fp32
+    LayerNorm by torch, then the split GEMM): every shape class of the path (K = C = 192 / 384 / 768, N = 3C and 4C, identity and
+    gathered rows, GELU), rows with a large common offset (|mean| = 50 sigma: the subtraction happens BEFORE the product, so nothing
+    cancels), and a row count that is not a multiple of the tile."""
+    g = G.load('small_b2')
+    eng, _ = _engine(g)
+    gen = torch.Generator().manual_seed(11)
+    for (T, M, N, K, act, offset) in [(512, None, 576, 192, 0, 0.0), (1000, 777, 768, 192, 2, 0.0), (256, None, 1152, 384, 0, 50.0),
+                                      (300, 300, 1536, 384, 2, 0.0), (130, None, 2304, 768, 0, 3.0), (256, 200, 3072, 768, 2, 50.0),
+                                      (66000, None, 576, 192, 0, 0.0)]:
+        x = torch.randn(T, K, generator=gen) * (1.0 + torch.rand(T, 1, generator=gen)) + offset * torch.randn(T, 1, generator=gen).sign()
+        w = torch.randn(N, K, generator=gen) / K ** 0.5
+        b = torch.randn(N, generator=gen) * 0.1
+        lg = 1.0 + 0.2 * torch.randn(K, generator=gen)
+        lb = 0.1 * torch.randn(K, generator=gen)
+        rows = torch.randperm(T, generator=gen)[:M].to(torch.int32) if M is not None else None
+        xs = x[rows.long()] if rows is not None else x
+        xd = xs.double()
+        y = (xd - xd.mean(1, keepdim=True)) / (xd.var(1, unbiased=False, keepdim=True) + 1e-5).sqrt() * lg.double() + lb.double()
+        ref = y @ w.double().T + b.double()
+        if act == 2:
+            ref = torch.nn.functional.gelu(ref)
+        mag = y.abs() @ w.double().abs().T + b.double().abs()
+        out = eng.op_ln_gemm(x.cuda(), w, b, lg, lb, rows.cuda() if rows is not None else None, act).cpu().double()
+        two = eng.op_gemm(torch.nn.functional.layer_norm(xs, (K,), lg, lb, 1e-5).cuda(), w.cuda(), b.cuda(), act, pipe='split').cpu().double()
+        e1, e2 = ((out - ref).abs() / mag), ((two - ref).abs() / mag)
+        print(f'T{T} M{M} N{N} K{K} act{act} offset{offset}: A_LN max {float(e1.max()):.2e} rms {float((e1 ** 2).mean().sqrt()):.2e} | LN kernel + GEMM max {float(e2.max()):.2e} rms {float((e2 ** 2).mean().sqrt()):.2e}')
+        assert torch.isfinite(out).all()
+        assert float((e1 ** 2).mean().sqrt()) <= 1.5 * float((e2 ** 2).mean().sqrt()) + 2e-8, (T, M, N, K)
+        assert float(e1.max()) <= (2e-5 if offset >= 50 else 2e-6), (T, M, N, K, float(e1.max()))
+
+
 @pytest.mark.parametrize('case', ['small_b2', 'small_wsi_b3', 'full_b1', 'five_b2'])
 def test_dense_stages_vs_oracle_and_golden(hip_device, case):
     from oracle import model as O

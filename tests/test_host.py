@@ -236,7 +236,7 @@ def test_packed_masks_behave_like_the_crop_list():
     rec_list = dict(tile=list(range(n)), box=[rng.random(4) * 6000 for _ in range(n)], score=rng.random(n).tolist(), label=rng.integers(0, 5, n).tolist(),
                     mask=crops, ring=[ring_xy[i, :ring_n[i]] for i in range(n)])
     pm.arrays = dict(tile=np.arange(n), box=np.stack(rec_list['box']), score=np.array(rec_list['score']), label=np.array(rec_list['label']),
-                     ring_n=ring_n, ring_xy=ring_xy)
+                     rings=wsi.RaggedRings(np.concatenate([ring_xy[i, :ring_n[i]] for i in range(n)], 0), ring_n))
     rec_packed = dict(rec_list, mask=pm)
     for kp in (None, keep):
         for a, b in zip(wsi.pack_records(rec_packed, kp, tile_base=7), wsi.pack_records(rec_list, kp, tile_base=7)):

@@ -9,6 +9,7 @@ from nuhtc_amd.engine import Engine
 ap = argparse.ArgumentParser()
 ap.add_argument('name'); ap.add_argument('values', nargs='+', type=int)
 ap.add_argument('--rounds', type=int, default=12); ap.add_argument('--steps', type=int, default=10)
+ap.add_argument('--tags', default='gemm', help='comma-separated tag prefixes whose launch times are summed per setting')
 args = ap.parse_args()
 eng = Engine(weights.bench_state_dict(), device=0, max_batch=16, tile=(256, 256))
 tiles = eng.to_device(synth.nuclei_tiles(16, 256))
@@ -31,5 +32,5 @@ for v in args.values:
     p = hip.profile_read(); hip.profile_enable(False)
     g = {}
     for k, x in p.items():
-        if k.startswith('gemm'): g[k.split('|')[0]] = g.get(k.split('|')[0], 0) + x['ms'] / 3
-    print(f'  {args.name}={v}: gemm tags', {k: round(x, 3) for k, x in sorted(g.items())}, 'sum', round(sum(g.values()), 3))
+        if any(k.startswith(t) for t in args.tags.split(',')): g[k.split('|')[0]] = g.get(k.split('|')[0], 0) + x['ms'] / 3
+    print(f'  {args.name}={v}: tags', {k: round(x, 3) for k, x in sorted(g.items())}, 'sum', round(sum(g.values()), 3))
