@@ -7,7 +7,10 @@ tiles/s); two identical chains started together stay in phase and gain nothing. 
 that copy blocks the submitting thread for ≈ 4 ms per batch, but staging through pinned buffers made the slide loop twice as slow
 (the CPU writes 3 MB into pinned memory at ≈ 0.5 GB/s, and with the host running ahead the copies of four streams got in the way of
 the kernels: 1431 -> 688 tiles/s; a staging buffer of ordinary memory page-locked with hipHostRegister: 613; the pageable copy on
-an idle per-slot copy stream: 1223), so the plain copy on the slot's stream stays.
+an idle per-slot copy stream: 1223), so the plain copy on the slot's stream stays.  Round 5 measured it once more with a ring of
+page-locked buffers per slot allocated ONCE (per_slot + 1 host and device buffers, host copy into the ring, asynchronous copy on the
+slot's stream, submit() never waiting for the GPU): 781-916 against 1859-1869 tiles/s on a 3600-tile slide, 896 against 1950 on the
+10 000-tile slide (profiles/r05_upload_ab.txt) -- the host's copy INTO page-locked memory takes 12-16 ms per 3 MB batch on these hosts.
 
 Round 3: the engines of a pipeline run the throughput schedule (include/nuhtc_hip.h: one stream per engine, 256-row tiles), and a
 slot holds up to two exported batches (see EnginePipeline.per_slot): with one batch per slot the batches in flight finish together
