@@ -602,12 +602,21 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void gemm_split_kernel
     u32x4 (&P_)[3] = PP_[mi];                                                                                  \
     const float x = (i_) == 0 ? a_lo[mi].x : (i_) == 1 ? a_lo[mi].z : (i_) == 2 ? a_hi[mi].x : a_hi[mi].z;     \
     const float y = (i_) == 0 ? a_lo[mi].y : (i_) == 1 ? a_lo[mi].w : (i_) == 2 ? a_hi[mi].y : a_hi[mi].w;     \
+    S_SPLIT_BODY(P_, i_, x, y)                                                                                 \
+  }
+#ifdef NUHTC_GEMM_PROBE_NOSPLIT   // dev probe (wrong results): the A operand's three-way split left out of the k-loop -- the most a producer-side split could give the consumer
+#define S_SPLIT_BODY(P_, i_, x, y)                                                                             \
+  { P_[0][(i_)] = __float_as_uint(x); P_[1][(i_)] = __float_as_uint(y); P_[2][(i_)] = __float_as_uint(x) ^ __float_as_uint(y); }
+#else
+#define S_SPLIT_BODY(P_, i_, x, y)                                                                             \
+  {                                                                                                            \
     const unsigned w1 = pk_bf16_rn(x, y);                                                                      \
     const float rx = x - __uint_as_float(w1 << 16), ry = y - __uint_as_float(w1 & 0xffff0000u);                \
     const unsigned w2 = pk_bf16_rn(rx, ry);                                                                    \
     const float sx = rx - __uint_as_float(w2 << 16), sy = ry - __uint_as_float(w2 & 0xffff0000u);              \
     P_[0][(i_)] = w1; P_[1][(i_)] = w2; P_[2][(i_)] = pk_bf16_rn(sx, sy);                                      \
   }
+#endif
 #define S_LOAD_ONE(f_, kt_)                                                                                   \
   {                                                                                                            \
     if ((f_) < NA) {                                                                                           \
@@ -709,6 +718,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void gemm_split_kernel
 #undef S_LOAD_ONE
 #undef S_STORE_ONE
 #undef S_SPLIT_PAIR
+#undef S_SPLIT_BODY
 #undef S_READ_A
 #undef S_READ_B
   __syncthreads();
@@ -916,6 +926,8 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
 const char* nuhtc_tu_probe_gemm() {
 #ifdef NUHTC_GEMM_NOSTORE
   return "NUHTC_GEMM_NOSTORE";
+#elif defined(NUHTC_GEMM_PROBE_NOSPLIT)
+  return "NUHTC_GEMM_PROBE_NOSPLIT";
 #else
   return nullptr;
 #endif
