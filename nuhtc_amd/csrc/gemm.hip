@@ -806,10 +806,15 @@ template <int MT, int NT>
 static void launch_split(const GemmParams& q, hipStream_t s) {
   const int mtiles = cdiv(q.M, 128 * MT);
   dim3 grid(cdiv(mtiles, 8) * 8 * (q.N / (32 * NT)), 1, q.batch > 0 ? q.batch : 1);
-  if (q.amode == A_CONV3) hipLaunchKernelGGL((gemm_split_kernel<MT, NT, A_CONV3>), grid, dim3(256), 0, s, q);
+  // dev: dynamic LDS the kernel never touches (NUHTC_GEMM_LDS_PAD bytes): caps the workgroups of this kernel per CU below what its
+  // registers allow, which leaves register and LDS room on every CU for OTHER kernels' workgroups (the memory-bound kernels of the
+  // batches in flight) instead of a third GEMM workgroup
+  static const int& lds_pad = dev_knob_ref("GEMM_LDS_PAD", 0);
+  const unsigned pad = (unsigned)lds_pad;
+  if (q.amode == A_CONV3) hipLaunchKernelGGL((gemm_split_kernel<MT, NT, A_CONV3>), grid, dim3(256), pad, s, q);
   else if (q.amode == A_LN) {
-    if constexpr (NT == 3) hipLaunchKernelGGL((gemm_split_kernel<MT, NT, A_LN>), grid, dim3(256), 0, s, q);   // launch_gemm admits A_LN for 96-column tiles only
-  } else hipLaunchKernelGGL((gemm_split_kernel<MT, NT, A_PLAIN>), grid, dim3(256), 0, s, q);
+    if constexpr (NT == 3) hipLaunchKernelGGL((gemm_split_kernel<MT, NT, A_LN>), grid, dim3(256), pad, s, q);   // launch_gemm admits A_LN for 96-column tiles only
+  } else hipLaunchKernelGGL((gemm_split_kernel<MT, NT, A_PLAIN>), grid, dim3(256), pad, s, q);
 }
 
 bool conv3_fuse_available() {
