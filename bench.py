@@ -742,6 +742,13 @@ def main():
         }
         if roi_load:
             out['real_slide_roi_load'] = roi_load
+            if 'in_flight' in roi_load:
+                # first-class beside `value`: the synthetic weights' RoIs are ~20 px, nuclei of a real 40x slide give 40-100 px RoIs after
+                # the x2 resize, and the RoI stage is the one part of the path whose cost follows the data -- THIS is the PanNuke-like rate
+                out['value_real_slide_roi_load'] = {'value': roi_load['in_flight']['value'], 'unit': 'tiles/s', 'ms_per_step': roi_load['in_flight']['ms_per_step'],
+                                                    'batches_in_flight': roi_load['in_flight']['batches_in_flight'],
+                                                    'workload': '1064 given RoIs of 40-100 network px and 64 detections per tile, same step, same engines in flight as `value`',
+                                                    'ratio_to_value': roi_load['in_flight']['value'] / (total_tiles / dt)}
         if fp32_pipe:
             out['fp32_mfma_pipe'] = fp32_pipe
         if sequential:
