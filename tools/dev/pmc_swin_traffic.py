@@ -2,7 +2,7 @@
     pmc_swin_traffic.py '<glob>' <steps in the profiled run> <tiles per step>"""
 import csv, glob, re, sys, collections
 steps, tiles = int(sys.argv[2]), int(sys.argv[3])
-SWIN = re.compile(r'gemm_split_kernel<[12], 3, 0>|swin_mlp_kernel|swin_lnqkv_kernel|qkv_pad_rows|layernorm|window_attn|merge_ln|patch_embed')
+SWIN = re.compile(r'gemm_split_kernel<[12], 3, [02]>|swin_mlp_kernel|swin_lnqkv_kernel|qkv_pad_rows|layernorm|ln_stats|window_attn|merge_ln|patch_embed')
 rd = collections.defaultdict(float); wr = collections.defaultdict(float)
 for f in glob.glob(sys.argv[1], recursive=True):
     for row in csv.DictReader(open(f)):
