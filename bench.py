@@ -240,21 +240,8 @@ class PowerLog:
 def self_launch(n):
     """Run this script as `n` ranks (one per GPU) under torch.distributed.run as a CHILD process and relay its output: the JSON line
     of rank 0 goes to stdout, everything else to stderr.  Returns the job's exit code.  Nothing here initialises the GPU."""
-    import socket
-    import subprocess
-    with socket.socket() as sk:
-        sk.bind(('127.0.0.1', 0))
-        port = sk.getsockname()[1]
-    env = dict(os.environ)
-    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // n)))
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    for line in p.stdout:
-        (sys.stdout if line.startswith('{"metric"') else sys.stderr).write(line)
-        sys.stdout.flush()
-    return p.wait()
+    from nuhtc_amd import parallel
+    return parallel.self_launch(n, __file__, sys.argv[1:], relay=lambda line: sys.stdout if line.startswith('{"metric"') else sys.stderr)
 
 
 def main():

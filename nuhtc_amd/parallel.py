@@ -22,6 +22,24 @@ def _free_port():
         return sk.getsockname()[1]
 
 
+def self_launch(n, script, argv, relay=None):
+    """Run `script argv` as `n` ranks (one per GPU) under torch.distributed.run as a CHILD process -- never an exec, and before anything in
+    the caller has touched the GPU -- and return the job's exit code.  `relay(line)` decides where each output line goes (default: stdout).
+    The reference's launcher is the same command typed by hand (tools/dist_test.sh -> torch.distributed.launch)."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(script)] + list(argv)
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in p.stdout:
+        (relay(line) if relay else sys.stdout).write(line)
+        sys.stdout.flush()
+    return p.wait()
+
+
 def init_from_env(backend=None):
     """One process per GPU, launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
     world = int(os.environ.get('WORLD_SIZE', 1))

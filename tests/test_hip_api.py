@@ -492,10 +492,19 @@ def test_infer_wsi_two_ranks_equal_one_rank_byte_for_byte(hip_device, tmp_path):
     print(out.stdout[-2000:])
     assert out.returncode == 0
     assert '48 tiles on 2 rank(s)' in out.stdout
+    # `--gpus 2` without a launcher: the tool starts its own ranks ("add --gpus N")
+    env = _two_rank_env()
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    out2 = subprocess.run([sys.executable] + common + ['--save_dir', str(tmp_path / 'self'), '--gpus', '2'], env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.STDOUT, text=True)
+    print(out2.stdout[-1500:])
+    assert out2.returncode == 0 and '48 tiles on 2 rank(s)' in out2.stdout
     for f in ('slide.geojson', 'slide_point.geojson', 'slide_merged.geojson'):
         a = open(tmp_path / 'one/nuclei/slide' / f, 'rb').read()
         b = open(tmp_path / 'two/nuclei/slide' / f, 'rb').read()
-        assert len(a) > 1000 and a == b, f
+        c = open(tmp_path / 'self/nuclei/slide' / f, 'rb').read()
+        assert len(a) > 1000 and a == b == c, f
 
 
 def test_rccl_branch_of_the_exchange_on_one_gpu(hip_device):

@@ -67,6 +67,7 @@ def build_parser():
     # ---- not in the reference
     p.add_argument('--seg_downsample', type=int, default=64, help='downsample of the (virtual) pyramid level seg_level / vis_level -1 resolve to (reference: the level nearest 64x)')
     p.add_argument('--coords', default=None, help="coordinate file of a single .npy slide: .npy (N,2) or .npz with `coords` [+ `patch_size`] -- the role of the reference's patches/<id>.h5")
+    p.add_argument('--gpus', type=int, default=1, help='one rank per GPU: the tool starts itself N times under torch.distributed.run (a child process) unless a launcher already did')
     p.add_argument('--merge', action='store_true', help='also run the cross-tile merge (tools/nuclei_merge.py) on rank 0 -> <id>_merged.geojson')
     p.add_argument('--overlap_threshold', type=float, default=0.05)
     return p
@@ -179,10 +180,15 @@ def main(argv=None):
         raise SystemExit('--save_dir is required (the reference joins it with "patches" / "masks" / "stitches" at once, :360-362)')
     if args.mode not in ('qupath', 'dsa', 'coco', 'sql', 'all'):
         raise SystemExit(f'--mode {args.mode}: one of qupath, dsa, coco, sql, all')
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:      # no launcher: become one (before anything here touches the GPU)
+        from nuhtc_amd import parallel
+        raise SystemExit(parallel.self_launch(args.gpus, __file__, sys.argv[1:] if argv is None else argv))
     import torch
     from nuhtc_amd import parallel, slides, tilestore
     from nuhtc_amd.apis import init_detector
     rank, local_rank, world = parallel.init_from_env()
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     say = print if rank == 0 else (lambda *a, **k: None)
     if args.async_test:
         say('--async-test: accepted; the reference never reads it in this tool either')
