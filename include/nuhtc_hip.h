@@ -229,13 +229,21 @@ int nuhtc_op_gemm(nuhtc_engine* e, const float* A, const float* W, const float* 
  * split of a constant weight is made on the host, as at nuhtc_finalize).  Synchronises `stream`. */
 int nuhtc_op_gemm_split(nuhtc_engine* e, const float* A, const float* W_dev, const float* W_host, const float* bias, float* C, int M,
                         int N, int K, int act, void* stream);
-/* ABI v8 (round 5).  A linear behind a LayerNorm with the norm in the product's A path (csrc/gemm.hip A_LN + csrc/swin.hip ln_stats_kernel; what the
- * QKV and fc1 linears of Swin stages 2-4 run: mmdet swin.py:358,365): C[M,N] = act(LN(X[rows[m]])[M,K] * W[N,K]^T + bias[N]) with
- * LN = LayerNorm(K, eps 1e-5, ln_g, ln_b).  W, bias, ln_g, ln_b are HOST arrays (the norm's affine part is folded into the linear on the
- * host exactly as nuhtc_finalize folds it: W' = W diag(ln_g) rounded once to fp32 and split exactly, bias' = bias + W ln_b in fp64); X and
- * `rows` (device int32 [M], or NULL for the identity) are device memory.  N % 96 == 0, K % 32 == 0.  Synchronises `stream`. */
-int nuhtc_op_ln_gemm(nuhtc_engine* e, const float* X_dev, const int* rows_dev, const float* W_host, const float* bias_host, const float* ln_g_host,
+/* ABI v8 (round 5).  A linear behind a LayerNorm with the norm in the product's A path (csrc/gemm.hip A_LN; what the QKV and fc1 linears of
+ * Swin stages 2-4 run: mmdet swin.py:358,365): C[M,N] = act(LN(X[rows[m]])[M,K] * W[N,K]^T + bias[N]) with LN = LayerNorm(K, eps 1e-5,
+ * ln_g, ln_b).  W, bias, ln_g, ln_b are HOST arrays (the norm's affine part is folded into the linear on the host exactly as nuhtc_finalize
+ * folds it: W' = W diag(ln_g) rounded once to fp32 and split exactly, bias' = bias + W ln_b in fp64); X [T][K] and `rows` (device int32 [M]
+ * indices into X, or NULL for the identity with M <= T) are device memory.  The row statistics come from ln_stats_kernel (csrc/swin.hip).
+ * N % 96 == 0, K % 32 == 0.  Synchronises `stream`. */
+int nuhtc_op_ln_gemm(nuhtc_engine* e, const float* X_dev, int T, const int* rows_dev, const float* W_host, const float* bias_host, const float* ln_g_host,
                      const float* ln_b_host, float* C_dev, int M, int N, int K, int act, void* stream);
+/* The same linear fed the way the engine feeds it: a producer product Y[row_map(m)] = A[M,Kp] * Wp[K,Kp]^T + bp (+ res[row_map(m)]) whose
+ * epilogue leaves, per row and 96 columns, {mean, sum of squared deviations} of what it stored (GemmParams.stats_out), and the A_LN linear
+ * C = act(LN(Y) * W^T + bias) that merges those partials -- no pass over Y computes statistics.  Y_dev [M][K] and C_dev [M][N] are outputs;
+ * row_map_dev (device int32 [M], a permutation of 0..M-1) and res_dev ([M][K]) may be NULL.  K % 96 == 0, N % 96 == 0.  Synchronises `stream`. */
+int nuhtc_op_gemm_ln_gemm(nuhtc_engine* e, const float* A_dev, const float* Wp_host, const float* bp_host, const float* res_dev, const int* row_map_dev,
+                          const float* W_host, const float* bias_host, const float* ln_g_host, const float* ln_b_host, float* Y_dev, float* C_dev, int M,
+                          int Kp, int K, int N, int act, void* stream);
 /* The fused FFN half of a Swin block (csrc/mlp.hip; mmdet swin.py:365-367): out[T,C] = x + W2 gelu(W1 LN(x) + b1) + b2 with
  * LN = LayerNorm(C, eps 1e-5, ln_g, ln_b), W1 [4C][C], W2 [C][4C] given as HOST arrays (packed like nuhtc_finalize packs them),
  * everything else device memory.  C must be a width the fused kernel serves (96).  Synchronises `stream`. */

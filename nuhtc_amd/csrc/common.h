@@ -96,12 +96,24 @@ struct GemmParams {
   const int* m_dev;    // optional device-side row count (rows >= min(M, *m_dev * m_mul) are skipped)
   int m_mul;
   int amode;
-  // A_LN (split pipe only): row m of the product is LayerNorm(A[a_rows ? a_rows[m] : m]) with the affine part folded into W and bias by
-  // the caller (W' = W diag(gamma), bias' = bias + W beta): the loader subtracts ln_stats[2m] (the row's mean) from every element it
-  // stages and the epilogue multiplies the row's sums by ln_stats[2m + 1] (its 1 / sqrt(var + eps)) before the bias -- the normalised
-  // rows never exist in memory.  ln_stats comes from launch_ln_stats (swin.hip).
-  const float* ln_stats;
+  // A_LN (split pipe only): row m of the product is LayerNorm(A[src]), src = a_rows ? a_rows[m] : m, with the affine part folded into W and
+  // bias by the caller (W' = W diag(gamma), bias' = bias + W beta): the loader subtracts the row's mean from every element it stages and the
+  // epilogue multiplies the row's sums by its 1 / sqrt(var + eps) before the bias -- the normalised rows never exist in memory.  The
+  // statistics come as `ln_nparts` partials per SOURCE row, ln_part[(src * ln_nparts + t) * 2 + {0, 1}] = {mean, sum of squared deviations}
+  // of 1 / ln_nparts of the row's K elements each (launch_ln_stats: one partial; a producer GEMM's epilogue: one per 96 columns, see
+  // stats_out), merged in order with the pairwise-update formula by the workgroup that stages the row.
+  const float* ln_part;
+  int ln_nparts;
   const int* a_rows;
+  // A_LN: `n_pad` rows `pad_rows` of C (row pitch ldc) are filled with pad_val[0..N) by extra workgroups of the launch (the window-padding
+  // rows of the QKV image, whose value is the ORIGINAL bias: LN of a zero-padded token is 0)
+  const int* pad_rows;
+  int n_pad;
+  const float* pad_val;
+  // producer side (split pipe, N % 96 == 0): besides storing C the epilogue leaves, per destination row and 96-column tile,
+  // stats_out[(row * (N / 96) + tile) * 2 + {0, 1}] = {mean, sum of squared deviations} of the 96 values it stored -- the partials the
+  // LayerNorm of the NEXT linear's A path needs (round 5: no statistics pass over the tensor at all)
+  float* stats_out;
   int cH, cW, cC;      // A_CONV3: NHWC image geometry (rows = b*cH*cW + y*cW + x), K = 9*cC
   const float* zeros;  // A_CONV3: >= 16 bytes of zeros that out-of-image taps read (launch_gemm supplies one when null)
   int act;
@@ -176,11 +188,10 @@ int launch_patch_embed(const float* img, const float* w, const float* b, const f
                        int B, int Hn, int Wn, hipStream_t s);
 // LayerNorm of `rows` rows of C channels: dst row m reads src row src_map[m] (or m when src_map==null); src_map[m]<0 -> zeros
 int launch_layernorm(const float* x, const int* src_map, const float* g, const float* b, float* y, int rows, int C, hipStream_t s);
-// per-row LayerNorm statistics for a product in A_LN mode: stats[2m] = mean, stats[2m + 1] = 1 / sqrt(var + 1e-5) of row src_rows[m] (or m) of
-// x, computed exactly like layernorm_kernel computes them (same loads, same summation order); the `n_pad` rows `pad_rows` of the window
-// QKV image are filled with pad_val[0..3C) on the way (pad_rows null: nothing to fill)
-int launch_ln_stats(const float* x, const int* src_rows, float* stats, int rows, int C, float* pad_dst, const int* pad_rows, int n_pad,
-                    const float* pad_val, hipStream_t s);
+// per-row LayerNorm statistics for a product in A_LN mode, as ONE partial per row (GemmParams.ln_part with ln_nparts = 1):
+// stats[2r] = mean, stats[2r + 1] = sum of squared deviations of row r of x (rows [0, rows)), computed with the loads, the two passes and
+// the summation order of layernorm_kernel.  Stand-alone op and dev fallback: in the engine the producer GEMM's epilogue leaves the partials.
+int launch_ln_stats(const float* x, float* stats, int rows, int C, hipStream_t s);
 // LN1 of a Swin block over the `rows` window rows: row r with src_map[r] >= 0 is normalised into y[dst_map[r]] (the compact,
 // padding-free window order); a padding row writes pad_val[0..3C) (the QKV bias) into pad_dst[r] (the window QKV image).
 int launch_layernorm_windows(const float* x, const int* src_map, const int* dst_map, const float* g, const float* b, float* y,

@@ -65,7 +65,8 @@ struct nuhtc_engine {
 
   // workspace
   float *img, *tokA, *tokB, *xw, *qkv, *att, *hid;
-  float* ln_stats = nullptr;   // [max_batch * tokens of stage 2][2]: mean, 1 / sqrt(var + eps) of the rows of the norm that rides in the next linear (A_LN)
+  float* ln_part = nullptr;    // LayerNorm partials of the current token tensor, [token][C / 96][2] = {mean, sum of squared deviations} per 96 channels:
+                               // written by the epilogue of the GEMM that produced the tensor (proj, fc2, patch merging), read by the next A_LN linear
   float *c[4], *lat[4], *x[4], *rpn[4], *semg[4];
   float *tmpA, *tmpB, *tmpR, *sem_feat, *sem_pred, *x0sem;   // tmpR: RPN conv output (side stream)
   // proposals / roi path

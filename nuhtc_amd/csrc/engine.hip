@@ -534,7 +534,7 @@ int nuhtc_finalize(nuhtc_engine* e) {
       (rc = ws(e, &e->xw, nullptr, {B, (int64_t)max_win}, 0)) || (rc = ws(e, &e->qkv, nullptr, {B, (int64_t)max_qkv}, 0)) ||
       (rc = ws(e, &e->att, nullptr, {B, (int64_t)max_win}, 0)) || (rc = ws(e, &e->hid, nullptr, {B, (int64_t)std::max(max_hid, max_qkv)}, 0)))
     return rc;
-  if ((rc = ws(e, &e->ln_stats, nullptr, {B, (int64_t)e->st[0].H * e->st[0].W, 2}, 0))) return rc;
+  if ((rc = ws(e, &e->ln_part, nullptr, {B, (int64_t)e->st[1].H * e->st[1].W, 8}, 0))) return rc;     // rows x (C / 96) x 2 is the same in stages 2-4
   for (int s = 0; s < 4; ++s) {
     const StageGeom& g = e->st[s];
     std::string n = std::to_string(s);
@@ -616,6 +616,9 @@ int run_backbone(nuhtc_engine* e, int B, hipStream_t s) {
   RUN(launch_patch_embed(e->img, e->pe_w, e->pe_b, e->pe_g, e->pe_beta, e->tokA, B, Hn, Wn, s));
   float* x = e->tokA;
   float* xalt = e->tokB;
+  // dev: 0 = the norms of stages 2-4 as kernels of their own (round 4); 1 = in the A path of the linear behind them, statistics by a kernel
+  // of their own; 2 (the tree) = statistics left by the epilogue of the GEMM that produced the tensor
+  static const int& ln_in_a = dev_knob_ref("LN_IN_A", 2);
   for (int st = 0; st < 4; ++st) {
     const StageGeom& g = e->st[st];
     const int T = B * g.H * g.W, Mw = B * g.nW * WS2, C = g.C;
@@ -628,13 +631,14 @@ int run_backbone(nuhtc_engine* e, int B, hipStream_t s) {
       // (LN of a zero-padded token is 0 after swin.py:341-343's F.pad, so its qkv is the bias), attention writes the
       // non-padding rows of its output compactly again and proj scatters them back to token order.
       static const int& fused_qkv = dev_knob_ref("FUSED_QKV", 1);
-      static const int& ln_in_a = dev_knob_ref("LN_IN_A", 1);        // dev: 0 = the norms of stages 2-4 as kernels of their own (round 4)
       if (w.qkv_stream && fused_qkv) {       // one kernel: LN1, window gather, QKV linear (mlp.hip) + the bias rows of the padding tokens
         RUN(launch_swin_lnqkv(x, e->qkv, g.ctok[sh], g.vrow[sh], g.prow[sh], B * g.npad, w.n1g, w.n1b, w.qkv_stream, w.qkv_b, T, C, s));
-      } else if (w.qkv_wln && ln_in_a) {     // the norm rides in the linear's A path: statistics (+ the bias rows of the padding tokens), then the product
-        RUN(launch_ln_stats(x, g.ctok[sh], e->ln_stats, T, C, e->qkv, g.prow[sh], B * g.npad, w.qkv_b, s));
+      } else if (w.qkv_wln && ln_in_a) {     // the norm rides in the linear's A path; the launch's extra workgroups write the bias rows of the padding tokens
+        const bool epi = ln_in_a >= 2;       // the statistics were left by the epilogue of the GEMM that produced x (fc2, or the patch merging)
+        if (!epi) RUN(launch_ln_stats(x, e->ln_part, T, C, s));
         GemmParams p = gp(x, w.qkv_wln, w.qkv_bln, e->qkv, T, 3 * C, C);
-        p.amode = A_LN; p.ln_stats = e->ln_stats; p.a_rows = g.ctok[sh];
+        p.amode = A_LN; p.ln_part = e->ln_part; p.ln_nparts = epi ? C / 96 : 1; p.a_rows = g.ctok[sh];
+        p.pad_rows = g.prow[sh]; p.n_pad = B * g.npad; p.pad_val = w.qkv_b;
         p.store = ST_ROWMAP; p.row_map = g.vrow[sh];
         RUN(linear(p));
       } else {
@@ -656,15 +660,17 @@ int run_backbone(nuhtc_engine* e, int B, hipStream_t s) {
       if (!proj1) {
         GemmParams p = gp(e->att, w.proj_w, w.proj_b, x, T, C, C);
         p.store = ST_ROWMAP; p.row_map = g.ctok[sh]; p.res = x; p.ldr = C;
+        if (w.f1_wln && ln_in_a >= 2) p.stats_out = e->ln_part;      // LN2 rides in fc1: its statistics leave with the rows
         RUN(linear(p));
       }
       if (mlp1) {      // one kernel: [attention projection + residual,] LN2, both linears, GELU and the residual (mlp.hip)
         RUN(launch_swin_mlp(x, x, w.n2g, w.n2b, w.mlp_stream, w.f1_b, w.f2_b, T, C, s, proj1 ? e->att : nullptr, w.proj_stream, w.proj_b));
       } else {
       if (w.f1_wln && ln_in_a) {
-        RUN(launch_ln_stats(x, nullptr, e->ln_stats, T, C, nullptr, nullptr, 0, nullptr, s));
+        const bool epi = ln_in_a >= 2;
+        if (!epi) RUN(launch_ln_stats(x, e->ln_part, T, C, s));
         GemmParams p = gp(x, w.f1_wln, w.f1_bln, e->hid, T, 4 * C, C);
-        p.amode = A_LN; p.ln_stats = e->ln_stats;
+        p.amode = A_LN; p.ln_part = e->ln_part; p.ln_nparts = epi ? C / 96 : 1;
         p.act = ACT_GELU;
         RUN(linear(p));
       } else {
@@ -678,6 +684,7 @@ int run_backbone(nuhtc_engine* e, int B, hipStream_t s) {
       {
         GemmParams p = gp(e->hid, w.f2_w, w.f2_b, x, T, C, 4 * C);
         p.res = x; p.ldr = C;
+        if (ln_in_a >= 2 && b + 1 < e->blocks[st].size() && e->blocks[st][b + 1].qkv_wln) p.stats_out = e->ln_part;   // LN1 of the next block rides in its QKV linear
         RUN(linear(p));
       }
       }
@@ -689,7 +696,11 @@ int run_backbone(nuhtc_engine* e, int B, hipStream_t s) {
     RUN(launch_layernorm(x, nullptr, e->on_g[st], e->on_b[st], e->c[st], T, C, s));   // swin.py:756-762 (tokens == NHWC)
     if (st < 3) {
       RUN(launch_merge_ln(x, e->mg_g[st], e->mg_b[st], e->xw, B, g.H, g.W, C, s));
-      RUN(linear(gp(e->xw, e->mg_w[st], nullptr, xalt, T / 4, 2 * C, 4 * C)));
+      {
+        GemmParams p = gp(e->xw, e->mg_w[st], nullptr, xalt, T / 4, 2 * C, 4 * C);
+        if (ln_in_a >= 2 && !e->blocks[st + 1].empty() && e->blocks[st + 1][0].qkv_wln) p.stats_out = e->ln_part;   // LN1 of the next stage's first block
+        RUN(linear(p));
+      }
       std::swap(x, xalt);
     }
   }
@@ -928,33 +939,39 @@ int nuhtc_op_gemm_split(nuhtc_engine* e, const float* A, const float* W_dev, con
   return 0;
 }
 
-int nuhtc_op_ln_gemm(nuhtc_engine* e, const float* X_dev, const int* rows_dev, const float* W_host, const float* bias_host, const float* ln_g_host,
-                     const float* ln_b_host, float* C_dev, int M, int N, int K, int act, void* stream) {
-  if (!e || !X_dev || !W_host || !ln_g_host || !ln_b_host || !C_dev || M < 1 || N < 1 || K < 1) return NUHTC_E_INVALID;
-  HIP_CHECK(e, hipSetDevice(e->device));
-  std::vector<float> w2((size_t)N * K), b2(N);
+static int fold_ln(const float* W_host, const float* bias_host, const float* g, const float* b, int N, int K, std::vector<float>& w2, std::vector<float>& b2) {
+  w2.resize((size_t)N * K); b2.resize(N);
   for (int n = 0; n < N; ++n) {
     double acc = bias_host ? bias_host[n] : 0.0;
     for (int k = 0; k < K; ++k) {
-      w2[(size_t)n * K + k] = W_host[(size_t)n * K + k] * ln_g_host[k];
-      acc += (double)W_host[(size_t)n * K + k] * (double)ln_b_host[k];
+      w2[(size_t)n * K + k] = W_host[(size_t)n * K + k] * g[k];
+      acc += (double)W_host[(size_t)n * K + k] * (double)b[k];
     }
     b2[n] = (float)acc;
   }
+  return 0;
+}
+
+int nuhtc_op_ln_gemm(nuhtc_engine* e, const float* X_dev, int T, const int* rows_dev, const float* W_host, const float* bias_host, const float* ln_g_host,
+                     const float* ln_b_host, float* C_dev, int M, int N, int K, int act, void* stream) {
+  if (!e || !X_dev || !W_host || !ln_g_host || !ln_b_host || !C_dev || M < 1 || N < 1 || K < 1 || T < 1) return NUHTC_E_INVALID;
+  HIP_CHECK(e, hipSetDevice(e->device));
+  std::vector<float> w2, b2;
+  fold_ln(W_host, bias_host, ln_g_host, ln_b_host, N, K, w2, b2);
   void* sp = nullptr;
   int rc = gemm_make_split(w2.data(), N, K, &sp);
   if (rc) FAIL(e, rc, "gemm_make_split failed (K % 8)");
   float *wd = nullptr, *bd = nullptr, *st = nullptr;
   hipError_t he = hipMalloc(&wd, w2.size() * 4);
   if (he == hipSuccess) he = hipMalloc(&bd, b2.size() * 4);
-  if (he == hipSuccess) he = hipMalloc(&st, (size_t)M * 8);
+  if (he == hipSuccess) he = hipMalloc(&st, (size_t)T * 8);
   if (he == hipSuccess) he = hipMemcpy(wd, w2.data(), w2.size() * 4, hipMemcpyHostToDevice);
   if (he == hipSuccess) he = hipMemcpy(bd, b2.data(), b2.size() * 4, hipMemcpyHostToDevice);
   if (he == hipSuccess) {
-    rc = launch_ln_stats(X_dev, rows_dev, st, M, K, nullptr, nullptr, 0, nullptr, (hipStream_t)stream);
+    rc = launch_ln_stats(X_dev, st, T, K, (hipStream_t)stream);
     if (!rc) {
       GemmParams p = gp(X_dev, wd, bd, C_dev, M, N, K);
-      p.act = act; p.Wsplit = sp; p.amode = A_LN; p.ln_stats = st; p.a_rows = rows_dev;
+      p.act = act; p.Wsplit = sp; p.amode = A_LN; p.ln_part = st; p.ln_nparts = 1; p.a_rows = rows_dev;
       rc = launch_gemm(p, (hipStream_t)stream);
     }
     he = hipStreamSynchronize((hipStream_t)stream);
@@ -962,6 +979,46 @@ int nuhtc_op_ln_gemm(nuhtc_engine* e, const float* X_dev, const int* rows_dev, c
   hipFree(sp); hipFree(wd); hipFree(bd); hipFree(st);
   if (rc) FAIL(e, rc, "ln_gemm launch failed (N % 96, K % 32 required)");
   if (he != hipSuccess) FAIL(e, NUHTC_E_HIP, "ln_gemm failed");
+  return 0;
+}
+
+int nuhtc_op_gemm_ln_gemm(nuhtc_engine* e, const float* A_dev, const float* Wp_host, const float* bp_host, const float* res_dev, const int* row_map_dev,
+                          const float* W_host, const float* bias_host, const float* ln_g_host, const float* ln_b_host, float* Y_dev, float* C_dev, int M,
+                          int Kp, int K, int N, int act, void* stream) {
+  if (!e || !A_dev || !Wp_host || !W_host || !ln_g_host || !ln_b_host || !Y_dev || !C_dev || M < 1 || N < 1 || K < 1 || Kp < 1 || K % 96) return NUHTC_E_INVALID;
+  HIP_CHECK(e, hipSetDevice(e->device));
+  std::vector<float> w2, b2;
+  fold_ln(W_host, bias_host, ln_g_host, ln_b_host, N, K, w2, b2);
+  void *sp = nullptr, *spp = nullptr;
+  int rc = gemm_make_split(w2.data(), N, K, &sp);
+  if (!rc) rc = gemm_make_split(Wp_host, K, Kp, &spp);
+  if (rc) { hipFree(sp); FAIL(e, rc, "gemm_make_split failed (K % 8)"); }
+  float *wd = nullptr, *bd = nullptr, *st = nullptr, *wpd = nullptr, *bpd = nullptr;
+  hipError_t he = hipMalloc(&wd, w2.size() * 4);
+  if (he == hipSuccess) he = hipMalloc(&bd, b2.size() * 4);
+  if (he == hipSuccess) he = hipMalloc(&st, (size_t)M * (K / 96) * 8);
+  if (he == hipSuccess) he = hipMalloc(&wpd, (size_t)K * Kp * 4);
+  if (he == hipSuccess && bp_host) he = hipMalloc(&bpd, (size_t)K * 4);
+  if (he == hipSuccess) he = hipMemcpy(wd, w2.data(), w2.size() * 4, hipMemcpyHostToDevice);
+  if (he == hipSuccess) he = hipMemcpy(bd, b2.data(), b2.size() * 4, hipMemcpyHostToDevice);
+  if (he == hipSuccess) he = hipMemcpy(wpd, Wp_host, (size_t)K * Kp * 4, hipMemcpyHostToDevice);
+  if (he == hipSuccess && bp_host) he = hipMemcpy(bpd, bp_host, (size_t)K * 4, hipMemcpyHostToDevice);
+  if (he == hipSuccess) {
+    GemmParams q = gp(A_dev, wpd, bpd, Y_dev, M, K, Kp);              // the producer: Y[row_map(m)] = A Wp^T + bp (+ res), statistics on the way out
+    q.Wsplit = spp; q.stats_out = st;
+    if (res_dev) { q.res = res_dev; q.ldr = K; }
+    if (row_map_dev) { q.store = ST_ROWMAP; q.row_map = row_map_dev; }
+    rc = launch_gemm(q, (hipStream_t)stream);
+    if (!rc) {
+      GemmParams p = gp(Y_dev, wd, bd, C_dev, M, N, K);
+      p.act = act; p.Wsplit = sp; p.amode = A_LN; p.ln_part = st; p.ln_nparts = K / 96;
+      rc = launch_gemm(p, (hipStream_t)stream);
+    }
+    he = hipStreamSynchronize((hipStream_t)stream);
+  }
+  hipFree(sp); hipFree(spp); hipFree(wd); hipFree(bd); hipFree(st); hipFree(wpd); hipFree(bpd);
+  if (rc) FAIL(e, rc, "gemm_ln_gemm launch failed");
+  if (he != hipSuccess) FAIL(e, NUHTC_E_HIP, "gemm_ln_gemm failed");
   return 0;
 }
 

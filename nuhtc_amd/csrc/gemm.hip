@@ -20,7 +20,7 @@
 // ---- epilogue shared by the fp32 and the split-bf16 main loops
 template <int MT, int NT, int WM, int WN>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[MT][NT], float* lds, float* __restrict__ C, int z, int m0, int n0,
-                                              int Meff) {
+                                              int Meff, const float* ln_rstd = nullptr /* A_LN: LDS, 1 / sqrt(var + eps) per row of the block tile */) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -81,10 +81,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
       for (int j = 0; j < 4; ++j) riv[j] = ri[mrow[j]];
     }
     float lnr[4] = {1.f, 1.f, 1.f, 1.f};      // A_LN: the row's 1 / sqrt(var + eps) scales its sums before the bias
-    if (p.ln_stats) {
+    if (ln_rstd) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) lnr[j] = p.ln_stats[2 * mrow[j] + 1];
+      for (int j = 0; j < 4; ++j) lnr[j] = ln_rstd[(wm * MT + mi) * 32 + 8 * j + rr];
     }
+    // stats_out: this workgroup's 96 columns of each row it stores, as {mean, sum of squared deviations} -- sums of (v - pivot) and
+    // (v - pivot)^2 over the row's 96 values with the row's first value as pivot (a sample of the row: nothing cancels), gathered
+    // while the tiles pass through the registers anyway
+    float s_piv[4] = {0.f, 0.f, 0.f, 0.f}, s_1[4] = {0.f, 0.f, 0.f, 0.f}, s_2[4] = {0.f, 0.f, 0.f, 0.f};
     // Vector-memory operations retire in issue order, so a load issued after a column tile's stores would wait for those
     // stores to be acknowledged (thousands of cycles under load) before its data counts as landed.  Bias / column norms of
     // every column tile are therefore loaded before the first store, and the row-dependent terms (residual, FPN parent)
@@ -122,7 +126,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         v[j] = *reinterpret_cast<const v4f*>(tb + (8 * j + rr) * 32 + c4) * p.alpha;
-        if (p.ln_stats) v[j] *= lnr[j];
+        if (ln_rstd) v[j] *= lnr[j];
         if (p.bias) v[j] += colv[t];
         if (p.act == ACT_RELU) {
           v[j].x = fmaxf(v[j].x, 0.f); v[j].y = fmaxf(v[j].y, 0.f); v[j].z = fmaxf(v[j].z, 0.f); v[j].w = fmaxf(v[j].w, 0.f);
@@ -135,6 +139,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
           v[j].w = fmaxf(v[j].w * riv[j] * colv[t].w - p.cos_tau, 0.f) + p.cos_tau;
         }
         if (rowp) v[j] += rowv[j];
+      }
+      if (p.stats_out) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (t == 0) s_piv[j] = __shfl(v[j].x, lane & ~7);
+          const v4f d = v[j] - s_piv[j];
+          s_1[j] += (d.x + d.y) + (d.z + d.w);
+          s_2[j] = fmaf(d.x, d.x, fmaf(d.y, d.y, fmaf(d.z, d.z, fmaf(d.w, d.w, s_2[j]))));
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       if (t + 1 < NT) EPI_LOADS(t + 1)          // requested before this tile's stores are issued
@@ -153,6 +166,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
         }
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the live ranges of one column tile from overlapping the next
+    }
+    if (p.stats_out) {
+      constexpr float inv_n = 1.0f / (32.0f * NT * WN);
+      const int ntn = p.N / (32 * NT * WN), tile_n = n0 / (32 * NT * WN);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) { s_1[j] += __shfl_xor(s_1[j], o); s_2[j] += __shfl_xor(s_2[j], o); }
+        if ((lane & 7) == 0 && ((okmask >> j) & 1u)) {
+          const float dm = s_1[j] * inv_n;
+          *reinterpret_cast<float2*>(p.stats_out + ((long long)drow[j] * ntn + tile_n) * 2) = make_float2(s_piv[j] + dm, fmaxf(s_2[j] - s_1[j] * dm, 0.f));
+        }
+      }
     }
 #undef EPI_LOADS
   }
@@ -440,13 +466,27 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void gemm_split_kernel
   constexpr int LDK = BK + 4;                                      // A image [row][20 floats]
   constexpr int BP = 28;                                           // B image [col][112 bytes = 28 floats]: 2 k-groups x 3 planes x 16 B + pad
   constexpr int NCH = BN * 6, NB = (NCH + 255) / 256;              // B staging: 16-byte chunks per k-tile, passes of 256 threads
-  __shared__ __attribute__((aligned(16))) float lds[2 * (LDK * BM + BP * BN) > 4 * 32 * 32 ? 2 * (LDK * BM + BP * BN) : 4 * 32 * 32];
+  constexpr int LDSF = 2 * (LDK * BM + BP * BN) > 4 * 32 * 32 ? 2 * (LDK * BM + BP * BN) : 4 * 32 * 32;
+  __shared__ __attribute__((aligned(16))) float lds[LDSF + (AMODE == A_LN ? BM : 0)];      // A_LN: + the block tile's rows' 1 / sqrt(var + eps)
   float* As = lds;                       // [2][BM][LDK]
   float* Bs = lds + 2 * LDK * BM;        // [2][BN][BP]
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int i32 = lane & 31, half = lane >> 5;
   const int nTilesN = p.N / BN;
+  if (AMODE == A_LN && p.n_pad > 0) {
+    // the workgroups past the tile grid fill the window-padding rows of C with pad_val (the QKV bias): 16 rows per wave
+    const int tile_blocks = ((p.M + BM - 1) / BM + 7) / 8 * 8 * nTilesN;
+    if ((int)blockIdx.x >= tile_blocks) {
+      const int r0 = ((int)blockIdx.x - tile_blocks) * 64 + wave * 16;
+      const v4f* src = reinterpret_cast<const v4f*>(p.pad_val);
+      for (int r = r0; r < r0 + 16 && r < p.n_pad; ++r) {
+        v4f* dst = reinterpret_cast<v4f*>(p.C + (long long)p.pad_rows[r] * p.ldc);
+        for (int c = lane; c < p.N / 4; c += 64) dst[c] = src[c];
+      }
+      return;
+    }
+  }
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int tile_m = (slot / nTilesN) * 8 + xcd, tile_n = slot % nTilesN;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -491,7 +531,17 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void gemm_split_kernel
       const long long src = p.a_rows ? p.a_rows[m] : m;
       a_ptr[j] = A + src * p.lda + kc * 4;
       a_ok[j] = 0;
-      a_mean[j] = p.ln_stats[2 * m];
+      // the row's statistics from its partials (equal shares of the K elements each), merged in order: mean = mean of the means,
+      // sum of squared deviations = sum of the partial ones + share * sum (partial mean - mean)^2
+      const float2* pp = reinterpret_cast<const float2*>(p.ln_part) + src * p.ln_nparts;
+      float msum = 0.f, m2 = 0.f;
+      for (int t = 0; t < p.ln_nparts; ++t) { const float2 q = pp[t]; msum += q.x; m2 += q.y; }
+      const float mean = msum / (float)p.ln_nparts;
+      float dev = 0.f;
+      for (int t = 0; t < p.ln_nparts; ++t) { const float d = pp[t].x - mean; dev = fmaf(d, d, dev); }
+      m2 = fmaf((float)(p.K / p.ln_nparts), dev, m2);
+      a_mean[j] = mean;
+      if (kc == 0) lds[LDSF + rbase + RPP * j] = 1.0f / sqrtf(m2 / (float)p.K + 1e-5f);      // read by the epilogue (behind its barrier)
     } else {
       const int hw = p.cH * p.cW;
       const int rr = m - (m / hw) * hw;
@@ -725,7 +775,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void gemm_split_kernel
 #undef S_LOAD_TILE
 #undef S_STORE_TILE
   STAMP(st2 = __builtin_amdgcn_s_memtime();)
-  gemm_epilogue<MT, NT, WM, WN>(p, acc, lds, C, z, m0, n0, Meff);
+  gemm_epilogue<MT, NT, WM, WN>(p, acc, lds, C, z, m0, n0, Meff, AMODE == A_LN ? lds + LDSF : nullptr);
 #ifdef NUHTC_GEMM_STAMPS
   st3 = __builtin_amdgcn_s_memtime();
   __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0)
@@ -806,6 +856,7 @@ template <int MT, int NT>
 static void launch_split(const GemmParams& q, hipStream_t s) {
   const int mtiles = cdiv(q.M, 128 * MT);
   dim3 grid(cdiv(mtiles, 8) * 8 * (q.N / (32 * NT)), 1, q.batch > 0 ? q.batch : 1);
+  if (q.amode == A_LN && q.n_pad > 0) grid.x += cdiv(q.n_pad, 64);          // workgroups that fill the padding rows (gemm_split_kernel)
   // dev: dynamic LDS the kernel never touches (NUHTC_GEMM_LDS_PAD bytes): caps the workgroups of this kernel per CU below what its
   // registers allow, which leaves register and LDS room on every CU for OTHER kernels' workgroups (the memory-bound kernels of the
   // batches in flight) instead of a third GEMM workgroup
@@ -829,7 +880,11 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
   if (p.amode == A_CONV3 && (p.cC % 32 != 0 || p.K != 9 * p.cC)) return NUHTC_E_INVALID;
   if ((p.res && p.up) || (p.act == ACT_COS && p.bias)) return NUHTC_E_INVALID;
   // LayerNorm in the A path: the split kernel's 96-column form only (the Swin linears that follow a norm), statistics required
-  if ((p.amode == A_LN) != (p.ln_stats != nullptr) || (p.amode == A_LN && (!p.Wsplit || p.N % 96 != 0 || p.batch > 1))) return NUHTC_E_INVALID;
+  if ((p.amode == A_LN) != (p.ln_part != nullptr) ||
+      (p.amode == A_LN && (!p.Wsplit || p.N % 96 != 0 || p.batch > 1 || p.ln_nparts < 1 || p.K % p.ln_nparts != 0 || (p.n_pad > 0 && (!p.pad_rows || !p.pad_val)))))
+    return NUHTC_E_INVALID;
+  // statistics for the next linear's LayerNorm: the split kernel's 96-column form, rows stored whole (plain or row-mapped)
+  if (p.stats_out && (!p.Wsplit || p.N % 96 != 0 || p.batch > 1 || (p.store != ST_PLAIN && p.store != ST_ROWMAP) || p.amode == A_CONV3)) return NUHTC_E_INVALID;
   if ((p.res && (long long)p.M * p.ldr >= (1ll << 31)) || (p.up && (long long)p.M * p.N >= (1ll << 31))) return NUHTC_E_INVALID;
   GemmParams q = p;
   if (q.alpha == 0.f) q.alpha = 1.f;

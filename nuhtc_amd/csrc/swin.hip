@@ -288,27 +288,17 @@ int launch_layernorm_windows(const float* x, const int* src_map, const int* dst_
 }
 
 // ---- LayerNorm statistics only (round 5): the norms of Swin stages 2-4 ride in the A path of the linear that consumes them
-// (gemm.hip, A_LN): this kernel reads each row once and leaves 8 bytes -- mean and 1 / sqrt(var + eps), computed with the loads,
-// the two passes and the summation order of layernorm_kernel -- instead of the normalised row.  One wave per row; the workgroups
-// past the rows fill the padding rows of the window QKV image with the QKV bias (what layernorm_kernel's pad_dst branch did).
+// (gemm.hip, A_LN).  In the engine the statistics are left by the epilogue of the GEMM that produced the tensor; this kernel is the
+// stand-alone form (nuhtc_op_ln_gemm, dev fallback LN_IN_A=1): it reads each row once and leaves 8 bytes -- the mean and the sum of
+// squared deviations, computed with the loads, the two passes and the summation order of layernorm_kernel.  One wave per row.
 template <int NV>
-__global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ x, const int* __restrict__ src_rows, float* __restrict__ stats,
-                                                       int rows, int C, float* __restrict__ pad_dst, const int* __restrict__ pad_rows, int n_pad,
-                                                       const float* __restrict__ pad_val) {
+__global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ x, float* __restrict__ stats, int rows, int C) {
   typedef float v4f __attribute__((ext_vector_type(4)));
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int C4 = C >> 2;
-  if (row >= rows) {
-    const long long i = row - (((long long)rows + 3) / 4) * 4;      // the pad-row workgroups start at the next multiple of four
-    if (i < 0 || i >= n_pad) return;
-    v4f* pr = reinterpret_cast<v4f*>(pad_dst + (long long)pad_rows[i] * 3 * C);
-    const v4f* pv = reinterpret_cast<const v4f*>(pad_val);
-    for (int c = lane; c < 3 * C4; c += 64) pr[c] = pv[c];
-    return;
-  }
-  const long long src = src_rows ? src_rows[row] : row;
-  const v4f* xr = reinterpret_cast<const v4f*>(x + src * C);
+  if (row >= rows) return;
+  const v4f* xr = reinterpret_cast<const v4f*>(x + row * C);
   v4f v[NV];
   float sum = 0.f;
 #pragma unroll
@@ -327,21 +317,20 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__
       var = fmaf(v[j].x, v[j].x, fmaf(v[j].y, v[j].y, fmaf(v[j].z, v[j].z, fmaf(v[j].w, v[j].w, var))));
     }
   }
-  const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)C + 1e-5f);
-  if (lane == 0) *reinterpret_cast<float2*>(stats + 2 * row) = make_float2(mean, rstd);
+  const float m2 = wave_sum(var);
+  if (lane == 0) *reinterpret_cast<float2*>(stats + 2 * row) = make_float2(mean, m2);
 }
 
-int launch_ln_stats(const float* x, const int* src_rows, float* stats, int rows, int C, float* pad_dst, const int* pad_rows, int n_pad,
-                    const float* pad_val, hipStream_t s) {
+int launch_ln_stats(const float* x, float* stats, int rows, int C, hipStream_t s) {
   { static const int& skip_ = dev_knob_ref("SKIP", 0); if (skip_ & 2) return 0; }   // dev: ablation of the step (tools/dev/r04_ablate.py)
   if (rows <= 0) return 0;
-  if (C % 4 != 0 || (n_pad > 0 && (!pad_dst || !pad_rows || !pad_val))) return NUHTC_E_INVALID;
-  ProfScope ps("layernorm", 0, 4.0 * rows * C + 8.0 * rows + 12.0 * n_pad * C, s);
-  dim3 grid(cdiv(rows, 4) + cdiv(n_pad > 0 ? n_pad : 0, 4)), blk(256);
+  if (C % 4 != 0) return NUHTC_E_INVALID;
+  ProfScope ps("layernorm", 0, 4.0 * rows * C + 8.0 * rows, s);
+  dim3 grid(cdiv(rows, 4)), blk(256);
   const int nv = cdiv(C, 256);
-  if (nv <= 1) hipLaunchKernelGGL(ln_stats_kernel<1>, grid, blk, 0, s, x, src_rows, stats, rows, C, pad_dst, pad_rows, n_pad, pad_val);
-  else if (nv <= 2) hipLaunchKernelGGL(ln_stats_kernel<2>, grid, blk, 0, s, x, src_rows, stats, rows, C, pad_dst, pad_rows, n_pad, pad_val);
-  else if (nv <= 3) hipLaunchKernelGGL(ln_stats_kernel<3>, grid, blk, 0, s, x, src_rows, stats, rows, C, pad_dst, pad_rows, n_pad, pad_val);
+  if (nv <= 1) hipLaunchKernelGGL(ln_stats_kernel<1>, grid, blk, 0, s, x, stats, rows, C);
+  else if (nv <= 2) hipLaunchKernelGGL(ln_stats_kernel<2>, grid, blk, 0, s, x, stats, rows, C);
+  else if (nv <= 3) hipLaunchKernelGGL(ln_stats_kernel<3>, grid, blk, 0, s, x, stats, rows, C);
   else return NUHTC_E_INVALID;
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
 }

@@ -359,19 +359,34 @@ class Engine:
         return C
 
     def op_ln_gemm(self, x, w, bias, ln_g, ln_b, rows=None, act=0):
-        """act(LayerNorm(x[rows]) @ w.T + bias) with the norm in the product's A path (csrc/gemm.hip A_LN + ln_stats_kernel: how the QKV and
-        fc1 linears of Swin stages 2-4 run); x (T, K) on the device, rows: optional device int32 (M,) row indices, the rest anywhere."""
-        K = x.shape[1]
-        M = int(rows.shape[0]) if rows is not None else x.shape[0]
+        """act(LayerNorm(x[rows]) @ w.T + bias) with the norm in the product's A path (csrc/gemm.hip A_LN, statistics by ln_stats_kernel);
+        x (T, K) on the device, rows: optional device int32 (M,) row indices, the rest anywhere."""
+        T, K = x.shape
+        M = int(rows.shape[0]) if rows is not None else T
         N = w.shape[0]
         out = torch.empty(M, N, dtype=torch.float32, device=self.device)
         h = lambda t: np.ascontiguousarray(t.detach().cpu().numpy(), dtype=np.float32)
         wh, gh, bh = h(w), h(ln_g), h(ln_b)
         bias_h = h(bias) if bias is not None else None
         vp = lambda a: a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
-        self._check(self.lib.nuhtc_op_ln_gemm(self.h, x.data_ptr(), rows.data_ptr() if rows is not None else None, vp(wh), vp(bias_h), vp(gh), vp(bh),
+        self._check(self.lib.nuhtc_op_ln_gemm(self.h, x.data_ptr(), T, rows.data_ptr() if rows is not None else None, vp(wh), vp(bias_h), vp(gh), vp(bh),
                                               out.data_ptr(), M, N, K, act, self._stream()))
         return out
+
+    def op_gemm_ln_gemm(self, a, wp, bp, w, bias, ln_g, ln_b, res=None, row_map=None, act=0):
+        """y[row_map] = a @ wp.T + bp (+ res[row_map]); c = act(LayerNorm(y) @ w.T + bias) the way the engine chains them: the producer's
+        epilogue leaves the row statistics per 96 columns, the consumer merges them (csrc/gemm.hip stats_out / A_LN).  -> (y, c)."""
+        M, Kp = a.shape
+        K, N = wp.shape[0], w.shape[0]
+        y = torch.zeros(M, K, dtype=torch.float32, device=self.device)
+        c = torch.empty(M, N, dtype=torch.float32, device=self.device)
+        h = lambda t: np.ascontiguousarray(t.detach().cpu().numpy(), dtype=np.float32) if t is not None else None
+        wph, bph, wh, bh, gh, lbh = h(wp), h(bp), h(w), h(bias), h(ln_g), h(ln_b)
+        vp = lambda x: x.ctypes.data_as(ctypes.c_void_p) if x is not None else None
+        self._check(self.lib.nuhtc_op_gemm_ln_gemm(self.h, a.data_ptr(), vp(wph), vp(bph), res.data_ptr() if res is not None else None,
+                                                   row_map.data_ptr() if row_map is not None else None, vp(wh), vp(bh), vp(gh), vp(lbh),
+                                                   y.data_ptr(), c.data_ptr(), M, Kp, K, N, act, self._stream()))
+        return y, c
 
     def op_swin_mlp(self, x, ln_g, ln_b, w1, b1, w2, b2):
         """x + W2 gelu(W1 LN(x) + b1) + b2 by the fused FFN kernel (csrc/mlp.hip); x (T, C) and the vectors on the device, w1 / w2 anywhere."""

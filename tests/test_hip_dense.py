@@ -125,6 +125,53 @@ def test_ln_gemm_kernel_vs_fp64(hip_device):
         assert float(e1.max()) <= (2e-5 if offset >= 50 else 2e-6), (T, M, N, K, float(e1.max()))
 
 
+def test_epilogue_ln_statistics_chain_vs_fp64(hip_device):
+    """The engine's chain for the norms of Swin stages 2-4 (round 5): the GEMM that PRODUCES a token tensor (proj + residual with its row
+    scatter, fc2 + residual, patch merging) leaves, per row and 96 columns, {mean, sum of squared deviations} of what it stores
+    (GemmParams.stats_out); the linear behind the LayerNorm merges those partials in its A path (A_LN) -- no pass over the tensor computes
+    statistics.  Against fp64 LayerNorm-then-linear of the tensor the producer actually stored, beside the two-kernel form: C = 192 / 384 /
+    768 (2 / 4 / 8 partials per row), with and without residual and row map, a row count that is not a tile multiple, rows with a large
+    common offset."""
+    g = G.load('small_b2')
+    eng, _ = _engine(g)
+    gen = torch.Generator().manual_seed(23)
+    for (M, Kp, K, N, act, use_res, use_map, offset) in [(512, 192, 192, 768, 2, True, True, 0.0), (1000, 768, 192, 576, 0, True, False, 0.0),
+                                                          (300, 384, 384, 1536, 2, True, True, 30.0), (130, 1536, 384, 1152, 0, False, False, 0.0),
+                                                          (256, 768, 768, 3072, 2, True, True, 0.0), (200, 1536, 768, 2304, 0, False, False, 30.0),
+                                                          (33000, 192, 192, 576, 0, True, True, 0.0)]:
+        a = torch.randn(M, Kp, generator=gen)
+        wp = torch.randn(K, Kp, generator=gen) / Kp ** 0.5
+        bp = torch.randn(K, generator=gen) * 0.1
+        res = (torch.randn(M, K, generator=gen) * 2.0 + offset * torch.randn(M, 1, generator=gen).sign()) if use_res else None
+        rmap = torch.randperm(M, generator=gen).to(torch.int32) if use_map else None
+        w = torch.randn(N, K, generator=gen) / K ** 0.5
+        b = torch.randn(N, generator=gen) * 0.1
+        lg = 1.0 + 0.2 * torch.randn(K, generator=gen)
+        lb = 0.1 * torch.randn(K, generator=gen)
+        y, c = eng.op_gemm_ln_gemm(a.cuda(), wp, bp, w, b, lg, lb, res.cuda() if res is not None else None, rmap.cuda() if rmap is not None else None, act)
+        y, c = y.cpu(), c.cpu().double()
+        # the producer itself: y[rmap[m]] = a wp^T + bp + res[rmap[m]]
+        yref = a.double() @ wp.double().T + bp.double()
+        dst = rmap.long() if rmap is not None else torch.arange(M)
+        if res is not None:
+            yref = yref + res.double()[dst]
+        full = torch.zeros(M, K, dtype=torch.float64)
+        full[dst] = yref
+        assert float((y.double() - full).abs().max()) <= 2e-5 * max(1.0, float(full.abs().max())), (M, K)
+        yd = y.double()
+        yn = (yd - yd.mean(1, keepdim=True)) / (yd.var(1, unbiased=False, keepdim=True) + 1e-5).sqrt() * lg.double() + lb.double()
+        ref = yn @ w.double().T + b.double()
+        if act == 2:
+            ref = torch.nn.functional.gelu(ref)
+        mag = yn.abs() @ w.double().abs().T + b.double().abs()
+        two = eng.op_gemm(torch.nn.functional.layer_norm(y, (K,), lg, lb, 1e-5).cuda(), w.cuda(), b.cuda(), act, pipe='split').cpu().double()
+        e1, e2 = ((c - ref).abs() / mag), ((two - ref).abs() / mag)
+        print(f'M{M} Kp{Kp} K{K} N{N} act{act} res{use_res} map{use_map} offset{offset}: chain max {float(e1.max()):.2e} rms {float((e1 ** 2).mean().sqrt()):.2e} | LN kernel + GEMM max {float(e2.max()):.2e} rms {float((e2 ** 2).mean().sqrt()):.2e}')
+        assert torch.isfinite(c).all()
+        assert float((e1 ** 2).mean().sqrt()) <= 1.5 * float((e2 ** 2).mean().sqrt()) + 3e-8, (M, K, N)
+        assert float(e1.max()) <= (2e-5 if offset else 2e-6), (M, K, N, float(e1.max()))
+
+
 @pytest.mark.parametrize('case', ['small_b2', 'small_wsi_b3', 'full_b1', 'five_b2'])
 def test_dense_stages_vs_oracle_and_golden(hip_device, case):
     from oracle import model as O
