@@ -467,18 +467,20 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void gemm_split_kernel
   constexpr int BP = 28;                                           // B image [col][112 bytes = 28 floats]: 2 k-groups x 3 planes x 16 B + pad
   constexpr int NCH = BN * 6, NB = (NCH + 255) / 256;              // B staging: 16-byte chunks per k-tile, passes of 256 threads
   constexpr int LDSF = 2 * (LDK * BM + BP * BN) > 4 * 32 * 32 ? 2 * (LDK * BM + BP * BN) : 4 * 32 * 32;
-  __shared__ __attribute__((aligned(16))) float lds[LDSF + (AMODE == A_LN ? BM : 0)];      // A_LN: + the block tile's rows' 1 / sqrt(var + eps)
+  __shared__ __attribute__((aligned(16))) float lds[LDSF + (AMODE == A_LN ? 2 * BM : 0)];  // A_LN: + the block tile's rows' 1 / sqrt(var + eps) and means
   float* As = lds;                       // [2][BM][LDK]
   float* Bs = lds + 2 * LDK * BM;        // [2][BN][BP]
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int i32 = lane & 31, half = lane >> 5;
   const int nTilesN = p.N / BN;
+  // A_LN: the FIRST workgroups of the launch (a multiple of 8 of them, so that the tile workgroups keep their XCDs) fill the window-padding
+  // rows of C with pad_val (the QKV bias), 16 rows per wave, beside the first round of tiles; at the end of the grid they were the launch's tail
+  int bid = blockIdx.x;
   if (AMODE == A_LN && p.n_pad > 0) {
-    // the workgroups past the tile grid fill the window-padding rows of C with pad_val (the QKV bias): 16 rows per wave
-    const int tile_blocks = ((p.M + BM - 1) / BM + 7) / 8 * 8 * nTilesN;
-    if ((int)blockIdx.x >= tile_blocks) {
-      const int r0 = ((int)blockIdx.x - tile_blocks) * 64 + wave * 16;
+    const int pad_blocks = ((p.n_pad + 63) / 64 + 7) / 8 * 8;
+    if (bid < pad_blocks) {
+      const int r0 = bid * 64 + wave * 16;
       const v4f* src = reinterpret_cast<const v4f*>(p.pad_val);
       for (int r = r0; r < r0 + 16 && r < p.n_pad; ++r) {
         v4f* dst = reinterpret_cast<v4f*>(p.C + (long long)p.pad_rows[r] * p.ldc);
@@ -486,8 +488,9 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void gemm_split_kernel
       }
       return;
     }
+    bid -= pad_blocks;
   }
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int xcd = bid & 7, slot = bid >> 3;
   const int tile_m = (slot / nTilesN) * 8 + xcd, tile_n = slot % nTilesN;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int z = blockIdx.z;
@@ -531,17 +534,6 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void gemm_split_kernel
       const long long src = p.a_rows ? p.a_rows[m] : m;
       a_ptr[j] = A + src * p.lda + kc * 4;
       a_ok[j] = 0;
-      // the row's statistics from its partials (equal shares of the K elements each), merged in order: mean = mean of the means,
-      // sum of squared deviations = sum of the partial ones + share * sum (partial mean - mean)^2
-      const float2* pp = reinterpret_cast<const float2*>(p.ln_part) + src * p.ln_nparts;
-      float msum = 0.f, m2 = 0.f;
-      for (int t = 0; t < p.ln_nparts; ++t) { const float2 q = pp[t]; msum += q.x; m2 += q.y; }
-      const float mean = msum / (float)p.ln_nparts;
-      float dev = 0.f;
-      for (int t = 0; t < p.ln_nparts; ++t) { const float d = pp[t].x - mean; dev = fmaf(d, d, dev); }
-      m2 = fmaf((float)(p.K / p.ln_nparts), dev, m2);
-      a_mean[j] = mean;
-      if (kc == 0) lds[LDSF + rbase + RPP * j] = 1.0f / sqrtf(m2 / (float)p.K + 1e-5f);      // read by the epilogue (behind its barrier)
     } else {
       const int hw = p.cH * p.cW;
       const int rr = m - (m / hw) * hw;
@@ -710,6 +702,34 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void gemm_split_kernel
   }
   const int nk = p.K / BK;
   S_LOAD_TILE(0)
+  if (AMODE == A_LN) {
+    // The rows' statistics from their partials (equal shares of the K elements each; launch_ln_stats: one, a producer GEMM's epilogue:
+    // one per 96 columns), merged in order while the first tile's loads are in flight: mean = mean of the partial means, sum of squared
+    // deviations = sum of the partial ones + share * sum (partial mean - mean)^2.  Thread r < BM merges row r of the block tile and
+    // leaves mean and 1 / sqrt(var + eps) in LDS: the staging threads pick up their rows' means, the epilogue the scale factors.
+    if (tid < BM) {
+      int m = m0 + tid;
+      m = m < Meff ? m : Meff - 1;
+      const long long src = p.a_rows ? p.a_rows[m] : m;
+      const float2* pp = reinterpret_cast<const float2*>(p.ln_part) + src * p.ln_nparts;
+      float2 q[8];
+      float msum = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) if (t < p.ln_nparts) q[t] = pp[t];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) if (t < p.ln_nparts) { msum += q[t].x; m2 += q[t].y; }
+      const float mean = msum / (float)p.ln_nparts;
+      float dev = 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) if (t < p.ln_nparts) { const float d = q[t].x - mean; dev = fmaf(d, d, dev); }
+      m2 = fmaf((float)(p.K / p.ln_nparts), dev, m2);
+      lds[LDSF + tid] = 1.0f / sqrtf(m2 / (float)p.K + 1e-5f);
+      lds[LDSF + BM + tid] = mean;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NA; ++j) a_mean[j] = lds[LDSF + BM + rbase + RPP * j];
+  }
   S_STORE_TILE(0)
   __syncthreads();
   if (nk > 1) S_LOAD_TILE(1)
@@ -856,7 +876,7 @@ template <int MT, int NT>
 static void launch_split(const GemmParams& q, hipStream_t s) {
   const int mtiles = cdiv(q.M, 128 * MT);
   dim3 grid(cdiv(mtiles, 8) * 8 * (q.N / (32 * NT)), 1, q.batch > 0 ? q.batch : 1);
-  if (q.amode == A_LN && q.n_pad > 0) grid.x += cdiv(q.n_pad, 64);          // workgroups that fill the padding rows (gemm_split_kernel)
+  if (q.amode == A_LN && q.n_pad > 0) grid.x += cdiv(cdiv(q.n_pad, 64), 8) * 8;          // workgroups that fill the padding rows (gemm_split_kernel)
   // dev: dynamic LDS the kernel never touches (NUHTC_GEMM_LDS_PAD bytes): caps the workgroups of this kernel per CU below what its
   // registers allow, which leaves register and LDS room on every CU for OTHER kernels' workgroups (the memory-bound kernels of the
   // batches in flight) instead of a third GEMM workgroup
@@ -881,7 +901,7 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
   if ((p.res && p.up) || (p.act == ACT_COS && p.bias)) return NUHTC_E_INVALID;
   // LayerNorm in the A path: the split kernel's 96-column form only (the Swin linears that follow a norm), statistics required
   if ((p.amode == A_LN) != (p.ln_part != nullptr) ||
-      (p.amode == A_LN && (!p.Wsplit || p.N % 96 != 0 || p.batch > 1 || p.ln_nparts < 1 || p.K % p.ln_nparts != 0 || (p.n_pad > 0 && (!p.pad_rows || !p.pad_val)))))
+      (p.amode == A_LN && (!p.Wsplit || p.N % 96 != 0 || p.batch > 1 || p.ln_nparts < 1 || p.ln_nparts > 8 || p.K % p.ln_nparts != 0 || (p.n_pad > 0 && (!p.pad_rows || !p.pad_val)))))
     return NUHTC_E_INVALID;
   // statistics for the next linear's LayerNorm: the split kernel's 96-column form, rows stored whole (plain or row-mapped)
   if (p.stats_out && (!p.Wsplit || p.N % 96 != 0 || p.batch > 1 || (p.store != ST_PLAIN && p.store != ST_ROWMAP) || p.amode == A_CONV3)) return NUHTC_E_INVALID;
