@@ -941,10 +941,12 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
   const char* tag = "gemm";
   if (prof_enabled()) {   // per-shape tags, e.g. "gemm_kernel<3>|N288|K96" (strings live for the process lifetime)
     static std::map<long long, std::string> names;
-    long long key = ((long long)nt << 40) | ((long long)p.N << 20) | p.K | ((long long)(p.amode == A_CONV3) << 44) | ((long long)halo << 45) | ((long long)(p.fuse ? p.fuse->N2 / 32 : 0) << 46);
+    long long key = ((long long)nt << 40) | ((long long)p.N << 20) | p.K | ((long long)(p.amode == A_CONV3) << 44) | ((long long)halo << 45) | ((long long)(p.fuse ? p.fuse->N2 / 32 : 0) << 46) |
+                    ((long long)(p.amode == A_LN) << 50) | ((long long)(p.stats_out != nullptr) << 51);
     auto it = names.find(key);
     if (it == names.end())
-      it = names.emplace(key, "gemm_kernel<" + std::to_string(nt) + ">|N" + std::to_string(p.N) + "|K" + std::to_string(p.K) + (p.amode == A_CONV3 ? (halo ? "|conv3halo" : "|conv3") : "") + (p.fuse ? "+pw" + std::to_string(p.fuse->N2) : "")).first;
+      it = names.emplace(key, "gemm_kernel<" + std::to_string(nt) + ">|N" + std::to_string(p.N) + "|K" + std::to_string(p.K) + (p.amode == A_CONV3 ? (halo ? "|conv3halo" : "|conv3") : "") + (p.fuse ? "+pw" + std::to_string(p.fuse->N2) : "") +
+                                    (p.amode == A_LN ? "|ln" : "") + (p.stats_out ? "|stats" : "")).first;   // "|ln": LayerNorm in the A path; "|stats": LayerNorm partials in the epilogue
     tag = it->second.c_str();
   }
   // algorithmic work of the launch (a device-side row count is applied when the records are read)
