@@ -443,7 +443,9 @@ def main():
     for st in streams:
         if st != torch.cuda.current_stream():
             torch.cuda.current_stream().wait_stream(st)
+    t_ex0 = time.perf_counter()
     gathered = exchange(last)            # once, inside the timed region: the records of step K
+    exchange_s = time.perf_counter() - t_ex0      # (includes the wait for the steps still in flight on the engine that ran step K)
     ranks_seen = sorted(int(g[-1][0]) for g in gathered)
     gathered_records = int(sum(g[0].shape[0] for g in gathered))
     gathered_bytes = int(sum(t.numel() * t.element_size() for g in gathered for t in g))
@@ -740,7 +742,7 @@ def main():
                          'backend': (dist.get_backend() if dist is not None else 'none: one rank, short-circuit'),
                          'communicator_ranks': (dist.get_world_size() if dist is not None else 1),
                          **({'note': collective_note} if collective_note else {}),
-                         'ranks_seen': ranks_seen, 'records': gathered_records, 'bytes': gathered_bytes,
+                         'ranks_seen': ranks_seen, 'records': gathered_records, 'bytes': gathered_bytes, 'seconds_inside_timed_region': round(exchange_s, 4),
                          'layout': 'head f64[n,9] | ring vertices i32[*,2] | crop boxes i64[n,6] | bit-packed mask crops i32[*] | rank id'},
         }
         if roi_load:

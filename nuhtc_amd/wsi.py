@@ -105,6 +105,12 @@ class RaggedRings:
     def __iter__(self):
         return (self.flat[self.off[i]:self.off[i + 1]] for i in range(len(self)))
 
+    def __add__(self, other):               # like the list it stands in for: concatenation gives a plain list of rings
+        return list(self) + list(other)
+
+    def __radd__(self, other):
+        return list(other) + list(self)
+
     def take(self, keep):
         """-> (vertices of the rings `keep`, concatenated; their lengths)."""
         keep = np.asarray(keep, np.int64)

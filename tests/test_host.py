@@ -404,3 +404,23 @@ def test_forced_collective_of_one_rank_equals_the_short_circuit():
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'NUHTC_FORCE_COLLECTIVE')}
     out = subprocess.run([sys.executable, '-c', _FORCED, 'gloo'], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and 'FORCED OK gloo' in out.stdout, out.stderr[-3000:]
+
+
+def test_ragged_rings_behave_like_the_list_of_arrays():
+    """wsi.RaggedRings (the slide loop's rings as one vertex array) against the list of per-record arrays it stands in for: len, indexing,
+    negative indices, slices, iteration, concatenation with a list or another RaggedRings (what callers that join two shards' records do),
+    and take() of a subset."""
+    from nuhtc_amd import wsi
+    rng = np.random.default_rng(2)
+    n = rng.integers(3, 9, 11)
+    rings = [rng.integers(0, 5000, (k, 2)).astype(np.int64) for k in n]
+    rr = wsi.RaggedRings(np.concatenate(rings, 0), n)
+    assert len(rr) == 11 and all(np.array_equal(a, b) for a, b in zip(rr, rings))
+    assert np.array_equal(rr[-1], rings[-1]) and all(np.array_equal(a, b) for a, b in zip(rr[2:5], rings[2:5]))
+    both = rr + rr
+    assert isinstance(both, list) and len(both) == 22 and np.array_equal(both[11], rings[0])
+    assert len([rings[0]] + rr) == 12 and len(rr + [rings[0]]) == 12
+    flat, cnt = rr.take([1, 4, 10])
+    assert cnt.tolist() == [int(n[1]), int(n[4]), int(n[10])] and np.array_equal(flat, np.concatenate([rings[1], rings[4], rings[10]], 0))
+    flat, cnt = rr.take(np.arange(11))
+    assert flat is rr.flat and cnt.tolist() == n.tolist()
