@@ -324,8 +324,9 @@ def main():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         try:
             torch.cuda.set_device(local_rank)
+            import datetime
             _d.init_process_group(os.environ.get('NUHTC_DIST_BACKEND', 'nccl'), init_method=f'tcp://127.0.0.1:{_par._free_port()}', rank=0, world_size=1,
-                                  device_id=torch.device('cuda', local_rank))
+                                  device_id=torch.device('cuda', local_rank), timeout=datetime.timedelta(seconds=120))
             os.environ['NUHTC_FORCE_COLLECTIVE'] = '1'
             dist = _d
         except Exception as e:                  # the communicator is evidence, not a dependency of the N = 1 line
