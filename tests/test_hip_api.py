@@ -240,6 +240,19 @@ def test_readme_command_lines_on_a_folder_of_slides(hip_device, tmp_path):
     one = tmp_path / 'one'
     subprocess.run([sys.executable, tool, str(src / 'b.npy')] + line1.split()[1:-6] + ['--save_dir', str(one), '--mode', 'qupath'], check=True, capture_output=True)
     assert json.load(open(one / 'nuclei/b/b.geojson')) == docs['b']
+    # the same folder on two ranks (`--gpus 2`: the tool starts them itself; rank 0 segments and patches, both shard every slide's tiles,
+    # one gather per slide): the same documents, byte for byte
+    env2 = _two_rank_env()
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env2.pop(k, None)
+    two = tmp_path / 'two_ranks'
+    r2 = subprocess.run([sys.executable, tool] + line1.split()[:-6] + ['--save_dir', str(two), '--mode', 'qupath', '--slide_ext', '.npy', '--gpus', '2'], env=env2,
+                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    print(r2.stdout[-1500:])
+    assert r2.returncode == 0 and 'tiles on 2 rank(s)' in r2.stdout
+    for sid in ('a', 'b'):
+        assert open(two / 'nuclei' / sid / f'{sid}.geojson', 'rb').read() == open(out / 'nuclei' / sid / f'{sid}.geojson', 'rb').read()
+        assert open(two / 'patches' / f'{sid}.npz', 'rb').read() == open(out / 'patches' / f'{sid}.npz', 'rb').read()
     # README.md:221-223 into the same directory: the coordinate files exist (auto-skip), both slides are inferred again with margin 1
     line2 = f'{src} {CFG} {ck} --patch --seg --stitch --patch_size 256 --step_size 192 --margin 1 --min_area 10 --batch_size 32 --save_dir {out} --mode qupath --slide_ext .npy'
     log2 = subprocess.run([sys.executable, tool] + line2.split() + ['--merge', '--det', '--score-thr', '0.5'], check=True, capture_output=True, text=True).stdout
