@@ -305,7 +305,44 @@ struct StreamTabs {
   float wx[7][SM_J];        // merged x weights of bin pw, tap j = pixel xlo[pw] + j
   int xlo[7];               // first footprint pixel (relative to fx0) of bin pw
   float wy[7][SM_FH];       // merged y weights of bin ph at footprint row yrel
+  // round 5: the samples of both axes (7 bins x <= 4 each), computed ONCE per map by the lane that owns them; the three tables above are
+  // built from these entries instead of recomputing a sample (coordinate, division, clamps: ~25 instructions) for every table entry it touches
+  AxisEnt smp[2][28];
+  unsigned char smv[2][28];   // (bytes: with the tables the kernel's LDS must stay within 20 KB, eight workgroups per CU)
 };
+
+// wx / wy from the stored samples: the sums run over a bin's samples in the order of the original loops, with the same terms
+__device__ __forceinline__ void sm_weights(StreamTabs* tb, int fx0, int fy0, int Sx, int Sy, int lane) {
+  if (lane < 7 * SM_J) {
+    const int pw = lane / SM_J, j = lane - pw * SM_J;
+    const int px = fx0 + tb->xlo[pw] + j;
+    float wsum = 0.f;
+    for (int is = 0; is < Sx; ++is) {
+      const AxisEnt q = tb->smp[0][pw * Sx + is];
+      if (tb->smv[0][pw * Sx + is]) { if (q.lo == px) wsum += q.h; if (q.hi == px) wsum += q.l; }
+    }
+    tb->wx[pw][j] = wsum / (float)Sx;
+  }
+  for (int t = lane; t < 7 * SM_FH; t += 64) {
+    const int ph = t / SM_FH, yr = t - ph * SM_FH;
+    float wsum = 0.f;
+    for (int is = 0; is < Sy; ++is) {
+      const AxisEnt q = tb->smp[1][ph * Sy + is];
+      if (tb->smv[1][ph * Sy + is]) { if (q.lo == fy0 + yr) wsum += q.h; if (q.hi == fy0 + yr) wsum += q.l; }
+    }
+    tb->wy[ph][yr] = wsum / (float)Sy;
+  }
+}
+
+// the samples of lane (axis, idx) into the table, and the first footprint pixel of every bin column (min over the bin's valid x samples:
+// Sx is 2 or 4 and a bin's samples sit in neighbouring lanes, so one or two exchanges)
+__device__ __forceinline__ void sm_store_samples(StreamTabs* tb, const AxisEnt& e, bool valid, bool is_y, int idx, int S, int Sx, int fx0) {
+  if (idx < 28) { tb->smp[is_y ? 1 : 0][idx] = e; tb->smv[is_y ? 1 : 0][idx] = (valid && idx < 7 * S) ? 1 : 0; }
+  int m = (valid && !is_y && idx < 7 * Sx) ? e.lo - fx0 : (1 << 30);
+  m = min(m, __shfl_xor(m, 1));
+  if (Sx > 2) m = min(m, __shfl_xor(m, 2));
+  if (!is_y && idx < 7 * Sx && idx % Sx == 0) tb->xlo[idx / Sx] = m == (1 << 30) ? 0 : m;
+}
 
 // sample s (0 .. 7*S-1) of an axis: mmcv's coordinate and bilinear entry
 __device__ __forceinline__ AxisEnt sm_sample(float start, float bs, int S, int s, int size, bool& valid) {
@@ -328,49 +365,6 @@ __device__ __forceinline__ void sm_accumulate(const float* __restrict__ map, int
   const int fx0 = __shfl(lo, 0), fx1 = __shfl(hi, 0), fy0 = __shfl(lo, 32), fy1 = __shfl(hi, 32);
   if (fx1 < 0 || fy1 < 0) return;                       // every sample of an axis lies outside the map: the term is 0
   const int fw = fx1 - fx0 + 1, fh = min(fy1 - fy0 + 1, SM_FH);     // (roi_classify_kernel admits only RoIs with fw <= 32, fh <= SM_FH)
-  // ---- merged per-axis weights.  x: lane = (bin, tap) of the 7 x SM_J table; y: 4 entries of the 7 x SM_FH table per lane
-  if (lane < 7) {
-    int m = 1 << 30;
-    for (int is = 0; is < Sx; ++is) {
-      bool v;
-      const AxisEnt q = sm_sample(x1, bw, Sx, lane * Sx + is, W, v);
-      if (v) m = min(m, q.lo - fx0);
-    }
-    tb->xlo[lane] = m == (1 << 30) ? 0 : m;
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  if (lane < 7 * SM_J) {
-    const int pw = lane / SM_J, j = lane - pw * SM_J;
-    const int px = fx0 + tb->xlo[pw] + j;
-    float wsum = 0.f;
-    for (int is = 0; is < Sx; ++is) {
-      bool v;
-      const AxisEnt q = sm_sample(x1, bw, Sx, pw * Sx + is, W, v);
-      if (v) { if (q.lo == px) wsum += q.h; if (q.hi == px) wsum += q.l; }
-    }
-    tb->wx[pw][j] = wsum / (float)Sx;
-  }
-  for (int t = lane; t < 7 * SM_FH; t += 64) {
-    const int ph = t / SM_FH, yr = t - ph * SM_FH;
-    float wsum = 0.f;
-    for (int is = 0; is < Sy; ++is) {
-      bool v;
-      const AxisEnt q = sm_sample(y1, bh, Sy, ph * Sy + is, H, v);
-      if (v) { if (q.lo == fy0 + yr) wsum += q.h; if (q.hi == fy0 + yr) wsum += q.l; }
-    }
-    tb->wy[ph][yr] = wsum / (float)Sy;
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  float wxr[7][SM_J];
-  int xbase[7];
-#pragma unroll
-  for (int pw = 0; pw < 7; ++pw) {
-    xbase[pw] = tb->xlo[pw] * 64 + lane;
-#pragma unroll
-    for (int j = 0; j < SM_J; ++j) wxr[pw][j] = tb->wx[pw][j];
-  }
   // ---- stream the rows: slot (yr & 1) of the ring holds row yr.  Row yr + 1 is loaded into registers (4 pixels = 1 KB per
   // wave instruction, 16 lanes x 16 bytes per pixel) before row yr is contracted and written to the other slot afterwards
   // (a wave-wide global->LDS instruction costs the SIMD ~100 issue cycles here, a dwordx4 load + ds_write_b128 pair ~25)
@@ -393,7 +387,22 @@ __device__ __forceinline__ void sm_accumulate(const float* __restrict__ map, int
     for (int q = 0; q < 8; ++q)
       if (q < n4) *reinterpret_cast<v4f*>(dst + (4 * q + sub) * 64 + c4) = stg[q];
   };
-  load_row(0);
+  load_row(0);                                         // round 5: the first row is requested BEFORE the tables are built and lands while they are
+  // ---- merged per-axis weights from the stored samples.  x: lane = (bin, tap) of the 7 x SM_J table; y: 4 entries of the 7 x SM_FH table per lane
+  sm_store_samples(tb, e, valid, is_y, idx, S, Sx, fx0);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  sm_weights(tb, fx0, fy0, Sx, Sy, lane);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  float wxr[7][SM_J];
+  int xbase[7];
+#pragma unroll
+  for (int pw = 0; pw < 7; ++pw) {
+    xbase[pw] = tb->xlo[pw] * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < SM_J; ++j) wxr[pw][j] = tb->wx[pw][j];
+  }
   store_row(0);
   for (int yr = 0; yr < fh; ++yr) {
     if (yr + 1 < fh) load_row(yr + 1);                 // stays in flight while row yr is contracted
@@ -501,38 +510,10 @@ __device__ __forceinline__ void smf_accumulate(const float* __restrict__ map, in
     const int fw = none ? 0 : fx1 - fx0 + 1, fh = none ? 0 : min(fy1 - fy0 + 1, SM_FH);
     if (lane == 0) { sh->fx0 = fx0; sh->fy0 = fy0; sh->fw = fw; sh->fh = fh; }
     if (!none) {
-      if (lane < 7) {
-        int m = 1 << 30;
-        for (int is = 0; is < Sx; ++is) {
-          bool v;
-          const AxisEnt q = sm_sample(x1, bw, Sx, lane * Sx + is, W, v);
-          if (v) m = min(m, q.lo - fx0);
-        }
-        tb->xlo[lane] = m == (1 << 30) ? 0 : m;
-      }
+      sm_store_samples(tb, e, valid, is_y, idx, S, Sx, fx0);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       __builtin_amdgcn_wave_barrier();
-      if (lane < 7 * SM_J) {
-        const int pw = lane / SM_J, j = lane - pw * SM_J;
-        const int px = fx0 + tb->xlo[pw] + j;
-        float wsum = 0.f;
-        for (int is = 0; is < Sx; ++is) {
-          bool v;
-          const AxisEnt q = sm_sample(x1, bw, Sx, pw * Sx + is, W, v);
-          if (v) { if (q.lo == px) wsum += q.h; if (q.hi == px) wsum += q.l; }
-        }
-        tb->wx[pw][j] = wsum / (float)Sx;
-      }
-      for (int t = lane; t < 7 * SM_FH; t += 64) {
-        const int ph = t / SM_FH, yr = t - ph * SM_FH;
-        float wsum = 0.f;
-        for (int is = 0; is < Sy; ++is) {
-          bool v;
-          const AxisEnt q = sm_sample(y1, bh, Sy, ph * Sy + is, H, v);
-          if (v) { if (q.lo == fy0 + yr) wsum += q.h; if (q.hi == fy0 + yr) wsum += q.l; }
-        }
-        tb->wy[ph][yr] = wsum / (float)Sy;
-      }
+      sm_weights(tb, fx0, fy0, Sx, Sy, lane);
     }
   }
   __syncthreads();
