@@ -246,7 +246,9 @@ def main(argv=None):
             if not os.path.exists(cpath):
                 say(f'\nskip {slide_id} due to no coord file')
                 continue
-            spath = os.path.join(folder, slide_id + ext)
+            spath = os.path.join(folder, entry)                # the list holds file names; the reference rebuilds them as slide_id + slide_ext (:452)
+            if not os.path.exists(spath):
+                spath = os.path.join(folder, slide_id + ext)
 
             def make(spath=spath, cpath=cpath):
                 z = np.load(cpath)
