@@ -424,3 +424,21 @@ def test_ragged_rings_behave_like_the_list_of_arrays():
     assert cnt.tolist() == [int(n[1]), int(n[4]), int(n[10])] and np.array_equal(flat, np.concatenate([rings[1], rings[4], rings[10]], 0))
     flat, cnt = rr.take(np.arange(11))
     assert flat is rr.flat and cnt.tolist() == n.tolist()
+
+
+def test_self_launch_starts_one_rank_per_gpu_as_children(tmp_path):
+    """parallel.self_launch (what `bench.py --gpus N` and `tools/infer_wsi.py --gpus N` call when no launcher started them): N ranks under
+    torch.distributed.run as a CHILD process on the loopback address and a free port; output relayed line by line; the job's exit code returned."""
+    import subprocess
+    script = tmp_path / 'rank.py'
+    script.write_text('import os, sys\nprint("rank", os.environ["RANK"], "of", os.environ["WORLD_SIZE"], os.environ["MASTER_ADDR"], sys.argv[1:], flush=True)\n'
+                      'sys.exit(3 if "--fail" in sys.argv and os.environ["RANK"] == "1" else 0)\n')
+    code = ("import sys; sys.path.insert(0, %r); from nuhtc_amd import parallel; "
+            "sys.exit(parallel.self_launch(2, %r, sys.argv[1:]))") % (ROOT, str(script))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    out = subprocess.run([sys.executable, '-c', code, '--x', '1'], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = sorted(l for l in out.stdout.splitlines() if l.startswith('rank'))
+    assert lines == ["rank 0 of 2 127.0.0.1 ['--x', '1']", "rank 1 of 2 127.0.0.1 ['--x', '1']"]
+    bad = subprocess.run([sys.executable, '-c', code, '--fail'], env=env, capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0
