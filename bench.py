@@ -78,8 +78,11 @@ def cpu_baseline(sd, tiles, eng=None, mode=1, batch=4, timed=3, warm=2, warm_bat
     # threads of the GPU box) was an accident of oversubscription.
     sb = sweep_batch or batch
     cand = sorted({p for p in sweep if p < ncpu} | {ncpu})
-    swept = {}
-    for pth in cand:
+    swept, skipped = {}, []
+    for pth in cand:                      # ascending; past the peak the rate only falls (0.03 tiles/s at 256 threads: two minutes per batch), so the sweep
+        if swept and swept[max(swept)] < 0.6 * max(swept.values()):      # stops once a count has fallen below 60 % of the best so far
+            skipped.append(pth)
+            continue
         torch.set_num_threads(pth)
         t0 = time.perf_counter()
         orc(tiles[:sb], mode)
@@ -100,14 +103,14 @@ def cpu_baseline(sd, tiles, eng=None, mode=1, batch=4, timed=3, warm=2, warm_bat
     order = ('preprocess', 'backbone', 'fpn_rpn_semantic', 'proposals', 'cascade', 'mask', 'post', 'other')
     dense = stage.get('backbone', 0) + stage.get('fpn_rpn_semantic', 0)
     out = dict(value=n / dt, unit='tiles/s', cores=best, threads=best, host_cpus=ncpu, kind='port',
-               thread_sweep={str(k): round(v, 3) for k, v in swept.items()},
+               thread_sweep={str(k): round(v, 3) for k, v in swept.items()}, thread_sweep_skipped=skipped,
                stage_s_per_tile={k: round(stage.get(k, 0.0) / n, 4) for k in order},
                stage_share={k: round(stage.get(k, 0.0) / dt, 3) for k in order},
                dense_part_tiles_per_s=round(n / dense, 3) if dense else None,
                kind_note='"port" = oracle/model.py, a correctness tool: its dense stages are torch-cpu fp32 operators like the reference\'s, its proposal and RoI stages '
                          '(RPN NMS and RoIAlign in plain one-thread C, the attention RoI extractor as Python loops over levels and RoIs, paste) are not tuned and '
                          'dominate (`proposals` + `cascade`: see stage_share), more than they would in mmdet + mmcv -- the oracle is not optimised on purpose; dense_part_tiles_per_s is the figure comparable with the 2.6 tiles/s BASELINE.md measured for the reference\'s own dense modules on 8 vCPUs',
-               sample=f'{timed} timed batches of {batch} synthetic nuclei tiles at {best} torch threads (best of the sweep {cand}, one batch of {sb} each) after {warm_batches} warm-up batch(es) of {warm} '
+               sample=f'{timed} timed batches of {batch} synthetic nuclei tiles at {best} torch threads (best of the sweep {sorted(swept)}, one batch of {sb} each; not run, past the peak: {skipped}) after {warm_batches} warm-up batch(es) of {warm} '
                       f'(oracle/model.py, fp32 torch-cpu + C RoIAlign/NMS), {dt:.1f} s; per batch {[round(batch / t, 3) for t in times]} tiles/s' +
                       ('; the full protocol of SURVEY 8d (2 warm-up + 10 timed batches of 16 tiles)' if (batch, timed, warm, warm_batches) == (16, 10, 16, 2) else
                        '; bounded deviation from SURVEY 8d (2 warm-up + 10 timed batches of 16 tiles: minutes of host time; `bench.py --cpu-full`, profiles/r05_cpu_baseline_full.json)'))
