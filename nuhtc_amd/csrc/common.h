@@ -131,6 +131,7 @@ struct GemmParams {
   int batch;
   long long sA, sW, sC, sRi, sRj;
   unsigned long long* stamps;   // dev instrumentation (-DNUHTC_GEMM_STAMPS), null otherwise
+  int row_fastest;              // split kernel: an XCD walks the ROW tiles of one column tile first (chosen by launch_gemm when the weight slice, not the A rows, is what overflows L2)
   int throughput;               // host-side: prefer the block tile that does most work per LDS byte (256-row tiles) over the one that fills the chip soonest
   const Conv3Fuse* fuse;        // host-side: pointwise layer fused into an A_CONV3 product (only on the conv.hip path; else NUHTC_E_INVALID)
 };

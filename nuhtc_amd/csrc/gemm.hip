@@ -491,7 +491,13 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void gemm_split_kernel
     bid -= pad_blocks;
   }
   const int xcd = bid & 7, slot = bid >> 3;
-  const int tile_m = (slot / nTilesN) * 8 + xcd, tile_n = slot % nTilesN;
+  // Workgroups go round the XCDs (each with its own L2); an XCD's consecutive slots walk the column tiles of one row tile (its A rows are
+  // fetched once into that L2 and every slice of W once per row tile) -- or, row_fastest, the row tiles of one column tile: when W is larger
+  // than an L2 and the XCD's share of A is not (the stage-4 QKV / fc1 linears: 10-14 MB of split weights, 1.5 MB of rows per XCD), W then
+  // crosses the fabric once per XCD instead of once per row tile.  Same time (round 4: `r04_ab_tile_order.txt`), a third less traffic there.
+  const int rowTilesPerXcd = ((p.M + BM - 1) / BM + 7) / 8;
+  const int tile_m = p.row_fastest ? (slot % rowTilesPerXcd) * 8 + xcd : (slot / nTilesN) * 8 + xcd;
+  const int tile_n = p.row_fastest ? slot / rowTilesPerXcd : slot % nTilesN;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int z = blockIdx.z;
   int Meff = p.M;
@@ -962,6 +968,13 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
   if (!stamp_buf && hipMalloc(&stamp_buf, 8ull * 8 * 4 * 65536) != hipSuccess) return NUHTC_E_HIP;
   q.stamps = stamp_buf;
 #endif
+  if (q.Wsplit && !halo && q.amode != A_CONV3 && !q.m_dev) {
+    // tile order inside an XCD (gemm_split_kernel): row tiles first when the split weight (6 B per element) overflows an XCD's 4 MB of L2 and the
+    // XCD's eighth of the A rows does not
+    static const int& order_knob = dev_knob_ref("SPLIT_ROW_FASTEST", -1);      // dev: 0 / 1 force
+    const double w_bytes = 6.0 * q.N * q.K, a_xcd_bytes = 4.0 * ((double)q.M / 8.0) * q.K;
+    q.row_fastest = order_knob >= 0 ? order_knob : (w_bytes > 6.0e6 && a_xcd_bytes < 3.0e6);
+  }
   if (halo) {
     const int rc = launch_conv3_split(q, s);
     if (rc) return rc;
