@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NUHTC_ABI_VERSION 8
+#define NUHTC_ABI_VERSION 9
 
 enum {
   NUHTC_OK = 0,
@@ -244,6 +244,13 @@ int nuhtc_op_ln_gemm(nuhtc_engine* e, const float* X_dev, int T, const int* rows
 int nuhtc_op_gemm_ln_gemm(nuhtc_engine* e, const float* A_dev, const float* Wp_host, const float* bp_host, const float* res_dev, const int* row_map_dev,
                           const float* W_host, const float* bias_host, const float* ln_g_host, const float* ln_b_host, float* Y_dev, float* C_dev, int M,
                           int Kp, int K, int N, int act, void* stream);
+/* ABI v9 (round 5).  PatchMerging (mmdet/models/utils/transformer.py:363-385: nn.Unfold(2, stride 2), LayerNorm(4C), Linear(4C -> 2C, no bias)) as
+ * the engine runs it on the split pipe: ONE product whose A rows are gathered from the token tensor as two runs of 2C floats (the 2 x 2 tokens of
+ * a merged row), the norm in the A path (csrc/gemm.hip A_LN with seg_k) and the row statistics merged from per-token partials over 96 channels.
+ * X_dev [B*H*W][C] tokens; W_host [2C][4C], ln_g_host / ln_b_host [4C] in the REFERENCE's column order k = c*4 + kh*2 + kw (re-ordered here exactly as
+ * nuhtc_finalize re-orders them); Y_dev [B*(H/2)*(W/2)][2C].  H, W even, C % 96 == 0.  Synchronises `stream`. */
+int nuhtc_op_merge_ln_gemm(nuhtc_engine* e, const float* X_dev, int B, int H, int W, int C, const float* W_host, const float* ln_g_host,
+                           const float* ln_b_host, float* Y_dev, void* stream);
 /* The fused FFN half of a Swin block (csrc/mlp.hip; mmdet swin.py:365-367): out[T,C] = x + W2 gelu(W1 LN(x) + b1) + b2 with
  * LN = LayerNorm(C, eps 1e-5, ln_g, ln_b), W1 [4C][C], W2 [C][4C] given as HOST arrays (packed like nuhtc_finalize packs them),
  * everything else device memory.  C must be a width the fused kernel serves (96).  Synchronises `stream`. */

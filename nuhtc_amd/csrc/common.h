@@ -105,6 +105,10 @@ struct GemmParams {
   const float* ln_part;
   int ln_nparts;
   const int* a_rows;
+  // A_LN over TWO contiguous segments per row (the PatchMerging gather, transformer.py:363-385: the 2 x 2 tokens of a merged row are two runs of 2 C
+  // floats, `seg_rows` source rows apart): seg_k = 0 -> one segment; else K = 2 seg_k, columns k >= seg_k come from A[(src + seg_rows) * lda + k - seg_k]
+  // and the row's partials from the two runs of ln_nparts / 2 partials at source rows src and src + seg_rows (each source row has ln_nparts / 4)
+  int seg_k, seg_rows;
   // A_LN: `n_pad` rows `pad_rows` of C (row pitch ldc) are filled with pad_val[0..N) by extra workgroups of the launch (the window-padding
   // rows of the QKV image, whose value is the ORIGINAL bias: LN of a zero-padded token is 0)
   const int* pad_rows;
@@ -156,7 +160,8 @@ void mlp_pack_stream(const float* w1, const float* w2, int C, std::vector<unsign
 size_t proj_stream_bytes(int C);
 void proj_pack_stream(const float* w, int C, std::vector<unsigned short>& out);
 int launch_swin_mlp(const float* x_in, float* x_out, const float* ln_g, const float* ln_b, const void* wstream, const float* b1, const float* b2,
-                    int T, int C, hipStream_t s, const float* att = nullptr, const void* pstream = nullptr, const float* bp = nullptr);
+                    int T, int C, hipStream_t s, const float* att = nullptr, const void* pstream = nullptr, const float* bp = nullptr,
+                    float* stats_out = nullptr /* [T][2]: LayerNorm partial {mean, sum of squared deviations} of every row stored */);
 
 // fused LN1 + QKV linear (mlp.hip, C = 96): qkv window image rows of the T real tokens + the bias rows of the padding tokens
 bool lnqkv_supported(int C);
@@ -203,7 +208,9 @@ int launch_merge_ln(const float* x, const float* g, const float* b, float* y, in
 // shift mask packed per lane (engine.hip pack_attn_terms), mask_any [nW] flags the windows with a non-zero mask (maskP null: no shift);
 // window row r is written to out row out_map[r] (skipped when negative), or to row r when out_map is null
 int launch_window_attn(const float* qkv, const float* biasP, const float* maskP, const int* mask_any, const int* out_map, float* out,
-                       int nWinTotal, int nWperImg, int C, int nH, int split_pipe /* 1: bf16 pipe, exactly split operands */, hipStream_t s);
+                       int nWinTotal, int nWperImg, int C, int nH, int split_pipe /* 1: bf16 pipe, exactly split operands */, hipStream_t s,
+                       const unsigned long long* padbits = nullptr /* split pipe: [nWperImg], bit j = row j of the window is padding: row bias_row is read instead */,
+                       int bias_row = 0);
 
 // ----------------------------------------------------------------------------- dense heads (dense.hip)
 int launch_sem_fuse(const float* g0, const float* g1, const float* g2, const float* g3, float* out, int B, int H, int W,

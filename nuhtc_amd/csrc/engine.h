@@ -13,6 +13,11 @@ struct StageGeom {
   int* vrow[2];        // dev: that compact index -> window row
   int* prow[2];        // dev: the padding rows of the window image (map < 0), per-tile lists back to back; npad per tile
   int npad;
+  // the attention kernel of the split pipe never reads a padding row: bit j of padbits[shift][window of the image] says row j of the window
+  // is one, and the kernel reads row `bias_row` (one row behind the window image of the largest batch, holding the block's QKV bias) instead
+  unsigned long long* padbits[2];
+  int* brow;           // dev: {bias_row}, the one-entry "padding row list" of the launches that write it
+  int bias_row;
   float* mask;         // dev: shift mask, packed per lane [nW][4096] (engine.hip pack_attn_terms)
   int* mask_any;       // dev: [nW] 1 where the window's mask has a non-zero entry
 };
@@ -54,6 +59,8 @@ struct nuhtc_engine {
   float *pe_w = nullptr, *pe_b = nullptr, *pe_g = nullptr, *pe_beta = nullptr;
   std::vector<BlockW> blocks[4];
   float *on_g[4], *on_b[4], *mg_g[3], *mg_b[3], *mg_w[3];
+  float *mg_wln[3] = {}, *mg_bln[3] = {};   // PatchMerging norm folded into its reduction linear (gemm.hip A_LN, two segments): W diag(gamma), W beta; split pipe only
+  int* mg_src[3] = {};                     // dev: merged row -> its top-left token (b, 2 y2, 2 x2) of the stage's token tensor, [max_batch * H/2 * W/2]
   // neck / dense heads
   float *lat_w[4], *lat_b[4], *fpn_w[4], *fpn_b[4];
   float *rpn_w, *rpn_b, *rpn_hw, *rpn_hb;
@@ -65,6 +72,7 @@ struct nuhtc_engine {
 
   // workspace
   float *img, *tokA, *tokB, *xw, *qkv, *att, *hid;
+  float* ln_part2 = nullptr;   // the partials the patch-merging GEMM leaves for the next stage's first block (it READS ln_part in the same launch)
   float* ln_part = nullptr;    // LayerNorm partials of the current token tensor, [token][C / 96][2] = {mean, sum of squared deviations} per 96 channels:
                                // written by the epilogue of the GEMM that produced the tensor (proj, fc2, patch merging), read by the next A_LN linear
   float *c[4], *lat[4], *x[4], *rpn[4], *semg[4];

@@ -323,6 +323,17 @@ static int build_stage_maps(nuhtc_engine* e, int s) {
     if (pr.empty()) pr.push_back(0);
     rc = upload_i(e, &g.prow[sh], pr);
     if (rc) return rc;
+    std::vector<int> pb((size_t)g.nW * 2, 0);          // 49 bits per window of the image (tile 0's windows; every tile has the same)
+    for (int w = 0; w < g.nW; ++w)
+      for (int j = 0; j < WS2; ++j)
+        if (m[(size_t)w * WS2 + j] < 0) pb[(size_t)2 * w + (j >> 5)] |= 1 << (j & 31);
+    rc = upload_i(e, reinterpret_cast<int**>(&g.padbits[sh]), pb);
+    if (rc) return rc;
+  }
+  g.bias_row = B * g.nW * WS2;
+  {
+    int rc = upload_i(e, &g.brow, std::vector<int>(1, g.bias_row));
+    if (rc) return rc;
   }
   // shift mask on the padded grid (swin.py:197-218)
   std::vector<int> ids((size_t)g.Hp * g.Wp);
@@ -351,6 +362,8 @@ static int build_stage_maps(nuhtc_engine* e, int s) {
   if (rc) return rc;
   return upload_i(e, &g.mask_any, any);
 }
+
+static int fold_ln(const float* W_host, const float* bias_host, const float* g, const float* b, int N, int K, std::vector<float>& w2, std::vector<float>& b2);
 
 int nuhtc_finalize(nuhtc_engine* e) {
   if (!e) return NUHTC_E_INVALID;
@@ -474,6 +487,17 @@ int nuhtc_finalize(nuhtc_engine* e) {
           for (int n = 0; n < 2 * C; ++n) w2[(size_t)n * 4 * C + q * C + ch] = rw->data[(size_t)n * 4 * C + ch * 4 + q];
         }
       if ((rc = upload(e, &e->mg_g[s], g2)) || (rc = upload(e, &e->mg_b[s], b2)) || (rc = upload_gemm_weight(e, &e->mg_w[s], w2, 2 * C, 4 * C))) return rc;
+      if (e->cfg.matrix_pipe == NUHTC_PIPE_BF16_SPLIT && e->st[s].H % 2 == 0 && e->st[s].W % 2 == 0) {
+        // the merging norm in the A path of the reduction linear (gemm.hip A_LN, two segments per row): W' = W diag(gamma), b' = W beta
+        std::vector<float> wl, bl;
+        fold_ln(w2.data(), nullptr, g2.data(), b2.data(), 2 * C, 4 * C, wl, bl);
+        const StageGeom& g = e->st[s];
+        std::vector<int> src((size_t)B * (g.H / 2) * (g.W / 2));
+        for (int b = 0; b < B; ++b)
+          for (int y2 = 0; y2 < g.H / 2; ++y2)
+            for (int x2 = 0; x2 < g.W / 2; ++x2) src[((size_t)b * (g.H / 2) + y2) * (g.W / 2) + x2] = (b * g.H + 2 * y2) * g.W + 2 * x2;
+        if ((rc = upload_gemm_weight(e, &e->mg_wln[s], wl, 2 * C, 4 * C)) || (rc = upload(e, &e->mg_bln[s], bl)) || (rc = upload_i(e, &e->mg_src[s], src))) return rc;
+      }
     }
   }
   // ---- FPN
@@ -523,6 +547,7 @@ int nuhtc_finalize(nuhtc_engine* e) {
   const StageGeom& g0 = e->st[0];
   if ((rc = ws(e, &e->img, "img", {B, Hn, Wn, 3}, 0))) return rc;
   size_t max_tok = 0, max_win = 0, max_qkv = 0, max_hid = 0;
+  const int max_c = e->st[3].C;      // + one row of 3 max_c behind the window image: the bias row of StageGeom::bias_row
   for (int s = 0; s < 4; ++s) {
     const StageGeom& g = e->st[s];
     max_tok = std::max(max_tok, (size_t)g.H * g.W * g.C);
@@ -531,10 +556,12 @@ int nuhtc_finalize(nuhtc_engine* e) {
     max_hid = std::max(max_hid, (size_t)g.H * g.W * 4 * g.C);
   }
   if ((rc = ws(e, &e->tokA, "tokens", {B, (int64_t)max_tok}, 0)) || (rc = ws(e, &e->tokB, nullptr, {B, (int64_t)max_tok}, 0)) ||
-      (rc = ws(e, &e->xw, nullptr, {B, (int64_t)max_win}, 0)) || (rc = ws(e, &e->qkv, nullptr, {B, (int64_t)max_qkv}, 0)) ||
+      (rc = ws(e, &e->xw, nullptr, {B, (int64_t)max_win}, 0)) || (rc = ws(e, &e->qkv, nullptr, {(int64_t)B * (int64_t)max_qkv + 3 * (int64_t)max_c}, 0)) ||
       (rc = ws(e, &e->att, nullptr, {B, (int64_t)max_win}, 0)) || (rc = ws(e, &e->hid, nullptr, {B, (int64_t)std::max(max_hid, max_qkv)}, 0)))
     return rc;
-  if ((rc = ws(e, &e->ln_part, nullptr, {B, (int64_t)e->st[1].H * e->st[1].W, 8}, 0))) return rc;     // rows x (C / 96) x 2 is the same in stages 2-4
+  if ((rc = ws(e, &e->ln_part, nullptr, {B, (int64_t)e->st[1].H * e->st[1].W, 8}, 0)) ||     // (stage 1, one partial per token: the same again)
+      (rc = ws(e, &e->ln_part2, nullptr, {B, (int64_t)e->st[1].H * e->st[1].W, 8}, 0)))
+    return rc;     // rows x (C / 96) x 2 is the same in stages 2-4
   for (int s = 0; s < 4; ++s) {
     const StageGeom& g = e->st[s];
     std::string n = std::to_string(s);
@@ -619,9 +646,13 @@ int run_backbone(nuhtc_engine* e, int B, hipStream_t s) {
   // dev: 0 = the norms of stages 2-4 as kernels of their own (round 4); 1 = in the A path of the linear behind them, statistics by a kernel
   // of their own; 2 (the tree) = statistics left by the epilogue of the GEMM that produced the tensor
   static const int& ln_in_a = dev_knob_ref("LN_IN_A", 2);
+  // dev: 1 (the tree) = the PatchMerging norms as well (two-segment rows, statistics from the last block's FFN); 0 = merge_ln_kernel + plain GEMM
+  static const int& merge_ln_in_a = dev_knob_ref("MERGE_LN_IN_A", 1);
+  const float* first_part = e->ln_part;      // where the first block of the stage finds its LN1 partials: ln_part2 behind a merging linear in A_LN form
   for (int st = 0; st < 4; ++st) {
     const StageGeom& g = e->st[st];
     const int T = B * g.H * g.W, Mw = B * g.nW * WS2, C = g.C;
+    const bool merge_a = st < 3 && e->mg_wln[st] && ln_in_a >= 2 && merge_ln_in_a && !e->blocks[st].empty();
     for (size_t b = 0; b < e->blocks[st].size(); ++b) {
       const BlockW& w = e->blocks[st][b];
       const int sh = (int)(b & 1);
@@ -631,14 +662,21 @@ int run_backbone(nuhtc_engine* e, int B, hipStream_t s) {
       // (LN of a zero-padded token is 0 after swin.py:341-343's F.pad, so its qkv is the bias), attention writes the
       // non-padding rows of its output compactly again and proj scatters them back to token order.
       static const int& fused_qkv = dev_knob_ref("FUSED_QKV", 1);
+      // On the split pipe the attention kernel never reads a padding row (StageGeom::padbits): the launch that writes the window image writes ONE
+      // bias row instead of the padding rows (stage 4: 72 % of the image's rows, stages 2-3: 20 %).  dev knob 0 = round 4's image
+      static const int& attn_padbits = dev_knob_ref("ATTN_PADBITS", 1);
+      const bool split_attn = e->cfg.matrix_pipe != NUHTC_PIPE_FP32;
+      bool one_bias_row = false;
       if (w.qkv_stream && fused_qkv) {       // one kernel: LN1, window gather, QKV linear (mlp.hip) + the bias rows of the padding tokens
-        RUN(launch_swin_lnqkv(x, e->qkv, g.ctok[sh], g.vrow[sh], g.prow[sh], B * g.npad, w.n1g, w.n1b, w.qkv_stream, w.qkv_b, T, C, s));
+        one_bias_row = split_attn && attn_padbits;
+        RUN(launch_swin_lnqkv(x, e->qkv, g.ctok[sh], g.vrow[sh], one_bias_row ? g.brow : g.prow[sh], one_bias_row ? 1 : B * g.npad, w.n1g, w.n1b, w.qkv_stream, w.qkv_b, T, C, s));
       } else if (w.qkv_wln && ln_in_a) {     // the norm rides in the linear's A path; the launch's extra workgroups write the bias rows of the padding tokens
         const bool epi = ln_in_a >= 2;       // the statistics were left by the epilogue of the GEMM that produced x (fc2, or the patch merging)
         if (!epi) RUN(launch_ln_stats(x, e->ln_part, T, C, s));
         GemmParams p = gp(x, w.qkv_wln, w.qkv_bln, e->qkv, T, 3 * C, C);
-        p.amode = A_LN; p.ln_part = e->ln_part; p.ln_nparts = epi ? C / 96 : 1; p.a_rows = g.ctok[sh];
-        p.pad_rows = g.prow[sh]; p.n_pad = B * g.npad; p.pad_val = w.qkv_b;
+        p.amode = A_LN; p.ln_part = epi && b == 0 ? first_part : e->ln_part; p.ln_nparts = epi ? C / 96 : 1; p.a_rows = g.ctok[sh];
+        one_bias_row = split_attn && attn_padbits;
+        p.pad_rows = one_bias_row ? g.brow : g.prow[sh]; p.n_pad = one_bias_row ? 1 : B * g.npad; p.pad_val = w.qkv_b;
         p.store = ST_ROWMAP; p.row_map = g.vrow[sh];
         RUN(linear(p));
       } else {
@@ -656,7 +694,7 @@ int run_backbone(nuhtc_engine* e, int B, hipStream_t s) {
       // Where the projection rides in front of the fused FFN kernel (stage 1, round 4) the attention kernel writes its rows in TOKEN
       // order (window row -> token map) instead of the compact window order the projection GEMM scatters from
       RUN(launch_window_attn(e->qkv, w.relbT, sh ? g.mask : nullptr, sh ? g.mask_any : nullptr, proj1 ? g.map[sh] : g.cidx[sh], e->att, B * g.nW, g.nW, C, g.nH,
-                             e->cfg.matrix_pipe != NUHTC_PIPE_FP32, s));
+                             split_attn, s, one_bias_row ? g.padbits[sh] : nullptr, g.bias_row));
       if (!proj1) {
         GemmParams p = gp(e->att, w.proj_w, w.proj_b, x, T, C, C);
         p.store = ST_ROWMAP; p.row_map = g.ctok[sh]; p.res = x; p.ldr = C;
@@ -664,7 +702,8 @@ int run_backbone(nuhtc_engine* e, int B, hipStream_t s) {
         RUN(linear(p));
       }
       if (mlp1) {      // one kernel: [attention projection + residual,] LN2, both linears, GELU and the residual (mlp.hip)
-        RUN(launch_swin_mlp(x, x, w.n2g, w.n2b, w.mlp_stream, w.f1_b, w.f2_b, T, C, s, proj1 ? e->att : nullptr, w.proj_stream, w.proj_b));
+        RUN(launch_swin_mlp(x, x, w.n2g, w.n2b, w.mlp_stream, w.f1_b, w.f2_b, T, C, s, proj1 ? e->att : nullptr, w.proj_stream, w.proj_b,
+                            merge_a && b + 1 == e->blocks[st].size() ? e->ln_part : nullptr));      // the merging norm's partials leave with the last block's rows
       } else {
       if (w.f1_wln && ln_in_a) {
         const bool epi = ln_in_a >= 2;
@@ -685,6 +724,7 @@ int run_backbone(nuhtc_engine* e, int B, hipStream_t s) {
         GemmParams p = gp(e->hid, w.f2_w, w.f2_b, x, T, C, 4 * C);
         p.res = x; p.ldr = C;
         if (ln_in_a >= 2 && b + 1 < e->blocks[st].size() && e->blocks[st][b + 1].qkv_wln) p.stats_out = e->ln_part;   // LN1 of the next block rides in its QKV linear
+        if (merge_a && b + 1 == e->blocks[st].size()) p.stats_out = e->ln_part;                                          // ... the merging norm in the reduction linear
         RUN(linear(p));
       }
       }
@@ -695,11 +735,19 @@ int run_backbone(nuhtc_engine* e, int B, hipStream_t s) {
     }
     RUN(launch_layernorm(x, nullptr, e->on_g[st], e->on_b[st], e->c[st], T, C, s));   // swin.py:756-762 (tokens == NHWC)
     if (st < 3) {
-      RUN(launch_merge_ln(x, e->mg_g[st], e->mg_b[st], e->xw, B, g.H, g.W, C, s));
-      {
-        GemmParams p = gp(e->xw, e->mg_w[st], nullptr, xalt, T / 4, 2 * C, 4 * C);
-        if (ln_in_a >= 2 && !e->blocks[st + 1].empty() && e->blocks[st + 1][0].qkv_wln) p.stats_out = e->ln_part;   // LN1 of the next stage's first block
+      const bool next_ln = ln_in_a >= 2 && !e->blocks[st + 1].empty() && e->blocks[st + 1][0].qkv_wln;   // LN1 of the next stage's first block rides in its QKV linear
+      if (merge_a) {     // transformer.py:363-385 in one launch: row m = LayerNorm of the 2 x 2 tokens at mg_src[m] (two runs of 2 C floats, W tokens apart)
+        GemmParams p = gp(x, e->mg_wln[st], e->mg_bln[st], xalt, T / 4, 2 * C, 4 * C);
+        p.lda = C; p.amode = A_LN; p.ln_part = e->ln_part; p.ln_nparts = 4 * (C / 96); p.a_rows = e->mg_src[st]; p.seg_k = 2 * C; p.seg_rows = g.W;
+        if (next_ln) p.stats_out = e->ln_part2;      // not ln_part: other workgroups of this launch are still reading it
         RUN(linear(p));
+        first_part = e->ln_part2;
+      } else {
+        RUN(launch_merge_ln(x, e->mg_g[st], e->mg_b[st], e->xw, B, g.H, g.W, C, s));
+        GemmParams p = gp(e->xw, e->mg_w[st], nullptr, xalt, T / 4, 2 * C, 4 * C);
+        if (next_ln) p.stats_out = e->ln_part;
+        RUN(linear(p));
+        first_part = e->ln_part;
       }
       std::swap(x, xalt);
     }
@@ -1019,6 +1067,50 @@ int nuhtc_op_gemm_ln_gemm(nuhtc_engine* e, const float* A_dev, const float* Wp_h
   hipFree(sp); hipFree(spp); hipFree(wd); hipFree(bd); hipFree(st); hipFree(wpd); hipFree(bpd);
   if (rc) FAIL(e, rc, "gemm_ln_gemm launch failed");
   if (he != hipSuccess) FAIL(e, NUHTC_E_HIP, "gemm_ln_gemm failed");
+  return 0;
+}
+
+int nuhtc_op_merge_ln_gemm(nuhtc_engine* e, const float* X_dev, int B, int H, int W, int C, const float* W_host, const float* ln_g_host, const float* ln_b_host,
+                           float* Y_dev, void* stream) {
+  if (!e || !X_dev || !W_host || !ln_g_host || !ln_b_host || !Y_dev || B < 1 || H < 2 || W < 2 || (H & 1) || (W & 1) || C < 96 || C % 96) return NUHTC_E_INVALID;
+  HIP_CHECK(e, hipSetDevice(e->device));
+  const int T = B * H * W, M = T / 4;
+  std::vector<float> g2(4 * C), b2(4 * C), w2((size_t)2 * C * 4 * C), wl, bl;      // gather order k' = q*C + c, q = kh*2 + kw (nuhtc_finalize)
+  for (int q = 0; q < 4; ++q)
+    for (int ch = 0; ch < C; ++ch) {
+      g2[q * C + ch] = ln_g_host[ch * 4 + q];
+      b2[q * C + ch] = ln_b_host[ch * 4 + q];
+      for (int n = 0; n < 2 * C; ++n) w2[(size_t)n * 4 * C + q * C + ch] = W_host[(size_t)n * 4 * C + ch * 4 + q];
+    }
+  fold_ln(w2.data(), nullptr, g2.data(), b2.data(), 2 * C, 4 * C, wl, bl);
+  std::vector<int> src(M);
+  for (int b = 0; b < B; ++b)
+    for (int y2 = 0; y2 < H / 2; ++y2)
+      for (int x2 = 0; x2 < W / 2; ++x2) src[((size_t)b * (H / 2) + y2) * (W / 2) + x2] = (b * H + 2 * y2) * W + 2 * x2;
+  void* sp = nullptr;
+  int rc = gemm_make_split(wl.data(), 2 * C, 4 * C, &sp);
+  if (rc) FAIL(e, rc, "gemm_make_split failed");
+  float *wd = nullptr, *bd = nullptr, *st = nullptr;
+  int* sd = nullptr;
+  hipError_t he = hipMalloc(&wd, wl.size() * 4);
+  if (he == hipSuccess) he = hipMalloc(&bd, bl.size() * 4);
+  if (he == hipSuccess) he = hipMalloc(&st, (size_t)T * (C / 96) * 8);
+  if (he == hipSuccess) he = hipMalloc(&sd, (size_t)M * 4);
+  if (he == hipSuccess) he = hipMemcpy(wd, wl.data(), wl.size() * 4, hipMemcpyHostToDevice);
+  if (he == hipSuccess) he = hipMemcpy(bd, bl.data(), bl.size() * 4, hipMemcpyHostToDevice);
+  if (he == hipSuccess) he = hipMemcpy(sd, src.data(), (size_t)M * 4, hipMemcpyHostToDevice);
+  if (he == hipSuccess) {
+    rc = launch_ln_stats(X_dev, st, T * (C / 96), 96, (hipStream_t)stream);       // a partial per token and 96 channels: what the producers' epilogues leave
+    if (!rc) {
+      GemmParams p = gp(X_dev, wd, bd, Y_dev, M, 2 * C, 4 * C);
+      p.Wsplit = sp; p.lda = C; p.amode = A_LN; p.ln_part = st; p.ln_nparts = 4 * (C / 96); p.a_rows = sd; p.seg_k = 2 * C; p.seg_rows = W;
+      rc = launch_gemm(p, (hipStream_t)stream);
+    }
+    he = hipStreamSynchronize((hipStream_t)stream);
+  }
+  hipFree(sp); hipFree(wd); hipFree(bd); hipFree(st); hipFree(sd);
+  if (rc) FAIL(e, rc, "merge_ln_gemm launch failed");
+  if (he != hipSuccess) FAIL(e, NUHTC_E_HIP, "merge_ln_gemm failed");
   return 0;
 }
 

@@ -577,6 +577,8 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void gemm_split_kernel
   u32x4 rb[NB];
   int cv_tap = 0, cv_c0 = 0;
   long long cv_off = 0;
+  const int seg_k = (AMODE == A_LN && p.seg_k) ? p.seg_k : 0x7fffffff, seg_skip = AMODE == A_LN ? p.seg_rows * p.lda - p.seg_k : 0;
+#define S_AOFF(kt_) ((kt_) * BK + (AMODE == A_LN && (kt_) * BK >= seg_k ? seg_skip : 0))   /* the A row's element offset of k-tile kt_ (A_LN: second segment) */
 #define S_LOAD_TILE(kt_)                                                                                       \
   {                                                                                                            \
     if (AMODE == A_CONV3) {                                                                                    \
@@ -584,7 +586,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void gemm_split_kernel
       cv_off = (long long)(ky * p.cW + kx) * p.cC + cv_c0;                                                     \
     }                                                                                                          \
     _Pragma("unroll") for (int j = 0; j < NA; ++j) {                                                           \
-      if (AMODE != A_CONV3) ra[j] = *reinterpret_cast<const v4f*>(a_ptr[j] + (kt_) * BK);                      \
+      if (AMODE != A_CONV3) ra[j] = *reinterpret_cast<const v4f*>(a_ptr[j] + S_AOFF(kt_));                     \
       else {                                                                                                   \
         const bool ok = (a_ok[j] >> cv_tap) & 1u;                                                              \
         ra[j] = *reinterpret_cast<const v4f*>(ok ? a_ptr[j] + cv_off : p.zeros);                               \
@@ -669,7 +671,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void gemm_split_kernel
   {                                                                                                            \
     if ((f_) < NA) {                                                                                           \
       const int j = (f_) < NA ? (f_) : 0;                                                                      \
-      if (AMODE != A_CONV3) ra[j] = *reinterpret_cast<const v4f*>(a_ptr[j] + (kt_) * BK);                      \
+      if (AMODE != A_CONV3) ra[j] = *reinterpret_cast<const v4f*>(a_ptr[j] + S_AOFF(kt_));                     \
       else {                                                                                                   \
         const bool ok = (a_ok[j] >> cv_tap) & 1u;                                                              \
         ra[j] = *reinterpret_cast<const v4f*>(ok ? a_ptr[j] + cv_off : p.zeros);                               \
@@ -717,17 +719,19 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void gemm_split_kernel
       int m = m0 + tid;
       m = m < Meff ? m : Meff - 1;
       const long long src = p.a_rows ? p.a_rows[m] : m;
-      const float2* pp = reinterpret_cast<const float2*>(p.ln_part) + src * p.ln_nparts;
-      float2 q[8];
+      // two segments: the partials of the row are two runs of ln_nparts / 2, `seg_rows` source rows (of ln_nparts / 4 partials each) apart
+      const float2* pp = reinterpret_cast<const float2*>(p.ln_part) + src * (p.seg_k ? p.ln_nparts >> 2 : p.ln_nparts);
+      const int half_parts = p.seg_k ? p.ln_nparts >> 1 : 16, second = p.seg_k ? p.seg_rows * (p.ln_nparts >> 2) - half_parts : 0;
+      float2 q[16];
       float msum = 0.f, m2 = 0.f;
 #pragma unroll
-      for (int t = 0; t < 8; ++t) if (t < p.ln_nparts) q[t] = pp[t];
+      for (int t = 0; t < 16; ++t) if (t < p.ln_nparts) q[t] = pp[t + (t >= half_parts ? second : 0)];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) if (t < p.ln_nparts) { msum += q[t].x; m2 += q[t].y; }
+      for (int t = 0; t < 16; ++t) if (t < p.ln_nparts) { msum += q[t].x; m2 += q[t].y; }
       const float mean = msum / (float)p.ln_nparts;
       float dev = 0.f;
 #pragma unroll
-      for (int t = 0; t < 8; ++t) if (t < p.ln_nparts) { const float d = q[t].x - mean; dev = fmaf(d, d, dev); }
+      for (int t = 0; t < 16; ++t) if (t < p.ln_nparts) { const float d = q[t].x - mean; dev = fmaf(d, d, dev); }
       m2 = fmaf((float)(p.K / p.ln_nparts), dev, m2);
       lds[LDSF + tid] = 1.0f / sqrtf(m2 / (float)p.K + 1e-5f);
       lds[LDSF + BM + tid] = mean;
@@ -799,6 +803,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 ? 3 : 2)) void gemm_split_kernel
 #undef S_READ_B
   __syncthreads();
 #undef S_LOAD_TILE
+#undef S_AOFF
 #undef S_STORE_TILE
   STAMP(st2 = __builtin_amdgcn_s_memtime();)
   gemm_epilogue<MT, NT, WM, WN>(p, acc, lds, C, z, m0, n0, Meff, AMODE == A_LN ? lds + LDSF : nullptr);
@@ -907,7 +912,8 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
   if ((p.res && p.up) || (p.act == ACT_COS && p.bias)) return NUHTC_E_INVALID;
   // LayerNorm in the A path: the split kernel's 96-column form only (the Swin linears that follow a norm), statistics required
   if ((p.amode == A_LN) != (p.ln_part != nullptr) ||
-      (p.amode == A_LN && (!p.Wsplit || p.N % 96 != 0 || p.batch > 1 || p.ln_nparts < 1 || p.ln_nparts > 8 || p.K % p.ln_nparts != 0 || (p.n_pad > 0 && (!p.pad_rows || !p.pad_val)))))
+      (p.amode == A_LN && (!p.Wsplit || p.N % 96 != 0 || p.batch > 1 || p.ln_nparts < 1 || p.ln_nparts > 16 || p.K % p.ln_nparts != 0 ||
+                           (p.seg_k && (p.K != 2 * p.seg_k || p.seg_k % 16 != 0 || p.ln_nparts % 4 != 0 || !p.a_rows || p.seg_rows < 1)) || (p.n_pad > 0 && (!p.pad_rows || !p.pad_val)))))
     return NUHTC_E_INVALID;
   // statistics for the next linear's LayerNorm: the split kernel's 96-column form, rows stored whole (plain or row-mapped)
   if (p.stats_out && (!p.Wsplit || p.N % 96 != 0 || p.batch > 1 || (p.store != ST_PLAIN && p.store != ST_ROWMAP) || p.amode == A_CONV3)) return NUHTC_E_INVALID;

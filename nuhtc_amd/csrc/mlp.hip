@@ -38,6 +38,9 @@ struct MlpParams {
   const float* att;       // [T][C] attention output in TOKEN order (the attention kernel scatters through the window -> token map)
   const char* pstream;    // C rows x (C/8) k-groups x 3 planes x 8 bf16 of the k-permuted projection weight (lnqkv_pack_rows)
   const float* bp;        // [C]
+  // LayerNorm partial of every row stored, {mean, sum of squared deviations} over its C = 96 values (what a GEMM's stats_out leaves per 96
+  // columns, gemm.hip): the PatchMerging norm behind stage 1 rides in the reduction linear's A path.  Null: none
+  float* stats_out;       // [T][2]
 };
 
 template <int C>
@@ -318,6 +321,7 @@ __global__ __launch_bounds__(64 * NW, 1) void swin_mlp_kernel(MlpParams p) {
   // per step for nothing.)
   if (tok_ok) {
     float* orow = p.x_out + tok * C + 4 * half;
+    float s_piv = 0.f, s_1 = 0.f, s_2 = 0.f;       // stats_out: sums of (v - pivot) and (v - pivot)^2, pivot = the row's first value
 #pragma unroll
     for (int t = 0; t < G::CT; ++t) {
       v4f res[4];
@@ -329,7 +333,19 @@ __global__ __launch_bounds__(64 * NW, 1) void swin_mlp_kernel(MlpParams p) {
         v4f o = {acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
         o = o + bb + res[q];
         *reinterpret_cast<v4f*>(orow + 32 * t + 8 * q) = o;
+        if (p.stats_out) {
+          if (t == 0 && q == 0) s_piv = __shfl(o.x, i32);      // the half-wave 0 lane of this token holds channel 0
+          const v4f d = o - s_piv;
+          s_1 += (d.x + d.y) + (d.z + d.w);
+          s_2 = fmaf(d.x, d.x, fmaf(d.y, d.y, fmaf(d.z, d.z, fmaf(d.w, d.w, s_2))));
+        }
       }
+    }
+    if (p.stats_out) {      // the token's other 48 channels are in lane ^ 32 (same token: active as well)
+      s_1 += __shfl_xor(s_1, 32);
+      s_2 += __shfl_xor(s_2, 32);
+      const float dm = s_1 * (1.0f / C);
+      if (half == 0) *reinterpret_cast<float2*>(p.stats_out + tok * 2) = make_float2(s_piv + dm, fmaxf(s_2 - s_1 * dm, 0.f));
     }
   }
 #ifdef NUHTC_MLP_STAMPS
@@ -587,13 +603,13 @@ void proj_pack_stream(const float* w, int C, std::vector<unsigned short>& out) {
 }
 
 int launch_swin_mlp(const float* x_in, float* x_out, const float* ln_g, const float* ln_b, const void* wstream, const float* b1, const float* b2,
-                    int T, int C, hipStream_t s, const float* att, const void* pstream, const float* bp) {
+                    int T, int C, hipStream_t s, const float* att, const void* pstream, const float* bp, float* stats_out) {
   { static const int& skip_ = dev_knob_ref("SKIP", 0); if (skip_ & 16) return 0; }   // dev: ablation of the step (tools/dev/r04_ablate.py)
   if (T <= 0) return 0;
   if (!mlp_supported(C) || !wstream) return NUHTC_E_INVALID;
   const bool proj = att != nullptr;
   if (proj && (!pstream || !bp)) return NUHTC_E_INVALID;
-  MlpParams p{x_in, x_out, ln_g, ln_b, reinterpret_cast<const char*>(wstream), b1, b2, T, nullptr, att, reinterpret_cast<const char*>(pstream), bp};
+  MlpParams p{x_in, x_out, ln_g, ln_b, reinterpret_cast<const char*>(wstream), b1, b2, T, nullptr, att, reinterpret_cast<const char*>(pstream), bp, stats_out};
 #ifdef NUHTC_MLP_STAMPS
   static unsigned long long* stamp_buf = nullptr;
   if (!stamp_buf && hipMalloc(&stamp_buf, 8ull * 8 * 8 * 4096) != hipSuccess) return NUHTC_E_HIP;

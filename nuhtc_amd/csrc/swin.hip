@@ -526,16 +526,22 @@ __global__ __launch_bounds__(256, 3) void window_attn_mfma_kernel(const float* _
 __global__ __launch_bounds__(256, 3) void window_attn_split_kernel(const float* __restrict__ qkv, const float* __restrict__ biasP,
                                                                 const float* __restrict__ maskP, const int* __restrict__ mask_any,
                                                                 const int* __restrict__ out_map, float* __restrict__ out, int nPairs,
-                                                                int nWperImg, int C, int nH) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                                                                int nWperImg, int C, int nH, const unsigned long long* __restrict__ padbits,
+                                                                int bias_row) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int pair = blockIdx.x * 4 + wave;
   if (pair >= nPairs) return;
   const int win = pair / nH, head = pair - win * nH;
   const int l32 = lane & 31, half = lane >> 5;
-  const long long ld = 3LL * C;
-  const float* base = qkv + (long long)win * WS2 * ld + head * HEAD_DIM;
-  const float* bP = biasP + (long long)head * 4096 + (half * 32 + l32) * 4;                      // + ti * 2048
+  const unsigned ld = 3u * C;
   const int wimg = win % nWperImg;
+  // Padding rows of the window (tokens F.pad added, swin.py:341-343) all hold the QKV bias: they are never read -- bit j of `pad` set ->
+  // row `bias_row` (one row, in L1 after its first use) stands in for row j.  Everything here is wave-uniform (scalar registers).
+  const unsigned long long pad = padbits ? padbits[wimg] : 0ull;
+  const unsigned row0 = (unsigned)win * WS2;
+  const float* base = qkv + head * HEAD_DIM;             // + ATTN_ROW(j): element offset of row j of this window (< 2^32: the image is < 4 GB)
+#define ATTN_ROW(j_) (__umul24(((pad >> (j_)) & 1ull) ? (unsigned)bias_row : row0 + (unsigned)(j_), ld))
+  const float* bP = biasP + (long long)head * 4096 + (half * 32 + l32) * 4;                      // + ti * 2048
   const float* mP = (maskP && mask_any[wimg]) ? maskP + (long long)wimg * 4096 + (half * 32 + l32) * 4 : nullptr;
   const float scale = 0.17677669529663687f;   // 32^-0.5
 
@@ -560,8 +566,9 @@ __global__ __launch_bounds__(256, 3) void window_attn_split_kernel(const float* 
 #if defined(NUHTC_ATTN_PROBE) && (NUHTC_ATTN_PROBE & 4)     // dev probe (wrong results): no K / Q loads
       kfa[tj][q] = (v4f){0.01f * lane, 0.02f, 0.03f * q, 0.04f}; qfa[tj][q] = (v4f){0.02f, 0.01f * lane, 0.01f, 0.03f * q};
 #else
-      kfa[tj][q] = *reinterpret_cast<const v4f*>(base + j * ld + C + lc * 4);
-      qfa[tj][q] = *reinterpret_cast<const v4f*>(base + j * ld + lc * 4);
+      const unsigned ro = ATTN_ROW(j);
+      kfa[tj][q] = *reinterpret_cast<const v4f*>(base + ro + C + lc * 4);
+      qfa[tj][q] = *reinterpret_cast<const v4f*>(base + ro + lc * 4);
 #endif
     }
   }
@@ -582,7 +589,7 @@ __global__ __launch_bounds__(256, 3) void window_attn_split_kernel(const float* 
 #if defined(NUHTC_ATTN_PROBE) && (NUHTC_ATTN_PROBE & 2)     // dev probe: no V loads
       vv[g][e] = 0.001f * (lane + r);
 #else
-      vv[g][e] = base[((g >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * ld + 2 * C + l32];
+      vv[g][e] = base[ATTN_ROW((g >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) + 2 * C + l32];
 #endif
     }
   __builtin_amdgcn_sched_barrier(0);
@@ -701,7 +708,7 @@ __global__ __launch_bounds__(256, 3) void window_attn_split_kernel(const float* 
 #if defined(NUHTC_ATTN_PROBE) && (NUHTC_ATTN_PROBE & 2)
       for (int g = 0; g < 4; ++g) v48[g] = (v4f){0.1f, 0.2f, 0.3f, 0.4f};
 #else
-      for (int g = 0; g < 4; ++g) v48[g] = *reinterpret_cast<const v4f*>(base + 48 * ld + 2 * C + 8 * g + 4 * half);
+      for (int g = 0; g < 4; ++g) v48[g] = *reinterpret_cast<const v4f*>(base + ATTN_ROW(48) + 2 * C + 8 * g + 4 * half);
 #endif
       const float p48 = __shfl(st[1][8], l32) * rsum;
 #pragma unroll
@@ -725,16 +732,17 @@ __global__ __launch_bounds__(256, 3) void window_attn_split_kernel(const float* 
   }
 }
 #undef ATTN_TO_OPERAND
+#undef ATTN_ROW
 
 int launch_window_attn(const float* qkv, const float* biasP, const float* maskP, const int* mask_any, const int* out_map, float* out,
-                       int nWinTotal, int nWperImg, int C, int nH, int split_pipe, hipStream_t s) {
+                       int nWinTotal, int nWperImg, int C, int nH, int split_pipe, hipStream_t s, const unsigned long long* padbits, int bias_row) {
   { static const int& skip_ = dev_knob_ref("SKIP", 0); if (skip_ & 1) return 0; }   // dev: ablation of the step (tools/dev/r04_ablate.py)
   ProfScope ps("window_attn", 4.0 * 49 * 49 * 32 * nWinTotal * nH, 16.0 * 49 * C * nWinTotal, s);
   int nPairs = nWinTotal * nH;
   if (nPairs <= 0) return 0;
-  if (!biasP || (maskP && !mask_any)) return NUHTC_E_INVALID;
+  if (!biasP || (maskP && !mask_any) || (padbits && !split_pipe)) return NUHTC_E_INVALID;
   if (split_pipe)
-    hipLaunchKernelGGL(window_attn_split_kernel, dim3(cdiv(nPairs, 4)), dim3(256), 0, s, qkv, biasP, maskP, mask_any, out_map, out, nPairs, nWperImg, C, nH);
+    hipLaunchKernelGGL(window_attn_split_kernel, dim3(cdiv(nPairs, 4)), dim3(256), 0, s, qkv, biasP, maskP, mask_any, out_map, out, nPairs, nWperImg, C, nH, padbits, bias_row);
   else
     hipLaunchKernelGGL(window_attn_mfma_kernel, dim3(cdiv(nPairs, 4)), dim3(256), 0, s, qkv, biasP, maskP, mask_any, out_map, out, nPairs, nWperImg, C, nH);
   return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;

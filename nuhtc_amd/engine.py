@@ -388,6 +388,17 @@ class Engine:
                                                    y.data_ptr(), c.data_ptr(), M, Kp, K, N, act, self._stream()))
         return y, c
 
+    def op_merge_ln_gemm(self, x, B, H, W, w, ln_g, ln_b):
+        """PatchMerging in one launch (csrc/gemm.hip A_LN over two segments per row): x (B*H*W, C) tokens on the device; w (2C, 4C), ln_g / ln_b (4C)
+        in the reference's nn.Unfold column order (transformer.py:363-385).  -> (B*H/2*W/2, 2C)."""
+        C = x.shape[1]
+        y = torch.empty(B * (H // 2) * (W // 2), 2 * C, dtype=torch.float32, device=self.device)
+        h = lambda t: np.ascontiguousarray(t.detach().cpu().numpy(), dtype=np.float32)
+        wh, gh, bh = h(w), h(ln_g), h(ln_b)
+        vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        self._check(self.lib.nuhtc_op_merge_ln_gemm(self.h, x.data_ptr(), B, H, W, C, vp(wh), vp(gh), vp(bh), y.data_ptr(), self._stream()))
+        return y
+
     def op_swin_mlp(self, x, ln_g, ln_b, w1, b1, w2, b2):
         """x + W2 gelu(W1 LN(x) + b1) + b2 by the fused FFN kernel (csrc/mlp.hip); x (T, C) and the vectors on the device, w1 / w2 anywhere."""
         T, C = x.shape

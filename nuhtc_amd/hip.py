@@ -41,7 +41,7 @@ EXPORTS = ['nuhtc_default_config', 'nuhtc_create', 'nuhtc_destroy', 'nuhtc_last_
            'nuhtc_finalize', 'nuhtc_infer', 'nuhtc_infer_fixed_load', 'nuhtc_check', 'nuhtc_get_buffer',
            'nuhtc_op_gemm', 'nuhtc_op_gemm_split', 'nuhtc_op_roi_align', 'nuhtc_op_nms', 'nuhtc_profile_enable', 'nuhtc_profile_read', 'nuhtc_dev_knob', 'nuhtc_export_crops',
            'nuhtc_mask_contours', 'nuhtc_merge_overlap', 'nuhtc_export_kept', 'nuhtc_clock_probe', 'nuhtc_op_swin_mlp', 'nuhtc_stream', 'nuhtc_op_swin_proj_mlp', 'nuhtc_bind_host_thread',
-           'nuhtc_bind_host_thread_pci', 'nuhtc_bind_host_thread_at', 'nuhtc_restore_host_thread', 'nuhtc_op_ln_gemm', 'nuhtc_op_gemm_ln_gemm']
+           'nuhtc_bind_host_thread_pci', 'nuhtc_bind_host_thread_at', 'nuhtc_restore_host_thread', 'nuhtc_op_ln_gemm', 'nuhtc_op_gemm_ln_gemm', 'nuhtc_op_merge_ln_gemm']
 
 _lib = None
 
@@ -77,6 +77,7 @@ def load():
     lib.nuhtc_op_gemm_split.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
     lib.nuhtc_op_ln_gemm.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
     lib.nuhtc_op_gemm_ln_gemm.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
+    lib.nuhtc_op_merge_ln_gemm.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp]
     lib.nuhtc_op_swin_mlp.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp]
     lib.nuhtc_op_swin_proj_mlp.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp]
     lib.nuhtc_op_roi_align.argtypes = [vp, vp, ci, ci, ci, vp, ci, ci, cf, ci, vp, vp]

@@ -125,6 +125,34 @@ def test_ln_gemm_kernel_vs_fp64(hip_device):
         assert float(e1.max()) <= (2e-5 if offset >= 50 else 2e-6), (T, M, N, K, float(e1.max()))
 
 
+def test_patch_merging_in_one_launch_vs_fp64(hip_device):
+    """PatchMerging (mmdet transformer.py:363-385: nn.Unfold(2, stride 2) -> LayerNorm(4C) -> Linear(4C, 2C, bias=False)) as ONE launch: the A rows
+    of the reduction linear are gathered from the token tensor as two runs of 2C floats, the norm rides in the A path and its statistics are
+    merged from per-token partials over 96 channels (gemm.hip A_LN with seg_k; 4 / 8 / 16 partials per merged row).  Against an fp64
+    restatement by torch's own Unfold, beside the two-kernel form (fp32 LayerNorm by torch, then the split GEMM): the three merges of the
+    path, a non-square grid, a row count that is not a tile multiple, tokens with a large common offset."""
+    g = G.load('small_b2')
+    eng, _ = _engine(g)
+    gen = torch.Generator().manual_seed(31)
+    for (B, H, W, C, offset) in [(2, 64, 64, 96, 0.0), (3, 32, 32, 192, 0.0), (5, 16, 16, 384, 0.0), (1, 10, 6, 96, 0.0), (2, 12, 20, 192, 30.0), (1, 6, 10, 384, 3.0)]:
+        x = torch.randn(B * H * W, C, generator=gen) * (1.0 + torch.rand(B * H * W, 1, generator=gen)) + offset * torch.randn(B * H * W, 1, generator=gen).sign()
+        w = torch.randn(2 * C, 4 * C, generator=gen) / (4 * C) ** 0.5
+        lg = 1.0 + 0.2 * torch.randn(4 * C, generator=gen)
+        lb = 0.1 * torch.randn(4 * C, generator=gen)
+        u = torch.nn.functional.unfold(x.view(B, H, W, C).permute(0, 3, 1, 2), kernel_size=2, stride=2).transpose(1, 2).reshape(-1, 4 * C)   # channel-major: k = c*4 + kh*2 + kw
+        ud = u.double()
+        y = (ud - ud.mean(1, keepdim=True)) / (ud.var(1, unbiased=False, keepdim=True) + 1e-5).sqrt() * lg.double() + lb.double()
+        ref = y @ w.double().T
+        mag = y.abs() @ w.double().abs().T + 1e-30
+        out = eng.op_merge_ln_gemm(x.cuda(), B, H, W, w, lg, lb).cpu().double()
+        two = eng.op_gemm(torch.nn.functional.layer_norm(u, (4 * C,), lg, lb, 1e-5).cuda(), w.cuda(), None, 0, pipe='split').cpu().double()
+        e1, e2 = ((out - ref).abs() / mag), ((two - ref).abs() / mag)
+        print(f'B{B} {H}x{W} C{C} offset{offset}: one launch max {float(e1.max()):.2e} rms {float((e1 ** 2).mean().sqrt()):.2e} | LN kernel + GEMM max {float(e2.max()):.2e} rms {float((e2 ** 2).mean().sqrt()):.2e}')
+        assert out.shape == ref.shape and torch.isfinite(out).all()
+        assert float((e1 ** 2).mean().sqrt()) <= 1.5 * float((e2 ** 2).mean().sqrt()) + 2e-8, (B, H, W, C)
+        assert float(e1.max()) <= (2e-5 if offset >= 30 else 2e-6), (B, H, W, C, float(e1.max()))
+
+
 def test_epilogue_ln_statistics_chain_vs_fp64(hip_device):
     """The engine's chain for the norms of Swin stages 2-4 (round 5): the GEMM that PRODUCES a token tensor (proj + residual with its row
     scatter, fc2 + residual, patch merging) leaves, per row and 96 columns, {mean, sum of squared deviations} of what it stores
