@@ -539,8 +539,8 @@ __global__ __launch_bounds__(256, 3) void window_attn_split_kernel(const float* 
   // row `bias_row` (one row, in L1 after its first use) stands in for row j.  Everything here is wave-uniform (scalar registers).
   const unsigned long long pad = padbits ? padbits[wimg] : 0ull;
   const unsigned row0 = (unsigned)win * WS2;
-  const float* base = qkv + head * HEAD_DIM;             // + ATTN_ROW(j): element offset of row j of this window (< 2^32: the image is < 4 GB)
-#define ATTN_ROW(j_) (__umul24(((pad >> (j_)) & 1ull) ? (unsigned)bias_row : row0 + (unsigned)(j_), ld))
+  const float* base = qkv + head * HEAD_DIM;             // + ATTN_ROW(j): element offset of row j of this window (one v_mad_u64_u32: any image size)
+#define ATTN_ROW(j_) ((unsigned long long)(((pad >> (j_)) & 1ull) ? (unsigned)bias_row : row0 + (unsigned)(j_)) * (unsigned long long)ld)
   const float* bP = biasP + (long long)head * 4096 + (half * 32 + l32) * 4;                      // + ti * 2048
   const float* mP = (maskP && mask_any[wimg]) ? maskP + (long long)wimg * 4096 + (half * 32 + l32) * 4 : nullptr;
   const float scale = 0.17677669529663687f;   // 32^-0.5
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(256, 3) void window_attn_split_kernel(const float* 
 #if defined(NUHTC_ATTN_PROBE) && (NUHTC_ATTN_PROBE & 4)     // dev probe (wrong results): no K / Q loads
       kfa[tj][q] = (v4f){0.01f * lane, 0.02f, 0.03f * q, 0.04f}; qfa[tj][q] = (v4f){0.02f, 0.01f * lane, 0.01f, 0.03f * q};
 #else
-      const unsigned ro = ATTN_ROW(j);
+      const unsigned long long ro = ATTN_ROW(j);
       kfa[tj][q] = *reinterpret_cast<const v4f*>(base + ro + C + lc * 4);
       qfa[tj][q] = *reinterpret_cast<const v4f*>(base + ro + lc * 4);
 #endif
@@ -737,7 +737,8 @@ __global__ __launch_bounds__(256, 3) void window_attn_split_kernel(const float* 
 int launch_window_attn(const float* qkv, const float* biasP, const float* maskP, const int* mask_any, const int* out_map, float* out,
                        int nWinTotal, int nWperImg, int C, int nH, int split_pipe, hipStream_t s, const unsigned long long* padbits, int bias_row) {
   { static const int& skip_ = dev_knob_ref("SKIP", 0); if (skip_ & 1) return 0; }   // dev: ablation of the step (tools/dev/r04_ablate.py)
-  ProfScope ps("window_attn", 4.0 * 49 * 49 * 32 * nWinTotal * nH, 16.0 * 49 * C * nWinTotal, s);
+  ProfScope ps(C == 96 ? "window_attn|c96" : C == 192 ? "window_attn|c192" : C == 384 ? "window_attn|c384" : C == 768 ? "window_attn|c768" : "window_attn",   // (tags group by the part before '|')
+               4.0 * 49 * 49 * 32 * nWinTotal * nH, 16.0 * 49 * C * nWinTotal, s);
   int nPairs = nWinTotal * nH;
   if (nPairs <= 0) return 0;
   if (!biasP || (maskP && !mask_any) || (padbits && !split_pipe)) return NUHTC_E_INVALID;
