@@ -355,6 +355,47 @@ def test_image_size_not_a_multiple_of_32(hip_device):
     assert allb[:, 2].max() <= w and allb[:, 3].max() <= h
 
 
+def test_tile_size_without_window_padding_in_any_stage(hip_device):
+    """112 x 112 tiles: the network input is 224 x 224, the four Swin stages have 56 / 28 / 14 / 7 tokens per side -- multiples of the 7 x 7
+    window, so no stage pads (swin.py:341-343 pads nothing), the window image has no padding rows, the engine's padding-row list is empty and
+    every padding mask of the attention kernel is zero; stage 4 is ONE window and its shifted block has no shift (7 <= window size is not the
+    case mmdet special-cases: shift stays 3, the mask applies).  Engine vs oracle: FPN maps, then end to end with the strict gates."""
+    import torch
+    import golden_util as G
+    from nuhtc_amd.engine import Engine
+    from oracle import model as O
+    g = G.load('five_b2')
+    sd = G.seeded_sd(g)
+    tiles = np.ascontiguousarray(g['tiles'][:, 40:152, 72:184])
+    B, (h, w) = len(tiles), tiles.shape[1:3]
+    assert (h, w) == (112, 112)
+    mode = int(g['channel_mode'])
+    eng = Engine(sd, device=0, max_batch=B, tile=(h, w))
+    eng.infer_async(eng.to_device(tiles), mode)
+    got = eng.results(B)
+    ref_img = O.preprocess(tiles, mode)
+    assert tuple(ref_img.shape) == (B, 3, 224, 224)
+    with torch.no_grad():
+        c = O.backbone(sd, ref_img)
+        x = O.fpn(sd, c)
+    assert [t.shape[-1] for t in c] == [56, 28, 14, 7]
+    for i in range(4):
+        ec = float((eng.buffer(f'c{i}')[:B].cpu().permute(0, 3, 1, 2) - c[i]).abs().max())
+        ex = float((eng.buffer(f'x{i}')[:B].cpu().permute(0, 3, 1, 2) - x[i]).abs().max())
+        print(f'c{i}: {ec:.2e}  x{i}: {ex:.2e}')
+        assert ec <= 2e-4 + 2e-4 * float(c[i].abs().max()) and ex <= 2e-4, (i, ec, ex)
+    ref, it = O.Oracle(sd)(tiles, mode, keep=True)
+    vals = P.oracle_paste_values(O, it, (h, w))
+    msgs = []
+    for i in range(B):
+        rep, fails = P.compare_strict(ref[i], got[i], values=vals[i], values_side='ref')
+        print(f'112 px tile {i} end-to-end vs oracle: {P.fmt(rep)}', *rep['explained'], sep='\n    ')
+        msgs += [f'tile {i}: {f}' for f in fails]
+        assert sum(len(b) for b in got[i][0]) > 10
+    assert not msgs, '\n'.join(msgs)
+    eng.close()
+
+
 def test_engine_creation_puts_the_submitting_thread_on_the_gpus_numa_node(hip_device, monkeypatch):
     """Engine(bind_host=True) calls nuhtc_bind_host_thread (the command processor reads every dispatch packet from host
     memory the submitter wrote; from the other socket that costs 0.3-0.4 ms per step): afterwards the calling thread runs on the CPUs sysfs
