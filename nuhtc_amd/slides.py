@@ -5,13 +5,15 @@
     file exists (:168-171), tissue segmentation (`--seg`, :254-265), mask picture (:267-270), tile coordinates (`--patch`,
     :272-276 -> patches/<slide_id>), stitched picture (`--stitch`, :278-284), status column.
 
-Differences, all forced by the image (no OpenSlide, no HDF5, no OpenCV) and stated where they apply:
+Differences, all forced by the image (no OpenSlide, no h5py, no OpenCV) and stated where they apply:
   * a slide is a level-0 RGB array (`.npy`, memory-mapped) or a store directory (nuhtc_amd.tilestore); other files of the folder
     get status `failed_open` and the loop goes on (the reference would raise inside OpenSlide);
   * the pyramid is virtual and dyadic: level k is the [::2^k] view of the array, so `seg_level = -1` resolves to the level whose
     downsample is `seg_downsample` (64, what `get_best_level_for_downsample(64)` gives for a pyramid that has it);
   * the coordinate file is patches/<slide_id>.npz (`coords`, `patch_size`, `patch_level`, `name`: the datasets / attributes of
-    the reference's .h5, tools/wsi_core/wsi_utils.py `initialize_hdf5_bag` / `save_hdf5`), written uncompressed;
+    the reference's .h5, tools/wsi_core/wsi_utils.py `initialize_hdf5_bag` / `save_hdf5`), written uncompressed -- AND, wherever an HDF5
+    back end exists (h5py or the HDF5 C library, nuhtc_amd.h5coords), the reference's own patches/<slide_id>.h5 beside it; a patch folder the
+    reference's tool made (only .h5 files) is read as it is: auto-skip and the slide loop accept either file;
   * the two pictures are drawn with PIL (outline width as `visWSI` computes it; not pixel-equal to cv2.drawContours).
 """
 import math
@@ -80,9 +82,42 @@ def coords_path(patch_save_dir, slide_id):
     return os.path.join(patch_save_dir, slide_id + '.npz')
 
 
-def save_coords(path, coords, patch_size, patch_level, name):
-    np.savez(path, coords=np.asarray(coords, np.int64).reshape(-1, 2), patch_size=np.int64(patch_size), patch_level=np.int64(patch_level),
-             name=np.str_(name))
+def h5_path(patch_save_dir, slide_id):
+    """patches/<slide_id>.h5 -- the reference's coordinate file (tools/infer_wsi.py:168,282,447)."""
+    return os.path.join(patch_save_dir, slide_id + '.h5')
+
+
+def save_coords(path, coords, patch_size, patch_level, name, level_dim=None, downsample=None):
+    """patches/<id>.npz and, with an HDF5 back end, the reference's patches/<id>.h5 with the attributes WholeSlideImage.process_contour gives it
+    (:483-489; `level_dim` = (W, H) of the patch level, `downsample` its level_downsamples entry)."""
+    coords = np.asarray(coords, np.int64).reshape(-1, 2)
+    np.savez(path, coords=coords, patch_size=np.int64(patch_size), patch_level=np.int64(patch_level), name=np.str_(name))
+    from . import h5coords
+    if h5coords.available():
+        attrs = dict(patch_size=int(patch_size), patch_level=int(patch_level))
+        if downsample is not None:
+            attrs['downsample'] = tuple(float(v) for v in downsample)
+        if level_dim is not None:
+            attrs['downsampled_level_dim'] = tuple(int(v) for v in level_dim)
+            attrs['level_dim'] = tuple(int(v) for v in level_dim)
+        attrs['name'] = str(name)
+        attrs['save_path'] = os.path.dirname(path)
+        h5coords.write_coords(os.path.splitext(path)[0] + '.h5', coords, attrs)
+
+
+def has_coords(patch_save_dir, slide_id):
+    return os.path.isfile(coords_path(patch_save_dir, slide_id)) or os.path.isfile(h5_path(patch_save_dir, slide_id))
+
+
+def load_coords(patch_save_dir, slide_id):
+    """-> (coords int64 (n, 2), patch_size, patch_level) of a slide: the .npz, else the reference's .h5 (Whole_Slide_Bag_FP, WholeSlideImage.py:862-865)."""
+    p = coords_path(patch_save_dir, slide_id)
+    if os.path.isfile(p):
+        z = np.load(p)
+        return np.asarray(z['coords'], np.int64).reshape(-1, 2), int(z['patch_size']), int(z['patch_level']) if 'patch_level' in z.files else 0
+    from . import h5coords
+    r = h5coords.read_coords(h5_path(patch_save_dir, slide_id))
+    return r['coords'], int(r['attrs']['patch_size']), int(r['attrs'].get('patch_level', 0))
 
 
 def open_array_slide(path):
@@ -181,7 +216,7 @@ def seg_and_patch(source, save_dir, patch_save_dir, mask_save_dir, stitch_save_d
         df.loc[idx, 'process'] = 0
         slide_id, _ = os.path.splitext(slide)
         cpath = coords_path(patch_save_dir, slide_id)
-        if not no_auto_skip and os.path.isfile(cpath):
+        if not no_auto_skip and has_coords(patch_save_dir, slide_id):
             log('{} already exist in destination location, skipped'.format(slide_id))
             df.loc[idx, 'status'] = 'already_exist'
             continue
@@ -232,14 +267,15 @@ def seg_and_patch(source, save_dir, patch_save_dir, mask_save_dir, stitch_save_d
                          for c, hs in zip(conts, holes)]
                 coords = np.concatenate(parts, 0) if parts else np.zeros((0, 2), np.int64)
             if len(coords):                                        # the reference creates the .h5 with the first contour that yields tiles (:397-403)
-                save_coords(cpath, coords, patch_size, patch_level, slide_id)
+                save_coords(cpath, coords, patch_size, patch_level, slide_id, level_dim=(W >> patch_level, H >> patch_level),
+                            downsample=(float(1 << patch_level), float(1 << patch_level)))
             log('tissue segmentation: {} contour(s), {} tiles'.format(0 if conts is None else len(conts), len(coords)))
             patch_time = time.time() - t0
         stitch_time = -1
-        if stitch and os.path.isfile(cpath):
+        if stitch and has_coords(patch_save_dir, slide_id):
             t0 = time.time()
-            z = np.load(cpath)
-            stitch_coords(img, z['coords'], int(z['patch_size']), downscale=64).save(os.path.join(stitch_save_dir, slide_id + '.jpg'))
+            sc, sps, _ = load_coords(patch_save_dir, slide_id)
+            stitch_coords(img, sc, sps, downscale=64).save(os.path.join(stitch_save_dir, slide_id + '.jpg'))
             stitch_time = time.time() - t0
         log('segmentation took {} seconds'.format(seg_time))
         log('patching took {} seconds'.format(patch_time))

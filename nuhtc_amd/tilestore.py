@@ -78,6 +78,10 @@ def write_store(path, slide, coords, patch_size=256):
 
 
 def _load_coords(path):
+    if path.endswith('.h5'):      # the reference's coordinate file (nuhtc_amd.h5coords)
+        from . import h5coords
+        r = h5coords.read_coords(path)
+        return r['coords'], int(r['attrs']['patch_size']) if 'patch_size' in r['attrs'] else None
     if path.endswith('.npz'):
         z = np.load(path)
         ps = int(z['patch_size']) if 'patch_size' in z.files else None

@@ -253,6 +253,21 @@ def test_readme_command_lines_on_a_folder_of_slides(hip_device, tmp_path):
     for sid in ('a', 'b'):
         assert open(two / 'nuclei' / sid / f'{sid}.geojson', 'rb').read() == open(out / 'nuclei' / sid / f'{sid}.geojson', 'rb').read()
         assert open(two / 'patches' / f'{sid}.npz', 'rb').read() == open(out / 'patches' / f'{sid}.npz', 'rb').read()
+    # a patch folder as the REFERENCE's tool leaves it -- only patches/<id>.h5 (WholeSlideImage.process_contours) --: the slides count as patched
+    # (auto-skip, tools/infer_wsi.py:168) and the slide loop reads the .h5 (Whole_Slide_Bag_FP): the same documents
+    from nuhtc_amd import h5coords
+    if h5coords.available():
+        import shutil
+        ref_made = tmp_path / 'ref_made'
+        os.makedirs(ref_made / 'patches')
+        for sid in ('a', 'b'):
+            assert os.path.exists(out / 'patches' / f'{sid}.h5')
+            shutil.copy(out / 'patches' / f'{sid}.h5', ref_made / 'patches' / f'{sid}.h5')
+        log_h5 = subprocess.run([sys.executable, tool] + line1.split()[:-6] + ['--save_dir', str(ref_made), '--mode', 'qupath', '--slide_ext', '.npy'], check=True,
+                                capture_output=True, text=True).stdout
+        assert 'a already exist in destination location, skipped' in log_h5 and not os.path.exists(ref_made / 'patches' / 'a.npz')
+        for sid in ('a', 'b'):
+            assert json.load(open(ref_made / 'nuclei' / sid / f'{sid}.geojson')) == docs[sid]
     # README.md:221-223 into the same directory: the coordinate files exist (auto-skip), both slides are inferred again with margin 1
     line2 = f'{src} {CFG} {ck} --patch --seg --stitch --patch_size 256 --step_size 192 --margin 1 --min_area 10 --batch_size 32 --save_dir {out} --mode qupath --slide_ext .npy'
     log2 = subprocess.run([sys.executable, tool] + line2.split() + ['--merge', '--det', '--score-thr', '0.5'], check=True, capture_output=True, text=True).stdout

@@ -8,7 +8,7 @@ sharded across GPUs.
 
 <source> is the reference's folder of slides: every file in it goes through `seg_and_patch` (nuhtc_amd/slides.py: process list
 -> <save_dir>/process_list_autogen.csv, `--seg` tissue segmentation, masks/<id>.png, `--patch` tile coordinates ->
-patches/<id>.npz, `--stitch` stitches/<id>.jpg; a slide whose coordinate file exists is skipped unless --no_auto_skip), then every
+patches/<id>.npz, `--stitch` stitches/<id>.jpg; a slide whose coordinate file -- that .npz or the reference's patches/<id>.h5 -- exists is skipped unless --no_auto_skip), then every
 slide of the process list that has a coordinate file and no <id>_merged.geojson yet (:445-458) is tiled, inferred and written.
 A slide is a level-0 RGB array (`.npy`, memory-mapped; pass `--slide_ext .npy`) or a store directory: OpenSlide / HDF5 do not
 exist offline.  Beyond the reference, <source> may be ONE slide: a `.npy` file (`--patch` is then implied: the
@@ -66,7 +66,7 @@ def build_parser():
     p.add_argument('--det', default=False, action='store_true')
     # ---- not in the reference
     p.add_argument('--seg_downsample', type=int, default=64, help='downsample of the (virtual) pyramid level seg_level / vis_level -1 resolve to (reference: the level nearest 64x)')
-    p.add_argument('--coords', default=None, help="coordinate file of a single .npy slide: .npy (N,2) or .npz with `coords` [+ `patch_size`] -- the role of the reference's patches/<id>.h5")
+    p.add_argument('--coords', default=None, help="coordinate file of a single .npy slide: .npy (N,2), .npz with `coords` [+ `patch_size`], or the reference's own patches/<id>.h5")
     p.add_argument('--gpus', type=int, default=1, help='one rank per GPU: the tool starts itself N times under torch.distributed.run (a child process) unless a launcher already did')
     p.add_argument('--merge', action='store_true', help='also run the cross-tile merge (tools/nuclei_merge.py) on rank 0 -> <id>_merged.geojson')
     p.add_argument('--overlap_threshold', type=float, default=0.05)
@@ -242,17 +242,16 @@ def main(argv=None):
             dist.barrier()
         for entry in slides.slide_list(args.save_dir):        # Dataset_All_Bags over process_list_autogen.csv (:437-439)
             slide_id = entry.split(ext)[0] if ext else entry
-            cpath = slides.coords_path(patch_save_dir, slide_id)
-            if not os.path.exists(cpath):
+            if not slides.has_coords(patch_save_dir, slide_id):     # patches/<id>.npz, or the reference's own patches/<id>.h5
                 say(f'\nskip {slide_id} due to no coord file')
                 continue
             spath = os.path.join(folder, entry)                # the list holds file names; the reference rebuilds them as slide_id + slide_ext (:452)
             if not os.path.exists(spath):
                 spath = os.path.join(folder, slide_id + ext)
 
-            def make(spath=spath, cpath=cpath):
-                z = np.load(cpath)
-                return tilestore.TileBag(slides.open_array_slide(spath), z['coords'], int(z['patch_size']))
+            def make(spath=spath, slide_id=slide_id):
+                c, ps, _ = slides.load_coords(patch_save_dir, slide_id)
+                return tilestore.TileBag(slides.open_array_slide(spath), c, ps)
             jobs.append((slide_id, make))
     total = len(jobs)
     for k, (slide_id, make) in enumerate(jobs):
