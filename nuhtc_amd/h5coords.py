@@ -63,7 +63,7 @@ def _lib():
             'H5Dget_create_plist': (H, [H]), 'H5Dread': (I, [H, H, H, H, H, P]), 'H5Dwrite': (I, [H, H, H, H, H, P]), 'H5Dclose': (I, [H]),
             'H5Screate': (H, [I]), 'H5Screate_simple': (H, [I, HP, HP]), 'H5Sget_simple_extent_ndims': (I, [H]),
             'H5Sget_simple_extent_dims': (I, [H, HP, HP]), 'H5Sget_simple_extent_npoints': (ctypes.c_int64, [H]), 'H5Sclose': (I, [H]),
-            'H5Pcreate': (H, [H]), 'H5Pset_chunk': (I, [H, I, HP]), 'H5Pget_chunk': (I, [H, I, HP]), 'H5Pget_layout': (I, [H]), 'H5Pclose': (I, [H]),
+            'H5Pcreate': (H, [H]), 'H5Pset_chunk': (I, [H, I, HP]), 'H5Pget_chunk': (I, [H, I, HP]), 'H5Pget_layout': (I, [H]), 'H5Pset_fill_time': (I, [H, I]), 'H5Pclose': (I, [H]),
             'H5Acreate2': (H, [H, CP, H, H, H, H]), 'H5Awrite': (I, [H, H, P]), 'H5Aread': (I, [H, H, P]), 'H5Aopen': (H, [H, CP, H]),
             'H5Aopen_by_idx': (H, [H, CP, I, I, _hsz, H, H]), 'H5Aget_name': (ctypes.c_ssize_t, [H, S, CP]), 'H5Aget_type': (H, [H]),
             'H5Aget_space': (H, [H]), 'H5Aclose': (I, [H]), 'H5Aexists': (I, [H, CP]),
@@ -276,6 +276,7 @@ def write_coords(path, coords, attrs):
         space = _ck(lib.H5Screate_simple(2, dims, maxd), 'H5Screate_simple')
         plist = _ck(lib.H5Pcreate(lib._ids['H5P_DATASET_CREATE']), 'H5Pcreate')
         _ck(lib.H5Pset_chunk(plist, 2, chunk), 'H5Pset_chunk')
+        lib.H5Pset_fill_time(plist, 0)      # H5D_FILL_TIME_ALLOC, h5py's setting: `h5dump -p` of the file equals that of one h5py wrote
         d = lib.H5Dcreate2(f, b'coords', lib._ids['H5T_STD_I64LE'], space, 0, plist, 0)
         lib.H5Pclose(plist); lib.H5Sclose(space)
         _ck(d, 'H5Dcreate2')

@@ -1,7 +1,8 @@
 """The reference's coordinate files patches/<slide_id>.h5 (tools/wsi_core/WholeSlideImage.py:388-406,481-492 + wsi_utils.save_hdf5 :66-85 write
-them, Whole_Slide_Bag_FP :862-865 reads them): nuhtc_amd.h5coords through the HDF5 C library (no h5py in this image).  The writer is checked
-against the HDF5 project's own `h5dump`, the reader against files made by direct C-API calls in the forms other writers produce (a resized
-dataset appended contour by contour as save_hdf5 does, 32-bit integers, fixed-length ASCII strings)."""
+them, Whole_Slide_Bag_FP :862-865 reads them): nuhtc_amd.h5coords through the HDF5 C library (no h5py for the interpreter the suite runs on).
+Pinned on a golden file the reference's own save_hdf5 wrote under the real h5py (oracle/ref_harness/make_h5_golden.py); the writer is also
+checked against the HDF5 project's `h5dump` and, where the image's Python 3.9 is present, by h5py itself; the reader also against files made by
+direct C-API calls in the forms other writers produce (32-bit integers, fixed-length ASCII strings, H5Dset_extent appends)."""
 import ctypes
 import os
 import shutil
@@ -110,6 +111,52 @@ def test_reader_on_files_of_other_writers(tmp_path):
     assert r['coords'].dtype == np.int64 and np.array_equal(r['coords'], np.concatenate(parts, 0))
     assert int(r['attrs']['patch_size']) == 512 and int(r['attrs']['patch_level']) == 1 and r['attrs']['name'] == 'slide7'
     assert r['chunks'] == (1, 2) and tuple(r['maxshape']) == (None, 2)
+
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def test_file_written_by_the_reference_with_h5py(tmp_path):
+    """tests/golden/coords_reference.h5 was written by the reference's OWN save_hdf5 under the real h5py (oracle/ref_harness/make_h5_golden.py:
+    mode 'w' with the attribute dict, then two appends, as process_contours does); coords_reference.json is what h5py reports for it.  The
+    reader returns the same coordinates, attributes and layout; a file written here from those values has the same `h5dump -p` description."""
+    import json
+    want = json.load(open(os.path.join(GOLD, 'coords_reference.json')))
+    r = H.read_coords(os.path.join(GOLD, 'coords_reference.h5'))
+    assert r['coords'].dtype == np.int64 and r['coords'].tolist() == want['coords'] and list(r['coords'].shape) == want['shape'] == [85, 2]
+    assert list(r['chunks']) == want['chunks'] == [1, 2] and list(r['maxshape']) == want['maxshape'] == [None, 2]
+    assert set(r['attrs']) == set(want['attrs']) == set(H.ATTR_ORDER)
+    for k, v in want['attrs'].items():
+        got = r['attrs'][k]
+        assert (got.tolist() if hasattr(got, 'tolist') else got) == v, k
+        assert (np.asarray(got).dtype.name if not isinstance(got, str) else 'str') == want['attr_dtypes'][k], k
+    assert int(r['attrs']['patch_level']) == want['patch_level'] and int(r['attrs']['patch_size']) == want['patch_size']
+    if _h5dump() is not None:
+        a = want['attrs']
+        mine = H.write_coords(str(tmp_path / 'mine.h5'), np.array(want['coords']), {k: (tuple(a[k]) if isinstance(a[k], list) else a[k]) for k in H.ATTR_ORDER})
+        dump = lambda p: subprocess.run([_h5dump(), '-p', p], capture_output=True, text=True, check=True).stdout.splitlines()[1:]
+        assert dump(mine) == dump(os.path.join(GOLD, 'coords_reference.h5'))
+
+
+@pytest.mark.skipif(not os.path.exists('/opt/conda/bin/python3.9'), reason="the image's second interpreter (the one that has h5py) is not here")
+def test_written_file_read_by_the_real_h5py(tmp_path):
+    """The other direction: a file written here, opened by h5py 3.3 the way Whole_Slide_Bag_FP opens it (WholeSlideImage.py:862-865, 890-891)."""
+    import json
+    probe = subprocess.run(['/opt/conda/bin/python3.9', '-c', 'import h5py'], capture_output=True)
+    if probe.returncode != 0:
+        pytest.skip('no h5py in /opt/conda/bin/python3.9')
+    coords = np.stack([np.arange(40) * 192, np.arange(40)[::-1] * 192 + 2 ** 33], 1).astype(np.int64)
+    p = H.write_coords(str(tmp_path / 's.h5'), coords, ATTRS)
+    code = ("import h5py, json, sys\n"
+            "f = h5py.File(sys.argv[1], 'r'); d = f['coords']\n"
+            "print(json.dumps(dict(n=len(d), patch_level=int(f['coords'].attrs['patch_level']), patch_size=int(f['coords'].attrs['patch_size']), coord7=d[7].tolist(),\n"
+            "    all=d[:].tolist(), dtype=str(d.dtype), chunks=list(d.chunks), maxshape=[v for v in d.maxshape], name=d.attrs['name'], save_path=d.attrs['save_path'],\n"
+            "    downsample=d.attrs['downsample'].tolist(), level_dim=d.attrs['level_dim'].tolist(), names=sorted(d.attrs.keys()))))\n")
+    out = json.loads(subprocess.run(['/opt/conda/bin/python3.9', '-c', code, p], capture_output=True, text=True, check=True).stdout)
+    assert out['n'] == 40 and out['all'] == coords.tolist() and out['coord7'] == coords[7].tolist() and out['dtype'] == 'int64'
+    assert out['patch_level'] == 0 and out['patch_size'] == 256 and out['chunks'] == [1, 2] and out['maxshape'] == [None, 2]
+    assert out['name'] == ATTRS['name'] and out['save_path'] == ATTRS['save_path'] and out['downsample'] == [1.0, 1.0] and out['level_dim'] == [40000, 30000]
+    assert out['names'] == sorted(H.ATTR_ORDER)
 
 
 def test_patch_folder_of_the_reference_is_consumed_as_it_is(tmp_path):
