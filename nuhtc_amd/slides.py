@@ -6,10 +6,12 @@
     :272-276 -> patches/<slide_id>), stitched picture (`--stitch`, :278-284), status column.
 
 Differences, all forced by the image (no OpenSlide, no h5py, no OpenCV) and stated where they apply:
-  * a slide is a level-0 RGB array (`.npy`, memory-mapped) or a store directory (nuhtc_amd.tilestore); other files of the folder
-    get status `failed_open` and the loop goes on (the reference would raise inside OpenSlide);
-  * the pyramid is virtual and dyadic: level k is the [::2^k] view of the array, so `seg_level = -1` resolves to the level whose
-    downsample is `seg_downsample` (64, what `get_best_level_for_downsample(64)` gives for a pyramid that has it);
+  * a slide is a level-0 RGB array (`.npy`, memory-mapped), a store directory (nuhtc_amd.tilestore) or a tiled TIFF / Aperio `.svs` read through
+    libtiff (nuhtc_amd.tiffslide: the two OpenSlide formats whose pixels are plain TIFF); other files of the folder get status `failed_open`
+    and the loop goes on (the reference would raise inside OpenSlide);
+  * the pyramid is virtual and dyadic: level k is the [::2^k] view of the array -- for a TIFF slide the image at that downsample taken from the
+    file's best pyramid level --, so `seg_level = -1` resolves to the level whose downsample is `seg_downsample` (64, what
+    `get_best_level_for_downsample(64)` gives for a pyramid that has it);
   * the coordinate file is patches/<slide_id>.npz (`coords`, `patch_size`, `patch_level`, `name`: the datasets / attributes of
     the reference's .h5, tools/wsi_core/wsi_utils.py `initialize_hdf5_bag` / `save_hdf5`), written uncompressed -- AND, wherever an HDF5
     back end exists (h5py or the HDF5 C library, nuhtc_amd.h5coords), the reference's own patches/<slide_id>.h5 beside it; a patch folder the
@@ -121,9 +123,13 @@ def load_coords(patch_save_dir, slide_id):
 
 
 def open_array_slide(path):
-    """-> (H, W, 3) uint8 array (memory-mapped) of a `.npy` slide or of a store directory's slide.npy."""
+    """-> the slide as an (H, W, 3) uint8 array-like: a memory-mapped `.npy` slide, a store directory's slide.npy, or a tiled TIFF / Aperio SVS
+    behind nuhtc_amd.tiffslide.TiffSlide (same indexing; `slide[::s, ::s]` comes from its pyramid)."""
     if os.path.isdir(path):
         path = os.path.join(path, 'slide.npy')
+    from . import tiffslide
+    if tiffslide.is_tiff_slide(path):
+        return tiffslide.TiffSlide(path)
     return tilestore.open_slide(path)
 
 
@@ -144,7 +150,7 @@ def vis_mask(slide, contours, holes, level, line_thickness=250, color=(0, 255, 0
     outline width int(line_thickness * sqrt(scale_x * scale_y)) like :221."""
     from PIL import Image, ImageDraw
     ds = 2 ** int(level)
-    img = Image.fromarray(np.ascontiguousarray(np.asarray(slide)[::ds, ::ds, :3]))
+    img = Image.fromarray(np.ascontiguousarray(np.asarray(slide[::ds, ::ds, :3])))
     width = max(1, int(line_thickness * math.sqrt((1 / ds) * (1 / ds))))
     dr = ImageDraw.Draw(img)
 
@@ -168,7 +174,7 @@ def stitch_coords(slide, coords, patch_size, downscale=64, bg_color=(0, 0, 0)):
     from PIL import Image
     lvl = _level_of(downscale)
     ds = 2 ** lvl
-    lv = np.asarray(slide)[::ds, ::ds, :3]
+    lv = np.asarray(slide[::ds, ::ds, :3])
     h, w = lv.shape[:2]
     canvas = np.zeros((h, w, 3), np.uint8)
     canvas[:] = bg_color

@@ -51,6 +51,8 @@ class TileBag:
         self.reads += max(0, hi - lo)
         if self.tiles is not None:
             return np.ascontiguousarray(self.tiles[lo:hi])
+        if hasattr(self.slide, 'read_regions'):          # a TIFF slide (nuhtc_amd.tiffslide): tiles assembled from its decoded TIFF tiles
+            return self.slide.read_regions(self.coords[lo:hi], P)
         H, W = self.slide.shape[:2]
         out = np.zeros((max(0, hi - lo), P, P, 3), np.uint8)
         for k, (x, y) in enumerate(self.coords[lo:hi]):

@@ -216,7 +216,7 @@ def segment_tissue(image, scale=64, sthresh=8, sthresh_up=255, mthresh=7, close=
     contours and, per contour, a list of hole contours."""
     fp = dict(FILTER_PARAMS if filter_params is None else filter_params)
     scale = int(scale)
-    img = np.asarray(image)[::scale, ::scale]
+    img = np.asarray(image[::scale, ::scale])          # (sliced first: a TIFF slide serves this from its pyramid, nuhtc_amd.tiffslide)
     sat = saturation_u8(img)
     med = median_blur(sat, mthresh)
     thr = otsu_threshold(med) if use_otsu else sthresh

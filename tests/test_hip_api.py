@@ -287,6 +287,48 @@ def test_readme_command_lines_on_a_folder_of_slides(hip_device, tmp_path):
     assert 'skip a.npy due to no coord file' in log4
 
 
+def test_readme_command_line_verbatim_on_svs_slides(hip_device, tmp_path):
+    """README.md:55-63 with NOTHING changed but the paths: the slides are Aperio-layout `.svs` files (tiled pyramidal TIFF, the reference's
+    default --slide_ext), opened through libtiff (nuhtc_amd.tiffslide) where the reference uses OpenSlide.  The file is written losslessly, so
+    its level-0 tiles are the source array's pixels: the same array as a `.npy` slide with the coordinate file of the `.svs` run gives the same
+    GeoJSON, byte for byte."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    from nuhtc_amd import synth, tiffslide, weights
+    if not tiffslide.available():
+        pytest.skip('libtiff not found')
+    H = W = 3072
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    blob = ((yy - 1500) / 1250.0) ** 2 + ((xx - 1600) / 1300.0) ** 2 <= 1
+    tex = np.concatenate([np.concatenate([synth.nuclei_tile(900 + 12 * r + c, 256) for c in range(W // 256)], 1) for r in range(H // 256)], 0)
+    img = np.full((H, W, 3), 235, np.uint8)
+    img[blob] = tex[blob]
+    src = tmp_path / 'wsi'
+    src.mkdir()
+    tiffslide.write_pyramid(str(src / 'TCGA-01.svs'), img, levels=4, tile=240, compression='lzw',
+                            description='Aperio Image Library v11.2.1\n3072x3072 (240x240) JPEG/RGB Q=30|AppMag = 40|MPP = 0.2520')
+    ck = tmp_path / 'pannuke.pth'
+    torch.save(dict(state_dict=weights.bench_state_dict(0)), ck)
+    tool = os.path.join(ROOT, 'tools/infer_wsi.py')
+    out = tmp_path / 'wsi_infer'
+    line = f'{src} {CFG} {ck} --patch --seg --stitch --patch_size 256 --step_size 192 --batch_size 16 --save_dir {out} --mode qupath'
+    log = subprocess.run([sys.executable, tool] + line.split(), check=True, capture_output=True, text=True).stdout
+    rows = open(out / 'process_list_autogen.csv').read().splitlines()
+    assert rows[1].startswith('TCGA-01.svs,0,processed,6,')
+    for f in (out / 'masks' / 'TCGA-01.png', out / 'patches' / 'TCGA-01.npz', out / 'stitches' / 'TCGA-01.jpg', out / 'nuclei' / 'TCGA-01' / 'TCGA-01_point.geojson'):
+        assert os.path.exists(f), f
+    doc = open(out / 'nuclei' / 'TCGA-01' / 'TCGA-01.geojson', 'rb').read()
+    n_tiles = len(np.load(out / 'patches' / 'TCGA-01.npz')['coords'])
+    assert len(json.loads(doc)) > 1000 and 100 < n_tiles < 260 and f'{n_tiles} tiles on 1 rank(s)' in log
+    np.save(tmp_path / 'TCGA-01.npy', img)
+    one = tmp_path / 'one'
+    subprocess.run([sys.executable, tool, str(tmp_path / 'TCGA-01.npy'), CFG, str(ck), '--patch_size', '256', '--step_size', '192', '--batch_size', '16', '--save_dir', str(one),
+                    '--mode', 'qupath', '--coords', str(out / 'patches' / 'TCGA-01.npz')], check=True, capture_output=True)
+    assert open(one / 'nuclei' / 'TCGA-01' / 'TCGA-01.geojson', 'rb').read() == doc
+
+
 def test_infer_patch_cli_writes_coco(hip_device, tmp_path):
     import json
     import subprocess
