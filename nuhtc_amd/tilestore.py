@@ -62,12 +62,35 @@ class TileBag:
                 out[k, y0 - y:y1 - y, x0 - x:x1 - x] = self.slide[y0:y1, x0:x1, :3]
         return out
 
+    def view(self, lo, hi):
+        """Tiles [lo, hi) as a lazy (n, P, P, 3) sequence: `view[a:b]` cuts / decodes only those tiles (the slide loop takes a batch at a time
+        while earlier batches are on the GPU; a rank's shard never sits in host memory as a whole)."""
+        return BagView(self, max(0, int(lo)), min(len(self), int(hi)))
+
     def __getitem__(self, i):
         """(tile, coord) like the reference's dataset item."""
         i = int(i)
         if i < 0:
             i += len(self)
         return self.read(i, i + 1)[0], self.coords[i]
+
+
+class BagView:
+    def __init__(self, bag, lo, hi):
+        self.bag, self.lo, self.hi = bag, lo, max(lo, hi)
+        self.shape = (self.hi - self.lo, bag.patch_size, bag.patch_size, 3)
+
+    def __len__(self):
+        return self.hi - self.lo
+
+    def __getitem__(self, s):
+        if isinstance(s, (int, np.integer)):
+            i = int(s) + (len(self) if s < 0 else 0)
+            return self.bag.read(self.lo + i, self.lo + i + 1)[0]
+        a, b, step = s.indices(len(self))
+        if step != 1:
+            raise IndexError('a tile view is read in contiguous runs')
+        return self.bag.read(self.lo + a, self.lo + max(a, b))
 
 
 def write_store(path, slide, coords, patch_size=256):

@@ -33,6 +33,8 @@ def main():
     ap.add_argument('--workers', type=int, default=16, help='host processes rendering the synthetic canvas')
     ap.add_argument('--config', default=os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'configs/nuhtc/htc_lite_swin_pannuke_infer.py'))
     ap.add_argument('--checkpoint', default=None, help='pannuke.pth when available; seeded synthetic weights otherwise')
+    ap.add_argument('--svs', default=None, choices=['jpeg', 'lzw'], help='one GPU: write the canvas as an Aperio-layout .svs first (240-pixel tiles, this compression; not timed) '
+                    'and feed the loop from the FILE through libtiff (nuhtc_amd.tiffslide) instead of from the array in memory')
     args = ap.parse_args()
     from nuhtc_amd import parallel, synth
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -43,6 +45,19 @@ def main():
     band, y0 = synth.nuclei_canvas_parallel(G, rows=(lo // G, (hi - 1) // G + 1), workers=args.workers)   # before any GPU call: the pool forks
     t_canvas = time.perf_counter() - t0
     tiles = synth.CanvasTiles(band, y0, G, lo, hi)
+    t_svs = None
+    if args.svs:
+        if world != 1:
+            raise SystemExit('--svs: one GPU (every rank would need the whole file)')
+        from nuhtc_amd import tiffslide, tilestore
+        t0 = time.perf_counter()
+        svs = f'/tmp/nuhtc_bench_wsi_{os.getpid()}.svs'
+        tiffslide.write_pyramid(svs, band, levels=1, tile=240, compression=args.svs, quality=70, thumbnail=False,
+                                description=f'Aperio Image Library (synthetic)\n{band.shape[1]}x{band.shape[0]} (240x240) JPEG/RGB Q=70|AppMag = 40|MPP = 0.2500')
+        t_svs = time.perf_counter() - t0
+        coords_all = tiles.coords
+        tiles = tilestore.TileBag(tiffslide.TiffSlide(svs), coords_all, 256).view(0, len(coords_all))
+        tiles.coords = coords_all
 
     import torch
     from nuhtc_amd import weights, wsi
@@ -79,11 +94,14 @@ def main():
             'tiles': total, 'n_gpus': world, 'infer_s': round(t_infer, 3), 'tiles_per_s_inference': round(total / t_infer, 1),
             'gather_pack_s': round(t_gather, 3), 'merge_s': round(t_merge, 4), 'tiles_per_s_end_to_end': round(total / (t_infer + t_gather + t_merge), 1),
             'detections_after_tile_nms': int(len(allp)), 'detections_after_merge': int(len(kept)),
-            'canvas_render_s_host': round(t_canvas, 1), 'weights': 'pannuke.pth' if args.checkpoint else 'seeded synthetic'}))
+            'canvas_render_s_host': round(t_canvas, 1), 'weights': 'pannuke.pth' if args.checkpoint else 'seeded synthetic',
+            **({'tile_source': f'{args.svs}-compressed .svs of {os.path.getsize(svs) >> 20} MiB read through libtiff (nuhtc_amd.tiffslide), written in {t_svs:.1f} s (not timed)'} if args.svs else {})}))
     if world > 1:
         torch.distributed.destroy_process_group()
     if args.checkpoint is None and os.path.exists(ck):
         os.remove(ck)
+    if args.svs and os.path.exists(svs):
+        os.remove(svs)
 
 
 if __name__ == '__main__':

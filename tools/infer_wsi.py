@@ -84,7 +84,7 @@ def run_slide(args, model, bag, slide_id, rank, local_rank, world):
     from nuhtc_amd import contours, parallel, wsi
     coords = bag.coords
     lo, hi = parallel.shard_range(len(bag), rank, world)
-    tiles = bag.read(lo, hi)                                  # this rank's tiles only
+    tiles = bag.view(lo, hi)                                  # this rank's tiles only, cut / decoded a batch at a time while earlier batches run
     rec = wsi.infer_tiles(model, tiles, coords[lo:hi], args.batch_size)
     # contours are traced on the rank that owns the tile; two variable-length gathers: records, then ring vertices
     rings = rec['ring']                                              # traced on the GPU (nuhtc_mask_contours)
