@@ -1,7 +1,10 @@
 """The tissue-segmentation primitives of the product (nuhtc_amd/tissue.py: numpy / scipy) against independent scalar restatements of
 the OpenCV routines (oracle/cv_ops.py), on hand-worked values and random inputs.  cv2 is absent: parity with the library itself is
 unpinned; what is pinned is that two separately written readings of the OpenCV sources agree."""
+import os
+
 import numpy as np
+import pytest
 
 from nuhtc_amd import tissue as T
 from oracle import cv_ops as O
@@ -74,3 +77,49 @@ def test_borders_with_holes_agree_with_the_suzuki_abe_oracle():
         assert len(got) == len(outer) and sum(len(hs) for _, hs in got) == len(holes)
         assert sorted(T.contour_area(c) for c, _ in got) == sorted(O.contour_area(conts[i].tolist()) for i in outer)
         assert sorted(T.contour_area(h) for _, hs in got for h in hs) == sorted(O.contour_area(conts[i].tolist()) for i in holes)
+
+
+@pytest.mark.skipif(not os.path.exists('/opt/conda/bin/python3.9'), reason="the image's second interpreter (the one that has scikit-image) is not here")
+def test_watershed_step_is_the_identity_under_the_real_skimage(tmp_path):
+    """`_watershed_proposal` (nuhtc/models/htc_roi_head_cus.py:303-319) floods -distance from markers = label(distance > 0.25) inside the filled
+    mask; the Euclidean distance of a foreground pixel is >= 1, so the markers cover the mask and the flooding assigns nothing: the golden
+    generator's stand-in (oracle/ref_harness/mmcv_stub.py `watershed`) and oracle/model.py `cc_proposals` rest on that.  Here
+    the REAL scipy.ndimage + skimage.segmentation.watershed (0.18, in the image's Python 3.9) run the reference's four lines on masks with
+    many touching / nested / one-pixel components: the labels equal scipy's 4-connected labels of the filled mask, which is what the
+    oracle computes."""
+    import subprocess
+    probe = subprocess.run(['/opt/conda/bin/python3.9', '-c', 'import skimage.segmentation, scipy.ndimage'], capture_output=True)
+    if probe.returncode != 0:
+        pytest.skip('no scikit-image in /opt/conda/bin/python3.9')
+    rng = np.random.default_rng(4)
+    masks = []
+    for k in range(6):
+        m = np.zeros((144, 180), np.float32)
+        for _ in range(60):
+            cy, cx, r = rng.integers(0, 144), rng.integers(0, 180), rng.integers(1, 9)
+            yy, xx = np.ogrid[:144, :180]
+            m[(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] = 1
+        m[rng.random(m.shape) < 0.002] = 1            # one-pixel components
+        if k % 2:
+            m[40:100, 50:120] = 1
+            m[60:80, 70:100] = 0                      # a hole (filled by binary_fill_holes) ...
+            m[68:72, 80:90] = 1                       # ... with an island inside
+        masks.append(m)
+    np.save(tmp_path / 'masks.npy', np.stack(masks))
+    code = ("import sys, numpy as np\n"
+            "from scipy import ndimage as ndi\n"
+            "from skimage.segmentation import watershed\n"
+            "out = []\n"
+            "for m in np.load(sys.argv[1]):\n"
+            "    m = ndi.binary_fill_holes(m).astype(np.float32)\n"            # :305 (assigned back into the float array)
+            "    distance = ndi.distance_transform_edt(m)\n"                    # :307
+            "    markers, _ = ndi.label(np.array(distance > 0.25, dtype=bool))\n"   # :317-318
+            "    out.append(watershed(-distance, markers, mask=m))\n"           # :319
+            "np.save(sys.argv[2], np.stack(out))\n")
+    subprocess.run(['/opt/conda/bin/python3.9', '-W', 'ignore', '-c', code, str(tmp_path / 'masks.npy'), str(tmp_path / 'ws.npy')], check=True, capture_output=True)
+    ws = np.load(tmp_path / 'ws.npy')
+    from scipy import ndimage as ndi
+    for m, w in zip(masks, ws):
+        filled = ndi.binary_fill_holes(m)
+        lab, n = ndi.label(filled)                    # 4-connected, raster order of first pixel: what oracle/model.py cc_proposals labels
+        assert n > 20 and np.array_equal(w, lab)
