@@ -10,8 +10,10 @@ path uses, for the formats whose pixels are plain TIFF:
   * `get_best_level_for_downsample(d)` = the last level whose downsample is <= d (level 0 below the first);
   * `read_region((x, y), level, (w, h))`: (x, y) in LEVEL-0 pixels, the region w x h in level pixels; pixels outside the level are 0 -- OpenSlide
     returns transparent black there and the reference's `.convert('RGB')` drops the alpha;
-  * JPEG tiles are decoded by libtiff with YCbCr -> RGB conversion; JPEG 2000 (Aperio compression 33003 / 33005) is not a codec of libtiff: such
-    slides are refused with a message, as are 16-bit and non-RGB layouts.
+  * JPEG tiles are decoded by libtiff with YCbCr -> RGB conversion; Aperio's JPEG 2000 tiles (compression 33003 YCbCr / 33005 RGB: a raw
+    codestream per tile, no codec of libtiff) are read raw and decoded by Pillow's OpenJPEG plugin -- OpenSlide uses OpenJPEG too --, the YCbCr
+    kind converted with libjpeg's fixed-point tables; chroma-subsampled codestreams are decoded as Pillow decodes them (no such file here to
+    test); 16-bit and non-RGB layouts go through libtiff's RGBA renderer or are refused.
   PARITY UNPINNED against OpenSlide itself (absent): lossless tiles are bit-exact by construction (tests/test_tiffslide.py checks every access
   pattern against the source arrays and against PIL's own TIFF reader); for JPEG tiles OpenSlide decodes with libjpeg-turbo, whose chroma
   upsampling can differ from this libtiff's libjpeg by an LSB.
@@ -34,6 +36,28 @@ EXTENSIONS = ('.svs', '.tif', '.tiff')
 _T = dict(IMAGEWIDTH=256, IMAGELENGTH=257, BITSPERSAMPLE=258, COMPRESSION=259, PHOTOMETRIC=262, IMAGEDESCRIPTION=270, SAMPLESPERPIXEL=277,
           ROWSPERSTRIP=278, PLANARCONFIG=284, TILEWIDTH=322, TILELENGTH=323, SUBFILETYPE=254, JPEGCOLORMODE=65538, JPEGQUALITY=65537)
 _COMPRESSION_JPEG, _PHOTOMETRIC_RGB, _PHOTOMETRIC_YCBCR = 7, 2, 6
+_APERIO_J2K_YCBCR, _APERIO_J2K_RGB = 33003, 33005          # Aperio's private compression tags: a raw JPEG 2000 codestream per tile
+
+
+def _j2k_decoder():
+    """Pillow's JPEG 2000 plugin (OpenJPEG) or None: libtiff has no codec for Aperio's 33003 / 33005 tiles, OpenSlide decodes them with OpenJPEG."""
+    try:
+        from PIL import Image, features
+        return Image if features.check('jpg_2000') else None
+    except Exception:
+        return None
+
+
+def _ycbcr_to_rgb(ycc):
+    """JFIF YCbCr -> RGB in the 16-bit fixed point of libjpeg's jdcolor.c (the tables OpenSlide's JPEG 2000 path is modelled on; OpenSlide's own
+    source is not here to compare: unpinned)."""
+    y = ycc[..., 0].astype(np.int32)
+    cb = ycc[..., 1].astype(np.int32) - 128
+    cr = ycc[..., 2].astype(np.int32) - 128
+    r = y + ((91881 * cr + 32768) >> 16)
+    g = y + ((-22554 * cb - 46802 * cr + 32768) >> 16)
+    b = y + ((116130 * cb + 32768) >> 16)
+    return np.clip(np.stack([r, g, b], -1), 0, 255).astype(np.uint8)
 _LIB = None
 _TRIED = False
 
@@ -58,7 +82,8 @@ def _lib():
             lib = ctypes.CDLL(cand)
             for name, res, args in (('TIFFOpen', P, [CP, CP]), ('TIFFClose', None, [P]), ('TIFFIsTiled', I, [P]), ('TIFFSetDirectory', I, [P, U16]),
                                     ('TIFFNumberOfDirectories', U16, [P]), ('TIFFTileSize', S64, [P]), ('TIFFComputeTile', U32, [P, U32, U32, U32, U16]),
-                                    ('TIFFReadEncodedTile', S64, [P, U32, P, S64]), ('TIFFReadRGBATile', I, [P, U32, U32, P]),
+                                    ('TIFFReadEncodedTile', S64, [P, U32, P, S64]), ('TIFFReadRawTile', S64, [P, U32, P, S64]), ('TIFFWriteRawTile', S64, [P, U32, P, S64]),
+                                    ('TIFFReadRGBATile', I, [P, U32, U32, P]),
                                     ('TIFFReadRGBAImageOriented', I, [P, U32, U32, P, I, I]), ('TIFFWriteEncodedTile', S64, [P, U32, P, S64]),
                                     ('TIFFWriteEncodedStrip', S64, [P, U32, P, S64]), ('TIFFWriteDirectory', I, [P]), ('TIFFSetWarningHandler', P, [P]),
                                     ('TIFFSetErrorHandler', P, [P]), ('TIFFIsCODECConfigured', I, [U16])):
@@ -127,9 +152,13 @@ class TiffSlide:
         if not dirs:
             raise TiffError(f'{path}: not a TIFF file libtiff can open')
         first = dirs[0]
-        if first.compression in (33003, 33005):
-            raise TiffError(f'{path}: JPEG 2000 tiles (Aperio compression {first.compression}) are not a codec of libtiff; convert the slide (e.g. to JPEG tiles)')
-        if not lib.TIFFIsCODECConfigured(first.compression):
+        self._j2k = None
+        if first.compression in (_APERIO_J2K_YCBCR, _APERIO_J2K_RGB):
+            self._j2k = _j2k_decoder()
+            if self._j2k is None:
+                raise TiffError(f'{path}: JPEG 2000 tiles (Aperio compression {first.compression}) need Pillow with OpenJPEG; convert the slide (e.g. to JPEG tiles)')
+            self._threads = max(self._threads, min(16, os.cpu_count() or 4))      # ~10 ms per 240-pixel tile in OpenJPEG (the GIL is released): batches go to the pool
+        elif not lib.TIFFIsCODECConfigured(first.compression):
             raise TiffError(f'{path}: TIFF compression {first.compression} is not configured in {lib._path}')
         if first.tiled:
             levels = [first]
@@ -229,7 +258,22 @@ class TiffSlide:
             if lv.compression == _COMPRESSION_JPEG and lv.photometric == _PHOTOMETRIC_YCBCR:
                 lib.TIFFSetField(ctypes.c_void_p(tif), ctypes.c_uint32(_T['JPEGCOLORMODE']), ctypes.c_int(1))      # JPEGCOLORMODE_RGB
         x, y = tx * lv.tw, ty * lv.th
-        if lv.fast:
+        if lv.compression in (_APERIO_J2K_YCBCR, _APERIO_J2K_RGB):      # the tile's bytes are a raw JPEG 2000 codestream: Pillow (OpenJPEG) decodes it
+            import io
+            raw = ctypes.create_string_buffer(lv.tw * lv.th * 4 + 65536)
+            n = lib.TIFFReadRawTile(tif, lib.TIFFComputeTile(tif, x, y, 0, 0), raw, len(raw))
+            if n <= 0:
+                raise TiffError(f'{self.path}: tile ({tx}, {ty}) of level {level} cannot be read')
+            try:
+                im = self._j2k.open(io.BytesIO(raw.raw[:n]))
+                a = np.asarray(im)
+            except Exception as e:
+                raise TiffError(f'{self.path}: JPEG 2000 tile ({tx}, {ty}) of level {level} cannot be decoded ({e})')
+            if a.ndim != 3 or a.shape[2] < 3 or a.dtype != np.uint8 or a.shape[0] > lv.th or a.shape[1] > lv.tw:
+                raise TiffError(f'{self.path}: JPEG 2000 tile ({tx}, {ty}) decodes to {a.shape} {a.dtype}, expected 8-bit colour of at most {lv.tw} x {lv.th}')
+            out = np.zeros((lv.th, lv.tw, 3), np.uint8)
+            out[:a.shape[0], :a.shape[1]] = _ycbcr_to_rgb(a[..., :3]) if lv.compression == _APERIO_J2K_YCBCR else a[..., :3]
+        elif lv.fast:
             out = np.empty((lv.th, lv.tw, 3), np.uint8)
             n = lib.TIFFReadEncodedTile(tif, lib.TIFFComputeTile(tif, x, y, 0, 0), out.ctypes.data_as(ctypes.c_void_p), out.nbytes)
             if n < 0:
@@ -350,7 +394,7 @@ def write_pyramid(path, image, levels=3, tile=256, compression='jpeg', descripti
     lib = _lib()
     if lib is None:
         raise TiffError('libtiff not found')
-    comp = dict(none=1, lzw=5, jpeg=7, deflate=8)[compression]
+    comp = {'none': 1, 'lzw': 5, 'jpeg': 7, 'deflate': 8, 'j2k-ycbcr': _APERIO_J2K_YCBCR, 'j2k-rgb': _APERIO_J2K_RGB}[compression]
     image = np.ascontiguousarray(np.asarray(image)[:, :, :3], np.uint8)
     pyr = [image]
     for _ in range(1, levels):
@@ -386,6 +430,20 @@ def write_pyramid(path, image, levels=3, tile=256, compression='jpeg', descripti
                 blk = a[ty:ty + tile, tx:tx + tile]
                 buf[:] = 0
                 buf[:blk.shape[0], :blk.shape[1]] = blk
+                if comp in (_APERIO_J2K_YCBCR, _APERIO_J2K_RGB):      # a raw, reversible JPEG 2000 codestream per tile, as Aperio scanners write (theirs are lossy)
+                    import io
+                    from PIL import Image
+                    src = buf
+                    if comp == _APERIO_J2K_YCBCR:                    # forward JFIF transform (libjpeg jccolor.c fixed point), components stored as they are
+                        r, g, b = (buf[..., k].astype(np.int32) for k in range(3))
+                        src = np.stack([(19595 * r + 38470 * g + 7471 * b + 32768) >> 16, ((-11059 * r - 21709 * g + 32768 * b + 32767) >> 16) + 128,
+                                        ((32768 * r - 27439 * g - 5329 * b + 32767) >> 16) + 128], -1).clip(0, 255).astype(np.uint8)
+                    bio = io.BytesIO()
+                    Image.fromarray(src).save(bio, format='JPEG2000', no_jp2=True, irreversible=False, mct=0)
+                    raw = bio.getvalue()
+                    if lib.TIFFWriteRawTile(tif, lib.TIFFComputeTile(tif, tx, ty, 0, 0), raw, len(raw)) < 0:
+                        raise TiffError('TIFFWriteRawTile failed')
+                    continue
                 if lib.TIFFWriteEncodedTile(tif, lib.TIFFComputeTile(tif, tx, ty, 0, 0), buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes) < 0:
                     raise TiffError('TIFFWriteEncodedTile failed')
         lib.TIFFWriteDirectory(tif)

@@ -86,6 +86,30 @@ def test_against_pils_own_tiff_reader(tmp_path):
     assert d.mean() < 0.5 and d.max() <= 12              # two JPEG decoders (chroma upsampling / IDCT rounding), not two pictures
 
 
+@pytest.mark.skipif(T._j2k_decoder() is None, reason='Pillow without OpenJPEG')
+def test_aperio_jpeg2000_tiles(tmp_path):
+    """Aperio's private compressions 33005 (JPEG 2000, RGB) and 33003 (JPEG 2000, YCbCr): a raw codestream per tile, read raw through libtiff and
+    decoded by Pillow's OpenJPEG.  Written here reversibly: the RGB kind returns the source pixels, the YCbCr kind the fixed-point JFIF
+    inverse (libjpeg's jdcolor.c tables) of the stored components -- evaluated independently below in floating point, within the 1 LSB of the
+    16-bit fixed point -- and the source within the forward + inverse rounding."""
+    img = _image(700, 900)
+    for kind, tol in (('j2k-rgb', 0), ('j2k-ycbcr', 1)):
+        p = str(tmp_path / f'{kind}.svs')
+        pyr = T.write_pyramid(p, img, levels=2, tile=240, compression=kind, description=DESC.replace('JPEG/RGB', 'J2K/KDU'))
+        s = T.TiffSlide(p)
+        assert s.level_count == 2 and s.properties['aperio.AppMag'] == '40'
+        for k in range(2):
+            assert np.abs(s.level_image(k).astype(np.int32) - pyr[k]).max() <= tol
+        t = s.read_regions(np.array([[-30, 500], [700, 10]]), 256)
+        assert np.abs(t[0][:200, 30:].astype(np.int32) - img[500:700, 0:226]).max() <= tol and not t[0][200:].any() and not t[0][:, :30].any()
+        assert np.abs(t[1][:, :200].astype(np.int32) - img[10:266, 700:900]).max() <= tol and not t[1][:, 200:].any()
+        s.close()
+    ycc = np.random.default_rng(1).integers(0, 256, (64, 64, 3), dtype=np.uint8)
+    f = ycc.astype(np.float64)
+    want = np.stack([f[..., 0] + 1.402 * (f[..., 2] - 128), f[..., 0] - 0.344136 * (f[..., 1] - 128) - 0.714136 * (f[..., 2] - 128), f[..., 0] + 1.772 * (f[..., 1] - 128)], -1)
+    assert np.abs(T._ycbcr_to_rgb(ycc).astype(np.float64) - np.clip(np.round(want), 0, 255)).max() <= 1
+
+
 def test_not_a_slide(tmp_path):
     (tmp_path / 'x.svs').write_bytes(b'II*\0garbage')
     with pytest.raises(T.TiffError):
