@@ -250,7 +250,9 @@ def main(argv=None):
                 spath = os.path.join(folder, slide_id + ext)
 
             def make(spath=spath, slide_id=slide_id):
-                c, ps, _ = slides.load_coords(patch_save_dir, slide_id)
+                c, ps, lvl = slides.load_coords(patch_save_dir, slide_id)
+                if lvl != 0:                                   # (a reference-made .h5 can carry another level; tiles are cut from level 0 here)
+                    raise SystemExit(f'{slide_id}: coordinate file was made for patch_level {lvl}; only patch_level 0 is supported')
                 return tilestore.TileBag(slides.open_array_slide(spath), c, ps)
             jobs.append((slide_id, make))
     total = len(jobs)
