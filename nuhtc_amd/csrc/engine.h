@@ -72,6 +72,13 @@ struct nuhtc_engine {
 
   // workspace
   float *img, *tokA, *tokB, *xw, *qkv, *att, *hid;
+  // Output norms of the stages (swin.py:756-762) in the A path of the FPN lateral that consumes them (round 5): every stage keeps its own token
+  // buffer and the partials of its final tensor until the neck has run; c[st] then exists only on request (nuhtc_get_buffer computes it)
+  float* tok[4] = {};           // tok[0] = tokA, tok[1] = tokB, two more
+  float* ln_out[4] = {};        // partials of the stage's final tensor, left by its last block's FFN
+  float *lat_wln[4] = {}, *lat_bln[4] = {};   // lateral 1x1 with the output norm folded in: W diag(gamma), b + W beta
+  bool out_ln_folded = false;   // the last run took that path (c[st] is stale until requested)
+  int last_batch = 0;
   float* ln_part2 = nullptr;   // the partials the patch-merging GEMM leaves for the next stage's first block (it READS ln_part in the same launch)
   float* ln_part = nullptr;    // LayerNorm partials of the current token tensor, [token][C / 96][2] = {mean, sum of squared deviations} per 96 channels:
                                // written by the epilogue of the GEMM that produced the tensor (proj, fc2, patch merging), read by the next A_LN linear

@@ -376,6 +376,7 @@ int nuhtc_finalize(nuhtc_engine* e) {
   const int Hn = (e->Hv + 31) / 32 * 32, Wn = (e->Wv + 31) / 32 * 32;                                            // pad_shape
   e->Hn = Hn; e->Wn = Wn;
   int rc;
+  std::vector<float> on_g_host[4], on_b_host[4];      // the stages' output norms, for the fold into the FPN laterals
   {
     std::vector<int> tx, ty;
     cv_linear_tables(e->vw, e->Wv, true, tx);
@@ -474,6 +475,7 @@ int nuhtc_finalize(nuhtc_engine* e) {
       std::string p = "backbone.norm" + std::to_string(s) + ".";
       RAW(w, p + "weight", C); RAW(b, p + "bias", C);
       if ((rc = upload(e, &e->on_g[s], w->data)) || (rc = upload(e, &e->on_b[s], b->data))) return rc;
+      on_g_host[s] = w->data; on_b_host[s] = b->data;
     }
     if (s < 3) {
       // PatchMerging: nn.Unfold order k = c*4 + q (q = kh*2+kw)  ->  gather order k' = q*C + c   (transformer.py:363-385)
@@ -510,6 +512,11 @@ int nuhtc_finalize(nuhtc_engine* e) {
     if ((rc = upload_gemm_weight(e, &e->lat_w[i], lw->data, 64, C)) || (rc = upload(e, &e->lat_b[i], lb->data)) ||
         (rc = upload_gemm_weight(e, &e->fpn_w[i], pack_conv3(*fw, 64, 64), 64, 576)) || (rc = upload(e, &e->fpn_b[i], fb->data)))
       return rc;
+    if (e->cfg.matrix_pipe == NUHTC_PIPE_BF16_SPLIT) {      // the stage's output norm folded into its lateral (gemm.hip A_LN, N = 64)
+      std::vector<float> wl, bl;
+      fold_ln(lw->data.data(), lb->data.data(), on_g_host[i].data(), on_b_host[i].data(), 64, C, wl, bl);
+      if ((rc = upload_gemm_weight(e, &e->lat_wln[i], wl, 64, C)) || (rc = upload(e, &e->lat_bln[i], bl))) return rc;
+    }
   }
   // ---- RPN: 3x3 conv, then cls(3)+reg(12) fused into one N=32 pointwise layer (cols 0-2 cls, 3-14 reg, rest 0)
   {
@@ -559,6 +566,11 @@ int nuhtc_finalize(nuhtc_engine* e) {
       (rc = ws(e, &e->xw, nullptr, {B, (int64_t)max_win}, 0)) || (rc = ws(e, &e->qkv, nullptr, {(int64_t)B * (int64_t)max_qkv + 3 * (int64_t)max_c}, 0)) ||
       (rc = ws(e, &e->att, nullptr, {B, (int64_t)max_win}, 0)) || (rc = ws(e, &e->hid, nullptr, {B, (int64_t)std::max(max_hid, max_qkv)}, 0)))
     return rc;
+  e->tok[0] = e->tokA; e->tok[1] = e->tokB;
+  for (int s = 2; s < 4; ++s)
+    if ((rc = ws(e, &e->tok[s], nullptr, {B, (int64_t)e->st[s].H * e->st[s].W * e->st[s].C}, 0))) return rc;
+  for (int s = 0; s < 4; ++s)
+    if ((rc = ws(e, &e->ln_out[s], nullptr, {B, (int64_t)e->st[1].H * e->st[1].W, 8}, 0))) return rc;
   if ((rc = ws(e, &e->ln_part, nullptr, {B, (int64_t)e->st[1].H * e->st[1].W, 8}, 0)) ||     // (stage 1, one partial per token: the same again)
       (rc = ws(e, &e->ln_part2, nullptr, {B, (int64_t)e->st[1].H * e->st[1].W, 8}, 0)))
     return rc;     // rows x (C / 96) x 2 is the same in stages 2-4
@@ -641,18 +653,23 @@ int run_backbone(nuhtc_engine* e, int B, hipStream_t s) {
   // the Swin linears take the block-tile form of the engine's schedule (nuhtc_config.schedule, gemm.hip)
   auto linear = [&](GemmParams p) { p.throughput = e->cfg.schedule == NUHTC_SCHED_THROUGHPUT; return egemm(e, p, s); };
   RUN(launch_patch_embed(e->img, e->pe_w, e->pe_b, e->pe_g, e->pe_beta, e->tokA, B, Hn, Wn, s));
-  float* x = e->tokA;
-  float* xalt = e->tokB;
+  float* x = e->tok[0];
   // dev: 0 = the norms of stages 2-4 as kernels of their own (round 4); 1 = in the A path of the linear behind them, statistics by a kernel
   // of their own; 2 (the tree) = statistics left by the epilogue of the GEMM that produced the tensor
   static const int& ln_in_a = dev_knob_ref("LN_IN_A", 2);
   // dev: 1 (the tree) = the PatchMerging norms as well (two-segment rows, statistics from the last block's FFN); 0 = merge_ln_kernel + plain GEMM
   static const int& merge_ln_in_a = dev_knob_ref("MERGE_LN_IN_A", 1);
   const float* first_part = e->ln_part;      // where the first block of the stage finds its LN1 partials: ln_part2 behind a merging linear in A_LN form
+  // dev: 1 (the tree) = the stages' output norms in the A path of the FPN laterals (run_neck_heads); 0 = layernorm kernels writing c[st]
+  static const int& out_ln_in_a = dev_knob_ref("OUT_LN_IN_A", 1);
+  e->out_ln_folded = e->lat_wln[0] && ln_in_a >= 2 && out_ln_in_a;
+  e->last_batch = B;
   for (int st = 0; st < 4; ++st) {
     const StageGeom& g = e->st[st];
     const int T = B * g.H * g.W, Mw = B * g.nW * WS2, C = g.C;
     const bool merge_a = st < 3 && e->mg_wln[st] && ln_in_a >= 2 && merge_ln_in_a && !e->blocks[st].empty();
+    const bool final_stats = merge_a || e->out_ln_folded;      // the last block's FFN leaves the partials of the stage's final tensor in ln_out[st]
+    float* xalt = st < 3 ? e->tok[st + 1] : nullptr;
     for (size_t b = 0; b < e->blocks[st].size(); ++b) {
       const BlockW& w = e->blocks[st][b];
       const int sh = (int)(b & 1);
@@ -703,7 +720,7 @@ int run_backbone(nuhtc_engine* e, int B, hipStream_t s) {
       }
       if (mlp1) {      // one kernel: [attention projection + residual,] LN2, both linears, GELU and the residual (mlp.hip)
         RUN(launch_swin_mlp(x, x, w.n2g, w.n2b, w.mlp_stream, w.f1_b, w.f2_b, T, C, s, proj1 ? e->att : nullptr, w.proj_stream, w.proj_b,
-                            merge_a && b + 1 == e->blocks[st].size() ? e->ln_part : nullptr));      // the merging norm's partials leave with the last block's rows
+                            final_stats && b + 1 == e->blocks[st].size() ? e->ln_out[st] : nullptr));      // the merging / output norm's partials leave with the last block's rows
       } else {
       if (w.f1_wln && ln_in_a) {
         const bool epi = ln_in_a >= 2;
@@ -724,7 +741,7 @@ int run_backbone(nuhtc_engine* e, int B, hipStream_t s) {
         GemmParams p = gp(e->hid, w.f2_w, w.f2_b, x, T, C, 4 * C);
         p.res = x; p.ldr = C;
         if (ln_in_a >= 2 && b + 1 < e->blocks[st].size() && e->blocks[st][b + 1].qkv_wln) p.stats_out = e->ln_part;   // LN1 of the next block rides in its QKV linear
-        if (merge_a && b + 1 == e->blocks[st].size()) p.stats_out = e->ln_part;                                          // ... the merging norm in the reduction linear
+        if (final_stats && b + 1 == e->blocks[st].size()) p.stats_out = e->ln_out[st];                                   // ... the merging norm in the reduction linear, the output norm in the FPN lateral
         RUN(linear(p));
       }
       }
@@ -733,12 +750,12 @@ int run_backbone(nuhtc_engine* e, int B, hipStream_t s) {
         if (it != e->bufs.end()) hipMemcpyAsync(it->second.ptr, x, (size_t)T * C * sizeof(float), hipMemcpyDeviceToDevice, s);
       }
     }
-    RUN(launch_layernorm(x, nullptr, e->on_g[st], e->on_b[st], e->c[st], T, C, s));   // swin.py:756-762 (tokens == NHWC)
+    if (!e->out_ln_folded) RUN(launch_layernorm(x, nullptr, e->on_g[st], e->on_b[st], e->c[st], T, C, s));   // swin.py:756-762 (tokens == NHWC); else: in the lateral's A path
     if (st < 3) {
       const bool next_ln = ln_in_a >= 2 && !e->blocks[st + 1].empty() && e->blocks[st + 1][0].qkv_wln;   // LN1 of the next stage's first block rides in its QKV linear
       if (merge_a) {     // transformer.py:363-385 in one launch: row m = LayerNorm of the 2 x 2 tokens at mg_src[m] (two runs of 2 C floats, W tokens apart)
         GemmParams p = gp(x, e->mg_wln[st], e->mg_bln[st], xalt, T / 4, 2 * C, 4 * C);
-        p.lda = C; p.amode = A_LN; p.ln_part = e->ln_part; p.ln_nparts = 4 * (C / 96); p.a_rows = e->mg_src[st]; p.seg_k = 2 * C; p.seg_rows = g.W;
+        p.lda = C; p.amode = A_LN; p.ln_part = e->ln_out[st]; p.ln_nparts = 4 * (C / 96); p.a_rows = e->mg_src[st]; p.seg_k = 2 * C; p.seg_rows = g.W;
         if (next_ln) p.stats_out = e->ln_part2;      // not ln_part: other workgroups of this launch are still reading it
         RUN(linear(p));
         first_part = e->ln_part2;
@@ -749,7 +766,7 @@ int run_backbone(nuhtc_engine* e, int B, hipStream_t s) {
         RUN(linear(p));
         first_part = e->ln_part;
       }
-      std::swap(x, xalt);
+      x = xalt;
     }
   }
   return 0;
@@ -760,6 +777,10 @@ int run_neck_heads(nuhtc_engine* e, int B, hipStream_t s) {
   for (int i = 3; i >= 0; --i) {
     const StageGeom& g = e->st[i];
     GemmParams p = gp(e->c[i], e->lat_w[i], e->lat_b[i], e->lat[i], B * g.H * g.W, 64, g.C);
+    if (e->out_ln_folded) {      // c[i] = LayerNorm(tok[i]) is never written: the lateral takes the stage's raw tokens and its partials (gemm.hip A_LN)
+      p.A = e->tok[i]; p.W = e->lat_wln[i]; p.bias = e->lat_bln[i];
+      p.amode = A_LN; p.ln_part = e->ln_out[i]; p.ln_nparts = g.C / 96;
+    }
     if (i < 3) { p.up = e->lat[i + 1]; p.upH = g.H; p.upW = g.W; }
     RUN(egemm(e, p, s));
   }
@@ -951,6 +972,17 @@ int nuhtc_get_buffer(nuhtc_engine* e, const char* name, void** ptr, int64_t* sha
   }
   auto it = e->bufs.find(name);
   if (it == e->bufs.end()) FAIL(e, NUHTC_E_NOTFOUND, std::string("unknown buffer: ") + name);
+  if (e->out_ln_folded && name[0] == 'c' && name[1] >= '0' && name[1] <= '3' && name[2] == 0) {
+    // the stage's output norm ran inside the FPN lateral: the tensor is computed now, from the stage's tokens, by the kernel that writes it on the
+    // other path (parity tests read c0..c3)
+    const int st = name[1] - '0';
+    const StageGeom& g = e->st[st];
+    HIP_CHECK(e, hipSetDevice(e->device));
+    HIP_CHECK(e, hipDeviceSynchronize());
+    const int rc = launch_layernorm(e->tok[st], nullptr, e->on_g[st], e->on_b[st], e->c[st], e->last_batch * g.H * g.W, g.C, nullptr);
+    if (rc) FAIL(e, rc, "layernorm for a requested c buffer failed");
+    HIP_CHECK(e, hipDeviceSynchronize());
+  }
   *ptr = it->second.ptr;
   if (ndim) *ndim = (int)it->second.shape.size();
   if (shape)
@@ -1173,6 +1205,7 @@ extern "C" int nuhtc_dev_realloc(nuhtc_engine* e, int which, unsigned long long*
   e->allocs.push_back(p);
   *slots[which] = (float*)p;
   if (which == 0) e->bufs["tokens"].ptr = p;
+  e->tok[0] = e->tokA; e->tok[1] = e->tokB;
   if (addr) *addr = (unsigned long long)p;
   return 0;
 }

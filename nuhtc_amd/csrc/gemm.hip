@@ -895,7 +895,7 @@ static void launch_split(const GemmParams& q, hipStream_t s) {
   const unsigned pad = (unsigned)lds_pad;
   if (q.amode == A_CONV3) hipLaunchKernelGGL((gemm_split_kernel<MT, NT, A_CONV3>), grid, dim3(256), pad, s, q);
   else if (q.amode == A_LN) {
-    if constexpr (NT == 3) hipLaunchKernelGGL((gemm_split_kernel<MT, NT, A_LN>), grid, dim3(256), pad, s, q);   // launch_gemm admits A_LN for 96-column tiles only
+    if constexpr (NT == 3 || (NT == 2 && MT == 1)) hipLaunchKernelGGL((gemm_split_kernel<MT, NT, A_LN>), grid, dim3(256), pad, s, q);   // launch_gemm admits A_LN for 96-column tiles and N = 64
   } else hipLaunchKernelGGL((gemm_split_kernel<MT, NT, A_PLAIN>), grid, dim3(256), pad, s, q);
 }
 
@@ -912,7 +912,7 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
   if ((p.res && p.up) || (p.act == ACT_COS && p.bias)) return NUHTC_E_INVALID;
   // LayerNorm in the A path: the split kernel's 96-column form only (the Swin linears that follow a norm), statistics required
   if ((p.amode == A_LN) != (p.ln_part != nullptr) ||
-      (p.amode == A_LN && (!p.Wsplit || p.N % 96 != 0 || p.batch > 1 || p.ln_nparts < 1 || p.ln_nparts > 16 || p.K % p.ln_nparts != 0 ||
+      (p.amode == A_LN && (!p.Wsplit || (p.N % 96 != 0 && p.N != 64) || p.batch > 1 || p.ln_nparts < 1 || p.ln_nparts > 16 || p.K % p.ln_nparts != 0 ||
                            (p.seg_k && (p.K != 2 * p.seg_k || p.seg_k % 16 != 0 || p.ln_nparts % 4 != 0 || !p.a_rows || p.seg_rows < 1)) || (p.n_pad > 0 && (!p.pad_rows || !p.pad_val)))))
     return NUHTC_E_INVALID;
   // statistics for the next linear's LayerNorm: the split kernel's 96-column form, rows stored whole (plain or row-mapped)
@@ -938,9 +938,10 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
     // tools/dev/nt_sweep.sh: stage-4 linears 93 / 63 / 153 us against 104 / 70 / 177 with 32 columns), the others narrow only
     // below 256 workgroups (NUHTC_SPLIT_FILL, dev)
     const int limit = q.Wsplit ? sfill : fill;
-    if (!(q.Wsplit && nt == 3))
+    if (!(q.Wsplit && nt == 3) && q.amode != A_LN)      // (A_LN exists for 96- and 64-column tiles only)
       while (nt > 1 && mt * (p.N / (32 * nt)) < limit) { if (nt > 2 && p.N % 64 == 0) nt = 2; else nt = 1; }
     if (force_nt > 0 && p.N % (32 * force_nt) == 0) nt = force_nt;
+    if (q.amode == A_LN && nt != 3 && nt != 2) return NUHTC_E_INVALID;      // no such instantiation: launch_split would launch nothing
   }
   if (q.amode == A_CONV3 && !q.zeros) {
     q.zeros = zero_page();

@@ -102,7 +102,9 @@ def test_ln_gemm_kernel_vs_fp64(hip_device):
     gen = torch.Generator().manual_seed(11)
     for (T, M, N, K, act, offset) in [(512, None, 576, 192, 0, 0.0), (1000, 777, 768, 192, 2, 0.0), (256, None, 1152, 384, 0, 50.0),
                                       (300, 300, 1536, 384, 2, 0.0), (130, None, 2304, 768, 0, 3.0), (256, 200, 3072, 768, 2, 50.0),
-                                      (66000, None, 576, 192, 0, 0.0)]:
+                                      (66000, None, 576, 192, 0, 0.0),
+                                      # N = 64: the FPN laterals behind the stages' output norms (swin.py:756-762 -> fpn.py:152), under- and well-filled grids
+                                      (1000, None, 64, 96, 0, 0.0), (513, 400, 64, 192, 0, 3.0), (300, None, 64, 768, 0, 0.0), (70000, None, 64, 96, 0, 0.0)]:
         x = torch.randn(T, K, generator=gen) * (1.0 + torch.rand(T, 1, generator=gen)) + offset * torch.randn(T, 1, generator=gen).sign()
         w = torch.randn(N, K, generator=gen) / K ** 0.5
         b = torch.randn(N, generator=gen) * 0.1

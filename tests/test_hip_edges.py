@@ -320,7 +320,9 @@ def test_image_size_not_a_multiple_of_32(hip_device):
         a, b = rpn_ref[i].numpy(), rpn[i, :rpn_counts[i]]
         assert len(a) == len(b), (i, len(a), len(b))
         assert b[:, 2].max() <= 180.0 and b[:, 3].max() <= 144.0 and b[:, :4].max() > 150.0
-        d = np.abs(G.canon_rows(a) - G.canon_rows(b)).max()
+        # in list order (both are in NMS order); the canonical sort is the fallback for exact score ties -- alone it mis-pairs rows whenever two
+        # scores one ulp apart swap places between the CPU's and the GPU's sigmoid
+        d = min(np.abs(a - b).max(), np.abs(G.canon_rows(a) - G.canon_rows(b)).max())
         print(f'tile {i}: {len(b)} rpn proposals, max diff {d:.2e}; cc proposals oracle/hip {len(cc_ref[i])}/{cc_counts[i]}')
         assert d <= 1e-3
         assert np.array_equal(cc_ref[i].numpy()[:, :4], cc[i, :cc_counts[i]]), i
