@@ -995,9 +995,7 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
     // 256-row form is kept for launches of at least 2048 such tiles, i.e. M >= 131072 at the path's widths)
     // (nuhtc_config.schedule = NUHTC_SCHED_THROUGHPUT: with other batches in flight the under-filled tail of a launch is
     // filled by their kernels and the 256-row tile's lower LDS traffic per MFMA wins: +1.5 % on four batches in flight, -3 % alone)
-    // (dev knob SPLIT_MT2_MIN: under the throughput schedule, 256-row tiles only for launches of at least that many of them)
-    static const int& mt2_min = dev_knob_ref("SPLIT_MT2_MIN", 0);
-    const bool mt2 = force_mt ? force_mt == 2 : (!p.m_dev && nt == 3 && ((p.throughput && blocks2 >= mt2_min) || (blocks2 >= 512 && p.M >= 131072)));
+    const bool mt2 = force_mt ? force_mt == 2 : (!p.m_dev && nt == 3 && (p.throughput || (blocks2 >= 512 && p.M >= 131072)));
     if (mt2 && nt == 3) launch_split<2, 3>(q, s);
     else if (nt == 1) launch_split<1, 1>(q, s);
     else if (nt == 2) launch_split<1, 2>(q, s);
