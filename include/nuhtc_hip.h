@@ -218,7 +218,10 @@ int nuhtc_check(nuhtc_engine* e, void* stream);
  * engine workspace; valid until the next call).  Names: "img", "c0".."c3", "x0".."x3", "rpn0".."rpn3",
  * "sem_pred", "sem_feat", "rpn_props", "rpn_counts", "cc_mask", "cc_props", "cc_counts", "rois", "roi_counts",
  * "cls0".."cls2", "reg0".."reg2", "bbox_feats", "mask_prob", "tokens<stage><block>" ...
- * shape receives up to 6 dims; *dtype: 0=f32, 1=i32, 2=u8, 3=u32. */
+ * shape receives up to 6 dims; *dtype: 0=f32, 1=i32, 2=u8, 3=u32.
+ * On the default (split) pipe two of them are not written by the step any more and are computed by this call, synchronising the device: "img" (the
+ * pre-processing runs inside the patch embedding; computed from the `tiles` of the last nuhtc_infer, which must still hold that batch) and "c0".."c3"
+ * (the stages' output norms run inside the FPN laterals; computed from the stages' token buffers). */
 int nuhtc_get_buffer(nuhtc_engine* e, const char* name, void** dev_ptr, int64_t* shape, int* ndim, int* dtype);
 
 /* Stand-alone ops for kernel-level parity tests (all pointers device memory, fp32). */

@@ -190,6 +190,8 @@ int launch_export_crops(const uint32_t* words, const int32_t* n_dev, int cap, in
 void cv_linear_tables(int ssize, int dsize, bool horizontal, std::vector<int>& tab);
 int launch_preproc(const uint8_t* tiles, float* img, int B, int th, int tw, int Hn, int Wn, int Hv, int Wv, const int* xtab, const int* ytab, int swap,
                    const float* mean_istd, hipStream_t s);
+int launch_patch_embed_tiles(const uint8_t* tiles, int B, int th, int tw, int Hn, int Wn, int Hv, int Wv, const int* xtab, const int* ytab, int swap,
+                             const float* mean_istd, const float* w, const float* b, const float* g, const float* beta, float* tok, hipStream_t s);
 int launch_patch_embed(const float* img, const float* w, const float* b, const float* g, const float* beta, float* tok,
                        int B, int Hn, int Wn, hipStream_t s);
 // LayerNorm of `rows` rows of C channels: dst row m reads src row src_map[m] (or m when src_map==null); src_map[m]<0 -> zeros

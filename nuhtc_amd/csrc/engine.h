@@ -77,6 +77,10 @@ struct nuhtc_engine {
   float* tok[4] = {};           // tok[0] = tokA, tok[1] = tokB, two more
   float* ln_out[4] = {};        // partials of the stage's final tensor, left by its last block's FFN
   float *lat_wln[4] = {}, *lat_bln[4] = {};   // lateral 1x1 with the output norm folded in: W diag(gamma), b + W beta
+  // pre-processing inside the patch embedding (round 5): the tiles of the running call; `img` is then computed only on request (nuhtc_get_buffer)
+  const uint8_t* in_tiles = nullptr;
+  int in_swap = 0;
+  bool img_stale = false;
   bool out_ln_folded = false;   // the last run took that path (c[st] is stale until requested)
   int last_batch = 0;
   float* ln_part2 = nullptr;   // the partials the patch-merging GEMM leaves for the next stage's first block (it READS ln_part in the same launch)

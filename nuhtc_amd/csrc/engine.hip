@@ -652,7 +652,20 @@ int run_backbone(nuhtc_engine* e, int B, hipStream_t s) {
   const int Hn = e->Hn, Wn = e->Wn;
   // the Swin linears take the block-tile form of the engine's schedule (nuhtc_config.schedule, gemm.hip)
   auto linear = [&](GemmParams p) { p.throughput = e->cfg.schedule == NUHTC_SCHED_THROUGHPUT; return egemm(e, p, s); };
-  RUN(launch_patch_embed(e->img, e->pe_w, e->pe_b, e->pe_g, e->pe_beta, e->tokA, B, Hn, Wn, s));
+  {
+    // dev: 1 (the tree) = resize + Normalize + Pad inside the patch embedding (one launch, no `img` tensor); 0 = preproc_kernel, then patch_embed_kernel
+    static const int& preproc_fused = dev_knob_ref("PREPROC_FUSED", 1);
+    float mi[6];
+    for (int i = 0; i < 3; ++i) { mi[i] = e->cfg.mean[i]; mi[3 + i] = (float)(1.0 / (double)e->cfg.std[i]); }
+    e->img_stale = preproc_fused != 0;
+    if (preproc_fused) {
+      RUN(launch_patch_embed_tiles(e->in_tiles, B, e->cfg.tile_h, e->cfg.tile_w, Hn, Wn, e->Hv, e->Wv, e->rs_xtab, e->rs_ytab, e->in_swap, mi, e->pe_w, e->pe_b, e->pe_g, e->pe_beta,
+                                   e->tokA, s));
+    } else {
+      RUN(launch_preproc(e->in_tiles, e->img, B, e->cfg.tile_h, e->cfg.tile_w, Hn, Wn, e->Hv, e->Wv, e->rs_xtab, e->rs_ytab, e->in_swap, mi, s));
+      RUN(launch_patch_embed(e->img, e->pe_w, e->pe_b, e->pe_g, e->pe_beta, e->tokA, B, Hn, Wn, s));
+    }
+  }
   float* x = e->tok[0];
   // dev: 0 = the norms of stages 2-4 as kernels of their own (round 4); 1 = in the A path of the linear behind them, statistics by a kernel
   // of their own; 2 (the tree) = statistics left by the epilogue of the GEMM that produced the tensor
@@ -863,9 +876,7 @@ int nuhtc_infer(nuhtc_engine* e, const uint8_t* tiles, int B, int channel_mode, 
   hipStream_t s = (hipStream_t)stream;
   HIP_CHECK(e, hipSetDevice(e->device));
   e->lastB = B;
-  float mi[6];
-  for (int i = 0; i < 3; ++i) { mi[i] = e->cfg.mean[i]; mi[3 + i] = (float)(1.0 / (double)e->cfg.std[i]); }
-  RUN(launch_preproc(tiles, e->img, B, e->cfg.tile_h, e->cfg.tile_w, e->Hn, e->Wn, e->Hv, e->Wv, e->rs_xtab, e->rs_ytab, channel_mode == NUHTC_CH_SWAP, mi, s));
+  e->in_tiles = tiles; e->in_swap = channel_mode == NUHTC_CH_SWAP;      // the backbone's first launch reads the tiles (swin.hip patch_embed_tiles_kernel)
   RUN(run_backbone(e, B, s));
   RUN(run_neck_heads(e, B, s));
   RUN(run_roi_path(e, B, nullptr, 0, 0, s, out));
@@ -880,9 +891,7 @@ int nuhtc_infer_fixed_load(nuhtc_engine* e, const uint8_t* tiles, int B, int cha
   hipStream_t s = (hipStream_t)stream;
   HIP_CHECK(e, hipSetDevice(e->device));
   e->lastB = B;
-  float mi[6];
-  for (int i = 0; i < 3; ++i) { mi[i] = e->cfg.mean[i]; mi[3 + i] = (float)(1.0 / (double)e->cfg.std[i]); }
-  RUN(launch_preproc(tiles, e->img, B, e->cfg.tile_h, e->cfg.tile_w, e->Hn, e->Wn, e->Hv, e->Wv, e->rs_xtab, e->rs_ytab, channel_mode == NUHTC_CH_SWAP, mi, s));
+  e->in_tiles = tiles; e->in_swap = channel_mode == NUHTC_CH_SWAP;      // the backbone's first launch reads the tiles (swin.hip patch_embed_tiles_kernel)
   RUN(run_backbone(e, B, s));
   RUN(run_neck_heads(e, B, s));
   RUN(run_roi_path(e, B, rois, n_rois, n_dets, s, out));
@@ -981,6 +990,17 @@ int nuhtc_get_buffer(nuhtc_engine* e, const char* name, void** ptr, int64_t* sha
     HIP_CHECK(e, hipDeviceSynchronize());
     const int rc = launch_layernorm(e->tok[st], nullptr, e->on_g[st], e->on_b[st], e->c[st], e->last_batch * g.H * g.W, g.C, nullptr);
     if (rc) FAIL(e, rc, "layernorm for a requested c buffer failed");
+    HIP_CHECK(e, hipDeviceSynchronize());
+  }
+  if (e->img_stale && strcmp(name, "img") == 0 && e->in_tiles) {
+    // the pre-processing ran inside the patch embedding: the normalised image is computed now, by the kernel that writes it on the other path, from
+    // the tiles of the last call (which must still be what they were: parity tests read `img` right after the call)
+    float mi[6];
+    for (int i = 0; i < 3; ++i) { mi[i] = e->cfg.mean[i]; mi[3 + i] = (float)(1.0 / (double)e->cfg.std[i]); }
+    HIP_CHECK(e, hipSetDevice(e->device));
+    HIP_CHECK(e, hipDeviceSynchronize());
+    const int rc = launch_preproc(e->in_tiles, e->img, e->last_batch, e->cfg.tile_h, e->cfg.tile_w, e->Hn, e->Wn, e->Hv, e->Wv, e->rs_xtab, e->rs_ytab, e->in_swap, mi, nullptr);
+    if (rc) FAIL(e, rc, "preproc for the requested img buffer failed");
     HIP_CHECK(e, hipDeviceSynchronize());
   }
   *ptr = it->second.ptr;

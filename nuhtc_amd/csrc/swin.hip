@@ -135,6 +135,82 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
   }
 }
 
+// The same with the pre-processing inside (round 5): the 48 inputs of a token are computed from the uint8 tile on the way into LDS -- cv2's 8-bit
+// linear resize from the per-axis tables, Normalize, zero Pad: the arithmetic of preproc_kernel, element for element, so the tokens are the
+// same bits -- and the normalised image (12 bytes per network pixel written and read back) never exists.  Every image pixel belongs to exactly
+// one 4 x 4 patch: nothing is computed twice.
+__global__ __launch_bounds__(256) void patch_embed_tiles_kernel(const uint8_t* __restrict__ tiles, int th, int tw, int Hv, int Wv,
+                                                                const int4* __restrict__ xtab, const int4* __restrict__ ytab, int swap, NormConst nc,
+                                                                const float* __restrict__ w, const float* __restrict__ bias, const float* __restrict__ g,
+                                                                const float* __restrict__ beta, float* __restrict__ tok, int nTok, int Hn, int Wn) {
+  __shared__ float wl[48 * 96];
+  __shared__ float pl[32 * 49];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < 48 * 96; e += 256) wl[e] = w[e];
+  const int Wt = Wn >> 2, Ht = Hn >> 2;
+  const int t0 = blockIdx.x * 32;
+  for (int e = tid; e < 32 * 48; e += 256) {
+    int tl = e / 48, k = e - tl * 48;
+    int t = t0 + tl;
+    float v = 0.f;
+    if (t < nTok) {
+      int tx = t % Wt, ty = (t / Wt) % Ht, b = t / (Wt * Ht);
+      int kh = k / 12, r = k - kh * 12;   // r = kw*3 + c
+      const int kw = r / 3, c = r - kw * 3;
+      const int x = 4 * tx + kw, y = 4 * ty + kh;
+      if (x < Wv && y < Hv) {             // (right of / below the resized image: the zeros of Pad)
+        const int4 ax = xtab[x], ay = ytab[y];
+        const uint8_t* tb = tiles + (long long)b * th * tw * 3;
+        const int sc = swap ? 2 - c : c;
+        const int s0 = tb[((long long)ay.x * tw + ax.x) * 3 + sc] * ax.z + tb[((long long)ay.x * tw + ax.y) * 3 + sc] * ax.w;
+        const int s1 = tb[((long long)ay.y * tw + ax.x) * 3 + sc] * ax.z + tb[((long long)ay.y * tw + ax.y) * 3 + sc] * ax.w;
+        const int u = (((ay.z * (s0 >> 4)) >> 16) + ((ay.w * (s1 >> 4)) >> 16) + 2) >> 2;
+        v = ((float)u - nc.mean[c]) * nc.istd[c];
+      }
+    }
+    pl[tl * 49 + k] = v;
+  }
+  __syncthreads();
+  const int tl = tid >> 3, cg = tid & 7;
+  float acc[12];
+#pragma unroll
+  for (int j = 0; j < 12; ++j) acc[j] = 0.f;
+  for (int k = 0; k < 48; ++k) {
+    float x = pl[tl * 49 + k];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) acc[j] = fmaf(x, wl[k * 96 + cg + 8 * j], acc[j]);
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < 12; ++j) { acc[j] += bias[cg + 8 * j]; sum += acc[j]; }
+  sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
+  const float mean = sum * (1.0f / 96.0f);
+  float var = 0.f;
+#pragma unroll
+  for (int j = 0; j < 12; ++j) { float d = acc[j] - mean; var = fmaf(d, d, var); }
+  var += __shfl_xor(var, 1); var += __shfl_xor(var, 2); var += __shfl_xor(var, 4);
+  const float rstd = 1.0f / sqrtf(var * (1.0f / 96.0f) + 1e-5f);
+  const int t = t0 + tl;
+  if (t < nTok) {
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      int c = cg + 8 * j;
+      tok[(long long)t * 96 + c] = (acc[j] - mean) * rstd * g[c] + beta[c];
+    }
+  }
+}
+
+int launch_patch_embed_tiles(const uint8_t* tiles, int B, int th, int tw, int Hn, int Wn, int Hv, int Wv, const int* xtab, const int* ytab, int swap,
+                             const float* mean_istd, const float* w, const float* b, const float* g, const float* beta, float* tok, hipStream_t s) {
+  ProfScope ps("patch_embed", 2.0 * 48 * 96 * B * (Hn / 4) * (Wn / 4), (double)B * 3.0 * th * tw + 4.0 * 96 * B * (Hn / 4) * (Wn / 4), s);
+  NormConst nc;
+  for (int i = 0; i < 3; ++i) { nc.mean[i] = mean_istd[i]; nc.istd[i] = mean_istd[3 + i]; }
+  int nTok = B * (Hn / 4) * (Wn / 4);
+  hipLaunchKernelGGL(patch_embed_tiles_kernel, dim3(cdiv(nTok, 32)), dim3(256), 0, s, tiles, th, tw, Hv, Wv, (const int4*)xtab, (const int4*)ytab, swap, nc,
+                     w, b, g, beta, tok, nTok, Hn, Wn);
+  return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
+}
+
 int launch_patch_embed(const float* img, const float* w, const float* b, const float* g, const float* beta, float* tok, int B,
                        int Hn, int Wn, hipStream_t s) {
   ProfScope ps("patch_embed", 2.0 * 48 * 96 * B * (Hn / 4) * (Wn / 4), 4.0 * B * Hn * Wn * 3 + 4.0 * 96 * B * (Hn / 4) * (Wn / 4), s);

@@ -167,12 +167,14 @@ class Engine:
     def infer_async(self, tiles_dev, channel_mode=hip.CH_AS_IS):
         """Enqueue the whole path for a device-resident batch; outputs land in self.boxes/labels/counts/masks/keep."""
         B = tiles_dev.shape[0]
+        self._last_tiles = tiles_dev          # (kept alive until the next call: buffer('img') is computed from them on request)
         self._check(self.lib.nuhtc_infer(self.h, ctypes.c_void_p(tiles_dev.data_ptr()), B, channel_mode, self._stream(),
                                          ctypes.byref(self.dets)))
         return B
 
     def infer_fixed_load_async(self, tiles_dev, rois_dev, n_dets, channel_mode=hip.CH_AS_IS):
         B, n_rois = tiles_dev.shape[0], rois_dev.shape[1]
+        self._last_tiles = tiles_dev
         self._check(self.lib.nuhtc_infer_fixed_load(self.h, ctypes.c_void_p(tiles_dev.data_ptr()), B, channel_mode,
                                                     ctypes.c_void_p(rois_dev.data_ptr()), n_rois, n_dets, self._stream(),
                                                     ctypes.byref(self.dets)))
