@@ -9,7 +9,7 @@ NS=$(python3 - <<'P'
 import csv, glob
 n = 0
 for f in glob.glob('/tmp/hf/**/*counter_collection.csv', recursive=True):
-    n += sum(1 for r in csv.DictReader(open(f)) if r['Kernel_Name'].startswith('preproc_kernel') and r['Counter_Name'] == 'FETCH_SIZE')
+    n += sum(1 for r in csv.DictReader(open(f)) if r['Kernel_Name'].startswith('patch_embed') and r['Counter_Name'] == 'FETCH_SIZE')
 print(n)
 P
 )
