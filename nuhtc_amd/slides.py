@@ -104,7 +104,11 @@ def save_coords(path, coords, patch_size, patch_level, name, level_dim=None, dow
             attrs['level_dim'] = tuple(int(v) for v in level_dim)
         attrs['name'] = str(name)
         attrs['save_path'] = os.path.dirname(path)
-        h5coords.write_coords(os.path.splitext(path)[0] + '.h5', coords, attrs)
+        try:
+            h5coords.write_coords(os.path.splitext(path)[0] + '.h5', coords, attrs)
+        except (h5coords.H5Error, OSError) as e:       # the .npz above is what this package reads: the reference's twin is a courtesy
+            import warnings
+            warnings.warn(f'{path}: the .h5 twin of the coordinate file was not written ({e})')
 
 
 def has_coords(patch_save_dir, slide_id):
