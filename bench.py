@@ -463,6 +463,33 @@ def main():
     counts = eng.counts[:B].cpu().numpy()
     roi_counts = eng.buffer('roi_counts')[:B].cpu().numpy()
 
+    # What the K-step window above leaves out: it starts with the `depth` engines empty and ends when the last of them has drained, so
+    # depth - 1 steps' worth of the window run on a partly filled GPU (K = 20 at the driver's settings).  `value_steady` is the same step
+    # in the same run with the pipeline already full: 2 * depth untimed steps, then the time between the completion of step F - 1 and of
+    # step F + S - 1 (HIP events on the streams those two steps ran on; S >= 100, a multiple of depth so both events sit on one stream),
+    # with 2 * depth further steps queued behind so that the GPU stays full until the second event.  `value` stays the contractual figure.
+    steady = None
+    if depth > 1:
+        F = 2 * depth
+        S = -(-max(100, args.steps) // depth) * depth
+        ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        sync_all()
+        mark('steady_in_flight')
+        for i in range(F + S + F):
+            with torch.cuda.stream(streams[i % depth]):
+                step_fn(engs[i % depth])
+                if i == F - 1:
+                    ev_a.record()
+                elif i == F + S - 1:
+                    ev_b.record()
+        sync_all()
+        mark('_after_steady')
+        ds = max_over_ranks(ev_a.elapsed_time(ev_b) * 1e-3)
+        for e in engs:
+            e.check()
+        steady = {'value': S * B * world / ds, 'ms_per_step': ds / S * 1e3, 'steps': S, 'untimed_steps_before_and_after': F,
+                  'fill_drain_equivalent_steps': round((dt - args.steps * ds / S) / (ds / S), 2)}
+
     # the step at the RoI sizes of a real slide, with the same engines in flight (throughput schedule): 40-100 px (40x nuclei after the
     # x2 resize) and 100-200 px (clumps / component proposals); the sequential figures and the RoI kernels' share follow further down
     roi_in_flight = {}
@@ -749,6 +776,14 @@ def main():
                          'ranks_seen': ranks_seen, 'records': gathered_records, 'bytes': gathered_bytes, 'seconds_inside_timed_region': round(exchange_s, 4),
                          'layout': 'head f64[n,9] | ring vertices i32[*,2] | crop boxes i64[n,6] | bit-packed mask crops i32[*] | rank id'},
         }
+        if steady:
+            out['value_steady'] = steady['value']
+            out['value_steady_detail'] = {**steady, 'unit': 'tiles/s',
+                                          'note': 'the same step, same run, pipeline already full (HIP events around S steps with 2 x batches_in_flight untimed steps before and after); '
+                                                  '`value` is the contractual K-step window, which starts with the engines empty and ends when they have drained'}
+            out['pipeline_fill_drain_steps'] = depth - 1
+            out['value_note'] = ('`value` times K steps through a pipeline of `batches_in_flight` engines that starts empty and drains inside the timed region, and includes the '
+                                 'exchange (at N = 1: two all_gathers on a one-rank RCCL communicator unless --no-force-collective); `value_steady` is the steady-state rate')
         if roi_load:
             out['real_slide_roi_load'] = roi_load
             if 'in_flight' in roi_load:

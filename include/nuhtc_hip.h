@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NUHTC_ABI_VERSION 9
+#define NUHTC_ABI_VERSION 10
 
 enum {
   NUHTC_OK = 0,
@@ -107,6 +107,11 @@ typedef struct nuhtc_config {
   float   mask_nms_thr;      /* 0.05 */
   int32_t matrix_pipe;       /* NUHTC_PIPE_BF16_SPLIT (default) or NUHTC_PIPE_FP32 */
   int32_t schedule;          /* NUHTC_SCHED_LATENCY (default) or NUHTC_SCHED_THROUGHPUT (v5) */
+  int32_t att_pool_fp16;     /* 0 (default): the attention-pool branch of AttentionRoIExtractor in fp32, as the reference computes it on a CPU
+                              * device (the north star's "fp32 tolerance").  1 (v10): as the reference computes it when its
+                              * feature maps are on a CUDA device -- it casts that branch to fp16 there (nuhtc/models/roi_extractors_cus.py:203,231):
+                              * every tensor operation of :231-237 rounds to fp16 (reductions accumulate in fp32), the fp16 result is added
+                              * into the fp32 RoI features.  Only the level-2 / level-3 tables change; see INTEGRATION.md section 6. */
 } nuhtc_config;
 
 /* Fills `cfg` with the PanNuke defaults listed above. */
@@ -219,9 +224,11 @@ int nuhtc_check(nuhtc_engine* e, void* stream);
  * "sem_pred", "sem_feat", "rpn_props", "rpn_counts", "cc_mask", "cc_props", "cc_counts", "rois", "roi_counts",
  * "cls0".."cls2", "reg0".."reg2", "bbox_feats", "mask_prob", "tokens<stage><block>" ...
  * shape receives up to 6 dims; *dtype: 0=f32, 1=i32, 2=u8, 3=u32.
- * On the default (split) pipe two of them are not written by the step any more and are computed by this call, synchronising the device: "img" (the
- * pre-processing runs inside the patch embedding; computed from the `tiles` of the last nuhtc_infer, which must still hold that batch) and "c0".."c3"
- * (the stages' output norms run inside the FPN laterals; computed from the stages' token buffers). */
+ * Two of them are not written by the step any more (either matrix pipe) and are computed by this call, synchronising the device: "img" (the
+ * pre-processing runs inside the patch embedding) and "c0".."c3" (the stages' output norms run inside the FPN laterals; computed from the
+ * stages' token buffers).  LIFETIME of "img": the engine keeps only the POINTER of the last nuhtc_infer's `tiles` and reads it again here --
+ * the caller must keep that device buffer alive and unchanged until it has fetched "img" (or never ask for it); a step that fails drops
+ * the pointer ("img" then returns whatever the buffer held). */
 int nuhtc_get_buffer(nuhtc_engine* e, const char* name, void** dev_ptr, int64_t* shape, int* ndim, int* dtype);
 
 /* Stand-alone ops for kernel-level parity tests (all pointers device memory, fp32). */
@@ -300,6 +307,30 @@ int nuhtc_bind_host_thread(int device);
 int nuhtc_bind_host_thread_pci(const char* pci_bdf);
 int nuhtc_bind_host_thread_at(const char* sysfs_root, const char* pci_bdf);
 int nuhtc_restore_host_thread(void);
+
+/* Text of the QuPath documents of a slide (v10).  The reference builds one dict per nucleus (tools/infer_wsi.py:550-585) and json.dump()s
+ * the lists (:659-664); these write the same bytes from arrays.  Host memory only, no device work, callable from any thread.
+ * head / mid / tail are NUL-terminated pieces of the feature template per class (the host cuts them out of json.dumps of one template
+ * feature, so key order, separators and the classification block are json's own); numbers are written the way json.dumps writes a Python
+ * int / float (float.__repr__: shortest round-trip digits, exponent form below 1e-4 and from 1e16 on).  Records are separated by ", ";
+ * the enclosing brackets are the caller's.
+ *   nuhtc_write_ring_features : record i = head | "[x, y], [x, y], ..." of ring i (verts[ring_off[i] .. ring_off[i+1]), int32 pairs) |
+ *       mid[label[i]] | repr(score[i]) | tail[label[i]].  Fills feat_start[0..n]: record i is out[feat_start[i] .. feat_start[i+1] - 2).
+ *       `threads` host threads share the records (0: the hardware's, at most 16).
+ *   nuhtc_write_point_features: record i = head | repr(xy[2i]) ", " repr(xy[2i+1]) | mid[label[i]] | repr(score[i]) | tail[label[i]].
+ *   nuhtc_join_features       : the records pick[0..n_pick) of a text written by nuhtc_write_ring_features (same feat_start convention),
+ *       joined by ", " (the merged document: the records the cross-tile merge kept).
+ * Each returns the number of bytes written.  When `out` is NULL or `cap` is below what the text needs, nothing is written and the
+ * needed size is returned (exact for the ring and join writers, an upper bound for the point writer): call once to size.
+ * Negative: NUHTC_E_INVALID (null argument, label outside [0, n_labels), n_labels > 64, decreasing offsets). */
+int64_t nuhtc_write_ring_features(const int32_t* verts, const int64_t* ring_off, const int32_t* label, const double* score, int64_t n,
+                                  const char* head, const char* const* mid, const char* const* tail, int32_t n_labels,
+                                  char* out, int64_t cap, int64_t* feat_start, int32_t threads);
+int64_t nuhtc_write_point_features(const double* xy, const int32_t* label, const double* score, int64_t n,
+                                   const char* head, const char* const* mid, const char* const* tail, int32_t n_labels,
+                                   char* out, int64_t cap);
+int64_t nuhtc_join_features(const char* text, const int64_t* feat_start, const int64_t* pick, int64_t n_pick, char* out, int64_t cap,
+                            int32_t threads);
 
 /* Per-kernel timing with HIP events recorded on the launch stream (process-wide switch; off by default).
  * nuhtc_profile_read synchronises the device and writes one text line per kernel tag,

@@ -240,6 +240,115 @@ def point_feature(box, label, score, class_names, colors=None):
                            "classification": {"name": class_names[int(label)], "color": colors[int(label) % len(colors)]}, "isLocked": False}}
 
 
+def _template_pieces(kind, label, class_names, colors=None):
+    """(head, mid, tail): the text json.dumps writes around the coordinates and around the score of a feature of class `label` --
+    cut out of the dump of one template feature, so key order, separators and the classification block are json's own."""
+    if kind == 'polygon':
+        s = json.dumps(feature(np.array([[987654321, 987654322]]), label, 0.123456789, class_names, colors))
+        head, rest = s.split('[987654321, 987654322]')
+    else:
+        s = json.dumps(point_feature(np.array([1.25, 2.25, 1.25, 2.25]), label, 0.123456789, class_names, colors))
+        head, rest = s.split('1.25, 2.25')
+    mid, tail = rest.split('0.123456789')
+    return head, mid, tail
+
+
+def _pieces_c(kind, class_names, colors):
+    import ctypes
+    nl = len(class_names)
+    pieces = [_template_pieces(kind, l, class_names, colors) for l in range(nl)]
+    head = pieces[0][0].encode('ascii')
+    assert all(p[0].encode('ascii') == head for p in pieces)
+    return head, (ctypes.c_char_p * nl)(*[p[1].encode('ascii') for p in pieces]), (ctypes.c_char_p * nl)(*[p[2].encode('ascii') for p in pieces]), nl
+
+
+def _sized_call(fn, args, tail=()):
+    """The library's text writers: one call to size, one to write -> uint8 array."""
+    import ctypes
+    need = fn(*args, None, 0, *tail)
+    if need < 0:
+        raise RuntimeError(f'{fn.__name__} failed ({need})')
+    out = np.empty(max(need, 1), np.uint8)
+    got = fn(*args, ctypes.c_void_p(out.ctypes.data), need, *tail)
+    if got < 0:
+        raise RuntimeError(f'{fn.__name__} failed ({got})')
+    return out[:got]
+
+
+def ring_features_text(verts, ring_n, labels, scores, class_names, colors=None, threads=0):
+    """The text of `json.dumps([feature(ring_i, label_i, score_i, class_names) for i ...])` without its enclosing brackets, written from
+    arrays by the library (nuhtc_write_ring_features: memory speed on a few host threads instead of ~40 us of dict building and dumping per
+    nucleus, tools/infer_wsi.py:550-566,659-664 of the reference): `verts` int32 (sum ring_n, 2) closed rings back to back, `ring_n` their
+    lengths.  Returns (text uint8 array, start int64 (n + 1)): feature i is text[start[i] : start[i + 1] - 2]."""
+    import ctypes
+    from . import hip
+    n = len(ring_n)
+    if n == 0:
+        return np.zeros(0, np.uint8), np.zeros(1, np.int64)
+    lib = hip.load()
+    verts = np.ascontiguousarray(verts, np.int32).reshape(-1, 2)
+    off = np.concatenate([[0], np.cumsum(np.asarray(ring_n, np.int64))]).astype(np.int64)
+    labels = np.ascontiguousarray(labels, np.int32)
+    scores = np.ascontiguousarray(scores, np.float64)
+    head, mid, tail, nl = _pieces_c('polygon', class_names, colors)
+    vp = lambda a: ctypes.c_void_p(a.ctypes.data)
+    start = np.zeros(n + 1, np.int64)
+    text = _sized_call(lib.nuhtc_write_ring_features, (vp(verts), vp(off), vp(labels), vp(scores), n, head, mid, tail, nl), (vp(start), int(threads)))
+    return text, start
+
+
+def point_features_text(boxes, labels, scores, class_names, colors=None):
+    """The text of `json.dumps([point_feature(box_i, label_i, score_i, class_names) ...])` without its brackets (uint8 array)."""
+    import ctypes
+    from . import hip
+    n = len(labels)
+    if n == 0:
+        return np.zeros(0, np.uint8)
+    b = np.asarray(boxes, np.float64)
+    xy = np.ascontiguousarray(np.stack([(b[:, 0] + b[:, 2]) / 2, (b[:, 1] + b[:, 3]) / 2], 1))       # point_feature's float(b0 + b2) / 2
+    labels = np.ascontiguousarray(labels, np.int32)
+    scores = np.ascontiguousarray(scores, np.float64)
+    head, mid, tail, nl = _pieces_c('point', class_names, colors)
+    vp = lambda a: ctypes.c_void_p(a.ctypes.data)
+    return _sized_call(hip.load().nuhtc_write_point_features, (vp(xy), vp(labels), vp(scores), n, head, mid, tail, nl))
+
+
+def join_features_text(text, start, pick, threads=0):
+    """The records `pick` of a ring_features_text result, joined by ", " (uint8 array)."""
+    import ctypes
+    from . import hip
+    pick = np.ascontiguousarray(pick, np.int64)
+    if len(pick) == 0:
+        return np.zeros(0, np.uint8)
+    text = np.ascontiguousarray(text, np.uint8)
+    start = np.ascontiguousarray(start, np.int64)
+    if pick.min() < 0 or pick.max() >= len(start) - 1:
+        raise IndexError('join_features_text: record index out of range')
+    vp = lambda a: ctypes.c_void_p(a.ctypes.data)
+    return _sized_call(hip.load().nuhtc_join_features, (vp(text), vp(start), vp(pick), len(pick)), (int(threads),))
+
+
+def concat_feature_texts(texts, starts=None):
+    """Per-rank texts of ring_features_text / point_features_text (rank order) -> the body of the whole list (uint8 array, ", " between
+    the ranks that have records) and, given the ranks' `start` arrays, the start array of the concatenation."""
+    live = [np.ascontiguousarray(t, np.uint8) for t in texts if len(t)]
+    total = sum(len(t) for t in live) + 2 * max(len(live) - 1, 0)
+    body = np.empty(total, np.uint8)
+    pos, bases = 0, []
+    for t in texts:
+        bases.append(pos)
+        if len(t):
+            body[pos:pos + len(t)] = t
+            pos += len(t)
+            if pos < total:
+                body[pos], body[pos + 1] = 44, 32           # ", "
+                pos += 2
+    if starts is None:
+        return body, None
+    st = [np.asarray(s, np.int64)[:-1] + b for s, b, t in zip(starts, bases, texts) if len(t)]
+    return body, np.concatenate(st + [np.array([total + 2], np.int64)])
+
+
 def merge_features(features, overlap_threshold=0.01, merge_strategy='probability'):
     """tools/nuclei_merge.py:62-174 on a list of GeoJSON features: sort by properties.score (descending, stable), greedy
     suppression of every not-yet-visited feature whose polygon IoU with the query exceeds the threshold; 'probability'
@@ -308,7 +417,8 @@ def merge_features(features, overlap_threshold=0.01, merge_strategy='probability
         visited[q] = True
     out = []
     for k in sorted(set(kept)):
-        f = json.loads(json.dumps(features[order[k]]))
-        f['properties']['nuclei_id'] = k
+        src = features[order[k]]
+        f = dict(src)                                    # the caller's features stay as they are: copy the two levels that change
+        f['properties'] = dict(src['properties'], nuclei_id=k)
         out.append(f)
     return out

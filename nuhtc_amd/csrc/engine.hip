@@ -34,6 +34,7 @@ void nuhtc_default_config(nuhtc_config* c) {
   c->margin = 2; c->min_area = 10; c->mask_nms_thr = 0.05f;
   c->matrix_pipe = NUHTC_PIPE_BF16_SPLIT;
   c->schedule = NUHTC_SCHED_LATENCY;
+  c->att_pool_fp16 = 0;
 }
 
 const char* nuhtc_last_error(const nuhtc_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
@@ -61,6 +62,7 @@ int nuhtc_create(const nuhtc_config* cfg, int device, nuhtc_engine** out) {
   if (cfg->max_per_img < 1 || cfg->max_per_img > 2048) { g_create_error = "max_per_img out of range"; return NUHTC_E_INVALID; }
   if (cfg->max_cc_proposals < 0 || cfg->max_cc_proposals > 4096) { g_create_error = "max_cc_proposals out of range"; return NUHTC_E_INVALID; }
   if (cfg->schedule != NUHTC_SCHED_LATENCY && cfg->schedule != NUHTC_SCHED_THROUGHPUT) { g_create_error = "schedule must be NUHTC_SCHED_LATENCY or NUHTC_SCHED_THROUGHPUT"; return NUHTC_E_INVALID; }
+  if (cfg->att_pool_fp16 != 0 && cfg->att_pool_fp16 != 1) { g_create_error = "att_pool_fp16 must be 0 or 1"; return NUHTC_E_INVALID; }
   if (cfg->matrix_pipe != NUHTC_PIPE_BF16_SPLIT && cfg->matrix_pipe != NUHTC_PIPE_FP32) { g_create_error = "matrix_pipe must be NUHTC_PIPE_BF16_SPLIT or NUHTC_PIPE_FP32"; return NUHTC_E_INVALID; }
   {
     const char* probes[4] = {nuhtc_tu_probe_conv(), nuhtc_tu_probe_gemm(), nuhtc_tu_probe_mlp(), nuhtc_tu_probe_swin()};
@@ -870,6 +872,15 @@ static int check_infer_args(nuhtc_engine* e, const uint8_t* tiles, int B) {
   return 0;
 }
 
+// one step; a step that fails forgets the caller's tile pointer (nuhtc_get_buffer("img") reads it again: include/nuhtc_hip.h)
+static int run_step(nuhtc_engine* e, int B, const float* rois, int n_rois, int n_dets, hipStream_t s, const nuhtc_dets* out) {
+  int rc = run_backbone(e, B, s);
+  if (!rc) rc = run_neck_heads(e, B, s);
+  if (!rc) rc = run_roi_path(e, B, rois, n_rois, n_dets, s, out);
+  if (rc) e->in_tiles = nullptr;
+  return rc;
+}
+
 int nuhtc_infer(nuhtc_engine* e, const uint8_t* tiles, int B, int channel_mode, void* stream, const nuhtc_dets* out) {
   int rc = check_infer_args(e, tiles, B);
   if (rc) return rc;
@@ -877,10 +888,7 @@ int nuhtc_infer(nuhtc_engine* e, const uint8_t* tiles, int B, int channel_mode, 
   HIP_CHECK(e, hipSetDevice(e->device));
   e->lastB = B;
   e->in_tiles = tiles; e->in_swap = channel_mode == NUHTC_CH_SWAP;      // the backbone's first launch reads the tiles (swin.hip patch_embed_tiles_kernel)
-  RUN(run_backbone(e, B, s));
-  RUN(run_neck_heads(e, B, s));
-  RUN(run_roi_path(e, B, nullptr, 0, 0, s, out));
-  return 0;
+  return run_step(e, B, nullptr, 0, 0, s, out);
 }
 
 int nuhtc_infer_fixed_load(nuhtc_engine* e, const uint8_t* tiles, int B, int channel_mode, const float* rois, int n_rois, int n_dets,
@@ -892,10 +900,7 @@ int nuhtc_infer_fixed_load(nuhtc_engine* e, const uint8_t* tiles, int B, int cha
   HIP_CHECK(e, hipSetDevice(e->device));
   e->lastB = B;
   e->in_tiles = tiles; e->in_swap = channel_mode == NUHTC_CH_SWAP;      // the backbone's first launch reads the tiles (swin.hip patch_embed_tiles_kernel)
-  RUN(run_backbone(e, B, s));
-  RUN(run_neck_heads(e, B, s));
-  RUN(run_roi_path(e, B, rois, n_rois, n_dets, s, out));
-  return 0;
+  return run_step(e, B, rois, n_rois, n_dets, s, out);
 }
 
 int nuhtc_mask_contours(nuhtc_engine* e, const nuhtc_dets* dets, int B, int cap, int16_t* xy, int32_t* n, void* stream) {

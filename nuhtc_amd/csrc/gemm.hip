@@ -942,6 +942,7 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
       while (nt > 1 && mt * (p.N / (32 * nt)) < limit) { if (nt > 2 && p.N % 64 == 0) nt = 2; else nt = 1; }
     if (force_nt > 0 && p.N % (32 * force_nt) == 0) nt = force_nt;
     if (q.amode == A_LN && nt != 3 && nt != 2) return NUHTC_E_INVALID;      // no such instantiation: launch_split would launch nothing
+    if (q.stats_out && nt != 3) return NUHTC_E_INVALID;                     // the statistics epilogue writes one partial per 32 * nt columns; every consumer reads 96-column partials
   }
   if (q.amode == A_CONV3 && !q.zeros) {
     q.zeros = zero_page();

@@ -88,6 +88,7 @@ struct TilePostParams {
 };
 
 int launch_attn_pool(const float* F, float* G, int B, int HW, float tau, hipStream_t s);
+int launch_attn_pool_fp16(const float* F, float* G, int B, int HW, float tau, hipStream_t s);   // the reference-on-CUDA arithmetic (nuhtc_config.att_pool_fp16)
 int launch_build_rois(const float* cc_boxes, const int* cc_counts, int cc_cap, const float* rpn_dets, const int* rpn_counts, int rpn_cap,
                       const float* fixed, int n_fixed, float* rois, int* roi_off, int* roi_cnt, int* total, int B, hipStream_t s);
 // `side` / `ev_fork` / `ev_join` (optional): the mid-size-RoI gather kernel of the P = 7 path runs on `side` beside the LDS-path

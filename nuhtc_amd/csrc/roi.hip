@@ -47,6 +47,44 @@ __global__ __launch_bounds__(256) void attn_pool_kernel(const float* __restrict_
   }
 }
 
+// The same table as the reference computes it when its feature maps are on a CUDA device: AttentionRoIExtractor casts this branch to fp16
+// there (`roi_dtype = torch.float16 if feats[0].is_cuda`, roi_extractors_cus.py:203,231), so every tensor operation of :231-237 rounds its
+// result to fp16 (reductions accumulate in fp32 and round once): feat.to(fp16); cosine_similarity of torch 1.13 = sum(x1*x2) /
+// sqrt(clamp_min(sum(x1*x1) * sum(x2*x2), eps^2)) with eps^2 = 1e-16 -> 0 in fp16; relu(cos - thres) + thres with the Python scalars applied in
+// fp32; feat * sim; mean over the map.  The fp16 values are then added into the fp32 RoI features (:247).  nuhtc_config.att_pool_fp16 = 1
+// selects it (default 0: the fp32 arithmetic of the reference's CPU path); accumulation order is this kernel's own.
+__device__ __forceinline__ float rh(float x) { return (float)(_Float16)x; }      // round to nearest even fp16 (overflow -> inf), back to fp32
+__global__ __launch_bounds__(256) void attn_pool_fp16_kernel(const float* __restrict__ F, float* __restrict__ G, int HW, float tau) {
+  __shared__ float part[4][64];
+  const int q = blockIdx.x, b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* Fb = F + (long long)b * HW * 64;
+  const float qv = rh(Fb[(long long)q * 64 + lane]);
+  const float w1 = rh(wsum64(rh(qv * qv)));
+  float acc = 0.f;
+  for (int p = wave; p < HW; p += 4) {
+    const float v = rh(Fb[(long long)p * 64 + lane]);
+    const float w12 = rh(wsum64(rh(qv * v)));
+    const float w2 = rh(wsum64(rh(v * v)));
+    const float n12 = rh(sqrtf(fmaxf(rh(w1 * w2), 0.f)));
+    const float cs = rh(w12 / n12);
+    const float sim = rh(fmaxf(rh(cs - tau), 0.f) + tau);     // (fmaxf drops a NaN cosine -- 0 / 0 -- the way torch's relu does not: see below)
+    acc += rh(v * (cs != cs ? cs : sim));                       // NaN propagates as in the reference
+  }
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0) {
+    const float s = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+    G[((long long)b * HW + q) * 64 + lane] = rh(s * (1.0f / (float)HW));
+  }
+}
+
+int launch_attn_pool_fp16(const float* F, float* G, int B, int HW, float tau, hipStream_t s) {
+  ProfScope ps("attn_pool_fp16", 4.0 * 64 * (double)HW * HW * B, 0, s);
+  hipLaunchKernelGGL(attn_pool_fp16_kernel, dim3(HW, B), dim3(256), 0, s, F, G, HW, tau);
+  return hipGetLastError() == hipSuccess ? 0 : NUHTC_E_HIP;
+}
+
 int launch_attn_pool(const float* F, float* G, int B, int HW, float tau, hipStream_t s) {
   ProfScope ps("attn_pool", 4.0 * 64 * (double)HW * HW * B, 0, s);
   hipLaunchKernelGGL(attn_pool_kernel, dim3(HW, B), dim3(256), 0, s, F, G, HW, tau);

@@ -276,7 +276,9 @@ int run_roi_path(nuhtc_engine* e, int B, const float* rois_fixed, int n_rois, in
   for (int l = 2; l < 4; ++l) {
     const int HW = e->st[l].H * e->st[l].W;
     float* G = l == 2 ? w->G2 : w->G3;
-    if (HW % 32 == 0) {
+    if (c.att_pool_fp16) {
+      RUN(launch_attn_pool_fp16(e->x[l], G, B, HW, c.att_thres, s));      // the reference-on-CUDA rounding (roi_extractors_cus.py:203,231)
+    } else if (HW % 32 == 0) {
       // S = relu(cos(F_q, F_p) - tau) + tau as one batched GEMM F·Fᵀ with the cosine epilogue, then G = S·F / HW
       RUN(launch_rownorm_inv(e->x[l], w->ap_inv, B * HW, 64, s));
       GemmParams p1 = gpr(e->x[l], e->x[l], nullptr, w->ap_S, HW, HW, 64);

@@ -28,7 +28,7 @@ class Config(ctypes.Structure):
         ('watershed_proposal', ctypes.c_int32), ('max_cc_proposals', ctypes.c_int32),
         ('stage_stds', (ctypes.c_float * 4) * 3),
         ('margin', ctypes.c_int32), ('min_area', ctypes.c_int32), ('mask_nms_thr', ctypes.c_float),
-        ('matrix_pipe', ctypes.c_int32), ('schedule', ctypes.c_int32),
+        ('matrix_pipe', ctypes.c_int32), ('schedule', ctypes.c_int32), ('att_pool_fp16', ctypes.c_int32),
     ]
 
 
@@ -41,7 +41,8 @@ EXPORTS = ['nuhtc_default_config', 'nuhtc_create', 'nuhtc_destroy', 'nuhtc_last_
            'nuhtc_finalize', 'nuhtc_infer', 'nuhtc_infer_fixed_load', 'nuhtc_check', 'nuhtc_get_buffer',
            'nuhtc_op_gemm', 'nuhtc_op_gemm_split', 'nuhtc_op_roi_align', 'nuhtc_op_nms', 'nuhtc_profile_enable', 'nuhtc_profile_read', 'nuhtc_dev_knob', 'nuhtc_export_crops',
            'nuhtc_mask_contours', 'nuhtc_merge_overlap', 'nuhtc_export_kept', 'nuhtc_clock_probe', 'nuhtc_op_swin_mlp', 'nuhtc_stream', 'nuhtc_op_swin_proj_mlp', 'nuhtc_bind_host_thread',
-           'nuhtc_bind_host_thread_pci', 'nuhtc_bind_host_thread_at', 'nuhtc_restore_host_thread', 'nuhtc_op_ln_gemm', 'nuhtc_op_gemm_ln_gemm', 'nuhtc_op_merge_ln_gemm']
+           'nuhtc_bind_host_thread_pci', 'nuhtc_bind_host_thread_at', 'nuhtc_restore_host_thread', 'nuhtc_op_ln_gemm', 'nuhtc_op_gemm_ln_gemm', 'nuhtc_op_merge_ln_gemm', 'nuhtc_write_ring_features',
+           'nuhtc_write_point_features', 'nuhtc_join_features']
 
 _lib = None
 
@@ -95,6 +96,10 @@ def load():
     lib.nuhtc_restore_host_thread.argtypes = []
     lib.nuhtc_stream.argtypes = [vp]
     lib.nuhtc_profile_read.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    pcp = ctypes.POINTER(ctypes.c_char_p)
+    lib.nuhtc_write_ring_features.argtypes = [vp, vp, vp, vp, ctypes.c_int64, ctypes.c_char_p, pcp, pcp, ctypes.c_int32, vp, ctypes.c_int64, vp, ctypes.c_int32]
+    lib.nuhtc_write_point_features.argtypes = [vp, vp, vp, ctypes.c_int64, ctypes.c_char_p, pcp, pcp, ctypes.c_int32, vp, ctypes.c_int64]
+    lib.nuhtc_join_features.argtypes = [vp, vp, vp, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int32]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is ctypes.c_int or name not in ('nuhtc_default_config', 'nuhtc_destroy', 'nuhtc_last_error', 'nuhtc_stream'):
@@ -103,6 +108,8 @@ def load():
     lib.nuhtc_default_config.restype = None
     lib.nuhtc_destroy.restype = None
     lib.nuhtc_stream.restype = ctypes.c_void_p
+    for fn in (lib.nuhtc_write_ring_features, lib.nuhtc_write_point_features, lib.nuhtc_join_features):
+        fn.restype = ctypes.c_int64
     _lib = lib
     return lib
 

@@ -56,6 +56,14 @@ def write_json(path, obj, **kw):
         json.dump(obj, f, **kw)
 
 
+def write_text_list(path, body):
+    """A JSON list whose elements are already text (contours.ring_features_text ...): "[" + body + "]", the bytes json.dump writes."""
+    with open(path, 'wb') as f:
+        f.write(b'[')
+        f.write(memoryview(body))
+        f.write(b']')
+
+
 # ----------------------------------------------------------------------------- SQLite contour table
 class SqlContourWriter:
     """`--mode sql` (infer_wsi.py:637-660,683-693): one row per contour + an R-tree over the bounding boxes.  The

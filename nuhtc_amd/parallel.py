@@ -40,13 +40,51 @@ def self_launch(n, script, argv, relay=None):
     return p.wait()
 
 
-def init_from_env(backend=None):
-    """One process per GPU, launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
+def env_ranks():
+    """(rank, local_rank, world) of this process from the launcher's environment, without forming the process group."""
     world = int(os.environ.get('WORLD_SIZE', 1))
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     if os.environ.get('NUHTC_ONE_DEVICE') == '1':       # test hook: several ranks on a one-GPU box (with NUHTC_DIST_BACKEND=gloo)
         local_rank = 0
+    return rank, local_rank, world
+
+
+def job_token():
+    """A name all ranks of ONE launch share and no other launch does: the rendezvous port plus the launcher's pid (the ranks of a
+    torch.distributed.run job are children of one agent process)."""
+    return f"{os.environ.get('MASTER_PORT', '0')}.{os.getppid()}"
+
+
+def host_phase_done(directory, rank, world, poll_s=0.2):
+    """Rank 0 has finished a host-only phase of unbounded length (tissue segmentation and patching of a whole folder of slides): it drops
+    a marker file, the other ranks poll for it.  Deliberately NOT a collective: a rank parked in an RCCL barrier is aborted by the
+    communicator's watchdog after its timeout (10 minutes by default), and a folder of real slides takes longer than that -- so this runs
+    BEFORE the process group exists.  If rank 0 dies the launcher ends the other ranks."""
+    import time
+    if world <= 1:
+        return
+    marker = os.path.join(directory, f'.host_phase_done.{job_token()}')
+    if rank == 0:
+        with open(marker, 'w') as f:
+            f.write('done\n')
+        return
+    while not os.path.exists(marker):
+        time.sleep(poll_s)
+
+
+def host_phase_cleanup(directory, rank, world):
+    """Remove rank 0's marker (call after a collective that every rank has passed)."""
+    if world > 1 and rank == 0:
+        try:
+            os.remove(os.path.join(directory, f'.host_phase_done.{job_token()}'))
+        except OSError:
+            pass
+
+
+def init_from_env(backend=None):
+    """One process per GPU, launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
+    rank, local_rank, world = env_ranks()
     if world == 1 and force_collective() and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', str(_free_port()))

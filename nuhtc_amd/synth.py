@@ -129,6 +129,12 @@ class CanvasTiles:
         idx = np.arange(lo, hi)
         self.coords = np.stack([idx % grid * step, idx // grid * step], 1).astype(np.int64)
 
+    @staticmethod
+    def grid_coords(grid, step=192):
+        """(grid * grid, 2) tile origins (x, y), row-major: the whole slide's coordinate list."""
+        idx = np.arange(grid * grid)
+        return np.stack([idx % grid * step, idx // grid * step], 1).astype(np.int64)
+
     def __len__(self):
         return self.hi - self.lo
 

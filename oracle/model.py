@@ -368,8 +368,18 @@ def cc_proposals(pred, img_hw, min_area=10):
 
 
 # ----------------------------------------------------------------------------- a16-a18 RoI features + bbox head
-def attention_pool(feat, rois, stride, thres=ATT_THRES):
-    """levels 2,3 of AttentionRoIExtractor.forward (nuhtc/models/roi_extractors_cus.py:220-238) -> (R,C) vectors."""
+ATT_POOL_FP16 = False      # module switch read by attention_pool: the reference's arithmetic on a CUDA device (see attention_pool)
+
+
+def attention_pool(feat, rois, stride, thres=ATT_THRES, fp16=None):
+    """levels 2,3 of AttentionRoIExtractor.forward (nuhtc/models/roi_extractors_cus.py:220-238) -> (R,C) vectors.
+
+    fp16 (default: the module switch ATT_POOL_FP16, off): what the reference computes when its feature maps are on a CUDA device --
+    `roi_dtype = torch.float16 if feats[0].is_cuda` (:203), `feat = feats[i].to(roi_dtype)` (:231): the very same tensor expressions on
+    fp16 tensors (each operation rounds to fp16, reductions accumulate in fp32), with cosine_similarity written out as torch 1.13.1 -- the
+    version the reference pins, README.md:86 -- computes it (w12 / sqrt(clamp_min(w1 * w2, eps^2)), ATen/native/Distance.cpp); the fp16
+    result is added into the fp32 RoI features (:247).  The engine's twin is nuhtc_config.att_pool_fp16."""
+    fp16 = ATT_POOL_FP16 if fp16 is None else fp16
     N, C, H, W = feat.shape
     b = rois[:, 0].long()
     cx = torch.div(rois[:, 1] + rois[:, 3], 2 * stride, rounding_mode='floor').clamp(0, W - 1).long()
@@ -377,6 +387,14 @@ def attention_pool(feat, rois, stride, thres=ATT_THRES):
     key = (b * H + cy) * W + cx
     uk, inv = torch.unique(key, return_inverse=True)
     ub, ucy, ucx = uk // (H * W), (uk // W) % H, uk % W
+    if fp16:
+        fh = feat.to(torch.float16)
+        x1 = fh[ub, :, ucy, ucx][:, None, :]                     # (U,1,C)
+        fv = fh.permute(0, 2, 3, 1).reshape(N, H * W, C)[ub]      # (U,HW,C)
+        w12, w1, w2 = (x1 * fv).sum(2), (x1 * x1).sum(2), (fv * fv).sum(2)
+        cos = w12 / (w1 * w2).clamp_min(1e-8 * 1e-8).sqrt()
+        sim = F.relu(cos - thres) + thres
+        return (fv * sim[..., None]).mean(1).float()[inv]
     q = feat[ub, :, ucy, ucx]                                    # (U,C)
     fv = feat.permute(0, 2, 3, 1).reshape(N, H * W, C)[ub]       # (U,HW,C)
     sim = F.relu(F.cosine_similarity(q[:, None, :], fv, dim=2) - thres) + thres

@@ -577,6 +577,52 @@ def test_infer_wsi_two_ranks_equal_one_rank_byte_for_byte(hip_device, tmp_path):
         assert len(a) > 1000 and a == b == c, f
 
 
+def test_eight_ranks_end_to_end_on_one_device(hip_device, tmp_path):
+    """The 8-GPU job on the hardware a test box has: eight ranks under torch.distributed.run sharing the one MI355X (NUHTC_ONE_DEVICE=1,
+    gloo for the exchange).  tools/infer_wsi.py --gpus 8 on a slide of SIX tiles (ranks 6 and 7 get none: empty shards travel through the
+    engine pipeline, the record packing, the text writers and the gather) and on a slide of 48 tiles writes the documents of the one-rank
+    run byte for byte, hears from every rank and ends (no rank left in a collective); bench.py --gpus 8 --batch 2 prints its one line with
+    all eight ranks in the exchange.  No rate is claimed: the ranks share a GPU."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    from nuhtc_amd import synth, weights
+    ck = tmp_path / 'w.pth'
+    torch.save(dict(state_dict=weights.bench_state_dict(0, obj_bias=0.0)), ck)
+    env = _two_rank_env()
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    env['OMP_NUM_THREADS'] = '2'
+    small = np.concatenate([np.concatenate([synth.nuclei_tile(60 + 3 * r + c, 64) for c in range(3)], 1) for r in range(2)], 0)       # 128 x 192: 2 x 3 tiles of 64
+    big = np.concatenate([np.concatenate([synth.nuclei_tile(40 + 3 * r + c, 128) for c in range(3)], 1) for r in range(2)], 0)        # 256 x 384: 6 x 8 tiles at stride 48
+    for name, img, step, ntile, shares in (('six', small, 64, 6, [1, 1, 1, 1, 1, 1, 0, 0]), ('fortyeight', big, 48, 48, [6] * 8)):
+        src = tmp_path / f'{name}.npy'
+        np.save(src, img)
+        common = [os.path.join(ROOT, 'tools/infer_wsi.py'), str(src), CFG, str(ck), '--patch_size', '64', '--step_size', str(step), '--batch_size', '4',
+                  '--merge', '--mode', 'qupath']
+        subprocess.check_call([sys.executable] + common + ['--save_dir', str(tmp_path / f'{name}_one')])
+        out = subprocess.run([sys.executable] + common + ['--save_dir', str(tmp_path / f'{name}_eight'), '--gpus', '8'], env=env, stdout=subprocess.PIPE,
+                             stderr=subprocess.STDOUT, text=True, timeout=1500)
+        print(out.stdout[-2500:])
+        assert out.returncode == 0
+        assert f'{ntile} tiles on 8 rank(s)' in out.stdout and f'records of ranks {list(range(8))}, tiles per rank {shares}' in out.stdout
+        for f in (f'{name}.geojson', f'{name}_point.geojson', f'{name}_merged.geojson'):
+            a = open(tmp_path / f'{name}_one/nuclei/{name}' / f, 'rb').read()
+            b = open(tmp_path / f'{name}_eight/nuclei/{name}' / f, 'rb').read()
+            assert a == b and len(a) > 2, f
+        assert not [f for f in os.listdir(tmp_path / f'{name}_eight') if f.startswith('.host_phase_done')]       # rank 0 removed its marker
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1', '--no-settle', '--no-fp32-pipe',
+                          '--no-roi-load', '--batch', '2', '--in-flight', '2'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
+    print(out.stderr[-3000:])
+    assert out.returncode == 0
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 8 and d['exchange']['ranks_seen'] == list(range(8)) and d['exchange']['communicator_ranks'] == 8 and 'cpu_baseline' not in d
+    assert abs(d['value'] - 8 * 2 * 2 / (d['ms_per_step'] * 2e-3)) < 1e-6 * d['value']
+
+
 def test_rccl_branch_of_the_exchange_on_one_gpu(hip_device):
     """The nccl (= RCCL) branch of `gather_blobs` on the hardware at hand: NUHTC_FORCE_COLLECTIVE=1 forms a communicator of one rank on
     the MI355X and both all_gathers run on DEVICE buffers; what comes back is byte-equal to the short-circuit path (the script of

@@ -408,3 +408,48 @@ def test_roi_features_long_lists_and_batch_independence(hip_device):
     feats_short = eng.buffer('bbox_feats')[:B * m].cpu()
     for b in range(B):
         assert torch.equal(feats_short[b * m:(b + 1) * m], feats_long[b * n:b * n + m]), f'tile {b}: features depend on the rest of the batch'
+
+
+def test_attention_pool_fp16_switch_is_the_reference_on_cuda_arithmetic(hip_device):
+    """nuhtc_config.att_pool_fp16 = 1: the level-2 / level-3 attention-pool tables as the reference computes them when its feature maps
+    sit on a CUDA device (it casts that branch to fp16 there, nuhtc/models/roi_extractors_cus.py:203,231) against the oracle's fp16 mode,
+    which runs the reference's own tensor expressions on fp16 tensors.  Every value is an fp16 number; it agrees with the oracle to one
+    fp16 unit (the fp32 sums inside each rounded operation run in another order) and nearly all values agree bit for bit.  Everything
+    upstream is untouched by the switch, and the default engine keeps the fp32 tables."""
+    from nuhtc_amd import hip, synth, weights
+    from nuhtc_amd.engine import Engine
+    from oracle import model as O
+    sd = weights.bench_state_dict(3)
+    B = 2
+    e16 = Engine(sd, device=0, max_batch=B, tile=(256, 256), att_pool_fp16=1)
+    e32 = Engine(sd, device=0, max_batch=B, tile=(256, 256))
+    tiles = e16.to_device(synth.nuclei_tiles(B, 256, start=11))
+    for e in (e16, e32):
+        e.infer_async(tiles, hip.CH_SWAP)
+        e.check()
+    changed = 0
+    for lvl, stride in ((2, 16), (3, 32)):
+        x = _nchw(e16.buffer(f'x{lvl}')[:B])
+        assert torch.equal(x, _nchw(e32.buffer(f'x{lvl}')[:B]))
+        H, W = x.shape[2:]
+        cy, cx = np.meshgrid(np.arange(H), np.arange(W), indexing='ij')
+        one = np.stack([cx * stride + 1.0, cy * stride + 1.0, cx * stride + stride - 1.0, cy * stride + stride - 1.0], -1).reshape(-1, 4)
+        rois = torch.from_numpy(np.concatenate([np.concatenate([np.full((H * W, 1), float(b)), one], 1) for b in range(B)]).astype(np.float32))
+        with torch.no_grad():
+            ref16 = O.attention_pool(x, rois, stride, fp16=True)
+            ref32 = O.attention_pool(x, rois, stride, fp16=False)
+        got16 = e16.buffer(f'G{lvl}')[:B].reshape(-1, 64).cpu()
+        got32 = e32.buffer(f'G{lvl}')[:B].reshape(-1, 64).cpu()
+        assert torch.equal(got16, got16.half().float())                      # fp16 numbers, carried in fp32
+        unit = torch.maximum(ref16.abs(), torch.tensor(2.0 ** -14)) * 2.0 ** -10
+        off = (got16 - ref16).abs()
+        same = float((got16 == ref16).float().mean())
+        print(f'level {lvl}: {got16.numel()} values, bit-equal to the oracle fp16 mode {same:.4f}, worst {float((off / unit).max()):.2f} fp16 units; '
+              f'fp16 vs fp32 tables differ by up to {float((got16 - got32).abs().max()):.2e}')
+        assert bool((off <= unit).all()) and same >= 0.97
+        assert float((got32 - ref32).abs().max()) <= 2e-5
+        changed += int((got16 != got32).sum())
+    assert changed > 0
+    n16, n32 = e16.counts[:B].cpu().numpy(), e32.counts[:B].cpu().numpy()
+    print('detections per tile, fp16 switch / default:', n16.tolist(), n32.tolist())
+    assert (np.abs(n16 - n32) <= np.maximum(3, n32 // 20)).all()

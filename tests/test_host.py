@@ -442,3 +442,31 @@ def test_self_launch_starts_one_rank_per_gpu_as_children(tmp_path):
     assert lines == ["rank 0 of 2 127.0.0.1 ['--x', '1']", "rank 1 of 2 127.0.0.1 ['--x', '1']"]
     bad = subprocess.run([sys.executable, '-c', code, '--fail'], env=env, capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0
+
+
+def test_ranks_wait_for_rank_0s_host_phase_on_a_file_not_a_collective(tmp_path, monkeypatch):
+    """tools/infer_wsi.py: the other ranks wait for rank 0's seg_and_patch by polling a marker file BEFORE the process group exists (a rank
+    parked in an RCCL barrier would be aborted by the watchdog after ten minutes; segmentation of a folder of slides has no bound).
+    Here: a 'rank 1' thread stays blocked until 'rank 0' reports, the marker carries the job's token, cleanup removes it."""
+    import threading
+    import time
+    from nuhtc_amd import parallel
+    monkeypatch.setenv('MASTER_PORT', '29555')
+    done = threading.Event()
+
+    def rank1():
+        parallel.host_phase_done(str(tmp_path), 1, 2, poll_s=0.01)
+        done.set()
+    th = threading.Thread(target=rank1)
+    th.start()
+    time.sleep(0.2)
+    assert not done.is_set()
+    parallel.host_phase_done(str(tmp_path), 0, 2)
+    th.join(5)
+    assert done.is_set()
+    marker = [f for f in os.listdir(tmp_path) if f.startswith('.host_phase_done.')]
+    assert marker == [f'.host_phase_done.29555.{os.getppid()}']
+    parallel.host_phase_cleanup(str(tmp_path), 0, 2)
+    assert not os.listdir(tmp_path)
+    parallel.host_phase_done(str(tmp_path), 0, 1)            # one rank: nothing to wait for, nothing written
+    assert not os.listdir(tmp_path)

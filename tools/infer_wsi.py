@@ -112,7 +112,16 @@ def run_slide(args, model, bag, slide_id, rank, local_rank, world):
                     save_result(model, batch[k], res, score_thr=args.score_thr, out_file=os.path.join(det_dir, f'img_{x}_{y}.jpg'))
     # the one exchange of the path: every rank's records (head, ring vertices, mask crops, RLE strings) in a single all-gather
     dev = torch.device('cuda', local_rank) if world > 1 and torch.cuda.is_available() else torch.device('cpu')
-    gathered = parallel.gather_blobs([t.to(dev) for t in wsi.pack_records(rec, keep, tile_base=lo, rles=rles)])
+    parts = wsi.pack_records(rec, keep, tile_base=lo, rles=rles)
+    if want('qupath'):
+        # every rank writes the GeoJSON text of ITS records (the reference's one Python loop over all nuclei, :533-585 + json.dump :659-664,
+        # is seconds per slide on the writing rank); the bytes travel in the same gather and rank 0 only concatenates
+        h0, v0 = parts[0].numpy(), parts[1].numpy()
+        lab = h0[:, 5].astype(np.int32)
+        ptxt, pstart = contours.ring_features_text(v0, h0[:, 6].astype(np.int64), lab, h0[:, 4], model.CLASSES)
+        parts += [torch.from_numpy(ptxt), torch.from_numpy(pstart), torch.from_numpy(contours.point_features_text(h0[:, :4], lab, h0[:, 4], model.CLASSES))]
+    parts.append(torch.tensor([rank], dtype=torch.int32))           # who sent it (printed by rank 0)
+    gathered = parallel.gather_blobs([t.to(dev) for t in parts])
     heads = [g[0] for g in gathered]
     vparts = [g[1] for g in gathered]
     bparts = [g[4] if want('coco') else None for g in gathered]
@@ -122,9 +131,12 @@ def run_slide(args, model, bag, slide_id, rank, local_rank, world):
     name = slide_id
     out_dir = os.path.join(args.save_dir, 'nuclei', name)
     os.makedirs(out_dir, exist_ok=True)
-    feats, points, dsa, annts, per_tile = [], [], [], [], {}
+    dsa, annts, per_tile = [], [], {}
     sql = outputs.SqlContourWriter(os.path.join(out_dir, name + '_dql.db')) if want('sql') else None
+    n_records = int(sum(len(h) for h in heads))
     for h, v, bl in zip(heads, vparts, bparts):
+        if not (want('dsa') or want('coco') or sql):       # the per-record loop serves the other document kinds only
+            break
         h, v = h.cpu().numpy(), v.cpu().numpy()
         bl = bl.cpu().numpy().tobytes() if bl is not None else b''
         off = boff = 0
@@ -135,9 +147,6 @@ def run_slide(args, model, bag, slide_id, rank, local_rank, world):
             label, score = int(row[5]), float(row[4])
             elementidx = len(per_tile.setdefault(annidx, []))
             per_tile[annidx].append(label)
-            if want('qupath'):
-                feats.append(contours.feature(ring, label, score, model.CLASSES))
-                points.append(contours.point_feature(row[:4], label, score, model.CLASSES))
             if want('dsa'):
                 dsa.append(outputs.dsa_element(ring, label, model.CLASSES))
             if want('coco'):
@@ -148,15 +157,17 @@ def run_slide(args, model, bag, slide_id, rank, local_rank, world):
                               'iscrowd': 0, 'segmentation': rle})
             if sql:
                 sql.add(annidx, elementidx, ring, label, score, model.CLASSES)
-    msg = f'{len(bag)} tiles on {world} rank(s): {sum(len(v) for v in per_tile.values())} nuclei after per-tile mask-NMS'
+    msg = f'{len(bag)} tiles on {world} rank(s): {n_records} nuclei after per-tile mask-NMS'
+    if world > 1:
+        msg += f' (records of ranks {sorted(int(g[-1][0]) for g in gathered)}, tiles per rank {[parallel.shard_range(len(bag), r, world)[1] - parallel.shard_range(len(bag), r, world)[0] for r in range(world)]})'
     if want('qupath'):
-        outputs.write_json(os.path.join(out_dir, name + '.geojson'), feats)
-        outputs.write_json(os.path.join(out_dir, name + '_point.geojson'), points)
+        body, start = contours.concat_feature_texts([g[5].cpu().numpy() for g in gathered], [g[6].cpu().numpy() for g in gathered])
+        outputs.write_text_list(os.path.join(out_dir, name + '.geojson'), body)
+        outputs.write_text_list(os.path.join(out_dir, name + '_point.geojson'), contours.concat_feature_texts([g[7].cpu().numpy() for g in gathered])[0])
         if args.merge:
             kept = wsi.merge_gathered(gathered, args.overlap_threshold, device=local_rank if world > 1 else (torch.device(args.device).index or 0))
-            merged = [feats[i] for i in kept]
-            outputs.write_json(os.path.join(out_dir, name + '_merged.geojson'), merged)
-            msg += f', {len(merged)} after the cross-tile merge'
+            outputs.write_text_list(os.path.join(out_dir, name + '_merged.geojson'), contours.join_features_text(body, start, kept))
+            msg += f', {len(kept)} after the cross-tile merge'
     if want('dsa'):
         outputs.write_json(os.path.join(out_dir, name + '_dsa.json'), outputs.dsa_document(dsa))
     if want('coco'):
@@ -186,7 +197,9 @@ def main(argv=None):
     import torch
     from nuhtc_amd import parallel, slides, tilestore
     from nuhtc_amd.apis import init_detector
-    rank, local_rank, world = parallel.init_from_env()
+    # the process group is formed AFTER seg_and_patch: rank 0's host phase (segmentation, masks, patching, stitching of every slide of the
+    # folder) has no time bound, and a rank waiting in an RCCL barrier is aborted by the watchdog after 10 minutes
+    rank, local_rank, world = parallel.env_ranks()
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     say = print if rank == 0 else (lambda *a, **k: None)
@@ -237,9 +250,7 @@ def main(argv=None):
                                  save_mask=True, stitch=args.stitch, patch_level=args.patch_level, patch=args.patch or single,
                                  process_list=process_list, no_auto_skip=args.no_auto_skip or (single and args.coords is None),
                                  slides=names, seg_downsample=args.seg_downsample)
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
+        parallel.host_phase_done(args.save_dir, rank, world)      # the other ranks poll a marker file (no collective, no timeout)
         for entry in slides.slide_list(args.save_dir):        # Dataset_All_Bags over process_list_autogen.csv (:437-439)
             slide_id = entry.split(ext)[0] if ext else entry
             if not slides.has_coords(patch_save_dir, slide_id):     # patches/<id>.npz, or the reference's own patches/<id>.h5
@@ -255,6 +266,7 @@ def main(argv=None):
                     raise SystemExit(f'{slide_id}: coordinate file was made for patch_level {lvl}; only patch_level 0 is supported')
                 return tilestore.TileBag(slides.open_array_slide(spath), c, ps)
             jobs.append((slide_id, make))
+    parallel.init_from_env()
     total = len(jobs)
     for k, (slide_id, make) in enumerate(jobs):
         say('\nprogress: {}/{}'.format(k, total))
@@ -264,6 +276,10 @@ def main(argv=None):
             say(f'skip {slide_id} due to existing results')
             continue
         run_slide(args, model, make(), slide_id, rank, local_rank, world)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()                                        # every rank is past the marker
+        parallel.host_phase_cleanup(args.save_dir, rank, world)
 
 
 if __name__ == '__main__':
