@@ -79,12 +79,14 @@ def _device_index(device):
     raise ValueError(f'unsupported device {device!r}')
 
 
-def init_detector(config, checkpoint=None, device='cuda:0', cfg_options=None, max_batch=16, bind_host=None):
+def init_detector(config, checkpoint=None, device='cuda:0', cfg_options=None, max_batch=16, bind_host=None, att_pool_fp16=0):
     """nuhtc/apis/inference.py:11-57.  Beyond the reference's arguments: `max_batch` (capacity of the engines the detector creates) and
     `bind_host` -- True places the thread that creates an engine on the CPUs of the GPU's NUMA node (nuhtc_bind_host_thread: worth
     8 % on the dense launches of a two-socket host; the thread's mask is restored when the engine is closed).  A
     library does not change its caller's CPU affinity unasked: the default (None) follows NUHTC_HOST_AFFINITY, which defaults to off;
-    the entry points that own their process (bench.py, tools/infer_wsi.py, tools/bench_wsi.py) switch it on."""
+    the entry points that own their process (bench.py, tools/infer_wsi.py, tools/bench_wsi.py) switch it on.
+    `att_pool_fp16=1`: the attention-pool branch of the RoI extractor in the fp16 arithmetic the reference uses when its maps are on a CUDA
+    device (roi_extractors_cus.py:203,231); the default is the fp32 arithmetic of its CPU path."""
     if isinstance(config, str):
         config = Config.fromfile(config)
     elif not isinstance(config, dict):
@@ -110,6 +112,8 @@ def init_detector(config, checkpoint=None, device='cuda:0', cfg_options=None, ma
         warnings.warn('init_detector called without a checkpoint: using seeded synthetic weights (the reference would keep its random init)')
         sd = weights.seeded_state_dict(0, opts['num_classes'])
     model = Detector(config, sd, dev, max_batch=max_batch, bind_host=bind_host)
+    if att_pool_fp16:
+        model.opts['att_pool_fp16'] = 1
     if classes is not None:
         model.CLASSES = classes
     return model

@@ -82,6 +82,13 @@ struct Conv3Fuse {
   const float* bn1;
   float* outn1;
   int store_out;          // the convolution's own output is stored to C (1) or dropped (0)
+  // Further maps of other sizes that take the SAME convolution and pointwise layer in the same launch (the RPN head over the FPN levels,
+  // rpn_head.py:62-68: one set of weights for all levels): map k = more_in[k] -> more_out2[k], the launch's image count of more_H[k] x
+  // more_W[k] pixels each.  Only with store_out = 0 and neither out3 nor outn1; the tiles of all maps share one persistent grid.
+  int n_more;
+  const float* more_in[3];
+  float* more_out2[3];
+  int more_H[3], more_W[3];
 };
 int conv3_pack_fuse(const float* w2_host, int N2, void** out_dev);      // caller hipFree()s the image
 

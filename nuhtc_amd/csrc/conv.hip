@@ -61,6 +61,12 @@ struct Conv3Params {
   const float* bn1;
   float* outn1;
   int act2, store_out;
+  // maps of several sizes in one launch (Conv3Fuse.n_more): segment k covers tiles [s_t0[k], s_t0[k + 1]) of the launch's tile list;
+  // segment 0 repeats in / out2 / H / W / tiles_x above.  nseg = 1 for every other launch (then s_t0 is not read).
+  int nseg;
+  const float* s_in[4];
+  float* s_out2[4];
+  int s_H[4], s_W[4], s_tx[4], s_timg[4], s_t0[5];
 };
 
 // N2 = 0: the plain convolution.  N2 = 32 / 64: a pointwise layer 64 -> N2 on the (biased, activated) output tile is computed in
@@ -79,8 +85,19 @@ __global__ __launch_bounds__(512, 1) void conv3_split_kernel(Conv3Params p) {
   // have an L2 each) and walks that XCD's contiguous share of the tile list with stride gridDim / 8: neighbouring tiles, which
   // share halo rows, meet in one L2.  With a device-side image count only the real images are shared out.
   const int nimg = p.nimg_dev ? min(p.nimg, *p.nimg_dev) : p.nimg;
-  const int tiles_img = p.tiles_y * p.tiles_x;
-  const int ntile = nimg * tiles_img;
+  const int ntile = p.nseg > 1 ? p.s_t0[p.nseg] : nimg * p.tiles_y * p.tiles_x;
+  // the map a tile belongs to (wave-uniform): its geometry and pointers; one map unless the launch carries several (s_t0 past nseg = INT_MAX)
+  struct Seg { const float* in; float* out2; int H, W, tx, timg, t0; };
+  auto seg_of = [&](int t) {
+    Seg g;
+    if (p.nseg > 1) {
+      const int k = (t >= p.s_t0[1]) + (t >= p.s_t0[2]) + (t >= p.s_t0[3]);
+      g.in = p.s_in[k]; g.out2 = p.s_out2[k]; g.H = p.s_H[k]; g.W = p.s_W[k]; g.tx = p.s_tx[k]; g.timg = p.s_timg[k]; g.t0 = p.s_t0[k];
+    } else {
+      g.in = p.in; g.out2 = p.out2; g.H = p.H; g.W = p.W; g.tx = p.tiles_x; g.timg = p.tiles_y * p.tiles_x; g.t0 = 0;
+    }
+    return g;
+  };
   const int per_xcd = (ntile + 7) >> 3;
   const int xcd = blockIdx.x & 7, xstride = gridDim.x >> 3;
   const int t_end = min((xcd + 1) * per_xcd, ntile);
@@ -114,16 +131,17 @@ __global__ __launch_bounds__(512, 1) void conv3_split_kernel(Conv3Params p) {
     hdst[j] = it < NIT ? hy * CV_ROW + hx * CV_PIX + (c4 >> 1) * 48 + (c4 & 1) * 8 : -1;
   }
 #define CV_HALO_LOAD(tile_)                                                                                       \
-  { const int img_ = (tile_) / tiles_img, tr_ = (tile_) - img_ * tiles_img;                                       \
-    const int ty_ = tr_ / p.tiles_x, tx_ = tr_ - ty_ * p.tiles_x;                                                 \
-    const float* map_ = p.in + (long long)img_ * p.H * p.W * 64;                                                  \
+  { const Seg g_ = seg_of(tile_);                                                                                 \
+    const int tl_ = (tile_) - g_.t0, img_ = tl_ / g_.timg, tr_ = tl_ - img_ * g_.timg;                            \
+    const int ty_ = tr_ / g_.tx, tx_ = tr_ - ty_ * g_.tx;                                                         \
+    const float* map_ = g_.in + (long long)img_ * g_.H * g_.W * 64;                                               \
     _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                              \
       const int it = tid + 512 * j;                                                                               \
       const int px = it >> 4, c4 = it & 15;                                                                       \
       const int hy = px / (CV_TW + 2), hx = px - hy * (CV_TW + 2);                                                \
       const int y = ty_ * CV_TH - 1 + hy, x = tx_ * CV_TW - 1 + hx;                                               \
-      const bool ok = it < NIT && y >= 0 && y < p.H && x >= 0 && x < p.W;                                         \
-      hv[j] = ok ? *reinterpret_cast<const v4f*>(map_ + ((long long)y * p.W + x) * 64 + c4 * 4) : v4f{0.f, 0.f, 0.f, 0.f}; \
+      const bool ok = it < NIT && y >= 0 && y < g_.H && x >= 0 && x < g_.W;                                       \
+      hv[j] = ok ? *reinterpret_cast<const v4f*>(map_ + ((long long)y * g_.W + x) * 64 + c4 * 4) : v4f{0.f, 0.f, 0.f, 0.f}; \
     } }
 
   CV_HALO_LOAD(tile)
@@ -172,8 +190,9 @@ __global__ __launch_bounds__(512, 1) void conv3_split_kernel(Conv3Params p) {
   v4f pend[N2 ? 1 : 4];
   float* pend_o = nullptr;
   for (; tile < t_end; tile += xstride) {
-    const int img = tile / tiles_img, tr = tile - img * tiles_img;
-    const int ty = tr / p.tiles_x, tx = tr - ty * p.tiles_x;
+    const Seg sg = seg_of(tile);
+    const int tl = tile - sg.t0, img = tl / sg.timg, tr = tl - img * sg.timg;
+    const int ty = tr / sg.tx, tx = tr - ty * sg.tx;
     const int y0 = ty * CV_TH, x0 = tx * CV_TW;
     // ---- split the halo once, three planes into LDS; weights of tap 0
 #pragma unroll
@@ -250,8 +269,8 @@ __global__ __launch_bounds__(512, 1) void conv3_split_kernel(Conv3Params p) {
     CSTAMP(sMain)
     // ---- epilogue: register r of lane (pixel, half) is output channel 32 (wave >> 2) + (r & 3) + 8 (r >> 2) + 4 half
     const int y = y0 + prow, x = x0 + pcol;
-    const bool inside = y < p.H && x < p.W;
-    const long long pix = ((long long)img * p.H + y) * p.W + x;
+    const bool inside = y < sg.H && x < sg.W;
+    const long long pix = ((long long)img * sg.H + y) * sg.W + x;
     if constexpr (N2 == 0) {
       pend_o = inside ? p.out + pix * 64 + 32 * (wave >> 2) + 4 * half : nullptr;
 #pragma unroll
@@ -334,7 +353,7 @@ __global__ __launch_bounds__(512, 1) void conv3_split_kernel(Conv3Params p) {
           v4f v = (chalf ? other + mine : mine + other) + *reinterpret_cast<const v4f*>(kst + 64 + c2 + 8 * q);
           if (p.act2 == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
           if (inside && !(NUHTC_CONV_PROBE_EPI & 1)) {
-            *reinterpret_cast<v4f*>(p.out2 + pix * 64 + c2 + 8 * q) = v;
+            *reinterpret_cast<v4f*>(sg.out2 + pix * 64 + c2 + 8 * q) = v;
             if (p.out3) *reinterpret_cast<v4f*>(p.out3 + pix * 64 + c2 + 8 * q) = res[q] + v;
           }
         }
@@ -347,7 +366,7 @@ __global__ __launch_bounds__(512, 1) void conv3_split_kernel(Conv3Params p) {
           const int c2 = 16 * chalf + 8 * q + 4 * half;          // registers 8 chalf + 4 q .. + 3  ->  channels 8 (2 chalf + q) + 4 half ..
           v4f v = (chalf ? other + mine : mine + other) + *reinterpret_cast<const v4f*>(kst + 64 + c2);
           if (p.act2 == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-          if (inside && !(NUHTC_CONV_PROBE_EPI & 1)) *reinterpret_cast<v4f*>(p.out2 + pix * 32 + c2) = v;
+          if (inside && !(NUHTC_CONV_PROBE_EPI & 1)) *reinterpret_cast<v4f*>(sg.out2 + pix * 32 + c2) = v;
         }
       }
     }
@@ -438,9 +457,10 @@ int launch_conv3_split(const GemmParams& g, hipStream_t s) {
   p.in = g.A; p.out = g.C; p.wsplit = reinterpret_cast<const char*>(g.Wsplit); p.bias = g.bias; p.nimg_dev = g.m_dev;
   p.nimg = g.M / (g.cH * g.cW); p.H = g.cH; p.W = g.cW; p.act = g.act;
   p.tiles_x = cdiv(g.cW, CV_TW); p.tiles_y = cdiv(g.cH, CV_TH);
-  const int ntile = p.nimg * p.tiles_x * p.tiles_y;
+  int ntile = p.nimg * p.tiles_x * p.tiles_y;
   if (ntile <= 0) return 0;
   int n2 = 0;
+  p.nseg = 1;
   if (const Conv3Fuse* f = g.fuse) {
     if ((f->N2 != 32 && f->N2 != 64) || !f->w2f || !f->out2 || (f->out3 && (!f->res2 || f->N2 != 64)) || (f->outn1 && !f->wn1) ||
         (f->act2 != ACT_NONE && f->act2 != ACT_RELU) || (f->store_out && !g.C))
@@ -448,6 +468,20 @@ int launch_conv3_split(const GemmParams& g, hipStream_t s) {
     n2 = f->N2;
     p.w2f = reinterpret_cast<const char*>(f->w2f); p.bias2 = f->bias2; p.out2 = f->out2; p.res2 = f->res2; p.out3 = f->out3;
     p.wn1 = f->wn1; p.bn1 = f->bn1; p.outn1 = f->outn1; p.act2 = f->act2; p.store_out = f->store_out;
+    if (f->n_more) {      // maps of other sizes through the same layers: one tile list, segment after segment
+      if (f->n_more < 0 || f->n_more > 3 || f->store_out || f->out3 || f->outn1 || g.m_dev) return NUHTC_E_INVALID;
+      p.nseg = 1 + f->n_more;
+      p.s_in[0] = p.in; p.s_out2[0] = p.out2; p.s_H[0] = p.H; p.s_W[0] = p.W; p.s_tx[0] = p.tiles_x; p.s_timg[0] = p.tiles_x * p.tiles_y; p.s_t0[0] = 0;
+      for (int k = 1; k <= 4; ++k) p.s_t0[k] = 0x7fffffff;
+      p.s_t0[1] = ntile;
+      for (int k = 1; k < p.nseg; ++k) {
+        if (!f->more_in[k - 1] || !f->more_out2[k - 1] || f->more_H[k - 1] <= 0 || f->more_W[k - 1] <= 0) return NUHTC_E_INVALID;
+        p.s_in[k] = f->more_in[k - 1]; p.s_out2[k] = f->more_out2[k - 1]; p.s_H[k] = f->more_H[k - 1]; p.s_W[k] = f->more_W[k - 1];
+        p.s_tx[k] = cdiv(p.s_W[k], CV_TW); p.s_timg[k] = p.s_tx[k] * cdiv(p.s_H[k], CV_TH);
+        p.s_t0[k + 1] = p.s_t0[k] + p.nimg * p.s_timg[k];
+      }
+      ntile = p.s_t0[p.nseg];
+    }
   }
   {
     const int rc = n2 == 64 ? conv3_raise_lds<64>() : n2 == 32 ? conv3_raise_lds<32>() : conv3_raise_lds<0>();

@@ -819,7 +819,17 @@ int run_neck_heads(nuhtc_engine* e, int B, hipStream_t s) {
   hipStream_t s2 = e->cfg.schedule == NUHTC_SCHED_THROUGHPUT ? s : e->side;
   if (s2 != s && (hipEventRecord(e->ev_fpn, s) != hipSuccess || hipStreamWaitEvent(s2, e->ev_fpn, 0) != hipSuccess))
     FAIL(e, NUHTC_E_HIP, "side-stream fork failed");
-  for (int i = 0; i < 4; ++i) {
+  // the RPN head shares its weights across the levels (rpn_head.py:62-68 runs forward_single per level with the same modules): the four
+  // maps go through ONE launch of the fused conv + cls/reg kernel -- the tiles of levels 1-3 (a third of level 0's) fill the tail of
+  // level 0's persistent grid instead of three launches of 32-512 tiles on 256 CUs (dev knob RPN_ONE_LAUNCH=0: one launch per level)
+  static const int& rpn_one = dev_knob_ref("RPN_ONE_LAUNCH", 1);
+  if (fuse && rpn_one) {
+    Conv3Fuse f = pointwise(32, e->rpn_hf, e->rpn_hb, e->rpn[0], ACT_NONE, 0);
+    f.n_more = 3;
+    for (int i = 1; i < 4; ++i) { f.more_in[i - 1] = e->x[i]; f.more_out2[i - 1] = e->rpn[i]; f.more_H[i - 1] = e->st[i].H; f.more_W[i - 1] = e->st[i].W; }
+    RUN(conv3x3(e, e->x[0], e->rpn_w, e->rpn_b, e->tmpR, B, e->st[0].H, e->st[0].W, ACT_RELU, nullptr, 1, s2, &f));
+  }
+  for (int i = 0; i < 4 && !(fuse && rpn_one); ++i) {
     const StageGeom& g = e->st[i];
     if (fuse) {
       const Conv3Fuse f = pointwise(32, e->rpn_hf, e->rpn_hb, e->rpn[i], ACT_NONE, 0);

@@ -955,11 +955,11 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
   const char* tag = "gemm";
   if (prof_enabled()) {   // per-shape tags, e.g. "gemm_kernel<3>|N288|K96" (strings live for the process lifetime)
     static std::map<long long, std::string> names;
-    long long key = ((long long)nt << 40) | ((long long)p.N << 20) | p.K | ((long long)(p.amode == A_CONV3) << 44) | ((long long)halo << 45) | ((long long)(p.fuse ? p.fuse->N2 / 32 : 0) << 46) |
+    long long key = ((long long)nt << 40) | ((long long)p.N << 20) | p.K | ((long long)(p.amode == A_CONV3) << 44) | ((long long)halo << 45) | ((long long)(p.fuse ? p.fuse->N2 / 32 : 0) << 46) | ((long long)(p.fuse ? p.fuse->n_more : 0) << 52) |
                     ((long long)(p.amode == A_LN) << 50) | ((long long)(p.stats_out != nullptr) << 51);
     auto it = names.find(key);
     if (it == names.end())
-      it = names.emplace(key, "gemm_kernel<" + std::to_string(nt) + ">|N" + std::to_string(p.N) + "|K" + std::to_string(p.K) + (p.amode == A_CONV3 ? (halo ? "|conv3halo" : "|conv3") : "") + (p.fuse ? "+pw" + std::to_string(p.fuse->N2) : "") +
+      it = names.emplace(key, "gemm_kernel<" + std::to_string(nt) + ">|N" + std::to_string(p.N) + "|K" + std::to_string(p.K) + (p.amode == A_CONV3 ? (halo ? "|conv3halo" : "|conv3") : "") + (p.fuse ? "+pw" + std::to_string(p.fuse->N2) + (p.fuse->n_more ? "x" + std::to_string(1 + p.fuse->n_more) + "maps" : "") : "") +
                                     (p.amode == A_LN ? "|ln" : "") + (p.stats_out ? "|stats" : "")).first;   // "|ln": LayerNorm in the A path; "|stats": LayerNorm partials in the epilogue
     tag = it->second.c_str();
   }
@@ -969,7 +969,12 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
   // a fused pointwise layer adds its own product and outputs, and takes away the convolution's output when that is not stored
   const double fuse_flop = p.fuse ? 2.0 * p.M * 64 * (p.fuse->N2 + (p.fuse->outn1 ? 1 : 0)) : 0.0;
   const double fuse_bytes = p.fuse ? 4.0 * p.M * (p.fuse->N2 * (p.fuse->out3 ? 3.0 : 1.0) + (p.fuse->outn1 ? 1 : 0) - (p.fuse->store_out ? 0 : p.N)) : 0.0;
-  ProfScope ps(tag, 2.0 * p.M * p.N * p.K * nb + fuse_flop, 4.0 * nb * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N + row_term) + fuse_bytes, s);
+  // further maps through the same fused layers (Conv3Fuse.n_more): their rows' convolution and pointwise work, map in and second output out
+  double more_rows = 0.0;
+  if (p.fuse && p.fuse->n_more > 0 && p.amode == A_CONV3)
+    for (int k = 0; k < p.fuse->n_more && k < 3; ++k) more_rows += (double)(p.M / (p.cH * p.cW)) * p.fuse->more_H[k] * p.fuse->more_W[k];
+  const double more_flop = p.fuse ? 2.0 * more_rows * 64 * (p.K + p.fuse->N2) : 0.0, more_bytes = p.fuse ? 4.0 * more_rows * (64 + p.fuse->N2) : 0.0;
+  ProfScope ps(tag, 2.0 * p.M * p.N * p.K * nb + fuse_flop + more_flop, 4.0 * nb * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N + row_term) + fuse_bytes + more_bytes, s);
   ps.device_rows(p.m_dev, p.m_mul, p.M);
 #ifdef NUHTC_GEMM_STAMPS
   static unsigned long long* stamp_buf = nullptr;

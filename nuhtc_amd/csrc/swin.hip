@@ -478,6 +478,14 @@ __global__ __launch_bounds__(256, 3) void window_attn_mfma_kernel(const float* _
   const float* base = qkv + (long long)win * WS2 * ld + head * HEAD_DIM;
   // additive score terms, packed for the lanes ([ti][q][lane][4], engine.hip pack_attn_terms): the q-th 16-byte load of a wave is 1 KB of contiguous memory.
   // Only the windows on the shifted image's last row / column of windows carry a non-zero shift mask.
+  // dev probes of round 6 (wrong results): 16 = K / Q / V taken as if they arrived already split by the QKV launch (their 44 of the 68 operand
+  // splits per pair replaced by bit moves; the 24 splits of the probabilities stay); 32 = half as many K / Q / V bytes again are loaded (three
+  // bf16 planes are 6 bytes per element against 4): 16 + 32 together = what a producer-split QKV image could give this kernel at most
+#if defined(NUHTC_ATTN_PROBE) && (NUHTC_ATTN_PROBE & 16)
+#define ATTN_SPLIT_IN(P_, d_, x_, y_) { (P_)[0][d_] = __float_as_uint(x_); (P_)[1][d_] = __float_as_uint(y_); (P_)[2][d_] = __float_as_uint(x_) ^ __float_as_uint(y_); }
+#else
+#define ATTN_SPLIT_IN(P_, d_, x_, y_) NUHTC_SPLIT3_INTO(P_, d_, x_, y_)
+#endif
   const float* bP = biasP + (long long)head * 4096 + (half * 32 + l32) * 4;                      // + ti * 2048
   const int wimg = win % nWperImg;
   const float* mP = (maskP && mask_any[wimg]) ? maskP + (long long)wimg * 4096 + (half * 32 + l32) * 4 : nullptr;
@@ -648,6 +656,22 @@ __global__ __launch_bounds__(256, 3) void window_attn_split_kernel(const float* 
 #endif
     }
   }
+#if defined(NUHTC_ATTN_PROBE) && (NUHTC_ATTN_PROBE & 32)    // dev probe: + 50 % K / Q / V bytes (the V third of the same rows, every other row group; folded into K so that it stays)
+  {
+    v4f ex[2][4];
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int j = min(tj * 32 + 8 * q + lr, WS2 - 1);
+        ex[tj][q] = *reinterpret_cast<const v4f*>(base + ATTN_ROW(j) + 2 * C + lc * 4);
+      }
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) kfa[tj][q] += ex[tj][q] * 1e-30f;
+  }
+#endif
   // raw_[q] (rows 8q + lr, chunk lc) -> out_[p] (row l32, chunk 4 half + p)
 #define ATTN_TO_OPERAND(raw_, out_)                                                                            \
   {                                                                                                            \
@@ -677,10 +701,10 @@ __global__ __launch_bounds__(256, 3) void window_attn_split_kernel(const float* 
     ATTN_TO_OPERAND(kfa[tj], kf)
 #pragma unroll
     for (int sk = 0; sk < 2; ++sk) {
-      NUHTC_SPLIT3_INTO(kp[tj][sk], 0, kf[2 * sk].x, kf[2 * sk].y)
-      NUHTC_SPLIT3_INTO(kp[tj][sk], 1, kf[2 * sk].z, kf[2 * sk].w)
-      NUHTC_SPLIT3_INTO(kp[tj][sk], 2, kf[2 * sk + 1].x, kf[2 * sk + 1].y)
-      NUHTC_SPLIT3_INTO(kp[tj][sk], 3, kf[2 * sk + 1].z, kf[2 * sk + 1].w)
+      ATTN_SPLIT_IN(kp[tj][sk], 0, kf[2 * sk].x, kf[2 * sk].y)
+      ATTN_SPLIT_IN(kp[tj][sk], 1, kf[2 * sk].z, kf[2 * sk].w)
+      ATTN_SPLIT_IN(kp[tj][sk], 2, kf[2 * sk + 1].x, kf[2 * sk + 1].y)
+      ATTN_SPLIT_IN(kp[tj][sk], 3, kf[2 * sk + 1].z, kf[2 * sk + 1].w)
     }
   }
   u32x4 vp[3][3];
@@ -711,10 +735,10 @@ __global__ __launch_bounds__(256, 3) void window_attn_split_kernel(const float* 
 #pragma unroll
     for (int sk = 0; sk < 2; ++sk) {
       const v4f a = qf[2 * sk] * scale, b = qf[2 * sk + 1] * scale;
-      NUHTC_SPLIT3_INTO(qpl[sk], 0, a.x, a.y)
-      NUHTC_SPLIT3_INTO(qpl[sk], 1, a.z, a.w)
-      NUHTC_SPLIT3_INTO(qpl[sk], 2, b.x, b.y)
-      NUHTC_SPLIT3_INTO(qpl[sk], 3, b.z, b.w)
+      ATTN_SPLIT_IN(qpl[sk], 0, a.x, a.y)
+      ATTN_SPLIT_IN(qpl[sk], 1, a.z, a.w)
+      ATTN_SPLIT_IN(qpl[sk], 2, b.x, b.y)
+      ATTN_SPLIT_IN(qpl[sk], 3, b.z, b.w)
     }
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj)
@@ -758,10 +782,10 @@ __global__ __launch_bounds__(256, 3) void window_attn_split_kernel(const float* 
     if (ti == 0) {
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
-        NUHTC_SPLIT3_INTO(vp[g], 0, vv[g][0], vv[g][1])
-        NUHTC_SPLIT3_INTO(vp[g], 1, vv[g][2], vv[g][3])
-        NUHTC_SPLIT3_INTO(vp[g], 2, vv[g][4], vv[g][5])
-        NUHTC_SPLIT3_INTO(vp[g], 3, vv[g][6], vv[g][7])
+        ATTN_SPLIT_IN(vp[g], 0, vv[g][0], vv[g][1])
+        ATTN_SPLIT_IN(vp[g], 1, vv[g][2], vv[g][3])
+        ATTN_SPLIT_IN(vp[g], 2, vv[g][4], vv[g][5])
+        ATTN_SPLIT_IN(vp[g], 3, vv[g][6], vv[g][7])
       }
     }
     // O^T[d][i] = sum_j V[j][d] P[i][j]: A = V planes (lane = d), B = the planes of the probability registers themselves
@@ -809,6 +833,7 @@ __global__ __launch_bounds__(256, 3) void window_attn_split_kernel(const float* 
 }
 #undef ATTN_TO_OPERAND
 #undef ATTN_ROW
+#undef ATTN_SPLIT_IN
 
 int launch_window_attn(const float* qkv, const float* biasP, const float* maskP, const int* mask_any, const int* out_map, float* out,
                        int nWinTotal, int nWperImg, int C, int nH, int split_pipe, hipStream_t s, const unsigned long long* padbits, int bias_row) {

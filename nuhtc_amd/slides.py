@@ -45,38 +45,40 @@ def default_parameters(preset=None, preset_dir='presets'):
     return seg, flt, vis, pat
 
 
+# the process list's columns after `slide_id`: (name, numpy dtype or None for "as given", which parameter dict, conversion) -- the schema
+# of tools/wsi_core/batch_process_utils.py:17-82 minus the heatmap / save_patches columns infer_wsi.py never asks for
+_PROCESS_COLUMNS = (
+    ('process', np.uint8, None, lambda _: 1), ('status', None, None, lambda _: 'tbp'),
+    ('seg_level', np.int8, 'seg', int), ('sthresh', np.uint8, 'seg', int), ('mthresh', np.uint8, 'seg', int), ('close', np.uint32, 'seg', int),
+    ('use_otsu', bool, 'seg', bool), ('keep_ids', None, 'seg', None), ('exclude_ids', None, 'seg', None),
+    ('a_t', np.float32, 'filter', int), ('a_h', np.float32, 'filter', int), ('max_n_holes', np.uint32, 'filter', int),
+    ('vis_level', np.int8, 'vis', int), ('line_thickness', np.uint32, 'vis', int),
+    ('use_padding', bool, 'patch', bool), ('contour_fn', None, 'patch', None))
+
+
 def initialize_df(slides, seg_params, filter_params, vis_params, patch_params):
-    """batch_process_utils.py:17-82 without the heatmap / save_patches columns infer_wsi.py never asks for: same columns, same
-    order, same dtypes (the CSV text is pinned to the reference's own function in tests/golden/process_list_autogen.csv)."""
+    """The process list (the reference's initialize_df): one row per slide, every column filled with the run's parameter -- same columns,
+    order and dtypes, so the CSV text equals the reference's (pinned in tests/golden/process_list_autogen.csv).  Given a DataFrame (a
+    user's --process_list) instead of a list of names, its own values win: only missing cells are filled, missing columns are appended."""
     import pandas as pd
-    total = len(slides)
-    slide_ids = slides.slide_id.values if isinstance(slides, pd.DataFrame) else slides
-    d = {'slide_id': slide_ids, 'process': np.full((total), 1, dtype=np.uint8),
-         'status': np.full((total), 'tbp'),
-         'seg_level': np.full((total), int(seg_params['seg_level']), dtype=np.int8),
-         'sthresh': np.full((total), int(seg_params['sthresh']), dtype=np.uint8),
-         'mthresh': np.full((total), int(seg_params['mthresh']), dtype=np.uint8),
-         'close': np.full((total), int(seg_params['close']), dtype=np.uint32),
-         'use_otsu': np.full((total), bool(seg_params['use_otsu']), dtype=bool),
-         'keep_ids': np.full((total), seg_params['keep_ids']),
-         'exclude_ids': np.full((total), seg_params['exclude_ids']),
-         'a_t': np.full((total), int(filter_params['a_t']), dtype=np.float32),
-         'a_h': np.full((total), int(filter_params['a_h']), dtype=np.float32),
-         'max_n_holes': np.full((total), int(filter_params['max_n_holes']), dtype=np.uint32),
-         'vis_level': np.full((total), int(vis_params['vis_level']), dtype=np.int8),
-         'line_thickness': np.full((total), int(vis_params['line_thickness']), dtype=np.uint32),
-         'use_padding': np.full((total), bool(patch_params['use_padding']), dtype=bool),
-         'contour_fn': np.full((total), patch_params['contour_fn'])}
-    if isinstance(slides, pd.DataFrame):
-        temp = pd.DataFrame(d)
-        for key in d:
-            if key in slides.columns:
-                mask = slides[key].isna()
-                slides.loc[mask, key] = temp.loc[mask, key]
-            else:
-                slides.insert(len(slides.columns), key, d[key])
-        return slides
-    return pd.DataFrame(d)
+    params = dict(seg=seg_params, filter=filter_params, vis=vis_params, patch=patch_params)
+    given = slides if isinstance(slides, pd.DataFrame) else None
+    ids = given.slide_id.values if given is not None else slides
+    n = len(ids)
+    cols = {'slide_id': ids}
+    for name, dtype, group, conv in _PROCESS_COLUMNS:
+        v = params[group][name] if group else None
+        v = conv(v) if conv else v
+        cols[name] = np.full(n, v) if dtype is None else np.full(n, v, dtype=dtype)
+    defaults = pd.DataFrame(cols)
+    if given is None:
+        return defaults
+    for name in cols:
+        if name not in given.columns:
+            given[name] = cols[name]                         # appended after the user's columns, in schema order
+        else:
+            given[name] = given[name].where(given[name].notna(), defaults[name])
+    return given
 
 
 def coords_path(patch_save_dir, slide_id):

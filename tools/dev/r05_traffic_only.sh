@@ -1,6 +1,6 @@
 # dev: the two PMC passes (FETCH_SIZE / WRITE_SIZE) of round5_all.sh alone -> gpurun_out/round5/r05_traffic.json + r05_hbm_per_kernel.txt
 R=r05; OUT=$GRAFT_REPO_ROOT/gpurun_out/round5; mkdir -p $OUT; cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/hf /tmp/hw
-P="--steps 3 --warmup 1 --no-cpu-baseline --no-roi-load --no-settle --no-fp32-pipe --in-flight 0"
+P="--steps 3 --warmup 1 --no-cpu-baseline --no-roi-load --no-settle --no-fp32-pipe --in-flight 0 --no-force-collective"
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/hf -- python3 $GRAFT_REPO_ROOT/bench.py $P > /dev/null 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/hw -- python3 $GRAFT_REPO_ROOT/bench.py $P > /dev/null 2>&1
 python3 $GRAFT_REPO_ROOT/tools/dev/pmc_traffic.py '/tmp/h[fw]/**/*counter_collection.csv' 'gemm_split_kernel<[12], 3, [02]>' $GRAFT_REPO_ROOT/nuhtc_amd/csrc/gemm.hip > $OUT/${R}_traffic.json; cat $OUT/${R}_traffic.json
