@@ -623,6 +623,29 @@ def test_eight_ranks_end_to_end_on_one_device(hip_device, tmp_path):
     assert abs(d['value'] - 8 * 2 * 2 / (d['ms_per_step'] * 2e-3)) < 1e-6 * d['value']
 
 
+def test_bench_wsi_reads_an_svs_file_on_every_rank(hip_device):
+    """tools/bench_wsi.py --svs with more than one rank: rank 0 writes the Aperio-layout file, the other rank waits for it on a marker file
+    (before the process group exists) and every rank decodes only the tiles of its own shard through libtiff -- the way the ranks of
+    tools/infer_wsi.py open a real slide.  Two ranks on the one device, gloo; the line reports both ranks' detections and the documents."""
+    import json
+    import subprocess
+    import sys
+    from nuhtc_amd import tiffslide
+    if not tiffslide.available():
+        pytest.skip('libtiff not found')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                          '--master-port', str(_free_port()), os.path.join(ROOT, 'tools/bench_wsi.py'), '--grid', '6', '--svs', 'lzw', '--batch_size', '4',
+                          '--depth', '2', '--workers', '2'], env=_two_rank_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
+    print(out.stderr[-2500:])
+    assert out.returncode == 0
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['tiles'] == 36 and d['detections_after_tile_nms'] > 50 and 0 < d['detections_after_merge'] <= d['detections_after_tile_nms']
+    assert 'libtiff' in d['tile_source'] and d['tiles_per_s_to_documents'] > 0 and set(d['document_bytes']) == {'slide.geojson', 'slide_point.geojson', 'slide_merged.geojson'}
+    assert not [f for f in os.listdir('/tmp') if f.startswith('.host_phase_done.')]
+
+
 def test_rccl_branch_of_the_exchange_on_one_gpu(hip_device):
     """The nccl (= RCCL) branch of `gather_blobs` on the hardware at hand: NUHTC_FORCE_COLLECTIVE=1 forms a communicator of one rank on
     the MI355X and both all_gathers run on DEVICE buffers; what comes back is byte-equal to the short-circuit path (the script of
