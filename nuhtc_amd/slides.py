@@ -151,17 +151,34 @@ def _level_of(downsample):
     return lvl
 
 
+def is_pyramid(slide):
+    """A slide with real pyramid levels (nuhtc_amd.tiffslide.TiffSlide): levels are then the FILE's levels, as in the reference; an array
+    slide has the virtual dyadic pyramid slide[::2**k, ::2**k]."""
+    return hasattr(slide, 'level_dimensions') and hasattr(slide, 'level_image')
+
+
+def level_downsample(slide, level):
+    """(x, y) downsample of a pyramid level the way `_assertLevelDownsamples` (WholeSlideImage.py:378-386) states it."""
+    w0, h0 = slide.level_dimensions[0]
+    w, h = slide.level_dimensions[level]
+    return (w0 / float(w), h0 / float(h))
+
+
 def vis_mask(slide, contours, holes, level, line_thickness=250, color=(0, 255, 0), hole_color=(0, 0, 255)):
     """`visWSI` (WholeSlideImage.py:201-256): the level image with the tissue contours (green) and their holes (blue) outlined;
     outline width int(line_thickness * sqrt(scale_x * scale_y)) like :221."""
     from PIL import Image, ImageDraw
-    ds = 2 ** int(level)
-    img = Image.fromarray(np.ascontiguousarray(np.asarray(slide[::ds, ::ds, :3])))
-    width = max(1, int(line_thickness * math.sqrt((1 / ds) * (1 / ds))))
+    if is_pyramid(slide):
+        dx, dy = level_downsample(slide, int(level))
+        img = Image.fromarray(np.ascontiguousarray(np.asarray(slide.level_image(int(level)))[:, :, :3]))
+    else:
+        dx = dy = 2 ** int(level)
+        img = Image.fromarray(np.ascontiguousarray(np.asarray(slide[::dx, ::dy, :3])))
+    width = max(1, int(line_thickness * math.sqrt((1 / dx) * (1 / dy))))
     dr = ImageDraw.Draw(img)
 
     def outline(c, col):
-        pts = [(int(x * (1 / ds)), int(y * (1 / ds))) for x, y in np.asarray(c).reshape(-1, 2)]      # scaleContourDim: astype(int32)
+        pts = [(int(x * (1 / dx)), int(y * (1 / dy))) for x, y in np.asarray(c).reshape(-1, 2)]      # scaleContourDim: astype(int32)
         if len(pts) > 1:
             dr.line(pts + pts[:1], fill=col, width=width)
         elif pts:
@@ -178,15 +195,19 @@ def stitch_coords(slide, coords, patch_size, downscale=64, bg_color=(0, 0, 0)):
     """`StitchCoords` + `DrawMapFromCoords` (wsi_utils.py:259-293,200-225): the tiles of the coordinate file pasted, down-scaled,
     onto a black canvas of the level nearest `downscale`."""
     from PIL import Image
-    lvl = _level_of(downscale)
-    ds = 2 ** lvl
-    lv = np.asarray(slide[::ds, ::ds, :3])
+    if is_pyramid(slide):                                                 # the file's level nearest `downscale` (wsi_utils.py:261)
+        lvl = slide.get_best_level_for_downsample(downscale)
+        dsx, dsy = level_downsample(slide, lvl)
+        lv = np.asarray(slide.level_image(lvl))[:, :, :3]
+    else:
+        dsx = dsy = 2 ** _level_of(downscale)
+        lv = np.asarray(slide[::dsy, ::dsx, :3])
     h, w = lv.shape[:2]
     canvas = np.zeros((h, w, 3), np.uint8)
     canvas[:] = bg_color
-    ps = int(math.ceil(patch_size / ds))
+    ps = int(math.ceil(patch_size / dsx))
     for x, y in np.asarray(coords, np.int64).reshape(-1, 2):
-        cx, cy = int(math.ceil(x / ds)), int(math.ceil(y / ds))
+        cx, cy = int(math.ceil(x / dsx)), int(math.ceil(y / dsy))
         sub = lv[cy:cy + ps, cx:cx + ps]                                  # read_region(coord, vis_level, patch_size)
         canvas[cy:cy + sub.shape[0], cx:cx + sub.shape[1]] = sub
     return Image.fromarray(canvas)
@@ -243,13 +264,27 @@ def seg_and_patch(source, save_dir, patch_save_dir, mask_save_dir, stitch_save_d
         cur_filter = {k: (filter_params if use_default_params else df.loc[idx])[k] for k in filter_params}
         cur_seg = {k: (seg_params if use_default_params else df.loc[idx])[k] for k in seg_params}
         cur_patch = {k: (patch_params if use_default_params else df.loc[idx])[k] for k in patch_params}
+        # level -1 = "the level nearest 64x" (tools/infer_wsi.py:213-229): on a pyramid file the FILE's level from
+        # get_best_level_for_downsample (level 0 for a single-level file), whatever its true downsample is -- a typical Aperio pyramid
+        # (1 / 4 / 16 / 32) segments at 32x; on an array slide the virtual dyadic level of exactly `seg_downsample`
+        pyr = is_pyramid(img)
+        if pyr:
+            best = 0 if len(img.level_dimensions) == 1 else img.get_best_level_for_downsample(seg_downsample)
         if cur_vis['vis_level'] < 0:
-            cur_vis['vis_level'] = auto_level
+            cur_vis['vis_level'] = best if pyr else auto_level
         if cur_seg['seg_level'] < 0:
-            cur_seg['seg_level'] = auto_level
+            cur_seg['seg_level'] = best if pyr else auto_level
         keep_ids, exclude_ids = _ids(cur_seg['keep_ids']), _ids(cur_seg['exclude_ids'])
-        sds = 2 ** int(cur_seg['seg_level'])
-        w, h = -(-W // sds), -(-H // sds)
+        if pyr:
+            if not 0 <= int(cur_seg['seg_level']) < len(img.level_dimensions) or not 0 <= int(cur_vis['vis_level']) < len(img.level_dimensions):
+                log('{}: seg_level / vis_level outside the {} level(s) of the file, aborting'.format(slide_id, len(img.level_dimensions)))
+                df.loc[idx, 'status'] = 'failed_seg'
+                continue
+            w, h = img.level_dimensions[int(cur_seg['seg_level'])]
+            sds = level_downsample(img, int(cur_seg['seg_level']))
+        else:
+            sds = 2 ** int(cur_seg['seg_level'])
+            w, h = -(-W // sds), -(-H // sds)
         if w * h > 1e8:
             log('level_dim {} x {} is likely too large for successful segmentation, aborting'.format(w, h))
             df.loc[idx, 'status'] = 'failed_seg'
@@ -260,7 +295,8 @@ def seg_and_patch(source, save_dir, patch_save_dir, mask_save_dir, stitch_save_d
         seg_time = -1
         if seg:
             t0 = time.time()
-            conts, holes = tissue.segment_tissue(img, scale=sds, sthresh=int(cur_seg['sthresh']), mthresh=int(cur_seg['mthresh']),
+            conts, holes = tissue.segment_tissue(img, scale=sds, level_image=img.level_image(int(cur_seg['seg_level'])) if pyr else None,
+                                                 sthresh=int(cur_seg['sthresh']), mthresh=int(cur_seg['mthresh']),
                                                  close=int(cur_seg['close']), use_otsu=bool(cur_seg['use_otsu']),
                                                  filter_params=dict(a_t=cur_filter['a_t'], a_h=cur_filter['a_h'], max_n_holes=int(cur_filter['max_n_holes'])),
                                                  keep_ids=keep_ids, exclude_ids=exclude_ids)

@@ -210,20 +210,30 @@ def _trace_all(mask):
 
 # ----------------------------------------------------------------------------- segmentTissue
 def segment_tissue(image, scale=64, sthresh=8, sthresh_up=255, mthresh=7, close=4, use_otsu=False, filter_params=None,
-                   ref_patch_size=512, exclude_ids=(), keep_ids=()):
+                   ref_patch_size=512, exclude_ids=(), keep_ids=(), level_image=None):
     """`WholeSlideImage.segmentTissue` on an RGB array.  `scale`: downsample factor of the segmentation level (the reference
     picks the pyramid level closest to 64x).  Returns (contours_tissue, holes_tissue) in level-0 pixels: lists of (n,2) int32
-    contours and, per contour, a list of hole contours."""
+    contours and, per contour, a list of hole contours.
+    `level_image`: the segmentation level of a pyramid slide as the reference reads it (`read_region((0, 0), seg_level, level_dim)`, :159);
+    `scale` is then that level's (x, y) downsample pair (`_assertLevelDownsamples`, :378-386): the area thresholds use scale[0] (:176) and
+    the contours go back to level 0 by `cont * scale` truncated to int32 (`scaleContourDim`, :371)."""
     fp = dict(FILTER_PARAMS if filter_params is None else filter_params)
-    scale = int(scale)
-    img = np.asarray(image[::scale, ::scale])          # (sliced first: a TIFF slide serves this from its pyramid, nuhtc_amd.tiffslide)
+    if level_image is not None:
+        scale = np.asarray(scale, np.float64).reshape(-1)
+        scale = np.array([scale[0], scale[-1]])
+        img = np.asarray(level_image)[:, :, :3]
+        ref_scale = float(scale[0])
+    else:
+        scale = int(scale)
+        img = np.asarray(image[::scale, ::scale])          # (sliced first: a TIFF slide serves this from its pyramid, nuhtc_amd.tiffslide)
+        ref_scale = scale
     sat = saturation_u8(img)
     med = median_blur(sat, mthresh)
     thr = otsu_threshold(med) if use_otsu else sthresh
     binary = np.where(med > thr, np.uint8(min(sthresh_up, 255)), np.uint8(0))
     if close > 0:
         binary = morph_close(binary, close)
-    scaled_ref = round(ref_patch_size / scale)
+    scaled_ref = round(ref_patch_size / ref_scale)
     a_t, a_h = fp['a_t'] * scaled_ref, fp['a_h'] * scaled_ref
     fore, holes = [], []
     for cont, hs in find_contours_ccomp(binary):

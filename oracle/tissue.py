@@ -19,9 +19,17 @@ from . import contour as OC
 from . import cv_ops as C
 
 
-def segment_tissue(img, scale, sthresh=8, sthresh_up=255, mthresh=7, close=4, use_otsu=False, a_t=100, a_h=16, max_n_holes=8, ref_patch_size=512):
-    """-> [(outer contour, [hole contours])] in level-0 pixels ((n, 2) int arrays)."""
-    lvl = np.asarray(img)[::scale, ::scale]                     # the pyramid level `read_region` would return (:161)
+def segment_tissue(img, scale, sthresh=8, sthresh_up=255, mthresh=7, close=4, use_otsu=False, a_t=100, a_h=16, max_n_holes=8, ref_patch_size=512,
+                   level_scale=None):
+    """-> [(outer contour, [hole contours])] in level-0 pixels ((n, 2) int arrays).
+    level_scale: `img` IS the segmentation level of a pyramid file (`read_region((0, 0), seg_level, level_dim[seg_level])`, :159) and
+    level_scale its (x, y) downsample pair from `_assertLevelDownsamples` (:378-386): thresholds from level_scale[0] (:176), contours back to
+    level 0 by `np.array(cont * scale, dtype='int32')` (`scaleContourDim`, :371)."""
+    if level_scale is not None:
+        lvl = np.asarray(img)
+        scale = float(level_scale[0])
+    else:
+        lvl = np.asarray(img)[::scale, ::scale]                 # the pyramid level `read_region` would return (:161)
     sat = C.saturation_u8(lvl.tolist())                         # img_hsv[:, :, 1] (:162)
     med = C.median_blur(sat, mthresh)                           # :163
     thr = C.otsu_threshold(med) if use_otsu else sthresh        # :166-169 (THRESH_BINARY: v > thr -> maxval)
@@ -46,6 +54,10 @@ def segment_tissue(img, scale, sthresh=8, sthresh_up=255, mthresh=7, close=4, us
     for cont_idx, hole_ids in zip(filtered, all_holes):                             # :136-152
         hs = sorted([conts[j] for j in hole_ids], key=area, reverse=True)[:max_n_holes]     # stable: equal areas keep list order
         hs = [h for h in hs if area(h) > a_h]
+        if level_scale is not None:
+            up = lambda c: np.array(np.asarray(c, np.int64) * np.asarray(level_scale, np.float64), dtype='int32').astype(np.int64)
+            out.append((up(conts[cont_idx]), [up(h) for h in hs]))
+            continue
         out.append((np.asarray(conts[cont_idx], np.int64) * scale, [np.asarray(h, np.int64) * scale for h in hs]))   # scaleContourDim
     return out
 

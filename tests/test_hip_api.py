@@ -316,7 +316,7 @@ def test_readme_command_line_verbatim_on_svs_slides(hip_device, tmp_path):
     line = f'{src} {CFG} {ck} --patch --seg --stitch --patch_size 256 --step_size 192 --batch_size 16 --save_dir {out} --mode qupath'
     log = subprocess.run([sys.executable, tool] + line.split(), check=True, capture_output=True, text=True).stdout
     rows = open(out / 'process_list_autogen.csv').read().splitlines()
-    assert rows[1].startswith('TCGA-01.svs,0,processed,6,')
+    assert rows[1].startswith('TCGA-01.svs,0,processed,3,')          # seg_level -1 -> the FILE's level nearest 64x: level 3 (8x) of this 1 / 2 / 4 / 8 pyramid
     for f in (out / 'masks' / 'TCGA-01.png', out / 'patches' / 'TCGA-01.npz', out / 'stitches' / 'TCGA-01.jpg', out / 'nuclei' / 'TCGA-01' / 'TCGA-01_point.geojson'):
         assert os.path.exists(f), f
     doc = open(out / 'nuclei' / 'TCGA-01' / 'TCGA-01.geojson', 'rb').read()

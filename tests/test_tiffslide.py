@@ -172,3 +172,38 @@ def test_folder_of_svs_slides_through_seg_and_patch_and_the_tile_bag(tmp_path):
         assert np.array_equal(t, want)
     assert np.array_equal(tiles[-1][:64, :64], img[1472:, 1984:]) and not tiles[-1][64:].any() and not tiles[-1][:, 64:].any()
     assert bag.reads == len(bag)
+
+
+def test_pyramid_without_a_64x_level_is_segmented_on_its_own_level(tmp_path):
+    """`seg_level = -1` on a pyramid FILE means the file's level from `get_best_level_for_downsample(64)` (tools/infer_wsi.py:222-229), whatever
+    its true downsample: a 1 / 2 / 4 pyramid (a typical Aperio file is 1 / 4 / 16 / 32) is segmented on its 4x level, read whole
+    (WholeSlideImage.py:159), thresholds and contour scaling from that level's own (non-integer) downsample pair (:176-191, :371-386) -- not on
+    a virtual 64x image.  The tile list of the `.svs` equals, as one sequence, what the oracle's restatement of the reference gives for that
+    level image; the process list records the level."""
+    from nuhtc_amd import slides
+    from oracle import tissue as OT
+    from test_tissue import tissue_slide_with_holes
+    img = np.ascontiguousarray(tissue_slide_with_holes(H=1024, W=1280)[0][:770, :1030])      # odd level sizes: non-integer downsample pairs
+    src = tmp_path / 'wsi'
+    os.makedirs(src)
+    pyr = T.write_pyramid(str(src / 'a.svs'), img, levels=3, tile=240, compression='lzw', description=DESC)
+    assert [p.shape[:2] for p in pyr] == [(770, 1030), (385, 515), (192, 257)]
+    out = tmp_path / 'out'
+    dirs = dict(source=str(src), save_dir=str(out), patch_save_dir=str(out / 'patches'), mask_save_dir=str(out / 'masks'), stitch_save_dir=str(out / 'stitches'))
+    for k, v in dirs.items():
+        if k != 'source':
+            os.makedirs(v)
+    seg, flt, vis, pat = slides.default_parameters()
+    flt = dict(flt, a_t=1, a_h=1)                       # (the default area thresholds are sized for 64x levels of real slides)
+    slides.seg_and_patch(**dirs, seg_params=seg, filter_params=flt, vis_params=vis, patch_params=pat, patch_size=64, step_size=64, seg=True, patch=True,
+                         stitch=True, slides=['a.svs'], log=lambda *a: None)
+    row = open(out / 'process_list_autogen.csv').read().splitlines()[1].split(',')
+    assert row[:4] == ['a.svs', '0', 'processed', '2']                  # seg_level = the file's level 2
+    got, ps, _ = slides.load_coords(str(out / 'patches'), 'a')
+    scale = (1030 / 257.0, 770 / 192.0)
+    want = []
+    for c, hs in OT.segment_tissue(pyr[2], 1, a_t=1, a_h=1, level_scale=scale):
+        want += OT.contour_tile_coords(c, hs, 64, 64)
+    assert ps == 64 and len(want) > 30 and np.array_equal(got, np.asarray(want, np.int64).reshape(-1, 2))
+    from PIL import Image
+    assert Image.open(out / 'masks' / 'a.png').size == (257, 192) and Image.open(out / 'stitches' / 'a.jpg').size == (257, 192)
