@@ -332,6 +332,17 @@ int64_t nuhtc_write_point_features(const double* xy, const int32_t* label, const
 int64_t nuhtc_join_features(const char* text, const int64_t* feat_start, const int64_t* pick, int64_t n_pick, char* out, int64_t cap,
                             int32_t threads);
 
+/* Rings of a written GeoJSON back into mask crops (v10; tools/nuclei_merge.py on the GPU).  A ring tools/infer_wsi.py writes is the traced outer
+ * border of one 8-connected pixel component (`cv2.findContours(...)[0][0]`, :51-58): vertices on pixel centres, edges along the 8 chain directions.
+ * The pixels inside or on it are that component with its holes filled -- what nuhtc_merge_overlap derives from a detection's mask crop before it
+ * measures polygons -- so the filled rings are a valid input of nuhtc_merge_overlap.  verts: int32 pairs, ring i = verts[ring_off[i] .. ring_off[i+1])
+ * WITHOUT the repeated closing vertex.  Fills boxes[n][4] (x0, y0, x1, y1 exclusive), areas[n] (set pixels), word_off[n] and the bit-packed crops
+ * (rows of (w + 31) / 32 words, pixel x in bit x & 31 of word x >> 5).  Returns the number of words; with `bits` NULL or `cap_words` too small only
+ * boxes and word_off are filled and the needed size is returned.  NUHTC_E_INVALID: an empty ring, an edge that is not horizontal, vertical or diagonal
+ * (not a traced ring: use the polygon path of the host), a ring wider or taller than 65535 pixels.  Host memory, any thread. */
+int64_t nuhtc_fill_rings(const int32_t* verts, const int64_t* ring_off, int64_t n, int32_t* boxes, int32_t* areas, int64_t* word_off,
+                         uint32_t* bits, int64_t cap_words, int32_t threads);
+
 /* Per-kernel timing with HIP events recorded on the launch stream (process-wide switch; off by default).
  * nuhtc_profile_read synchronises the device and writes one text line per kernel tag,
  * "tag launches total_ms algorithmic_flops algorithmic_bytes", then resets the records. */

@@ -349,6 +349,72 @@ def concat_feature_texts(texts, starts=None):
     return body, np.concatenate(st + [np.array([total + 2], np.int64)])
 
 
+def fill_rings(rings, threads=0):
+    """Closed traced rings (integer vertices on pixel centres, edges along the 8 chain directions; the repeated closing vertex is dropped
+    here) -> the mask crops nuhtc_merge_overlap takes: (boxes int32 (n,4) x1 / y1 exclusive, areas int32 (n,), bits uint32, off int64 (n,)).
+    The pixels inside or on such a ring are the traced component with its holes filled (nuhtc_fill_rings).  None when a ring is not a
+    traced ring (an edge off the chain directions, non-integer coordinates, fewer than one vertex)."""
+    import ctypes
+    from . import hip
+    n = len(rings)
+    if n == 0:
+        return np.zeros((0, 4), np.int32), np.zeros(0, np.int32), np.zeros(1, np.uint32), np.zeros(0, np.int64)
+    parts, lens = [], np.zeros(n, np.int64)
+    for i, r in enumerate(rings):
+        r = np.asarray(r)
+        if r.ndim != 2 or r.shape[1] != 2 or len(r) == 0:
+            return None
+        if r.dtype.kind == 'f':
+            ri = np.rint(r)
+            if not np.array_equal(ri, r):
+                return None
+            r = ri
+        if len(r) > 1 and (r[0] == r[-1]).all():
+            r = r[:-1]
+        parts.append(r.astype(np.int32))
+        lens[i] = len(r)
+    verts = np.ascontiguousarray(np.concatenate(parts, 0))
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    boxes, areas, woff = np.zeros((n, 4), np.int32), np.zeros(n, np.int32), np.zeros(n, np.int64)
+    vp = lambda a: ctypes.c_void_p(a.ctypes.data)
+    lib = hip.load()
+    need = lib.nuhtc_fill_rings(vp(verts), vp(off), n, vp(boxes), vp(areas), vp(woff), None, 0, int(threads))
+    if need < 0:
+        return None
+    bits = np.zeros(max(int(need), 1), np.uint32)
+    if lib.nuhtc_fill_rings(vp(verts), vp(off), n, vp(boxes), vp(areas), vp(woff), vp(bits), int(need), int(threads)) < 0:
+        return None
+    return boxes, areas, bits, woff
+
+
+def merge_features_device(features, overlap_threshold=0.01, device=0):
+    """merge_features(..., 'probability') on the GPU for a file of TRACED rings (what tools/infer_wsi.py writes): the rings are filled back
+    into mask crops (fill_rings) and nuhtc_merge_overlap measures the reference's polygon IoU on them exactly (csrc/merge.hip) -- the same
+    kept features and nuclei_ids as the host path, ~1 ms per feature faster.  None when the file holds anything else (the caller then
+    takes the host path)."""
+    from . import wsi
+    n = len(features)
+    order = sorted(range(n), key=lambda i: -features[i]['properties'].get('score', 0))
+    try:
+        rings = [np.asarray(features[i]['geometry']['coordinates'][0]) for i in order]
+    except (KeyError, IndexError, TypeError, ValueError):
+        return None
+    if any(r.ndim != 2 or len(r) < 2 for r in rings):
+        return None
+    crops = fill_rings(rings)
+    if crops is None:
+        return None
+    scores = np.array([features[i]['properties'].get('score', 0) for i in order], np.float64)
+    kept = wsi.merge_overlap_packed(crops[0], scores, crops[1], crops[2], crops[3], overlap_threshold, device, 'polygon')
+    out = []
+    for k in kept.tolist():
+        src = features[order[k]]
+        f = dict(src)
+        f['properties'] = dict(src['properties'], nuclei_id=k)
+        out.append(f)
+    return out
+
+
 def merge_features(features, overlap_threshold=0.01, merge_strategy='probability'):
     """tools/nuclei_merge.py:62-174 on a list of GeoJSON features: sort by properties.score (descending, stable), greedy
     suppression of every not-yet-visited feature whose polygon IoU with the query exceeds the threshold; 'probability'

@@ -178,3 +178,76 @@ extern "C" int64_t nuhtc_join_features(const char* text, const int64_t* feat_sta
   });
   return total;
 }
+
+// ---- rings of a written GeoJSON back into mask crops (tools/nuclei_merge.py on the GPU).  A ring infer_wsi.py writes is the traced outer border of
+// one 8-connected pixel component (cv2.findContours(...)[0][0], tools/infer_wsi.py:51-58): vertices on pixel centres, edges along the 8 chain
+// directions.  The pixels inside or on it are that component with its holes filled -- exactly the set nuhtc_merge_overlap derives from a
+// detection's mask crop before it measures polygons (csrc/merge.hip) -- so filling the ring gives the merge the input the masks would have given.
+// Fill: the border is drawn (integer steps along every edge), the outside is flooded from a one-pixel frame through 4-neighbours (an 8-connected
+// border cannot be crossed that way), everything not outside is the component.
+extern "C" int64_t nuhtc_fill_rings(const int32_t* verts, const int64_t* ring_off, int64_t n, int32_t* boxes, int32_t* areas, int64_t* word_off,
+                                    uint32_t* bits, int64_t cap_words, int32_t threads) {
+  if (n < 0) return NUHTC_E_INVALID;
+  if (n == 0) return 0;
+  if (!verts || !ring_off || !boxes || !areas || !word_off) return NUHTC_E_INVALID;
+  int64_t total = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t a = ring_off[i], b = ring_off[i + 1];
+    if (b <= a) return NUHTC_E_INVALID;
+    int32_t x0 = verts[2 * a], x1 = x0, y0 = verts[2 * a + 1], y1 = y0;
+    for (int64_t v = a; v < b; ++v) {
+      const int32_t x = verts[2 * v], y = verts[2 * v + 1];
+      x0 = x < x0 ? x : x0; x1 = x > x1 ? x : x1; y0 = y < y0 ? y : y0; y1 = y > y1 ? y : y1;
+      const int64_t nx = v + 1 < b ? v + 1 : a;
+      const int64_t dx = (int64_t)verts[2 * nx] - x, dy = (int64_t)verts[2 * nx + 1] - y;
+      if (dx != 0 && dy != 0 && (dx < 0 ? -dx : dx) != (dy < 0 ? -dy : dy)) return NUHTC_E_INVALID;      // not a chain-direction edge: not a traced ring
+    }
+    if ((int64_t)x1 - x0 > 65535 || (int64_t)y1 - y0 > 65535) return NUHTC_E_INVALID;
+    boxes[4 * i] = x0; boxes[4 * i + 1] = y0; boxes[4 * i + 2] = x1 + 1; boxes[4 * i + 3] = y1 + 1;
+    word_off[i] = total;
+    total += (int64_t)(y1 - y0 + 1) * ((x1 - x0 + 1 + 31) / 32);
+  }
+  if (!bits || cap_words < total) return total;
+  parallel_for(n, threads, [&](int64_t lo, int64_t hi) {
+    std::vector<uint8_t> g;
+    std::vector<int32_t> stack;
+    for (int64_t i = lo; i < hi; ++i) {
+      const int32_t x0 = boxes[4 * i], y0 = boxes[4 * i + 1];
+      const int w = boxes[4 * i + 2] - x0, h = boxes[4 * i + 3] - y0, W = w + 2, H = h + 2;
+      g.assign((size_t)W * H, 0);
+      const int64_t a = ring_off[i], b = ring_off[i + 1];
+      for (int64_t v = a; v < b; ++v) {                        // the border, edge by edge (both end points included)
+        const int64_t nx = v + 1 < b ? v + 1 : a;
+        int x = verts[2 * v] - x0 + 1, y = verts[2 * v + 1] - y0 + 1;
+        const int ex = verts[2 * nx] - x0 + 1, ey = verts[2 * nx + 1] - y0 + 1;
+        const int sx = (ex > x) - (ex < x), sy = (ey > y) - (ey < y);
+        g[(size_t)y * W + x] = 1;
+        while (x != ex || y != ey) { x += sx; y += sy; g[(size_t)y * W + x] = 1; }
+      }
+      stack.clear();
+      stack.push_back(0);
+      g[0] = 2;
+      while (!stack.empty()) {                                  // the outside, from the frame, through 4-neighbours
+        const int p = stack.back();
+        stack.pop_back();
+        const int px = p % W, py = p / W;
+        if (px > 0 && !g[p - 1]) { g[p - 1] = 2; stack.push_back(p - 1); }
+        if (px + 1 < W && !g[p + 1]) { g[p + 1] = 2; stack.push_back(p + 1); }
+        if (py > 0 && !g[p - W]) { g[p - W] = 2; stack.push_back(p - W); }
+        if (py + 1 < H && !g[p + W]) { g[p + W] = 2; stack.push_back(p + W); }
+      }
+      const int wpr = (w + 31) / 32;
+      uint32_t* dst = bits + word_off[i];
+      int32_t area = 0;
+      for (int y = 0; y < h; ++y)
+        for (int k = 0; k < wpr; ++k) {
+          uint32_t word = 0;
+          for (int t = 0; t < 32 && 32 * k + t < w; ++t)
+            if (g[(size_t)(y + 1) * W + 32 * k + t + 1] != 2) { word |= 1u << t; ++area; }
+          dst[(size_t)y * wpr + k] = word;
+        }
+      areas[i] = area;
+    }
+  });
+  return total;
+}

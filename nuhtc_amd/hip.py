@@ -42,7 +42,7 @@ EXPORTS = ['nuhtc_default_config', 'nuhtc_create', 'nuhtc_destroy', 'nuhtc_last_
            'nuhtc_op_gemm', 'nuhtc_op_gemm_split', 'nuhtc_op_roi_align', 'nuhtc_op_nms', 'nuhtc_profile_enable', 'nuhtc_profile_read', 'nuhtc_dev_knob', 'nuhtc_export_crops',
            'nuhtc_mask_contours', 'nuhtc_merge_overlap', 'nuhtc_export_kept', 'nuhtc_clock_probe', 'nuhtc_op_swin_mlp', 'nuhtc_stream', 'nuhtc_op_swin_proj_mlp', 'nuhtc_bind_host_thread',
            'nuhtc_bind_host_thread_pci', 'nuhtc_bind_host_thread_at', 'nuhtc_restore_host_thread', 'nuhtc_op_ln_gemm', 'nuhtc_op_gemm_ln_gemm', 'nuhtc_op_merge_ln_gemm', 'nuhtc_write_ring_features',
-           'nuhtc_write_point_features', 'nuhtc_join_features']
+           'nuhtc_write_point_features', 'nuhtc_join_features', 'nuhtc_fill_rings']
 
 _lib = None
 
@@ -100,6 +100,7 @@ def load():
     lib.nuhtc_write_ring_features.argtypes = [vp, vp, vp, vp, ctypes.c_int64, ctypes.c_char_p, pcp, pcp, ctypes.c_int32, vp, ctypes.c_int64, vp, ctypes.c_int32]
     lib.nuhtc_write_point_features.argtypes = [vp, vp, vp, ctypes.c_int64, ctypes.c_char_p, pcp, pcp, ctypes.c_int32, vp, ctypes.c_int64]
     lib.nuhtc_join_features.argtypes = [vp, vp, vp, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int32]
+    lib.nuhtc_fill_rings.argtypes = [vp, vp, ctypes.c_int64, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int32]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is ctypes.c_int or name not in ('nuhtc_default_config', 'nuhtc_destroy', 'nuhtc_last_error', 'nuhtc_stream'):
@@ -108,7 +109,7 @@ def load():
     lib.nuhtc_default_config.restype = None
     lib.nuhtc_destroy.restype = None
     lib.nuhtc_stream.restype = ctypes.c_void_p
-    for fn in (lib.nuhtc_write_ring_features, lib.nuhtc_write_point_features, lib.nuhtc_join_features):
+    for fn in (lib.nuhtc_write_ring_features, lib.nuhtc_write_point_features, lib.nuhtc_join_features, lib.nuhtc_fill_rings):
         fn.restype = ctypes.c_int64
     _lib = lib
     return lib

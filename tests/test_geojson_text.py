@@ -79,3 +79,35 @@ def test_merge_features_leaves_its_input_alone():
     out = contours.merge_features(feats, 0.05)
     assert json.dumps(feats) == before and all('nuclei_id' in f['properties'] for f in out)
     assert list(out[0]['properties'])[-1] == 'nuclei_id'
+
+
+def test_filled_rings_are_the_traced_components_with_their_holes_filled():
+    """nuhtc_fill_rings (what lets tools/nuclei_merge.py hand a written GeoJSON to the GPU merge): the pixels inside or on the traced outer
+    border of an 8-connected component are that component with its holes filled -- scipy's binary_fill_holes (4-connected background, like
+    OpenCV's) of the component, on random fragmented masks, crops and areas in the packed layout; anything that is not a traced ring is refused."""
+    from scipy import ndimage as ndi
+    from nuhtc_amd import wsi
+    rng = np.random.default_rng(5)
+    rings, want = [], []
+    for _ in range(200):
+        h, w = rng.integers(3, 40, 2)
+        m = rng.random((h, w)) < rng.uniform(0.3, 0.8)
+        lab, k = ndi.label(m, structure=np.ones((3, 3)))
+        if k == 0:
+            continue
+        comp = lab == lab[np.nonzero(m)][0]
+        ring = contours.trace_outer_contour(comp)
+        shift = rng.integers(-50, 5000, 2)
+        rings.append(np.concatenate([ring, ring[:1]]) + shift)              # closed, as the files hold them
+        f = ndi.binary_fill_holes(comp)
+        ys, xs = np.nonzero(f)
+        want.append((f[ys.min():ys.max() + 1, xs.min():xs.max() + 1], xs.min() + shift[0], ys.min() + shift[1]))
+    boxes, areas, bits, off = contours.fill_rings(rings)
+    got = wsi.PackedMasks(boxes, areas, bits, off)
+    assert len(got) == len(want) > 150
+    for (m, x0, y0), (wm, wx, wy), a in zip(got, want, areas):
+        assert (x0, y0) == (wx, wy) and np.array_equal(m, wm) and a == wm.sum()
+    assert contours.fill_rings([np.array([[0, 0], [5, 1], [3, 3]])]) is None                # an edge off the chain directions
+    assert contours.fill_rings([np.array([[0.5, 0], [4, 0], [4, 4]])]) is None              # not on pixel centres
+    one = contours.fill_rings([np.array([[7, 9], [7, 9]])])                                 # a one-pixel component
+    assert one[0].tolist() == [[7, 9, 8, 10]] and one[1].tolist() == [1]

@@ -1,5 +1,7 @@
 """Cross-tile merge: the sequential oracle on hand-made cases (CPU) and the HIP kernel against the oracle,
 bit for bit, on random detection sets (GPU)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -179,3 +181,46 @@ def test_device_merge_slide_scale_properties(hip_device):
                 if kept[j] and (sc[j] > sc[i] or (sc[j] == sc[i] and j < i)):
                     sup_by_kept = True
         assert kept[i] != sup_by_kept          # dropped exactly when a kept, higher-priority neighbour overlaps it
+
+
+@pytest.mark.gpu
+def test_geojson_file_merged_on_the_gpu_equals_the_host_polygon_path(hip_device, tmp_path):
+    """tools/nuclei_merge.py on a written GeoJSON: the rings (traced outer borders, as tools/infer_wsi.py writes them) are filled back into mask
+    crops (nuhtc_fill_rings) and merged by nuhtc_merge_overlap with the reference's polygon measure -- the SAME kept features, in the same order,
+    with the same nuclei_ids as the host's exact polygon code (contours.merge_features: shapely's semantics restated), on a slide of fragmented
+    discs with tile-overlap duplicates and exact score ties, plus one-pixel, line, pinched and holed shapes; the CLI picks the GPU by itself,
+    `--host` forces the polygon code, and a file with a user-drawn (non-traced) polygon falls back to it."""
+    import json
+    import subprocess
+    import sys
+    from nuhtc_amd import contours
+    rng = np.random.default_rng(11)
+    rec = random_slide(rng, 1500, 1400, quant=50)
+    extra = [np.ones((1, 1), bool), np.ones((1, 9), bool), np.eye(7, dtype=bool), np.ones((6, 6), bool)]
+    pinch = np.zeros((8, 8), bool); pinch[:4, :4] = True; pinch[4:7, 4:7] = True                     # two squares (4 x 4, 3 x 3) that touch in a point
+    ring_m = np.ones((9, 9), bool); ring_m[3:6, 3:6] = False                                          # a hole
+    for m in extra + [pinch, ring_m]:
+        for k in range(3):
+            rec['mask'].append((m, 300 + 2 * k, 300 + k)); rec['score'].append(0.5 + 0.01 * k)
+    classes = ('T', 'I', 'C', 'D', 'E')
+    feats = []
+    for (m, x0, y0), s in zip(rec['mask'], rec['score']):
+        if not m.any():
+            continue
+        c = contours.trace_outer_contour(m)
+        feats.append(contours.feature(np.concatenate([c, c[:1]]) + np.array([x0, y0]), int(rng.integers(0, 5)), s, classes))
+    host = contours.merge_features(feats, 0.05)
+    dev = contours.merge_features_device(feats, 0.05)
+    assert dev is not None and len(host) == len(dev) and 600 < len(host) < len(feats)
+    assert json.dumps(host) == json.dumps(dev)
+    src = tmp_path / 'slide.geojson'
+    json.dump(feats, open(src, 'w'))
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools/nuclei_merge.py')
+    out = subprocess.run([sys.executable, tool, '--geojson', str(src), '--overlap_threshold', '0.05'], check=True, capture_output=True, text=True).stdout
+    assert 'GPU' in out
+    a = open(tmp_path / 'slide_merged.geojson').read()
+    out = subprocess.run([sys.executable, tool, '--geojson', str(src), '--overlap_threshold', '0.05', '--host', '--output_name', 'h'], check=True,
+                         capture_output=True, text=True).stdout
+    assert 'host polygons' in out and open(tmp_path / 'h.geojson').read() == a == json.dumps(host)
+    drawn = feats[:50] + [contours.feature(np.array([[0, 0], [40, 3], [17, 29], [0, 0]]), 0, 0.9, classes)]      # not a traced ring
+    assert contours.merge_features_device(drawn, 0.05) is None
