@@ -153,7 +153,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
       if (t + 1 < NT) EPI_LOADS(t + 1)          // requested before this tile's stores are issued
       __builtin_amdgcn_sched_barrier(0);
 #ifdef NUHTC_GEMM_NOSTORE   // dev probe: the launch without its output stores (results are lost): what hiding the store phase could buy at most
-      if (p.alpha == 12345.f)
+#ifndef NUHTC_GEMM_NOSTORE_K   // (-DNUHTC_GEMM_NOSTORE_K=3136: only the launches of that depth lose their stores)
+#define NUHTC_GEMM_NOSTORE_K 0
+#endif
+      if (p.alpha == 12345.f || (NUHTC_GEMM_NOSTORE_K && p.K != NUHTC_GEMM_NOSTORE_K))
 #endif
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
